@@ -1,0 +1,92 @@
+"""ctypes binding of libartp.so (include/artp_c.h).  Fails loudly when the HIP library is missing or
+no GPU is present -- there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libartp.so")
+
+# every symbol include/artp_c.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "artp_params_defaults", "artp_params_yaml", "artp_status_string", "artp_last_error",
+    "artp_device_arch", "artp_create", "artp_destroy", "artp_set_stream", "artp_synchronize",
+    "artp_upload_layer", "artp_update_layer_rect", "artp_check_boxes", "artp_check_boxes_dev",
+    "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
+    "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
+    "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
+    "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_algorithmic_vertices_dev",
+]
+
+
+class ArtpError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("torso_length", "torso_width", "torso_height", "torso_off_x", "torso_off_y",
+                 "torso_off_z", "feet_off_x", "feet_off_y", "feet_off_z", "reach_x", "reach_y",
+                 "reach_z")] + [("unknown_space_untraversable", C.c_int),
+                                ("max_pitch_pert", C.c_double), ("max_roll_pert", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libartp.so; raise ArtpError if it was not built (run `python -c 'import __graft_entry__ as
+    g; g.build()'` or `make -C art_planner_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ArtpError(f"{LIB_PATH} is missing: build the HIP extension first "
+                        "(make -C art_planner_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64, dbl, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_double, C.c_int
+    L.artp_params_defaults.argtypes = [C.POINTER(Params)]
+    L.artp_params_yaml.argtypes = [C.POINTER(Params)]
+    L.artp_status_string.argtypes = [i32]
+    L.artp_status_string.restype = C.c_char_p
+    L.artp_last_error.argtypes = [vp]
+    L.artp_last_error.restype = C.c_char_p
+    L.artp_device_arch.argtypes = [vp]
+    L.artp_device_arch.restype = C.c_char_p
+    L.artp_create.argtypes = [i32, C.POINTER(Params), C.POINTER(vp)]
+    L.artp_destroy.argtypes = [vp]
+    L.artp_destroy.restype = None
+    L.artp_set_stream.argtypes = [vp, vp]
+    L.artp_synchronize.argtypes = [vp]
+    L.artp_upload_layer.argtypes = [vp, i32, vp, i32, i32, dbl, dbl, dbl, dbl]
+    L.artp_update_layer_rect.argtypes = [vp, i32, vp, i32, i32, i32, i32]
+    for name in ("artp_check_boxes", "artp_check_boxes_dev"):
+        getattr(L, name).argtypes = [vp, i32, vp, vp, sz, vp, vp]
+    for name in ("artp_validate_states", "artp_validate_states_dev"):
+        getattr(L, name).argtypes = [vp, vp, sz, vp, vp]
+    L.artp_upload_sampler_layers.argtypes = [vp] + [vp] * 7 + [i32, i32, dbl, dbl, dbl, dbl]
+    for name in ("artp_sample_states", "artp_sample_states_dev"):
+        getattr(L, name).argtypes = [vp, u64, u64, sz, vp]
+    L.artp_sample_and_validate_dev.argtypes = [vp, u64, u64, sz, vp, vp, C.POINTER(sz)]
+    L.artp_set_z_bounds.argtypes = [vp, dbl, dbl]
+    for name in ("artp_check_motions", "artp_check_motions_dev"):
+        getattr(L, name).argtypes = [vp, vp, vp, sz, vp]
+    for name in ("artp_check_edges_interp", "artp_check_edges_interp_dev"):
+        getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp]
+    L.artp_compact_valid_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("artp_destroy",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(ctx, rc: int, what: str) -> None:
+    if rc != 0:
+        L = load()
+        msg = L.artp_status_string(rc).decode()
+        detail = L.artp_last_error(ctx).decode() if ctx else ""
+        raise ArtpError(f"{what} failed: {msg} ({rc}) {detail}")

@@ -1,0 +1,186 @@
+"""Python view of one artp_ctx (one GPU).  Thin plumbing over the C ABI: numpy for host buffers,
+torch only for device memory / streams in the `_dev` calls.  All compute is in libartp.so (HIP)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+
+
+def make_params(kind="yaml", **overrides) -> _capi.Params:
+    L = _capi.load()
+    p = _capi.Params()
+    (L.artp_params_yaml if kind == "yaml" else L.artp_params_defaults)(C.byref(p))
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def _f32F(a) -> np.ndarray:
+    return np.asfortranarray(a, dtype=np.float32)
+
+
+class Context:
+    """Mirrors what art_planner::Planner owns for the hot path: the validity checker's two height
+    fields, the sampler's layers and the state-space bounds (art_planner/src/planner.cpp:75-163)."""
+
+    def __init__(self, device: int = 0, params="yaml"):
+        self.L = _capi.load()
+        self.params = params if isinstance(params, _capi.Params) else make_params(params)
+        h = C.c_void_p()
+        rc = self.L.artp_create(device, C.byref(self.params), C.byref(h))
+        _capi.check(None, rc, "artp_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.artp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def arch(self) -> str:
+        return self.L.artp_device_arch(self.h).decode()
+
+    def _chk(self, rc, what):
+        _capi.check(self.h, rc, what)
+
+    # ---- map ---------------------------------------------------------------------------------
+    def upload_layer(self, slot, layer, len_x, len_y, pos_x=0.0, pos_y=0.0):
+        layer = _f32F(layer)
+        self._chk(self.L.artp_upload_layer(self.h, slot, layer.ctypes.data, layer.shape[0], layer.shape[1],
+                                           len_x, len_y, pos_x, pos_y), "artp_upload_layer")
+
+    def update_layer_rect(self, slot, patch, row0, col0):
+        patch = _f32F(patch)
+        self._chk(self.L.artp_update_layer_rect(self.h, slot, patch.ctypes.data, row0, col0,
+                                                patch.shape[0], patch.shape[1]), "artp_update_layer_rect")
+
+    def upload_map(self, gm, body_layer="elevation", feet_layer="elevation_masked", sampler=True):
+        """Planner::setMap (planner.cpp:135-163): both height fields, the sampler layers and the
+        z bounds (min/max finite elevation -/+ reach.z/2)."""
+        self.upload_layer(0, gm[body_layer], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+        self.upload_layer(1, gm[feet_layer], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+        elev = gm[body_layer]
+        fin = elev[np.isfinite(elev)]
+        lo = float(fin.min()) if fin.size else 0.0
+        hi = float(fin.max()) if fin.size else 0.0
+        self._chk(self.L.artp_set_z_bounds(self.h, lo - self.params.reach_z / 2, hi + self.params.reach_z / 2),
+                  "artp_set_z_bounds")
+        if sampler and "cum_prob" in gm.layers:
+            ls = [_f32F(gm["cum_prob"]), np.ascontiguousarray(gm["cum_prob_rowwise"], np.float32),
+                  _f32F(gm[body_layer]), _f32F(gm["normal_x"]), _f32F(gm["normal_y"]),
+                  _f32F(gm["normal_z"]), _f32F(gm["plane_fit_std_dev"])]
+            self._chk(self.L.artp_upload_sampler_layers(self.h, *[a.ctypes.data for a in ls], gm.rows,
+                                                        gm.cols, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y),
+                      "artp_upload_sampler_layers")
+
+    # ---- host-buffer entry points ------------------------------------------------------------
+    def check_boxes(self, slot, box, poses, want_exit_codes=False):
+        box = np.ascontiguousarray(box, np.float32)
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        n = poses.shape[0]
+        hit = np.empty(n, np.uint8)
+        ec = np.empty(n, np.uint8) if want_exit_codes else None
+        self._chk(self.L.artp_check_boxes(self.h, slot, box.ctypes.data, poses.ctypes.data, n,
+                                          hit.ctypes.data, ec.ctypes.data if want_exit_codes else None),
+                  "artp_check_boxes")
+        return (hit, ec) if want_exit_codes else hit
+
+    def validate_states(self, se3, want_detail=False):
+        se3 = np.ascontiguousarray(se3, np.float64).reshape(-1, 7)
+        n = se3.shape[0]
+        valid = np.empty(n, np.uint8)
+        detail = np.empty((n, 6), np.int8) if want_detail else None
+        self._chk(self.L.artp_validate_states(self.h, se3.ctypes.data, n, valid.ctypes.data,
+                                              detail.ctypes.data if want_detail else None),
+                  "artp_validate_states")
+        return (valid, detail) if want_detail else valid
+
+    def sample_states(self, seed, first_index, n):
+        out = np.empty((n, 7), np.float64)
+        self._chk(self.L.artp_sample_states(self.h, seed, first_index, n, out.ctypes.data),
+                  "artp_sample_states")
+        return out
+
+    def check_motions(self, s1, s2):
+        s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
+        s2 = np.ascontiguousarray(s2, np.float64).reshape(-1, 7)
+        valid = np.empty(s1.shape[0], np.uint8)
+        self._chk(self.L.artp_check_motions(self.h, s1.ctypes.data, s2.ctypes.data, s1.shape[0],
+                                            valid.ctypes.data), "artp_check_motions")
+        return valid
+
+    def check_edges_interp(self, s1, s2):
+        s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
+        s2 = np.ascontiguousarray(s2, np.float64).reshape(-1, 7)
+        n = s1.shape[0]
+        valid = np.empty(n, np.uint8)
+        nint = np.empty(n, np.uint32)
+        self._chk(self.L.artp_check_edges_interp(self.h, s1.ctypes.data, s2.ctypes.data, n,
+                                                 valid.ctypes.data, nint.ctypes.data),
+                  "artp_check_edges_interp")
+        return valid, nint
+
+    # ---- device-buffer entry points (torch tensors on this context's GPU) ----------------------
+    def use_torch_stream(self):
+        import torch
+        self._chk(self.L.artp_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                  "artp_set_stream")
+
+    def synchronize(self):
+        self._chk(self.L.artp_synchronize(self.h), "artp_synchronize")
+
+    def validate_states_dev(self, se3_t, valid_t, detail_t=None):
+        n = se3_t.shape[0]
+        self._chk(self.L.artp_validate_states_dev(self.h, se3_t.data_ptr(), n, valid_t.data_ptr(),
+                                                  detail_t.data_ptr() if detail_t is not None else None),
+                  "artp_validate_states_dev")
+
+    def sample_states_dev(self, seed, first_index, n, out_t):
+        self._chk(self.L.artp_sample_states_dev(self.h, seed, first_index, n, out_t.data_ptr()),
+                  "artp_sample_states_dev")
+
+    def sample_and_validate_dev(self, seed, first_index, n, se3_t, valid_t, count=False) -> Optional[int]:
+        cnt = C.c_size_t(0)
+        self._chk(self.L.artp_sample_and_validate_dev(self.h, seed, first_index, n, se3_t.data_ptr(),
+                                                      valid_t.data_ptr(), C.byref(cnt) if count else None),
+                  "artp_sample_and_validate_dev")
+        return cnt.value if count else None
+
+    def check_motions_dev(self, s1_t, s2_t, valid_t):
+        self._chk(self.L.artp_check_motions_dev(self.h, s1_t.data_ptr(), s2_t.data_ptr(), s1_t.shape[0],
+                                                valid_t.data_ptr()), "artp_check_motions_dev")
+
+    def check_edges_interp_dev(self, s1_t, s2_t, valid_t, nint_t=None):
+        self._chk(self.L.artp_check_edges_interp_dev(self.h, s1_t.data_ptr(), s2_t.data_ptr(), s1_t.shape[0],
+                                                     valid_t.data_ptr(),
+                                                     nint_t.data_ptr() if nint_t is not None else None),
+                  "artp_check_edges_interp_dev")
+
+    def check_boxes_dev(self, slot, box, poses_t, hit_t, ec_t=None):
+        box = np.ascontiguousarray(box, np.float32)
+        self._chk(self.L.artp_check_boxes_dev(self.h, slot, box.ctypes.data, poses_t.data_ptr(),
+                                              poses_t.shape[0], hit_t.data_ptr(),
+                                              ec_t.data_ptr() if ec_t is not None else None),
+                  "artp_check_boxes_dev")
+
+    def compact_valid_dev(self, se3_t, valid_t, out_t, count_t):
+        """count_t: 1-element int64/uint64 device tensor."""
+        self._chk(self.L.artp_compact_valid_dev(self.h, se3_t.data_ptr(), valid_t.data_ptr(), se3_t.shape[0],
+                                                out_t.data_ptr(), count_t.data_ptr()), "artp_compact_valid_dev")
+
+    def algorithmic_vertices_dev(self, se3_t) -> int:
+        v = C.c_uint64(0)
+        self._chk(self.L.artp_algorithmic_vertices_dev(self.h, se3_t.data_ptr(), se3_t.shape[0], C.byref(v)),
+                  "artp_algorithmic_vertices_dev")
+        return v.value

@@ -1,0 +1,681 @@
+// artp_capi.hip -- C ABI (include/artp_c.h) over the gfx950 kernels.  No CPU compute path exists
+// here: without a HIP device artp_create fails with ARTP_ERR_NO_DEVICE.
+#include "../../include/artp_c.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace artp;
+
+struct artp_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  artp_params params{};
+  RobotDev robot{};
+  MapGeom geom{};
+  bool have_geom = false;
+  FieldDev field[2]{};
+  float* field_data[2] = {nullptr, nullptr};
+  size_t field_elems[2] = {0, 0};
+  bool have_field[2] = {false, false};
+  std::vector<float> field_host[2];  // ODE-layout host mirror (for rect updates / has_nan)
+  SamplerDev sampler{};
+  float* sampler_buf = nullptr;
+  bool have_sampler = false;
+  double z_low = 0.0, z_high = 0.0;
+  bool have_z = false;
+  int cap_verts = 0, cap_tris = 0;
+  size_t lds_bytes = 0;
+  int n_cus = 256;
+  // device scratch
+  int* d_error = nullptr;
+  unsigned long long* d_count = nullptr;
+  void* tmp[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t tmp_cap[4] = {0, 0, 0, 0};
+  void* cub_tmp = nullptr;
+  size_t cub_cap = 0;
+  std::string last_error;
+  std::string arch;
+  std::mutex mu;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);      \
+      return ARTP_ERR_HIP;                                                        \
+    }                                                                             \
+  } while (0)
+
+int ensure_tmp(artp_ctx* c, int slot, size_t bytes) {
+  if (c->tmp_cap[slot] >= bytes) return ARTP_OK;
+  if (c->tmp[slot]) HIP_TRY(c, hipFree(c->tmp[slot]));
+  c->tmp[slot] = nullptr;
+  c->tmp_cap[slot] = 0;
+  const size_t want = bytes + bytes / 4 + 256;
+  HIP_TRY(c, hipMalloc(&c->tmp[slot], want));
+  c->tmp_cap[slot] = want;
+  return ARTP_OK;
+}
+
+void fill_robot(artp_ctx* c) {
+  const artp_params& p = c->params;
+  RobotDev& r = c->robot;
+  // HeightMapBoxChecker(float, float, float) ctor args (validity_checker_body.cpp:10-14,
+  // validity_checker_feet.cpp:13-18): doubles narrowed to float at the call.
+  r.torso[0] = (float)p.torso_length;
+  r.torso[1] = (float)p.torso_width;
+  r.torso[2] = (float)p.torso_height;
+  r.foot[0] = (float)p.reach_x;
+  r.foot[1] = (float)p.reach_y;
+  r.foot[2] = (float)p.reach_z;
+  // Pose3FromXYZ(Scalar, Scalar, Scalar) args (validity_checker.cpp:41-43)
+  r.torso_off[0] = (float)p.torso_off_x;
+  r.torso_off[1] = (float)p.torso_off_y;
+  r.torso_off[2] = (float)(p.torso_off_z - p.feet_off_z);
+  r.feet_off_x = (float)p.feet_off_x;
+  r.feet_off_y = (float)p.feet_off_y;
+  r.unknown_space_untraversable = p.unknown_space_untraversable;
+  r.reach_z = p.reach_z;
+  r.max_pitch_pert = p.max_pitch_pert;
+  r.max_roll_pert = p.max_roll_pert;
+}
+
+// dRFrom2Axes (ode/ode/src/rotation.cpp:94-130) for the field rotation.
+void r_from_2_axes(float* R, float ax, float ay, float az, float bx, float by, float bz) {
+  float l = sqrtf(ax * ax + ay * ay + az * az);
+  if (l <= 0.0f) return;
+  l = 1.0f / l;
+  ax *= l; ay *= l; az *= l;
+  const float k = ax * bx + ay * by + az * bz;
+  bx -= k * ax; by -= k * ay; bz -= k * az;
+  l = sqrtf(bx * bx + by * by + bz * bz);
+  if (l <= 0.0f) return;
+  l = 1.0f / l;
+  bx *= l; by *= l; bz *= l;
+  R[0] = ax; R[4] = ay; R[8] = az;
+  R[1] = bx; R[5] = by; R[9] = bz;
+  R[2] = -by * az + ay * bz;
+  R[6] = -bz * ax + az * bx;
+  R[10] = -bx * ay + ax * by;
+  R[3] = R[7] = R[11] = 0.0f;
+}
+
+// LDS window tile sized from the largest box diagonal and the sample spacing (any orientation).
+int size_scratch(artp_ctx* c) {
+  const artp_params& p = c->params;
+  const double d_torso = std::sqrt(p.torso_length * p.torso_length + p.torso_width * p.torso_width +
+                                   p.torso_height * p.torso_height);
+  const double d_foot = std::sqrt(p.reach_x * p.reach_x + p.reach_y * p.reach_y + p.reach_z * p.reach_z);
+  double diag = d_torso > d_foot ? d_torso : d_foot;
+  double spacing = 1e30;
+  int max_n = 2;
+  for (int s = 0; s < 2; ++s) {
+    if (!c->have_field[s]) continue;
+    spacing = std::fmin(spacing, (double)std::fmin(c->field[s].sample_w, c->field[s].sample_d));
+    max_n = std::max(max_n, std::max(c->field[s].nW, c->field[s].nD));
+  }
+  if (spacing > 1e29) return ARTP_OK;
+  int maxdim = (int)std::ceil(diag / spacing) + 4;
+  if (maxdim > max_n) maxdim = max_n;
+  if (maxdim < 4) maxdim = 4;
+  long verts = (long)maxdim * maxdim;
+  long tris = 2L * (maxdim - 1) * (maxdim - 1);
+  if (tris > 4096) tris = 4096;  // 64 lanes x 64-bit assignment mask
+  verts = (verts + 3) & ~3L;
+  tris = (tris + 7) & ~7L;
+  const size_t per_wave = (size_t)verts * 4 + (size_t)tris * 2;
+  if (per_wave * ARTP_WAVES_PER_BLOCK > 160 * 1024) {
+    c->last_error = "box too large for the LDS window tile";
+    return ARTP_ERR_CAPACITY;
+  }
+  c->cap_verts = (int)verts;
+  c->cap_tris = (int)tris;
+  c->lds_bytes = per_wave * ARTP_WAVES_PER_BLOCK;
+  return ARTP_OK;
+}
+
+int set_kernel_lds(artp_ctx* c) {
+  // > 64 KiB of dynamic LDS needs the opt-in attribute
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(check_boxes_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(validate_states_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(expanded_validate_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+  return ARTP_OK;
+}
+
+int wave_grid(const artp_ctx* c, size_t tasks) {
+  // persistent waves: enough blocks to fill every CU several times over, grid-stride the rest
+  const size_t blocks_needed = (tasks + ARTP_WAVES_PER_BLOCK - 1) / ARTP_WAVES_PER_BLOCK;
+  const size_t cap = (size_t)c->n_cus * 16;
+  size_t g = blocks_needed < cap ? blocks_needed : cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int check_error_flag(artp_ctx* c) {
+  int flag = 0;
+  HIP_TRY(c, hipMemcpyAsync(&flag, c->d_error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (flag) {
+    HIP_TRY(c, hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
+    c->last_error = "a box window exceeded the LDS tile capacity";
+    return ARTP_ERR_CAPACITY;
+  }
+  return ARTP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void artp_params_defaults(artp_params* p) {  // art_planner/include/art_planner/params.h:80-119
+  p->torso_length = 1.05; p->torso_width = 0.55; p->torso_height = 0.2;
+  p->torso_off_x = 0.0; p->torso_off_y = 0.0; p->torso_off_z = 0.0;
+  p->feet_off_x = 0.362; p->feet_off_y = 0.225; p->feet_off_z = -0.525;
+  p->reach_x = 0.25; p->reach_y = 0.1; p->reach_z = 0.15;
+  p->unknown_space_untraversable = 1;
+  p->max_pitch_pert = 10.0 / 180 * M_PI;
+  p->max_roll_pert = 3.33 / 180 * M_PI;
+}
+
+void artp_params_yaml(artp_params* p) {  // art_planner_ros/config/params.yaml:44-45,55-71
+  p->torso_length = 1.31; p->torso_width = 0.65; p->torso_height = 0.3;
+  p->torso_off_x = 0.0; p->torso_off_y = 0.0; p->torso_off_z = 0.04;
+  p->feet_off_x = 0.51; p->feet_off_y = 0.2; p->feet_off_z = -0.475;
+  p->reach_x = 0.2; p->reach_y = 0.2; p->reach_z = 0.2;
+  p->unknown_space_untraversable = 1;
+  p->max_pitch_pert = 10 * M_PI / 180;
+  p->max_roll_pert = 3.33 * M_PI / 180;
+}
+
+const char* artp_status_string(int s) {
+  switch (s) {
+    case ARTP_OK: return "ok";
+    case ARTP_ERR_INVALID_ARG: return "invalid argument";
+    case ARTP_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case ARTP_ERR_HIP: return "HIP runtime error";
+    case ARTP_ERR_NO_MAP: return "required layer not uploaded";
+    case ARTP_ERR_CAPACITY: return "box window exceeds the LDS tile capacity";
+    case ARTP_ERR_NO_WEIGHTS: return "motion-cost weights not loaded";
+    default: return "unknown status";
+  }
+}
+
+const char* artp_last_error(const artp_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* artp_device_arch(const artp_ctx* ctx) { return ctx ? ctx->arch.c_str() : ""; }
+
+int artp_create(int device, const artp_params* params, artp_ctx** out) {
+  if (!params || !out) return ARTP_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return ARTP_ERR_NO_DEVICE;
+  artp_ctx* c = new artp_ctx();
+  c->device = device;
+  c->params = *params;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete c;
+    return ARTP_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete c;
+    return ARTP_ERR_NO_DEVICE;
+  }
+  c->arch = prop.gcnArchName;
+  c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&c->d_error, sizeof(int)) != hipSuccess ||
+      hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->d_error, 0, sizeof(int)) != hipSuccess) {
+    artp_destroy(c);
+    return ARTP_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  fill_robot(c);
+  *out = c;
+  return ARTP_OK;
+}
+
+void artp_destroy(artp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int s = 0; s < 2; ++s)
+    if (c->field_data[s]) (void)hipFree(c->field_data[s]);
+  if (c->sampler_buf) (void)hipFree(c->sampler_buf);
+  for (int s = 0; s < 4; ++s)
+    if (c->tmp[s]) (void)hipFree(c->tmp[s]);
+  if (c->cub_tmp) (void)hipFree(c->cub_tmp);
+  if (c->d_error) (void)hipFree(c->d_error);
+  if (c->d_count) (void)hipFree(c->d_count);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int artp_set_stream(artp_ctx* c, void* hip_stream) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return ARTP_OK;
+}
+
+int artp_synchronize(artp_ctx* c) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
+}
+
+int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int cols, double len_x,
+                      double len_y, double pos_x, double pos_y) {
+  if (!c || !layer || slot < 0 || slot > 1 || rows < 2 || cols < 2) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t elems = (size_t)rows * cols;
+  // field_.mat = layer.rowwise().reverse() (height_map_box_checker.cpp:44): ODE sample (x, z) =
+  // layer(x, cols-1-z), stored x-fastest.
+  std::vector<float>& host = c->field_host[slot];
+  host.resize(elems);
+  int has_nan = 0;
+  for (int j = 0; j < cols; ++j)
+    for (int i = 0; i < rows; ++i) {
+      const float v = layer[(size_t)i + (size_t)(cols - 1 - j) * rows];
+      host[(size_t)i + (size_t)j * rows] = v;
+      has_nan |= (v != v);
+    }
+  if (c->field_elems[slot] < elems) {
+    if (c->field_data[slot]) HIP_TRY(c, hipFree(c->field_data[slot]));
+    c->field_data[slot] = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->field_data[slot]), elems * sizeof(float)));
+    c->field_elems[slot] = elems;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->field_data[slot], host.data(), elems * sizeof(float),
+                            hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  FieldDev& f = c->field[slot];
+  f.data = c->field_data[slot];
+  // dxHeightfieldData::SetData (ode/ode/src/heightfield.cpp:130-169), single precision
+  f.nW = rows;
+  f.nD = cols;
+  f.width = (float)len_x;
+  f.depth = (float)len_y;
+  f.half_w = f.width / 2.0f;
+  f.half_d = f.depth / 2.0f;
+  f.sample_w = f.width / ((float)f.nW - 1.0f);
+  f.sample_d = f.depth / ((float)f.nD - 1.0f);
+  f.zx_aspect = f.sample_d / f.sample_w;
+  f.inv_w = 1.0f / f.sample_w;
+  f.inv_d = 1.0f / f.sample_d;
+  f.pos[0] = (float)pos_x;
+  f.pos[1] = (float)pos_y;
+  f.pos[2] = 0.0f;
+  std::memset(f.R, 0, sizeof(f.R));
+  r_from_2_axes(f.R, -1, 0, 0, 0, 0, 1);  // height_map_box_checker.cpp:22
+  orthogonalize_R(f.R);                  // dBodySetRotation, :25
+  f.has_nan = has_nan;
+  c->have_field[slot] = true;
+  c->geom.len_x = len_x;
+  c->geom.len_y = len_y;
+  c->geom.pos_x = pos_x;
+  c->geom.pos_y = pos_y;
+  c->geom.rows = rows;
+  c->geom.cols = cols;
+  c->geom.res = len_x / rows;
+  c->have_geom = true;
+  const int rc = size_scratch(c);
+  if (rc != ARTP_OK) return rc;
+  return set_kernel_lds(c);
+}
+
+int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, int col0, int nrows,
+                           int ncols) {
+  if (!c || !patch || slot < 0 || slot > 1) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
+  const int rows = c->field[slot].nW, cols = c->field[slot].nD;
+  if (row0 < 0 || col0 < 0 || nrows <= 0 || ncols <= 0 || row0 + nrows > rows || col0 + ncols > cols)
+    return ARTP_ERR_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<float>& host = c->field_host[slot];
+  // grid column j maps to ODE z = cols-1-j; copy each touched z-row segment (contiguous in x)
+  for (int jj = 0; jj < ncols; ++jj) {
+    const int z = cols - 1 - (col0 + jj);
+    float* dst = host.data() + (size_t)row0 + (size_t)z * rows;
+    std::memcpy(dst, patch + (size_t)jj * nrows, sizeof(float) * nrows);
+    HIP_TRY(c, hipMemcpyAsync(c->field_data[slot] + (size_t)row0 + (size_t)z * rows, dst,
+                              sizeof(float) * nrows, hipMemcpyHostToDevice, c->stream));
+  }
+  int has_nan = 0;
+  for (float v : host) has_nan |= (v != v);
+  c->field[slot].has_nan = has_nan;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
+}
+
+int artp_check_boxes_dev(artp_ctx* c, int slot, const float box[3], const float* dposes, size_t n,
+                         uint8_t* hit, uint8_t* exit_codes) {
+  if (!c || !box || slot < 0 || slot > 1 || (n && (!dposes || !hit))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
+  if (n == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(check_boxes_kernel, dim3(wave_grid(c, n)), dim3(64 * ARTP_WAVES_PER_BLOCK),
+                     c->lds_bytes, c->stream, c->field[slot], box[0], box[1], box[2], dposes, n, hit,
+                     exit_codes, c->cap_verts, c->cap_tris, c->d_error);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+int artp_check_boxes(artp_ctx* c, int slot, const float box[3], const float* dposes, size_t n,
+                     uint8_t* hit, uint8_t* exit_codes) {
+  if (!c || (n && (!dposes || !hit))) return ARTP_ERR_INVALID_ARG;
+  if (n == 0) return ARTP_OK;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_tmp(c, 0, n * 16 * sizeof(float));
+    if (rc) return rc;
+    rc = ensure_tmp(c, 1, n * 2);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], dposes, n * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
+  uint8_t* d_hit = static_cast<uint8_t*>(c->tmp[1]);
+  uint8_t* d_ec = d_hit + n;
+  int rc = artp_check_boxes_dev(c, slot, box, static_cast<const float*>(c->tmp[0]), n, d_hit,
+                                exit_codes ? d_ec : nullptr);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipMemcpyAsync(hit, d_hit, n, hipMemcpyDeviceToHost, c->stream));
+  if (exit_codes) HIP_TRY(c, hipMemcpyAsync(exit_codes, d_ec, n, hipMemcpyDeviceToHost, c->stream));
+  return check_error_flag(c);
+}
+
+int artp_validate_states_dev(artp_ctx* c, const double* se3, size_t n, uint8_t* valid, int8_t* detail) {
+  if (!c || (n && (!se3 || !valid))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
+  if (n == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(validate_states_kernel, dim3(wave_grid(c, n)), dim3(64 * ARTP_WAVES_PER_BLOCK),
+                     c->lds_bytes, c->stream, c->field[0], c->field[1], c->geom, c->robot, se3, n,
+                     valid, detail, c->cap_verts, c->cap_tris, c->d_error,
+                     (unsigned long long*)nullptr);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+int artp_validate_states(artp_ctx* c, const double* se3, size_t n, uint8_t* valid, int8_t* detail) {
+  if (!c || (n && (!se3 || !valid))) return ARTP_ERR_INVALID_ARG;
+  if (n == 0) return ARTP_OK;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
+    if (rc) return rc;
+    rc = ensure_tmp(c, 1, n * 7);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], se3, n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  uint8_t* d_valid = static_cast<uint8_t*>(c->tmp[1]);
+  int8_t* d_detail = reinterpret_cast<int8_t*>(d_valid + n);
+  int rc = artp_validate_states_dev(c, static_cast<const double*>(c->tmp[0]), n, d_valid,
+                                    detail ? d_detail : nullptr);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+  if (detail) HIP_TRY(c, hipMemcpyAsync(detail, d_detail, n * 6, hipMemcpyDeviceToHost, c->stream));
+  return check_error_flag(c);
+}
+
+int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* cum_prob_rowwise,
+                               const float* elevation, const float* normal_x, const float* normal_y,
+                               const float* normal_z, const float* plane_fit_std_dev, int rows,
+                               int cols, double len_x, double len_y, double pos_x, double pos_y) {
+  if (!c || !cum_prob || !cum_prob_rowwise || !elevation || !normal_x || !normal_y || !normal_z ||
+      !plane_fit_std_dev || rows < 1 || cols < 1)
+    return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t e = (size_t)rows * cols;
+  if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
+  c->sampler_buf = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_buf), (6 * e + rows) * sizeof(float)));
+  float* p = c->sampler_buf;
+  const float* src[6] = {cum_prob, elevation, normal_x, normal_y, normal_z, plane_fit_std_dev};
+  const float** dst[6] = {&c->sampler.cum_prob, &c->sampler.elevation, &c->sampler.normal_x,
+                          &c->sampler.normal_y, &c->sampler.normal_z, &c->sampler.plane_fit_std_dev};
+  for (int k = 0; k < 6; ++k) {
+    HIP_TRY(c, hipMemcpyAsync(p, src[k], e * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    *dst[k] = p;
+    p += e;
+  }
+  HIP_TRY(c, hipMemcpyAsync(p, cum_prob_rowwise, rows * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  c->sampler.cum_prob_rowwise = p;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->have_geom) {
+    c->geom.len_x = len_x; c->geom.len_y = len_y; c->geom.pos_x = pos_x; c->geom.pos_y = pos_y;
+    c->geom.rows = rows; c->geom.cols = cols; c->geom.res = len_x / rows;
+    c->have_geom = true;
+  }
+  c->have_sampler = true;
+  return ARTP_OK;
+}
+
+int artp_sample_states_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out) {
+  if (!c || (n && !se3_out)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_sampler) return ARTP_ERR_NO_MAP;
+  if (n == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t blocks = (n + 255) / 256;
+  if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+  hipLaunchKernelGGL(sample_states_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
+                     c->geom, c->robot, seed, first_index, n, se3_out);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+int artp_sample_states(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out) {
+  if (!c || (n && !se3_out)) return ARTP_ERR_INVALID_ARG;
+  if (n == 0) return ARTP_OK;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
+    if (rc) return rc;
+  }
+  int rc = artp_sample_states_dev(c, seed, first_index, n, static_cast<double*>(c->tmp[0]));
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipMemcpyAsync(se3_out, c->tmp[0], n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
+}
+
+int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n,
+                                 double* se3_out, uint8_t* valid_out, size_t* n_valid) {
+  if (!c || (n && (!se3_out || !valid_out))) return ARTP_ERR_INVALID_ARG;
+  int rc = artp_sample_states_dev(c, seed, first_index, n, se3_out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
+  if (n == 0) {
+    if (n_valid) *n_valid = 0;
+    return ARTP_OK;
+  }
+  if (n_valid) HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(validate_states_kernel, dim3(wave_grid(c, n)), dim3(64 * ARTP_WAVES_PER_BLOCK),
+                     c->lds_bytes, c->stream, c->field[0], c->field[1], c->geom, c->robot,
+                     (const double*)se3_out, n, valid_out, (int8_t*)nullptr, c->cap_verts, c->cap_tris,
+                     c->d_error, n_valid ? c->d_count : (unsigned long long*)nullptr);
+  HIP_TRY(c, hipGetLastError());
+  if (n_valid) {
+    unsigned long long cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_valid = (size_t)cnt;
+  }
+  return ARTP_OK;
+}
+
+int artp_set_z_bounds(artp_ctx* c, double z_low, double z_high) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->z_low = z_low;
+  c->z_high = z_high;
+  c->have_z = true;
+  return ARTP_OK;
+}
+
+static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
+                         uint8_t* valid, uint32_t* aux_out) {
+  if (!c || (n && (!s1 || !s2 || !valid))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
+  if (mode == 0 && !c->have_z) {
+    c->last_error = "artp_set_z_bounds must be called before artp_check_motions";
+    return ARTP_ERR_NO_MAP;
+  }
+  if (n == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n)
+  int rc = ensure_tmp(c, 2, (3 * n + 2) * sizeof(uint32_t));
+  if (rc) return rc;
+  uint32_t* counts = static_cast<uint32_t*>(c->tmp[2]);
+  uint32_t* offsets = counts + (n + 1);
+  uint32_t* aux = aux_out ? aux_out : offsets + (n + 1);
+  HIP_TRY(c, hipMemsetAsync(counts + n, 0, sizeof(uint32_t), c->stream));
+  size_t blocks = (n + 255) / 256;
+  if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+  hipLaunchKernelGGL(motion_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->geom,
+                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid);
+  HIP_TRY(c, hipGetLastError());
+  size_t need = 0;
+  HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(n + 1), c->stream));
+  if (c->cub_cap < need) {
+    if (c->cub_tmp) HIP_TRY(c, hipFree(c->cub_tmp));
+    c->cub_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->cub_tmp, need + 256));
+    c->cub_cap = need + 256;
+  }
+  size_t cap = c->cub_cap;
+  HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, cap, counts, offsets, (int)(n + 1), c->stream));
+  // grid: the expanded task count lives on the device; use a persistent grid
+  hipLaunchKernelGGL(expanded_validate_kernel, dim3((unsigned)c->n_cus * 16),
+                     dim3(64 * ARTP_WAVES_PER_BLOCK), c->lds_bytes, c->stream, c->field[0], c->field[1],
+                     c->geom, c->robot, mode, s1, s2, n, (const uint32_t*)offsets, (const uint32_t*)aux,
+                     valid, c->cap_verts, c->cap_tris, c->d_error);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
+                          uint8_t* valid, uint32_t* aux_out) {
+  if (!c || (n && (!s1 || !s2 || !valid))) return ARTP_ERR_INVALID_ARG;
+  if (n == 0) return ARTP_OK;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_tmp(c, 0, 2 * n * 7 * sizeof(double));
+    if (rc) return rc;
+    rc = ensure_tmp(c, 1, n + 4 * n + 16);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], s1, n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(static_cast<double*>(c->tmp[0]) + 7 * n, s2, n * 7 * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+  }
+  uint32_t* d_aux = static_cast<uint32_t*>(c->tmp[1]);
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_aux + n);
+  int rc = run_edges_dev(c, mode, static_cast<const double*>(c->tmp[0]),
+                         static_cast<const double*>(c->tmp[0]) + 7 * n, n, d_valid, d_aux);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+  if (aux_out) HIP_TRY(c, hipMemcpyAsync(aux_out, d_aux, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  return check_error_flag(c);
+}
+
+int artp_check_motions_dev(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid) {
+  return run_edges_dev(c, 0, s1, s2, n, valid, nullptr);
+}
+int artp_check_motions(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid) {
+  return run_edges_host(c, 0, s1, s2, n, valid, nullptr);
+}
+int artp_check_edges_interp_dev(artp_ctx* c, const double* s1, const double* s2, size_t n,
+                                uint8_t* valid, uint32_t* n_interp_out) {
+  return run_edges_dev(c, 1, s1, s2, n, valid, n_interp_out);
+}
+int artp_check_edges_interp(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                            uint32_t* n_interp_out) {
+  return run_edges_host(c, 1, s1, s2, n, valid, n_interp_out);
+}
+
+
+namespace {
+struct Se3Row { double v[7]; };
+}
+
+int artp_compact_valid_dev(artp_ctx* c, const double* se3, const uint8_t* valid, size_t n,
+                           double* out_se3, uint64_t* n_out_dev) {
+  if (!c || (n && (!se3 || !valid || !out_se3)) || !n_out_dev) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n == 0) {
+    HIP_TRY(c, hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), c->stream));
+    return ARTP_OK;
+  }
+  const Se3Row* in = reinterpret_cast<const Se3Row*>(se3);
+  Se3Row* out = reinterpret_cast<Se3Row*>(out_se3);
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(n_out_dev);
+  size_t need = 0;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, need, in, valid, out, cnt, (int)n, c->stream));
+  if (c->cub_cap < need) {
+    if (c->cub_tmp) HIP_TRY(c, hipFree(c->cub_tmp));
+    c->cub_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->cub_tmp, need + 256));
+    c->cub_cap = need + 256;
+  }
+  size_t cap = c->cub_cap;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->cub_tmp, cap, in, valid, out, cnt, (int)n, c->stream));
+  return ARTP_OK;
+}
+
+int artp_algorithmic_vertices_dev(artp_ctx* c, const double* se3, size_t n, uint64_t* total) {
+  if (!c || (n && !se3) || !total) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
+  if (n) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+    hipLaunchKernelGGL(alg_vertices_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->field[0],
+                       c->field[1], c->geom, c->robot, se3, n, c->d_count);
+    HIP_TRY(c, hipGetLastError());
+  }
+  unsigned long long v = 0;
+  HIP_TRY(c, hipMemcpyAsync(&v, c->d_count, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *total = v;
+  return ARTP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// kernels.h -- gfx950 kernels of the validity / sampling / edge hot path.
+//
+//   check_boxes_kernel      R3  HeightMapBoxChecker::checkCollision, one wavefront per dPose
+//   validate_states_kernel  R1+R2 StateValidityChecker::isValid, one wavefront per state
+//   sample_states_kernel    R6  SE3FromSE2Sampler::sampleUniform, one lane per sample
+//   motion_plan_kernel / expanded_validate_kernel
+//                           R7  DiscreteMotionValidator::checkMotion and the 0.5 m edge
+//                               interpolation of PRMMotionCost::addValidMilestone: every interior
+//                               state becomes one wave-task of the same validity code
+#pragma once
+
+#include "box_check.h"
+
+namespace artp {
+
+struct RobotDev {  // float views of the artp_params numbers, converted once on the host
+  float torso[3];  // HeightMapBoxChecker(torso.length, torso.width, torso.height) ctor args (float)
+  float foot[3];   // reach.x, reach.y, reach.z
+  float torso_off[3];  // (torso.offset.x, torso.offset.y, torso.offset.z - feet.offset.z) as float
+  float feet_off_x, feet_off_y;
+  int unknown_space_untraversable;
+  double reach_z;
+  double max_pitch_pert, max_roll_pert;
+};
+
+struct MapGeom {  // grid_map geometry (doubles, as grid_map stores them)
+  double len_x, len_y, pos_x, pos_y, res;
+  int rows, cols;
+};
+
+struct SamplerDev {
+  const float* cum_prob;          // col-major rows x cols
+  const float* cum_prob_rowwise;  // rows
+  const float* elevation;
+  const float* normal_x;
+  const float* normal_y;
+  const float* normal_z;
+  const float* plane_fit_std_dev;
+};
+
+#define ARTP_WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ WaveScratch carve_scratch(char* smem, int wave_in_block, int cap_verts,
+                                                     int cap_tris) {
+  const size_t per_wave = (size_t)cap_verts * 4 + (size_t)cap_tris * 2;
+  char* base = smem + per_wave * wave_in_block;
+  WaveScratch s;
+  s.h = reinterpret_cast<float*>(base);
+  s.tri = reinterpret_cast<unsigned short*>(base + (size_t)cap_verts * 4);
+  s.cap_verts = cap_verts;
+  s.cap_tris = cap_tris;
+  return s;
+}
+
+// grid_map isInside (checkIfPositionWithinMap): t = -((p - c) - L/2), 0 <= t < L, in double.
+__device__ __forceinline__ bool map_is_inside(const MapGeom& g, double px, double py) {
+  const double tx = -((px - g.pos_x) - 0.5 * g.len_x);
+  const double ty = -((py - g.pos_y) - 0.5 * g.len_y);
+  return tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y;
+}
+
+// ---- R3 ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * ARTP_WAVES_PER_BLOCK)
+check_boxes_kernel(FieldDev f, float sx, float sy, float sz, const float* __restrict__ poses,
+                   size_t n, uint8_t* __restrict__ hit, uint8_t* __restrict__ exit_codes,
+                   int cap_verts, int cap_tris, int* __restrict__ error_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const WaveScratch s = carve_scratch(smem, wave_in_block, cap_verts, cap_tris);
+  const size_t wave0 = (size_t)blockIdx.x * ARTP_WAVES_PER_BLOCK + wave_in_block;
+  const size_t stride = (size_t)gridDim.x * ARTP_WAVES_PER_BLOCK;
+  for (size_t i = wave0; i < n; i += stride) {
+    float pose[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pose[k] = poses[16 * i + k];
+    BoxHF b;
+    setup_box(f, pose, sx, sy, sz, b);
+    int ec;
+    const int r = wave_check_box(f, b, s, lane, &ec);
+    if (r < 0) {
+      if (lane == 0) atomicExch(error_flag, 1);
+    }
+    if (lane == 0) {
+      hit[i] = (uint8_t)(r > 0);
+      if (exit_codes) exit_codes[i] = (uint8_t)(ec < 0 ? 255 : ec);
+    }
+    wave_lds_sync();
+  }
+}
+
+// ---- R1 + R2 ---------------------------------------------------------------------------------------
+// Pose3FromSE3 (art_planner/include/art_planner/utils.h:25-38): Eigen::Quaternionf(w,x,y,z)
+// .toRotationMatrix(); R row-major 3x3.
+__device__ __forceinline__ void pose3_from_se3(const double* se3, float t[3], float R[9]) {
+  t[0] = (float)se3[0];
+  t[1] = (float)se3[1];
+  t[2] = (float)se3[2];
+  const float x = (float)se3[3], y = (float)se3[4], z = (float)se3[5], w = (float)se3[6];
+  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0f - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.0f - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.0f - (txx + tyy);
+}
+
+// One full StateValidityChecker::isValid for the state held (wave-uniformly) in se3[7].
+// detail6 (global memory, may be nullptr) receives the per-box exit codes.  Returns 0/1, or -1 on
+// scratch overflow.
+__device__ __forceinline__ int wave_state_valid(const FieldDev& fb, const FieldDev& ff,
+                                                const MapGeom& g, const RobotDev& rb,
+                                                const double* se3, const WaveScratch& s, int lane,
+                                                int8_t* detail6) {
+  float t[3], R[9];
+  pose3_from_se3(se3, t, R);
+  if (detail6 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) detail6[k] = -2;
+    detail6[5] = 0;
+  }
+  int valid = 1;
+  int err = 0;
+  // box 0 = torso against the body layer, boxes 1..4 = feet against the masked layer, in the
+  // reference order (+,+),(+,-),(-,+),(-,-) (validity_checker_feet.cpp:64-68); the loop stops at the
+  // first failing box like the reference's short-circuit.
+  for (int k = 0; k < 5 && valid; ++k) {
+    const bool body = (k == 0);
+    const float ox = body ? rb.torso_off[0] : ((k <= 2) ? rb.feet_off_x : -rb.feet_off_x);
+    const float oy = body ? rb.torso_off[1] : ((k & 1) ? rb.feet_off_y : -rb.feet_off_y);
+    const float oz = body ? rb.torso_off[2] : 0.0f;
+    // pose * Pose3FromXYZ(o): Eigen affine product, translation = R*o + t with the 3-term dot
+    // summed as x0 + (x1 + x2) (Eigen's unrolled redux).
+    float pose[16];
+    pose[0] = (R[0] * ox + (R[1] * oy + R[2] * oz)) + t[0];
+    pose[1] = (R[3] * ox + (R[4] * oy + R[5] * oz)) + t[1];
+    pose[2] = (R[6] * ox + (R[7] * oy + R[8] * oz)) + t[2];
+    pose[3] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      pose[4 + 4 * r + 0] = R[3 * r + 0];
+      pose[4 + 4 * r + 1] = R[3 * r + 1];
+      pose[4 + 4 * r + 2] = R[3 * r + 2];
+      pose[4 + 4 * r + 3] = 0.0f;
+    }
+    const bool inside = map_is_inside(g, (double)pose[0], (double)pose[1]);
+    int ok;
+    int ec = -1;
+    if (!inside) {
+      // body: outside -> valid (validity_checker_body.cpp:29-32);
+      // feet: outside -> !unknown_space_untraversable (validity_checker_feet.cpp:34-37)
+      ok = body ? 1 : !rb.unknown_space_untraversable;
+    } else {
+      const FieldDev& fk = body ? fb : ff;
+      BoxHF b;
+      setup_box(fk, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
+                body ? rb.torso[2] : rb.foot[2], b);
+      int r = wave_check_box(fk, b, s, lane, &ec);
+      wave_lds_sync();
+      if (r < 0) {
+        err = 1;
+        r = 0;
+      }
+      ok = body ? !r : r;
+    }
+    if (detail6 && lane == 0) detail6[k] = (int8_t)ec;
+    valid = valid && ok;
+  }
+  return err ? -1 : valid;
+}
+
+__global__ void __launch_bounds__(64 * ARTP_WAVES_PER_BLOCK)
+validate_states_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb,
+                       const double* __restrict__ se3, size_t n, uint8_t* __restrict__ valid,
+                       int8_t* __restrict__ detail, int cap_verts, int cap_tris,
+                       int* __restrict__ error_flag, unsigned long long* __restrict__ n_valid) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const WaveScratch s = carve_scratch(smem, wave_in_block, cap_verts, cap_tris);
+  const size_t wave0 = (size_t)blockIdx.x * ARTP_WAVES_PER_BLOCK + wave_in_block;
+  const size_t stride = (size_t)gridDim.x * ARTP_WAVES_PER_BLOCK;
+  unsigned long long local_valid = 0;
+  for (size_t i = wave0; i < n; i += stride) {
+    double st[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st[k] = se3[7 * i + k];
+    const int v = wave_state_valid(fb, ff, g, rb, st, s, lane, detail ? detail + 6 * i : nullptr);
+    if (v < 0 && lane == 0) atomicExch(error_flag, 1);
+    if (lane == 0) {
+      valid[i] = (uint8_t)(v > 0);
+      local_valid += (v > 0);
+    }
+  }
+  if (n_valid && lane == 0 && local_valid) atomicAdd(n_valid, local_valid);
+}
+
+// ---- R6 ------------------------------------------------------------------------------------------
+// Counter-based uniform01 (replaces ompl::RNG::uniform01): splitmix64 finaliser over
+// (seed, index, k) -- integer-exact, identical on host and device.
+ARTP_HD double uniform01(uint64_t seed, uint64_t index, unsigned k) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (index * 8u + (uint64_t)k + 1u);
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  x += seed;
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// SE3FromSE2Sampler::sampleUniform (art_planner/src/sampler.cpp:82-131) with
+// samplePositionInMapFromDist (:56-78).  The two linear CDF scans become binary searches for the
+// same "first index whose cumulative value exceeds u, else the last index".
+__device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& g, const RobotDev& rb,
+                                           uint64_t seed, uint64_t index, double out[7]) {
+  const double samp_col = uniform01(seed, index, 0);
+  const double samp_row = uniform01(seed, index, 1);
+  int lo = 0, hi = g.rows - 1;  // answer in [0, rows-1]
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((double)sm.cum_prob_rowwise[mid] > samp_row) hi = mid; else lo = mid + 1;
+  }
+  const int row = lo;
+  lo = 0;
+  hi = g.cols - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((double)sm.cum_prob[(size_t)row + (size_t)mid * g.rows] > samp_col) hi = mid; else lo = mid + 1;
+  }
+  const int col = lo;
+  // grid_map getPosition: (c + (L/2 - res/2)) + res * (-i)
+  const double px = (g.pos_x + (0.5 * g.len_x - 0.5 * g.res)) + g.res * (double)(-row);
+  const double py = (g.pos_y + (0.5 * g.len_y - 0.5 * g.res)) + g.res * (double)(-col);
+  // getIndexOfPosition (sampler.cpp:95) -- reproduces (row, col)
+  const int ri = (int)(-(((px - 0.5 * g.len_x) - g.pos_x) / g.res));
+  const int ci = (int)(-(((py - 0.5 * g.len_y) - g.pos_y) / g.res));
+  const size_t ind = (size_t)ri + (size_t)ci * g.rows;
+  double v0 = px, v1 = py, v2 = (double)sm.elevation[ind];
+  const double nwx = (double)sm.normal_x[ind];
+  const double nwy = (double)sm.normal_y[ind];
+  const double nwz = (double)sm.normal_z[ind];
+  const float sd = sm.plane_fit_std_dev[ind];
+  const float sd_min = (0.5f < sd) ? 0.5f : sd;  // std::min(std, 0.5f)
+  const double u_pert = uniform01(seed, index, 2);
+  const double pert = ((1.0 - (-1.0)) * u_pert + (-1.0)) * (double)sd_min * rb.reach_z;
+  v0 += nwx * pert;
+  v1 += nwy * pert;
+  v2 += nwz * pert;
+  out[0] = v0;
+  out[1] = v1;
+  out[2] = v2;
+  const double pi = 3.14159265358979323846;
+  double rpy0 = pi * (-2.0 * uniform01(seed, index, 3) + 1.0);
+  double rpy1 = acos(1.0 - 2.0 * uniform01(seed, index, 4)) - pi / 2.0;
+  const double rpy2 = pi * (-2.0 * uniform01(seed, index, 5) + 1.0);
+  {
+    // normal_b = Quaterniond(AngleAxisd(yaw, Z)).inverse() * normal_w (sampler.cpp:120-123)
+    const double ha = 0.5 * rpy2;
+    const double qw = cos(ha), qz = sin(ha);
+    const double n2 = qw * qw + qz * qz;
+    const double iw = qw / n2, ix = -0.0 / n2, iy = -0.0 / n2, iz = -qz / n2;
+    double uv0 = iy * nwz - iz * nwy;
+    double uv1 = iz * nwx - ix * nwz;
+    double uv2 = ix * nwy - iy * nwx;
+    uv0 += uv0;
+    uv1 += uv1;
+    uv2 += uv2;
+    const double nbx = nwx + iw * uv0 + (iy * uv2 - iz * uv1);
+    const double nby = nwy + iw * uv1 + (iz * uv0 - ix * uv2);
+    const double nbz = nwz + iw * uv2 + (ix * uv1 - iy * uv0);
+    rpy0 = -atan2(nby, nbz) + rpy0 * rb.max_roll_pert / 1.57079632679489661923;
+    rpy1 = atan2(nbx, nbz) + rpy1 * rb.max_pitch_pert / 0.78539816339744830962;
+  }
+  {  // setSO3FromRPY (utils.h:101-115)
+    const double r2 = rpy0 * 0.5, p2 = rpy1 * 0.5, y2 = rpy2 * 0.5;
+    const double cr = cos(r2), cp = cos(p2), cy = cos(y2);
+    const double sr = sin(r2), sp = sin(p2), sy = sin(y2);
+    out[6] = cy * cp * cr + sy * sp * sr;
+    out[3] = cy * cp * sr - sy * sp * cr;
+    out[4] = sy * cp * sr + cy * sp * cr;
+    out[5] = sy * cp * cr - cy * sp * sr;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t first_index,
+                     size_t n, double* __restrict__ se3_out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    double st[7];
+    sample_one(sm, g, rb, seed, first_index + i, st);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) se3_out[7 * i + k] = st[k];
+  }
+}
+
+// ---- R7 ------------------------------------------------------------------------------------------
+#define ARTP_MAX_QUATERNION_NORM_ERROR 1e-9
+
+__device__ __forceinline__ double so3_arc_length(const double* q1, const double* q2) {
+  const double dq = fabs(q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3]);
+  if (dq > 1.0 - ARTP_MAX_QUATERNION_NORM_ERROR) return 0.0;
+  return acos(dq);
+}
+
+// OMPL SE3StateSpace::interpolate: R^3 lerp + SO3 slerp.
+__device__ __forceinline__ void se3_interpolate(const double* a, const double* b, double t,
+                                                double* out) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[i] = a[i] + (b[i] - a[i]) * t;
+  const double* q1 = a + 3;
+  const double* q2 = b + 3;
+  const double theta = so3_arc_length(q1, q2);
+  if (theta > 2.220446049250313e-16) {
+    const double d = 1.0 / sin(theta);
+    const double s0 = sin((1.0 - t) * theta);
+    double s1 = sin(t * theta);
+    const double dq = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+    if (dq < 0) s1 = -s1;
+    out[3] = (q1[0] * s0 + q2[0] * s1) * d;
+    out[4] = (q1[1] * s0 + q2[1] * s1) * d;
+    out[5] = (q1[2] * s0 + q2[2] * s1) * d;
+    out[6] = (q1[3] * s0 + q2[3] * s1) * d;
+  } else {
+    out[3] = q1[0];
+    out[4] = q1[1];
+    out[5] = q1[2];
+    out[6] = q1[3];
+  }
+}
+
+// mode 0: DiscreteMotionValidator::checkMotion -> tasks = 1 (s2) + max(nd-1, 0), nd = validSegmentCount
+// mode 1: PRMMotionCost::addValidMilestone     -> tasks = n_interp = floor(lateral / 0.5)
+// counts[e] = number of wave-tasks of edge e, aux[e] = nd (mode 0) or n_interp (mode 1).
+__global__ void __launch_bounds__(256)
+motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restrict__ s1,
+                   const double* __restrict__ s2, size_t n, uint32_t* __restrict__ counts,
+                   uint32_t* __restrict__ aux, uint8_t* __restrict__ valid) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const double* a = s1 + 7 * e;
+    const double* b = s2 + 7 * e;
+    uint32_t cnt, ax;
+    if (mode == 0) {
+      // CompoundStateSpace::validSegmentCount: max over R^3 and SO3 of ceil(dist / (0.01*maxExtent));
+      // R^3 bounds = map centre -/+ FULL length (art_planner/src/planner.cpp:146-156).
+      const double ex = (g.pos_x + g.len_x) - (g.pos_x - g.len_x);
+      const double ey = (g.pos_y + g.len_y) - (g.pos_y - g.len_y);
+      double ext = 0.0;
+      ext += ex * ex;
+      ext += ey * ey;
+      ext += z_extent * z_extent;
+      const double seg_r3 = sqrt(ext) * 0.01;
+      double d2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double diff = a[i] - b[i];
+        d2 += diff * diff;
+      }
+      const unsigned n_r3 = (unsigned)ceil(sqrt(d2) / seg_r3);
+      const double seg_so3 = (0.5 * 3.14159265358979323846) * 0.01;
+      const unsigned n_so3 = (unsigned)ceil(so3_arc_length(a + 3, b + 3) / seg_so3);
+      const unsigned nd = n_r3 > n_so3 ? n_r3 : n_so3;
+      ax = nd;
+      cnt = 1u + (nd >= 2 ? nd - 1 : 0u);
+    } else {
+      const double dx = b[0] - a[0];
+      const double dy = b[1] - a[1];
+      const double dist = sqrt(dx * dx + dy * dy);
+      const unsigned n_interp = (unsigned)(dist / 0.5);
+      ax = n_interp;
+      cnt = n_interp;
+    }
+    counts[e] = cnt;
+    aux[e] = ax;
+    valid[e] = 1;
+  }
+}
+
+// offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  Each wave-task validates
+// one state of one edge; an invalid state clears the edge's label (all writers store 0).
+__global__ void __launch_bounds__(64 * ARTP_WAVES_PER_BLOCK)
+expanded_validate_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, int mode,
+                         const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
+                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
+                         uint8_t* __restrict__ valid, int cap_verts, int cap_tris,
+                         int* __restrict__ error_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const WaveScratch s = carve_scratch(smem, wave_in_block, cap_verts, cap_tris);
+  const size_t total = offsets[n];
+  const size_t wave0 = (size_t)blockIdx.x * ARTP_WAVES_PER_BLOCK + wave_in_block;
+  const size_t stride = (size_t)gridDim.x * ARTP_WAVES_PER_BLOCK;
+  for (size_t w = wave0; w < total; w += stride) {
+    // edge e with offsets[e] <= w < offsets[e+1]
+    size_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+      const size_t mid = (lo + hi) >> 1;
+      if (offsets[mid] <= w) lo = mid; else hi = mid;
+    }
+    const size_t e = lo;
+    const uint32_t k = (uint32_t)(w - offsets[e]);
+    const double* a = s1 + 7 * e;
+    const double* b = s2 + 7 * e;
+    double st[7];
+    if (mode == 0) {
+      if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st[i] = b[i];
+      } else {
+        const uint32_t nd = aux[e];
+        se3_interpolate(a, b, (double)k / (double)nd, st);
+      }
+    } else {
+      const uint32_t n_interp = aux[e];
+      const double n_interp_div = 1.0 / (n_interp + 1);
+      se3_interpolate(a, b, (k + 1) * n_interp_div, st);
+    }
+    const int v = wave_state_valid(fb, ff, g, rb, st, s, lane, nullptr);
+    if (v < 0 && lane == 0) atomicExch(error_flag, 1);
+    if (v == 0 && lane == 0) valid[e] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+count_valid_kernel(const uint8_t* __restrict__ valid, size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    c += valid[i] ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+
+// Measurement helper: algorithmic window vertices of a batch (one lane per state).
+__global__ void __launch_bounds__(256)
+alg_vertices_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const double* __restrict__ se3,
+                    size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    double st[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st[k] = se3[7 * i + k];
+    float t[3], R[9];
+    pose3_from_se3(st, t, R);
+    for (int k = 0; k < 5; ++k) {
+      const bool body = (k == 0);
+      const float ox = body ? rb.torso_off[0] : ((k <= 2) ? rb.feet_off_x : -rb.feet_off_x);
+      const float oy = body ? rb.torso_off[1] : ((k & 1) ? rb.feet_off_y : -rb.feet_off_y);
+      const float oz = body ? rb.torso_off[2] : 0.0f;
+      float pose[16];
+      pose[0] = (R[0] * ox + (R[1] * oy + R[2] * oz)) + t[0];
+      pose[1] = (R[3] * ox + (R[4] * oy + R[5] * oz)) + t[1];
+      pose[2] = (R[6] * ox + (R[7] * oy + R[8] * oz)) + t[2];
+      pose[3] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        pose[4 + 4 * r + 0] = R[3 * r + 0];
+        pose[4 + 4 * r + 1] = R[3 * r + 1];
+        pose[4 + 4 * r + 2] = R[3 * r + 2];
+        pose[4 + 4 * r + 3] = 0.0f;
+      }
+      if (!map_is_inside(g, (double)pose[0], (double)pose[1])) continue;
+      BoxHF b;
+      if (body)
+        setup_box(fb, pose, rb.torso[0], rb.torso[1], rb.torso[2], b);
+      else
+        setup_box(ff, pose, rb.foot[0], rb.foot[1], rb.foot[2], b);
+      if (b.on_field) c += (unsigned long long)((b.maxX - b.minX + 1) * (b.maxZ - b.minZ + 1));
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+}  // namespace artp

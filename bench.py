@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""bench.py -- validated states/s (+ edges/s) of the sampling + validity hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): lazy_prm_star_min_update front end, 400x400 @ 0.04 m
+Perlin terrain + obstacles (seed 1234), YAML robot, one batch validity checker per GPU.
+A "step" = one pass of the hot path over one batch of S = 2^22 candidate states per GPU:
+    SE3FromSE2Sampler::sampleUniform (batched, counter-based RNG)  ->  StateValidityChecker::isValid
+with all inputs (map layers) resident in HBM before the timed region.  With N > 1 GPUs every rank
+owns a disjoint sample-index range (weak scaling) and the accepted states are compacted and
+all-gathered over RCCL on a side stream (the planners need every accepted state on every rank).
+
+Prints ONE JSON line on rank 0 (see the repo prompt's bench contract) incl. `roofline` and
+`cpu_baseline`.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(gm, states, target_s=12.0):
+    """The CPU oracle ("port": bit-identical restatement of the reference OMPL+ODE validity path,
+    faithful algorithmic structure) timed on this box's host cores on a bounded sample of the SAME
+    states the GPU validated.  Only the checker is used here -- never the product path."""
+    import oracle_py as O
+    rob = O.robot("yaml")
+    om = O.OracleMap(gm)
+    n1 = min(16384, len(states))
+    t0 = time.perf_counter()
+    v1 = om.states_valid(rob, states[:n1])
+    t1 = time.perf_counter()
+    r1 = n1 / (t1 - t0)
+    cores = os.cpu_count() or 1
+    n = int(min(len(states), max(n1, r1 * target_s * min(cores, 8) / 2)))
+    chunks = np.array_split(np.arange(n), cores)
+    out = np.empty(n, np.uint8)
+    maps = [O.OracleMap(gm) for _ in range(cores)]  # one private checker pair per thread
+
+    def work(k):
+        idx = chunks[k]
+        if len(idx):
+            out[idx] = maps[k].states_valid(rob, states[idx])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "states/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} sampler states of batch 0 (seed 42), oracle/artp_oracle.c faithful mode, "
+                      f"{cores} threads with private checkers; single thread: {r1:.0f} states/s on {n1}",
+            "single_core_value": r1}, out, v1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1 << 22, help="candidate states per GPU per step")
+    ap.add_argument("--edges", type=int, default=1 << 18)
+    ap.add_argument("--map", type=int, default=400)
+    ap.add_argument("--res", type=float, default=0.04)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    N = args.gpus
+    assert world == N or (N == 1 and world == 1), f"--gpus {N} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+
+    gm = make_map(args.map, args.res, seed=1234)
+    ctx = Context(local_rank, "yaml")
+    ctx.upload_map(gm)
+    ctx.use_torch_stream()
+
+    S, K, W, seed = args.batch, args.steps, args.warmup, 42
+    se3 = torch.empty((S, 7), dtype=torch.float64, device=dev)
+    valid = torch.empty(S, dtype=torch.uint8, device=dev)
+    do_gather = N > 1 and not args.no_gather
+    comm = torch.cuda.Stream(device=dev) if do_gather else None
+
+    def first_index(step):
+        return (step * N + rank) * S
+
+    # ---- warmup (also sizes the fixed-capacity all-gather blocks) -----------------------------
+    cap = 0
+    compact = [None, None]
+    counts = [None, None]
+    gathered = gcounts = None
+    for i in range(max(W, 1)):
+        c = ctx.sample_and_validate_dev(seed, first_index(1000000 + i), S, se3, valid, count=True)
+        cap = max(cap, c)
+    torch.cuda.synchronize()
+    if do_gather:
+        cap_t = torch.tensor([int(cap * 1.1) + 1024], device=dev, dtype=torch.int64)
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        cap = min(int(cap_t.item()), S)
+        compact = [torch.zeros((S, 7), dtype=torch.float64, device=dev) for _ in range(2)]
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+        gathered = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)
+        gcounts = torch.empty(N, dtype=torch.int64, device=dev)
+        done_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in done_ev:
+            e.record()
+
+    def step(i):
+        ctx.sample_and_validate_dev(seed, first_index(i), S, se3, valid)
+        if do_gather:
+            b = i & 1
+            torch.cuda.current_stream().wait_event(done_ev[b])  # buffer b free again
+            ctx.compact_valid_dev(se3, valid, compact[b], counts[b])
+            ready = torch.cuda.Event()
+            ready.record()
+            comm.wait_event(ready)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gcounts, counts[b])
+                dist.all_gather_into_tensor(gathered.view(N, -1), compact[b][:cap].reshape(-1))
+                done_ev[b].record()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides -----------------------
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        assert int(gcounts.max().item()) <= cap, "all-gather block capacity exceeded"
+    total_states = N * S * K
+    value = total_states / dt
+
+    if rank != 0:
+        if N > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- everything below: rank 0, outside the timed region ------------------------------------
+    # batch 0 again (deterministic) for the roofline, label hash, edges and CPU baseline
+    ctx.sample_and_validate_dev(seed, 0, S, se3, valid)
+    torch.cuda.synchronize()
+    labels = valid.cpu().numpy()
+    label_hash = hashlib.sha1(labels.tobytes()).hexdigest()[:16]
+    valid_frac = float(labels.mean())
+
+    # dominant kernel: validate_states_kernel; HIP events on the stream it is launched on
+    alg_vertices = ctx.algorithmic_vertices_dev(se3)
+    alg_bytes = 4 * alg_vertices + 29 * S  # 28 B pose in (7 f32) + 1 B label out per state
+    reps = max(5, min(K, 20))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.validate_states_dev(se3, valid)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        ctx.validate_states_dev(se3, valid)
+    ev1.record()
+    torch.cuda.synchronize()
+    k_ms = ev0.elapsed_time(ev1) / reps
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("validate_states_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "validate_states_kernel", "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_bytes_per_state": alg_bytes / S,
+                "validate_only_states_per_s": S / (k_ms * 1e-3)}
+
+    # sampler alone
+    ev0.record()
+    for _ in range(reps):
+        ctx.sample_states_dev(seed, 0, S, se3)
+    ev1.record()
+    torch.cuda.synchronize()
+    sample_ms = ev0.elapsed_time(ev1) / reps
+    ctx.sample_and_validate_dev(seed, 0, S, se3, valid)
+    torch.cuda.synchronize()
+
+    # edges: accepted state i paired with accepted state i+1 when their lateral distance < 2 m
+    states = se3.cpu().numpy()
+    acc = states[labels != 0]
+    a, b = acc[:-1], acc[1:]
+    near = np.hypot(a[:, 0] - b[:, 0], a[:, 1] - b[:, 1]) < 2.0
+    a, b = a[near][:args.edges], b[near][:args.edges]
+    E = len(a)
+    edges = {}
+    if E > 0:
+        s1 = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        s2 = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
+        ev = torch.empty(E, dtype=torch.uint8, device=dev)
+        for name, fn in (("check_motion", lambda: ctx.check_motions_dev(s1, s2, ev)),
+                         ("interp_0p5m", lambda: ctx.check_edges_interp_dev(s1, s2, ev))):
+            fn()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(3):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1) / 3
+            edges[name] = {"edges": E, "edges_per_s": E / (ms * 1e-3), "ms": ms,
+                           "valid_frac": float(ev.float().mean().item())}
+
+    cpu = None
+    if N == 1 and not args.no_cpu_baseline:
+        cpu, cpu_labels, _ = cpu_baseline(gm, states)
+        n_cpu = len(cpu_labels)
+        cpu["labels_match_gpu"] = bool(np.array_equal(cpu_labels, labels[:n_cpu]))
+        # the real patched ODE (kind "reference"), single thread, when oracle/_ref travelled here
+        try:
+            import oracle_py as O
+            if O.have_ref():
+                rob = O.robot("yaml")
+                om = O.OracleMap(gm)
+                m = min(20000, len(states))
+                poses, inside = om.state_poses(rob, states[:m])
+                rb = O.RefChecker(rob.torso, gm["elevation"], gm.len_x, gm.len_y)
+                rf = O.RefChecker(rob.foot, gm["elevation_masked"], gm.len_x, gm.len_y)
+                t0 = time.perf_counter()
+                hb = rb.check(poses[:, 0])
+                ok = (hb == 0) | (inside[:, 0] == 0)
+                nbox = m
+                for k in range(4):  # same short-circuit as the reference
+                    idx = np.flatnonzero(ok)
+                    hk = rf.check(poses[idx, 1 + k])
+                    nbox += len(idx)
+                    ok[idx] = np.where(inside[idx, 1 + k] != 0, hk != 0, False)
+                dtr = time.perf_counter() - t0
+                cpu["reference_ode_single_core_states_per_s"] = m / dtr
+                cpu["reference_ode_labels_match_gpu"] = bool(np.array_equal(ok.astype(np.uint8), labels[:m]))
+        except Exception as e:  # pragma: no cover
+            cpu["reference_ode_error"] = repr(e)
+
+    out = {
+        "metric": "validated states/sec on 400x400@0.04m map (sample + validity check)",
+        "value": value, "unit": "states/s", "n_gpus": N, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: lazy_prm_star_min_update front end, 400x400@0.04m Perlin terrain "
+                               "(seed 1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
+                   "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}",
+                   "sharding": f"sample-index ranges over {N} GPU(s)" +
+                               (", compacted valid states all-gathered over RCCL" if do_gather else "")},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
+        "sampler_ms_per_batch": sample_ms, "edges": edges,
+        "device": ctx.arch,
+    }
+    print(json.dumps(out))
+    sys.stdout.flush()
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/*
+ * artp_c.h -- C ABI of libartp.so: the MI355X (gfx950) implementation of art_planner's
+ * sampling + validity + edge hot path.
+ *
+ * This is the drop-in boundary.  The reference has no C/FFI seam for this path; its
+ * seams are C++ virtuals.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree); art_planner_amd/host/ holds the C++ classes with the
+ * reference's names/signatures that forward to these calls.
+ *
+ * Conventions
+ *   - opaque context per device; all entry points return 0 (ARTP_OK) or a negative artp_status and
+ *     never throw; calls on one context are serialised internally, contexts are independent.
+ *   - plain pointers and sizes only.  Pointers are HOST memory unless the function name ends in
+ *     `_dev`, in which case every buffer argument is DEVICE memory on the context's GPU and the call
+ *     is asynchronous on the context's stream (artp_set_stream / artp_synchronize).
+ *   - states are OMPL SE3 states flattened as 7 doubles: x y z qx qy qz qw.
+ *   - dPose is the reference's HeightMapBoxChecker::dPose: 16 floats = origin[4], rotation[12]
+ *     (row-major 3x4), art_planner/include/art_planner/validity_checker/height_map_box_checker.h:20-25.
+ *   - layers are grid_map::Matrix storage: float32, column-major, rows = size.x, cols = size.y.
+ */
+#ifndef ARTP_C_H
+#define ARTP_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct artp_ctx artp_ctx;
+
+typedef enum {
+  ARTP_OK = 0,
+  ARTP_ERR_INVALID_ARG = -1,
+  ARTP_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture: the product has NO CPU fallback */
+  ARTP_ERR_HIP = -3,         /* a HIP runtime call failed; artp_last_error() has the text */
+  ARTP_ERR_NO_MAP = -4,      /* a required layer was not uploaded (reference: hasMap() == false) */
+  ARTP_ERR_CAPACITY = -5,    /* box too large for the LDS window tile of this context */
+  ARTP_ERR_NO_WEIGHTS = -6
+} artp_status;
+
+/* Numeric fields of art_planner::Params the hot path reads
+ * (art_planner/include/art_planner/params.h:14-123).  Angles in radians. */
+typedef struct {
+  double torso_length, torso_width, torso_height;   /* params.h:93-95  */
+  double torso_off_x, torso_off_y, torso_off_z;     /* params.h:97-101 */
+  double feet_off_x, feet_off_y, feet_off_z;        /* params.h:107-111 */
+  double reach_x, reach_y, reach_z;                 /* params.h:113-117 */
+  int unknown_space_untraversable;                  /* params.h:26 */
+  double max_pitch_pert, max_roll_pert;             /* params.h:80-81 */
+} artp_params;
+
+void artp_params_defaults(artp_params* p);          /* params.h defaults */
+void artp_params_yaml(artp_params* p);              /* art_planner_ros/config/params.yaml:55-71 */
+
+const char* artp_status_string(int status);
+const char* artp_last_error(const artp_ctx* ctx);
+/* "gfx950" etc. of the context's device. */
+const char* artp_device_arch(const artp_ctx* ctx);
+
+/* Planner / StateValidityChecker construction (art_planner/src/planner.cpp:75-131,
+ * validity_checker.cpp:9-15).  Fails with ARTP_ERR_NO_DEVICE when there is no GPU. */
+int artp_create(int device, const artp_params* params, artp_ctx** out);
+void artp_destroy(artp_ctx* ctx);
+int artp_set_stream(artp_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+int artp_synchronize(artp_ctx* ctx);
+
+/* ---- map upload: HeightMapBoxChecker::setHeightField
+ *      (art_planner/src/validity_checker/height_map_box_checker.cpp:38-54) ----------------------
+ * slot 0 = body checker's layer (params.planner.elevation_layer, validity_checker_body.cpp:52-55),
+ * slot 1 = feet checker's layer ("elevation_masked", validity_checker_feet.cpp:80-83).
+ * Both slots share the grid geometry (also used for grid_map isInside). */
+enum { ARTP_SLOT_BODY = 0, ARTP_SLOT_FEET = 1 };
+int artp_upload_layer(artp_ctx* ctx, int slot, const float* layer_colmajor, int rows, int cols,
+                      double len_x, double len_y, double pos_x, double pos_y);
+/* Config-5 incremental update: overwrite the rectangle [row0,row0+nrows) x [col0,col0+ncols) of a
+ * previously uploaded layer; `patch` is column-major nrows x ncols. */
+int artp_update_layer_rect(artp_ctx* ctx, int slot, const float* patch, int row0, int col0,
+                           int nrows, int ncols);
+
+/* ---- HeightMapBoxChecker::checkCollision (height_map_box_checker.cpp:58-72) -------------------
+ * hit[i] = (dCollide(box, field, 1, ...) != 0) for pose i.  exit_codes (optional, may be NULL)
+ * receives which early-out of dCollideHeightfieldZone decided (ARTP_EXIT_*). */
+enum {
+  ARTP_EXIT_AABB_OFF = 0, ARTP_EXIT_ABOVE = 1, ARTP_EXIT_UNDER = 2, ARTP_EXIT_SPANS = 3,
+  ARTP_EXIT_FLAT_PLANE = 4, ARTP_EXIT_VERTEX = 5, ARTP_EXIT_PLANE = 6, ARTP_EXIT_VERTEX2 = 7,
+  ARTP_EXIT_NONE = 8
+};
+int artp_check_boxes(artp_ctx* ctx, int slot, const float box_lengths[3], const float* dposes,
+                     size_t n, uint8_t* hit, uint8_t* exit_codes);
+int artp_check_boxes_dev(artp_ctx* ctx, int slot, const float box_lengths[3], const float* dposes,
+                         size_t n, uint8_t* hit, uint8_t* exit_codes);
+
+/* ---- ob::StateValidityChecker::isValid, batched
+ *      (art_planner/src/validity_checker/validity_checker.cpp:39-45) ----------------------------
+ * valid[i] = body_ok && feet_ok for state i.  detail (optional): n x 6 int8 =
+ * {body exit code | -1 outside map, 4 x foot exit code | -1 outside | -2 not evaluated, 0}. */
+int artp_validate_states(artp_ctx* ctx, const double* se3, size_t n, uint8_t* valid, int8_t* detail);
+int artp_validate_states_dev(artp_ctx* ctx, const double* se3, size_t n, uint8_t* valid,
+                             int8_t* detail);
+
+/* ---- ob::StateSampler::sampleUniform, batched
+ *      (art_planner/src/sampler.cpp:56-131; SE3FromSE2Sampler) ----------------------------------
+ * The seven layers the sampler reads (sampler.cpp:61-63,99-103; map.h:64-116), same geometry as the
+ * validity layers.  cum_prob_rowwise = column 0 of "cum_prob_rowwise_hack" (rows floats). */
+int artp_upload_sampler_layers(artp_ctx* ctx, const float* cum_prob, const float* cum_prob_rowwise,
+                               const float* elevation, const float* normal_x, const float* normal_y,
+                               const float* normal_z, const float* plane_fit_std_dev, int rows,
+                               int cols, double len_x, double len_y, double pos_x, double pos_y);
+/* State k of the batch is a pure function of (seed, first_index + k): six counter-based uniforms in
+ * the reference's draw order replace ompl::RNG's mt19937 stream (SURVEY.md 8c "same seed"). */
+int artp_sample_states(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n, double* se3_out);
+int artp_sample_states_dev(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n,
+                           double* se3_out);
+/* Fused rejection-sampling step of the planners' hot loop
+ * (prm_motion_cost.cpp:174-186, lazy_prm_star_min_update.cpp:552-554): sample n states, validate
+ * them, write states + labels.  n_valid (host pointer, optional) receives the number of valid ones
+ * (forces a stream sync when non-NULL). */
+int artp_sample_and_validate_dev(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n,
+                                 double* se3_out, uint8_t* valid_out, size_t* n_valid);
+
+/* ---- ob::MotionValidator::checkMotion (OMPL DiscreteMotionValidator; call sites
+ *      prm_motion_cost.cpp:652, lazy_prm_star_min_update.cpp:725), batched -----------------------
+ * valid[i] = isValid(s2_i) && all interior states of the discretised segment are valid.
+ * R^3 bounds for validSegmentCount follow planner.cpp:146-156; z bounds come from
+ * artp_set_z_bounds (min/max finite elevation -/+ reach.z/2). */
+int artp_set_z_bounds(artp_ctx* ctx, double z_low, double z_high);
+int artp_check_motions(artp_ctx* ctx, const double* s1, const double* s2, size_t n, uint8_t* valid);
+int artp_check_motions_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
+                           uint8_t* valid);
+/* PRM-build edge validation of PRMMotionCost::addValidMilestone (prm_motion_cost.cpp:340-377):
+ * n_interp = floor(lateral distance / 0.5) interior states at t = step * (1/(n_interp+1)), each
+ * must be valid.  n_interp_out optional (uint32 per edge). */
+int artp_check_edges_interp(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
+                            uint8_t* valid, uint32_t* n_interp_out);
+int artp_check_edges_interp_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
+                                uint8_t* valid, uint32_t* n_interp_out);
+
+/* ---- batch plumbing around the hot path ---------------------------------------------------------
+ * Stream compaction of the valid states (the planners keep only accepted samples,
+ * prm_motion_cost.cpp:174-187): out_se3 receives the states with valid[i] != 0 in input order,
+ * *n_out_dev (device uint64) their number.  out_se3 must hold n states. */
+int artp_compact_valid_dev(artp_ctx* ctx, const double* se3, const uint8_t* valid, size_t n,
+                           double* out_se3, uint64_t* n_out_dev);
+/* Measurement helper: the ALGORITHMIC window size of a batch = sum over states of
+ * the heightfield vertices (nMaxX-nMinX+1)*(nMaxZ-nMinZ+1) of all five boxes, no credit for
+ * early-outs or short-circuiting, 0 for a box whose centre is outside the map or whose AABB is off
+ * the field.  Host result. */
+int artp_algorithmic_vertices_dev(artp_ctx* ctx, const double* se3, size_t n, uint64_t* total_vertices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTP_C_H */
