@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libartp.so")
 # every symbol include/artp_c.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "artp_params_defaults", "artp_params_yaml", "artp_status_string", "artp_last_error",
-    "artp_device_arch", "artp_create", "artp_destroy", "artp_set_stream", "artp_synchronize",
+    "artp_device_arch", "artp_create", "artp_destroy", "artp_set_stream", "artp_use_own_stream",
+    "artp_synchronize",
     "artp_upload_layer", "artp_update_layer_rect", "artp_check_boxes", "artp_check_boxes_dev",
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
@@ -44,6 +45,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ArtpError(f"{LIB_PATH} is missing: build the HIP extension first "
                         "(make -C art_planner_amd/csrc). There is no CPU fallback.")
+    try:
+        # torch bundles its own HIP runtime: it must be the first one loaded in the process, otherwise
+        # two copies of libamdhip64 end up side by side and neither sees the device properly.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u64, dbl, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_double, C.c_int
     L.artp_params_defaults.argtypes = [C.POINTER(Params)]
@@ -58,6 +65,7 @@ def load():
     L.artp_destroy.argtypes = [vp]
     L.artp_destroy.restype = None
     L.artp_set_stream.argtypes = [vp, vp]
+    L.artp_use_own_stream.argtypes = [vp]
     L.artp_synchronize.argtypes = [vp]
     L.artp_upload_layer.argtypes = [vp, i32, vp, i32, i32, dbl, dbl, dbl, dbl]
     L.artp_update_layer_rect.argtypes = [vp, i32, vp, i32, i32, i32, i32]

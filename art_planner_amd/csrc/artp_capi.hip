@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "kernels.h"
+#include "pipeline.h"
 
 using namespace artp;
 
@@ -34,14 +34,19 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
-  int cap_verts = 0, cap_tris = 0;
-  size_t lds_bytes = 0;
+  // map tables (pipeline.h): per layer 2 x 6 levels of floats + two summed-area tables
+  float* table_buf[2] = {nullptr, nullptr};
+  int* sat_buf[2] = {nullptr, nullptr};
+  size_t table_elems[2] = {0, 0};
+  TablesDev tables[2]{};
+  ScratchCaps caps_full{0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
+  ScratchCaps caps_scan{0, 0, 0};  // window tile only (ARTP_WAVES_PER_BLOCK waves / block)
   int n_cus = 256;
   // device scratch
   int* d_error = nullptr;
   unsigned long long* d_count = nullptr;
-  void* tmp[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t tmp_cap[4] = {0, 0, 0, 0};
+  void* tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t tmp_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void* cub_tmp = nullptr;
   size_t cub_cap = 0;
   std::string last_error;
@@ -137,35 +142,115 @@ int size_scratch(artp_ctx* c) {
   if (tris > 4096) tris = 4096;  // 64 lanes x 64-bit assignment mask
   verts = (verts + 3) & ~3L;
   tris = (tris + 7) & ~7L;
-  const size_t per_wave = (size_t)verts * 4 + (size_t)tris * 2;
-  if (per_wave * ARTP_WAVES_PER_BLOCK > 160 * 1024) {
+  long tab = 64;
+  while (tab < 2 * tris && tab < 4096) tab <<= 1;  // partner-detection fast path up to tab/2 triangles
+  c->caps_full = ScratchCaps{(int)verts, (int)tris, (int)tab};
+  c->caps_scan = ScratchCaps{(int)verts, (int)tris, 0};  // window tile + triangle list
+  if (scratch_bytes_per_wave(c->caps_full) > 160 * 1024 ||
+      scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK > 160 * 1024) {
     c->last_error = "box too large for the LDS window tile";
     return ARTP_ERR_CAPACITY;
   }
-  c->cap_verts = (int)verts;
-  c->cap_tris = (int)tris;
-  c->lds_bytes = per_wave * ARTP_WAVES_PER_BLOCK;
   return ARTP_OK;
 }
+
+size_t lds_full(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_full); }
+size_t lds_scan(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK; }
 
 int set_kernel_lds(artp_ctx* c) {
   // > 64 KiB of dynamic LDS needs the opt-in attribute
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(check_boxes_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(validate_states_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(expanded_validate_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(check_boxes_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(validate_states_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(plane_stage_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
   return ARTP_OK;
 }
 
-int wave_grid(const artp_ctx* c, size_t tasks) {
-  // persistent waves: enough blocks to fill every CU several times over, grid-stride the rest
-  const size_t blocks_needed = (tasks + ARTP_WAVES_PER_BLOCK - 1) / ARTP_WAVES_PER_BLOCK;
-  const size_t cap = (size_t)c->n_cus * 16;
-  size_t g = blocks_needed < cap ? blocks_needed : cap;
-  if (g < 1) g = 1;
-  return (int)g;
+// persistent grids: as many blocks as fit the LDS on every CU (the rest is grid-stride / work queue)
+int grid_full(const artp_ctx* c, size_t tasks) {
+  size_t per_cu = (160 * 1024) / (lds_full(c) ? lds_full(c) : 1);
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) per_cu = 1;
+  size_t g = (size_t)c->n_cus * per_cu;
+  if (tasks && tasks < g) g = tasks;
+  return (int)(g ? g : 1);
+}
+int grid_scan(const artp_ctx* c) {
+  size_t per_cu = (160 * 1024) / (lds_scan(c) ? lds_scan(c) : 1);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  return (int)((size_t)c->n_cus * per_cu);
+}
+
+// Range tables of one layer (pipeline.h).  Levels 0..5 (block 1..32); the kernels use levels 2..5.
+int build_tables(artp_ctx* c, int slot) {
+  const FieldDev& f = c->field[slot];
+  const size_t elems = (size_t)f.nW * f.nD;
+  const size_t sat_elems = (size_t)(f.nW + 1) * (f.nD + 1);
+  if (c->table_elems[slot] < elems) {
+    if (c->table_buf[slot]) HIP_TRY(c, hipFree(c->table_buf[slot]));
+    if (c->sat_buf[slot]) HIP_TRY(c, hipFree(c->sat_buf[slot]));
+    c->table_buf[slot] = nullptr;
+    c->sat_buf[slot] = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->table_buf[slot]), 12 * elems * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sat_buf[slot]), 2 * sat_elems * sizeof(int)));
+    c->table_elems[slot] = elems;
+  }
+  float* mx[6];
+  float* mn[6];
+  for (int l = 0; l < 6; ++l) {
+    mx[l] = c->table_buf[slot] + (size_t)(2 * l) * elems;
+    mn[l] = c->table_buf[slot] + (size_t)(2 * l + 1) * elems;
+  }
+  const int n = (int)elems;
+  hipLaunchKernelGGL(table_level0_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, f.data, n, mx[0], mn[0]);
+  for (int l = 1; l < 6; ++l)
+    hipLaunchKernelGGL(table_level_up_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                       (const float*)mx[l - 1], (const float*)mn[l - 1], f.nW, f.nD, 1 << (l - 1), mx[l], mn[l]);
+  int* s_nf = c->sat_buf[slot];
+  int* s_nan = f.has_nan ? c->sat_buf[slot] + sat_elems : nullptr;
+  hipLaunchKernelGGL(sat_rows_kernel, dim3((f.nD + 63) / 64), dim3(64), 0, c->stream, f.data, f.nW, f.nD, s_nf, s_nan);
+  hipLaunchKernelGGL(sat_cols_kernel, dim3((f.nW + 1 + 63) / 64), dim3(64), 0, c->stream, f.nW, f.nD, s_nf, s_nan);
+  HIP_TRY(c, hipGetLastError());
+  TablesDev& t = c->tables[slot];
+  for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) {
+    t.maxT[l] = mx[l + 2];
+    t.minT[l] = mn[l + 2];
+  }
+  t.sat_nonfinite = s_nf;
+  t.sat_nan = s_nan;
+  t.valid = 1;
+  return ARTP_OK;
+}
+
+// classify -> resolve -> plane stage on the context's stream (all asynchronous).
+int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* valid) {
+  if (n >= (1ull << 32)) {
+    c->last_error = "batch too large (state index is 32 bit)";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  int rc = ensure_tmp(c, 4, 5 * n * sizeof(PendingBox));
+  if (rc) return rc;
+  rc = ensure_tmp(c, 5, 5 * n * sizeof(unsigned) + 64);
+  if (rc) return rc;
+  PipelineQueues q;
+  q.q1 = static_cast<PendingBox*>(c->tmp[4]);
+  q.counters = static_cast<unsigned long long*>(c->tmp[5]);
+  q.q2 = reinterpret_cast<unsigned*>(q.counters + 8);
+  HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
+  hipLaunchKernelGGL(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK>, dim3(grid_scan(c)),
+                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->field[1],
+                     c->robot, q, valid, c->caps_scan, c->d_error);
+  hipLaunchKernelGGL(plane_stage_kernel<1>, dim3(grid_full(c, 0)), dim3(64), lds_full(c), c->stream,
+                     c->field[0], c->field[1], c->robot, q, valid, c->caps_full, c->d_error);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
 }
 
 int check_error_flag(artp_ctx* c) {
@@ -260,8 +345,12 @@ void artp_destroy(artp_ctx* c) {
   for (int s = 0; s < 2; ++s)
     if (c->field_data[s]) (void)hipFree(c->field_data[s]);
   if (c->sampler_buf) (void)hipFree(c->sampler_buf);
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < 8; ++s)
     if (c->tmp[s]) (void)hipFree(c->tmp[s]);
+  for (int s = 0; s < 2; ++s) {
+    if (c->table_buf[s]) (void)hipFree(c->table_buf[s]);
+    if (c->sat_buf[s]) (void)hipFree(c->sat_buf[s]);
+  }
   if (c->cub_tmp) (void)hipFree(c->cub_tmp);
   if (c->d_error) (void)hipFree(c->d_error);
   if (c->d_count) (void)hipFree(c->d_count);
@@ -272,7 +361,14 @@ void artp_destroy(artp_ctx* c) {
 int artp_set_stream(artp_ctx* c, void* hip_stream) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(c->mu);
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream
+  return ARTP_OK;
+}
+
+int artp_use_own_stream(artp_ctx* c) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->stream = c->own_stream;
   return ARTP_OK;
 }
 
@@ -340,9 +436,14 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
   c->geom.cols = cols;
   c->geom.res = len_x / rows;
   c->have_geom = true;
-  const int rc = size_scratch(c);
+  int rc = size_scratch(c);
   if (rc != ARTP_OK) return rc;
-  return set_kernel_lds(c);
+  rc = set_kernel_lds(c);
+  if (rc != ARTP_OK) return rc;
+  rc = build_tables(c, slot);
+  if (rc != ARTP_OK) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
 }
 
 int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, int col0, int nrows,
@@ -366,6 +467,8 @@ int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, 
   int has_nan = 0;
   for (float v : host) has_nan |= (v != v);
   c->field[slot].has_nan = has_nan;
+  const int rc = build_tables(c, slot);  // the whole map is ~1 MB: rebuilding beats tracking dirty blocks
+  if (rc != ARTP_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
 }
@@ -377,9 +480,9 @@ int artp_check_boxes_dev(artp_ctx* c, int slot, const float box[3], const float*
   if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(check_boxes_kernel, dim3(wave_grid(c, n)), dim3(64 * ARTP_WAVES_PER_BLOCK),
-                     c->lds_bytes, c->stream, c->field[slot], box[0], box[1], box[2], dposes, n, hit,
-                     exit_codes, c->cap_verts, c->cap_tris, c->d_error);
+  hipLaunchKernelGGL(check_boxes_kernel<1>, dim3(grid_full(c, n)), dim3(64), lds_full(c), c->stream,
+                     c->field[slot], box[0], box[1], box[2], dposes, n, hit, exit_codes, c->caps_full,
+                     c->d_error);
   HIP_TRY(c, hipGetLastError());
   return ARTP_OK;
 }
@@ -414,12 +517,15 @@ int artp_validate_states_dev(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(validate_states_kernel, dim3(wave_grid(c, n)), dim3(64 * ARTP_WAVES_PER_BLOCK),
-                     c->lds_bytes, c->stream, c->field[0], c->field[1], c->geom, c->robot, se3, n,
-                     valid, detail, c->cap_verts, c->cap_tris, c->d_error,
-                     (unsigned long long*)nullptr);
-  HIP_TRY(c, hipGetLastError());
-  return ARTP_OK;
+  if (detail) {
+    // per-box exit codes in the reference's evaluation order: wave-per-state kernel
+    hipLaunchKernelGGL(validate_states_kernel<1>, dim3(grid_full(c, n)), dim3(64), lds_full(c), c->stream,
+                       c->field[0], c->field[1], c->geom, c->robot, se3, n, valid, detail, c->caps_full,
+                       c->d_error, (unsigned long long*)nullptr);
+    HIP_TRY(c, hipGetLastError());
+    return ARTP_OK;
+  }
+  return launch_validate_pipeline(c, se3, n, valid);
 }
 
 int artp_validate_states(artp_ctx* c, const double* se3, size_t n, uint8_t* valid, int8_t* detail) {
@@ -521,12 +627,17 @@ int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_inde
     if (n_valid) *n_valid = 0;
     return ARTP_OK;
   }
-  if (n_valid) HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(validate_states_kernel, dim3(wave_grid(c, n)), dim3(64 * ARTP_WAVES_PER_BLOCK),
-                     c->lds_bytes, c->stream, c->field[0], c->field[1], c->geom, c->robot,
-                     (const double*)se3_out, n, valid_out, (int8_t*)nullptr, c->cap_verts, c->cap_tris,
-                     c->d_error, n_valid ? c->d_count : (unsigned long long*)nullptr);
-  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rcv = launch_validate_pipeline(c, se3_out, n, valid_out);
+  if (rcv) return rcv;
+  if (n_valid) {
+    HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+    hipLaunchKernelGGL(count_valid_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                       (const uint8_t*)valid_out, n, c->d_count);
+    HIP_TRY(c, hipGetLastError());
+  }
   if (n_valid) {
     unsigned long long cnt = 0;
     HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
@@ -578,11 +689,26 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   }
   size_t cap = c->cub_cap;
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, cap, counts, offsets, (int)(n + 1), c->stream));
-  // grid: the expanded task count lives on the device; use a persistent grid
-  hipLaunchKernelGGL(expanded_validate_kernel, dim3((unsigned)c->n_cus * 16),
-                     dim3(64 * ARTP_WAVES_PER_BLOCK), c->lds_bytes, c->stream, c->field[0], c->field[1],
-                     c->geom, c->robot, mode, s1, s2, n, (const uint32_t*)offsets, (const uint32_t*)aux,
-                     valid, c->cap_verts, c->cap_tris, c->d_error);
+  // expand every interior state into one state batch, validate it with the standard pipeline, then
+  // fold the labels back onto the edges
+  uint32_t total = 0;
+  HIP_TRY(c, hipMemcpyAsync(&total, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (total == 0) return ARTP_OK;
+  rc = ensure_tmp(c, 3, (size_t)total * (7 * sizeof(double) + sizeof(uint32_t) + 1) + 64);
+  if (rc) return rc;
+  double* ex_states = static_cast<double*>(c->tmp[3]);
+  uint32_t* edge_of = reinterpret_cast<uint32_t*>(ex_states + (size_t)7 * total);
+  uint8_t* ex_valid = reinterpret_cast<uint8_t*>(edge_of + total);
+  size_t eb = ((size_t)total + 255) / 256;
+  if (eb > (size_t)c->n_cus * 32) eb = (size_t)c->n_cus * 32;
+  hipLaunchKernelGGL(expand_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream, mode, s1, s2, n,
+                     (const uint32_t*)offsets, (const uint32_t*)aux, ex_states, edge_of);
+  HIP_TRY(c, hipGetLastError());
+  rc = launch_validate_pipeline(c, ex_states, total, ex_valid);
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream,
+                     (const uint8_t*)ex_valid, (const uint32_t*)edge_of, (const uint32_t*)offsets, n, valid);
   HIP_TRY(c, hipGetLastError());
   return ARTP_OK;
 }

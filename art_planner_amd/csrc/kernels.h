@@ -40,15 +40,28 @@ struct SamplerDev {
 
 #define ARTP_WAVES_PER_BLOCK 4
 
-__device__ __forceinline__ WaveScratch carve_scratch(char* smem, int wave_in_block, int cap_verts,
-                                                     int cap_tris) {
-  const size_t per_wave = (size_t)cap_verts * 4 + (size_t)cap_tris * 2;
-  char* base = smem + per_wave * wave_in_block;
+// ---- per-wave LDS carve --------------------------------------------------------------------------
+struct ScratchCaps {  // sized on the host from the box diagonals / sample spacing
+  int verts;  // heights tile, floats (multiple of 4)
+  int tris;   // kept-triangle list, u16 (multiple of 8); 0 = stage has no list
+  int tab;    // hash table entries, u32 (power of two); 0 = stage has no table
+};
+
+__host__ __device__ __forceinline__ size_t scratch_bytes_per_wave(const ScratchCaps& c) {
+  return 2048 /* candidate planes + ids */ + (size_t)c.verts * 4 + (size_t)c.tab * 4 + (size_t)c.tris * 2;
+}
+
+__device__ __forceinline__ WaveScratch carve_scratch(char* smem, int wave_in_block, const ScratchCaps& c) {
+  char* base = smem + scratch_bytes_per_wave(c) * wave_in_block;
   WaveScratch s;
+  s.cand = reinterpret_cast<float*>(base);
+  base += 2048;
   s.h = reinterpret_cast<float*>(base);
-  s.tri = reinterpret_cast<unsigned short*>(base + (size_t)cap_verts * 4);
-  s.cap_verts = cap_verts;
-  s.cap_tris = cap_tris;
+  s.tab = reinterpret_cast<unsigned*>(base + (size_t)c.verts * 4);
+  s.tri = reinterpret_cast<unsigned short*>(base + (size_t)c.verts * 4 + (size_t)c.tab * 4);
+  s.cap_verts = c.verts;
+  s.cap_tris = c.tris;
+  s.tab_size = c.tab;
   return s;
 }
 
@@ -59,17 +72,18 @@ __device__ __forceinline__ bool map_is_inside(const MapGeom& g, double px, doubl
   return tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y;
 }
 
-// ---- R3 ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64 * ARTP_WAVES_PER_BLOCK)
+// ---- R3: HeightMapBoxChecker::checkCollision, one wavefront per dPose -----------------------------
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 check_boxes_kernel(FieldDev f, float sx, float sy, float sz, const float* __restrict__ poses,
                    size_t n, uint8_t* __restrict__ hit, uint8_t* __restrict__ exit_codes,
-                   int cap_verts, int cap_tris, int* __restrict__ error_flag) {
+                   ScratchCaps caps, int* __restrict__ error_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
-  const WaveScratch s = carve_scratch(smem, wave_in_block, cap_verts, cap_tris);
-  const size_t wave0 = (size_t)blockIdx.x * ARTP_WAVES_PER_BLOCK + wave_in_block;
-  const size_t stride = (size_t)gridDim.x * ARTP_WAVES_PER_BLOCK;
+  const WaveScratch s = carve_scratch(smem, wave_in_block, caps);
+  const size_t wave0 = (size_t)blockIdx.x * WAVES + wave_in_block;
+  const size_t stride = (size_t)gridDim.x * WAVES;
   for (size_t i = wave0; i < n; i += stride) {
     float pose[16];
 #pragma unroll
@@ -176,17 +190,21 @@ __device__ __forceinline__ int wave_state_valid(const FieldDev& fb, const FieldD
   return err ? -1 : valid;
 }
 
-__global__ void __launch_bounds__(64 * ARTP_WAVES_PER_BLOCK)
+// v1: one wavefront per state, boxes in the reference's order with its short-circuit.  Kept for the
+// `detail` output (per-box exit codes exactly as the reference would evaluate them); the throughput
+// path is the classify -> resolve -> plane-stage pipeline below.
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 validate_states_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb,
                        const double* __restrict__ se3, size_t n, uint8_t* __restrict__ valid,
-                       int8_t* __restrict__ detail, int cap_verts, int cap_tris,
+                       int8_t* __restrict__ detail, ScratchCaps caps,
                        int* __restrict__ error_flag, unsigned long long* __restrict__ n_valid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
-  const WaveScratch s = carve_scratch(smem, wave_in_block, cap_verts, cap_tris);
-  const size_t wave0 = (size_t)blockIdx.x * ARTP_WAVES_PER_BLOCK + wave_in_block;
-  const size_t stride = (size_t)gridDim.x * ARTP_WAVES_PER_BLOCK;
+  const WaveScratch s = carve_scratch(smem, wave_in_block, caps);
+  const size_t wave0 = (size_t)blockIdx.x * WAVES + wave_in_block;
+  const size_t stride = (size_t)gridDim.x * WAVES;
   unsigned long long local_valid = 0;
   for (size_t i = wave0; i < n; i += stride) {
     double st[7];
@@ -390,24 +408,16 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
   }
 }
 
-// offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  Each wave-task validates
-// one state of one edge; an invalid state clears the edge's label (all writers store 0).
-__global__ void __launch_bounds__(64 * ARTP_WAVES_PER_BLOCK)
-expanded_validate_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, int mode,
-                         const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
-                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
-                         uint8_t* __restrict__ valid, int cap_verts, int cap_tris,
-                         int* __restrict__ error_flag) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave_in_block = threadIdx.x >> 6;
-  const WaveScratch s = carve_scratch(smem, wave_in_block, cap_verts, cap_tris);
+// offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  One lane per wave-task:
+// writes the interpolated state of (edge, k) and remembers its edge.
+__global__ void __launch_bounds__(256)
+expand_edges_kernel(int mode, const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
+                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
+                    double* __restrict__ states_out, uint32_t* __restrict__ edge_of) {
   const size_t total = offsets[n];
-  const size_t wave0 = (size_t)blockIdx.x * ARTP_WAVES_PER_BLOCK + wave_in_block;
-  const size_t stride = (size_t)gridDim.x * ARTP_WAVES_PER_BLOCK;
-  for (size_t w = wave0; w < total; w += stride) {
-    // edge e with offsets[e] <= w < offsets[e+1]
-    size_t lo = 0, hi = n;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+       w += (size_t)gridDim.x * blockDim.x) {
+    size_t lo = 0, hi = n;  // edge e with offsets[e] <= w < offsets[e+1]
     while (hi - lo > 1) {
       const size_t mid = (lo + hi) >> 1;
       if (offsets[mid] <= w) lo = mid; else hi = mid;
@@ -430,10 +440,20 @@ expanded_validate_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, int m
       const double n_interp_div = 1.0 / (n_interp + 1);
       se3_interpolate(a, b, (k + 1) * n_interp_div, st);
     }
-    const int v = wave_state_valid(fb, ff, g, rb, st, s, lane, nullptr);
-    if (v < 0 && lane == 0) atomicExch(error_flag, 1);
-    if (v == 0 && lane == 0) valid[e] = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) states_out[7 * w + i] = st[i];
+    edge_of[w] = (uint32_t)e;
   }
+}
+
+// an invalid interior state clears its edge's label (all writers store 0)
+__global__ void __launch_bounds__(256)
+reduce_edges_kernel(const uint8_t* __restrict__ state_valid, const uint32_t* __restrict__ edge_of,
+                    const uint32_t* __restrict__ offsets, size_t n, uint8_t* __restrict__ edge_valid) {
+  const size_t total = offsets[n];
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+       w += (size_t)gridDim.x * blockDim.x)
+    if (!state_valid[w]) edge_valid[edge_of[w]] = 0;
 }
 
 __global__ void __launch_bounds__(256)

@@ -1,0 +1,374 @@
+// pipeline.h -- the throughput path of StateValidityChecker::isValid on gfx950.
+//
+// The reference decides ~3/4 of all box checks from three window statistics alone (max height, min
+// finite height, all-finite): exits (b)(c)(d)(e) of dCollideHeightfieldZone
+// (ode/ode/src/heightfield.cpp:1027-1064,1139-1160) -- but only after scanning the whole window.
+// max / min are idempotent, so exact 2-D range-max / range-min-of-finite tables over power-of-two
+// blocks (built once per map upload, resident in HBM/L2) give bit-identical statistics from a handful
+// of loads; non-finite / NaN counts come from summed-area tables.  That turns the common case into
+// lane-parallel work (one lane per STATE, 64 states per wavefront instruction) and leaves the
+// wave-cooperative window work to the boxes that really need it:
+//
+//   classify_states_kernel   1 lane / state : poses, frame change, AABB, window, table statistics,
+//                                             exits (b)-(e); undecided boxes -> queue 1
+//   resolve_boxes_kernel     1 wave / box   : window -> LDS, (re-)decide exits, (f) vertex-in-box,
+//                                             count kept triangles; boxes with triangles -> queue 2
+//   plane_stage_kernel       1 wave / box   : window -> LDS, kept-triangle list, (g) plane stage
+//
+// A state's label is the AND over its boxes of "torso does not touch" / "foot touches", so boxes can
+// be decided in any order and in different kernels; a failing box stores 0 into the state's label.
+// Evaluating boxes the reference would have short-circuited cannot change the label.
+#pragma once
+
+#include "kernels.h"
+
+namespace artp {
+
+#define ARTP_TABLE_LEVELS 4  // block sizes 4, 8, 16, 32 samples
+
+struct TablesDev {
+  const float* maxT[ARTP_TABLE_LEVELS];  // max over [x, x+B) x [z, z+B), NaN samples count as -inf
+  const float* minT[ARTP_TABLE_LEVELS];  // min over the FINITE samples of the block, +inf if none
+  const int* sat_nonfinite;              // (nW+1) x (nD+1) summed-area table of !isfinite
+  const int* sat_nan;                    // same for NaN; nullptr when the layer has none
+  int valid;
+};
+
+// ---- table construction (map upload) ---------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+table_level0_kernel(const float* __restrict__ data, int n, float* __restrict__ mx, float* __restrict__ mn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float h = data[i];
+    mx[i] = is_nan(h) ? -INFINITY : h;
+    mn[i] = is_finite(h) ? h : INFINITY;
+  }
+}
+
+// out = combine of the four half-size blocks at offsets (0,0), (h,0), (0,h), (h,h); indices clamp at
+// the border (blocks hanging over the edge are never queried).
+__global__ void __launch_bounds__(256)
+table_level_up_kernel(const float* __restrict__ in_mx, const float* __restrict__ in_mn, int nW, int nD,
+                      int half, float* __restrict__ out_mx, float* __restrict__ out_mn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nW * nD) return;
+  const int x = i % nW, z = i / nW;
+  const int x1 = min(x + half, nW - 1), z1 = min(z + half, nD - 1);
+  const float a = in_mx[x + z * nW], b = in_mx[x1 + z * nW], c = in_mx[x + z1 * nW], d = in_mx[x1 + z1 * nW];
+  const float ab = (b > a) ? b : a, cd = (d > c) ? d : c;
+  out_mx[i] = (cd > ab) ? cd : ab;
+  const float e = in_mn[x + z * nW], f = in_mn[x1 + z * nW], g = in_mn[x + z1 * nW], h = in_mn[x1 + z1 * nW];
+  const float ef = (f < e) ? f : e, gh = (h < g) ? h : g;
+  out_mn[i] = (gh < ef) ? gh : ef;
+}
+
+// Summed-area tables, two passes (rows then columns); S is (nW+1) x (nD+1), row/col 0 are zero.
+__global__ void __launch_bounds__(64)
+sat_rows_kernel(const float* __restrict__ data, int nW, int nD, int* __restrict__ S_nf, int* __restrict__ S_nan) {
+  const int z = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per sample row z
+  if (z >= nD) return;
+  const int W1 = nW + 1;
+  int a = 0, bnan = 0;
+  S_nf[(z + 1) * W1] = 0;
+  if (S_nan) S_nan[(z + 1) * W1] = 0;
+  for (int x = 0; x < nW; ++x) {
+    const float h = data[x + z * nW];
+    a += is_finite(h) ? 0 : 1;
+    bnan += is_nan(h) ? 1 : 0;
+    S_nf[(x + 1) + (z + 1) * W1] = a;
+    if (S_nan) S_nan[(x + 1) + (z + 1) * W1] = bnan;
+  }
+}
+__global__ void __launch_bounds__(64)
+sat_cols_kernel(int nW, int nD, int* __restrict__ S_nf, int* __restrict__ S_nan) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per column x in [0, nW]
+  if (x > nW) return;
+  const int W1 = nW + 1;
+  int a = 0, b = 0;
+  S_nf[x] = 0;
+  if (S_nan) S_nan[x] = 0;
+  for (int z = 1; z <= nD; ++z) {
+    a += S_nf[x + z * W1];
+    S_nf[x + z * W1] = a;
+    if (S_nan) {
+      b += S_nan[x + z * W1];
+      S_nan[x + z * W1] = b;
+    }
+  }
+}
+
+// Exact window statistics from the tables.  Returns false when the tables cannot answer (window
+// thinner than the smallest block, or a NaN in the window -> the running-dMAX quirk needs the scan).
+__device__ __forceinline__ bool table_window_stats(const FieldDev& f, const TablesDev& t, const BoxHF& b,
+                                                   WindowStats& w) {
+  const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
+  const int m = wX < wZ ? wX : wZ;
+  if (m < 4) return false;
+  const int W1 = f.nW + 1;
+  const int x0 = b.minX, x1 = b.maxX + 1, z0 = b.minZ, z1 = b.maxZ + 1;
+  if (t.sat_nan) {
+    const int nn = t.sat_nan[x1 + z1 * W1] - t.sat_nan[x0 + z1 * W1] - t.sat_nan[x1 + z0 * W1] + t.sat_nan[x0 + z0 * W1];
+    if (nn) return false;
+  }
+  const int nf = t.sat_nonfinite[x1 + z1 * W1] - t.sat_nonfinite[x0 + z1 * W1] -
+                 t.sat_nonfinite[x1 + z0 * W1] + t.sat_nonfinite[x0 + z0 * W1];
+  w.allFinite = (nf == 0);
+  const int lvl = m >= 32 ? 3 : (m >= 16 ? 2 : (m >= 8 ? 1 : 0));
+  const int B = 4 << lvl;
+  const float* __restrict__ mx = t.maxT[lvl];
+  const float* __restrict__ mn = t.minT[lvl];
+  float vmax = -INFINITY, vmin = INFINITY;
+  const int lastX = b.maxX - B + 1, lastZ = b.maxZ - B + 1;
+  for (int zz = b.minZ;; zz += B) {
+    const int zc = zz < lastZ ? zz : lastZ;
+    for (int xx = b.minX;; xx += B) {
+      const int xc = xx < lastX ? xx : lastX;
+      const float a = mx[xc + zc * f.nW];
+      const float c = mn[xc + zc * f.nW];
+      vmax = (a > vmax) ? a : vmax;
+      vmin = (c < vmin) ? c : vmin;
+      if (xx >= lastX) break;
+    }
+    if (zz >= lastZ) break;
+  }
+  w.maxY = vmax;
+  w.minY = vmin;
+  return true;
+}
+
+// ---- queue record ------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) PendingBox {  // 96 bytes
+  float pos[3];
+  float R[9];
+  float aabb[6];
+  short minX, maxX, minZ, maxZ;
+  unsigned state;
+  unsigned kind;  // 0 = torso vs body layer (ok = no contact), 1 = foot vs masked layer (ok = contact)
+  unsigned pad[2];
+};
+
+struct PipelineQueues {
+  PendingBox* q1;                // undecided boxes
+  unsigned* q2;                  // indices into q1 of boxes that need the plane stage
+  unsigned long long* counters;  // [0] q1 count, [1] q2 count, [2] resolve cursor, [3] plane cursor
+};
+
+__device__ __forceinline__ void box_from_record(const PendingBox& r, const RobotDev& rb, BoxHF& b) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) b.pos[i] = r.pos[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) b.R[i] = r.R[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) b.aabb[i] = r.aabb[i];
+  b.side[0] = r.kind ? rb.foot[0] : rb.torso[0];
+  b.side[1] = r.kind ? rb.foot[1] : rb.torso[1];
+  b.side[2] = r.kind ? rb.foot[2] : rb.torso[2];
+  b.minX = r.minX;
+  b.maxX = r.maxX;
+  b.minZ = r.minZ;
+  b.maxZ = r.maxZ;
+  b.on_field = 1;
+}
+
+// dPose of box k of a state (validity_checker.cpp:40-43, validity_checker_feet.cpp:64-68).
+__device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t[3], const float R[9], int k,
+                                               float pose[16]) {
+  const bool body = (k == 0);
+  const float ox = body ? rb.torso_off[0] : ((k <= 2) ? rb.feet_off_x : -rb.feet_off_x);
+  const float oy = body ? rb.torso_off[1] : ((k & 1) ? rb.feet_off_y : -rb.feet_off_y);
+  const float oz = body ? rb.torso_off[2] : 0.0f;
+  // pose * Pose3FromXYZ(o): Eigen affine product, translation = R*o + t with the 3-term dot summed as
+  // x0 + (x1 + x2) (Eigen's unrolled redux).
+  pose[0] = (R[0] * ox + (R[1] * oy + R[2] * oz)) + t[0];
+  pose[1] = (R[3] * ox + (R[4] * oy + R[5] * oz)) + t[1];
+  pose[2] = (R[6] * ox + (R[7] * oy + R[8] * oz)) + t[2];
+  pose[3] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    pose[4 + 4 * r + 0] = R[3 * r + 0];
+    pose[4 + 4 * r + 1] = R[3 * r + 1];
+    pose[4 + 4 * r + 2] = R[3 * r + 2];
+    pose[4 + 4 * r + 3] = 0.0f;
+  }
+}
+
+// ---- stage 1: one lane per state --------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, MapGeom g, RobotDev rb,
+                       const double* __restrict__ se3, size_t n, uint8_t* __restrict__ valid,
+                       PipelineQueues q) {
+  const size_t i_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < n;
+  const size_t i = live ? i_raw : n - 1;  // dead lanes shadow the last state and write nothing
+  double st[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) st[k] = se3[7 * i + k];
+  float t[3], R[9];
+  pose3_from_se3(st, t, R);
+  int ok = 1;
+  unsigned pending = 0;
+  for (int k = 0; k < 5; ++k) {
+    const bool body = (k == 0);
+    float pose[16];
+    state_box_pose(rb, t, R, k, pose);
+    if (!map_is_inside(g, (double)pose[0], (double)pose[1])) {
+      // body outside -> valid (validity_checker_body.cpp:29-32); foot outside ->
+      // !unknown_space_untraversable (validity_checker_feet.cpp:34-37)
+      if (!body && rb.unknown_space_untraversable) ok = 0;
+      continue;
+    }
+    const FieldDev& fk = body ? fb : ff;
+    BoxHF b;
+    setup_box(fk, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
+              body ? rb.torso[2] : rb.foot[2], b);
+    int hit = 0;
+    if (b.on_field) {
+      WindowStats w;
+      int ec;
+      const TablesDev& tk = body ? tb : tf;
+      if (!(tk.valid && table_window_stats(fk, tk, b, w) && decide_exits(b, w, hit, ec))) {
+        pending |= 1u << k;
+        continue;
+      }
+    }
+    if (body ? hit : !hit) ok = 0;
+  }
+  if (!ok || !live) pending = 0;  // a decided box already fails: the label is 0 whatever the others say
+  if (live) valid[i] = (uint8_t)ok;
+  // queue slots for the whole wavefront with ONE atomic (a single word sustains only ~88 returning
+  // atomics per microsecond, MI355X_MICROARCH.md "dequeue")
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int before = 0, wave_total = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const unsigned long long bal = __ballot((pending >> k) & 1u);
+    before += __popcll(bal & lt_mask);
+    wave_total += __popcll(bal);
+  }
+  unsigned long long wave_base = 0;
+  if (wave_total) {
+    if (lane == 0) wave_base = atomicAdd(&q.counters[0], (unsigned long long)wave_total);
+    wave_base = __shfl(wave_base, 0, 64);
+  }
+  unsigned long long slot = wave_base + (unsigned long long)before;
+  // second sweep: write the undecided boxes (recomputed -- cheaper than keeping five records live)
+  for (int k = 0; k < 5; ++k) {
+    if (!((pending >> k) & 1u)) continue;
+    const bool body = (k == 0);
+    float pose[16];
+    state_box_pose(rb, t, R, k, pose);
+    const FieldDev& fk = body ? fb : ff;
+    BoxHF b;
+    setup_box(fk, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
+              body ? rb.torso[2] : rb.foot[2], b);
+    PendingBox* r = q.q1 + slot;
+    ++slot;
+    float4* dst = reinterpret_cast<float4*>(r);
+    dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
+    dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
+    dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
+    dst[3] = make_float4(b.aabb[0], b.aabb[1], b.aabb[2], b.aabb[3]);
+    const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
+    const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
+    dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
+    dst[5] = make_float4(__uint_as_float((unsigned)i), __uint_as_float(body ? 0u : 1u), 0.0f, 0.0f);
+  }
+}
+
+__device__ __forceinline__ unsigned long long wave_fetch_item(unsigned long long* cursor, int lane) {
+  unsigned long long item = 0;
+  if (lane == 0) item = atomicAdd(cursor, 1ull);
+  return __shfl(item, 0, 64);
+}
+
+// ---- stage 2: one wavefront per undecided box ---------------------------------------------------------
+// Static striding over queue 1 (a shared work cursor would serialise on one atomic word).
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+resolve_boxes_kernel(FieldDev fb, FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
+                     ScratchCaps caps, int* __restrict__ error_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const WaveScratch s = carve_scratch(smem, threadIdx.x >> 6, caps);
+  const unsigned long long count = q.counters[0];
+  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES;
+  for (unsigned long long item = (unsigned long long)blockIdx.x * WAVES + (threadIdx.x >> 6); item < count;
+       item += stride) {
+    const PendingBox rec = q.q1[item];
+    if (valid[rec.state] == 0) continue;  // another box of this state already failed
+    BoxHF b;
+    box_from_record(rec, rb, b);
+    const FieldDev& f = rec.kind ? ff : fb;
+    const int total = (b.maxX - b.minX + 1) * (b.maxZ - b.minZ + 1);
+    if (total > s.cap_verts) {
+      if (lane == 0) atomicExch(error_flag, 1);
+      continue;
+    }
+    WindowStats w;
+    wave_scan_window(f, b, s, lane, w);
+    int result = 0, ec;
+    bool decided = decide_exits(b, w, result, ec);
+    if (!decided) {
+      if (wave_vertex_pass(f, b, s, lane, w.allFinite)) {
+        result = 1;
+        decided = true;
+      } else {
+        const int T = wave_compact_triangles<true>(b, s, lane);
+        if (T < 0) {
+          if (lane == 0) atomicExch(error_flag, 1);
+          wave_lds_sync();
+          continue;
+        }
+        const int r = (T == 0) ? 0 : wave_plane_stage_corners(f, b, s, lane, T);
+        if (r != 2) {
+          result = r;
+          decided = true;
+        } else if (lane == 0) {  // a corner candidate has an epsilon-equal partner: exact grouping
+          const unsigned long long slot = atomicAdd(&q.counters[1], 1ull);
+          q.q2[slot] = (unsigned)item;
+        }
+      }
+    }
+    if (decided && lane == 0) {
+      const bool ok = rec.kind ? (result != 0) : (result == 0);
+      if (!ok) valid[rec.state] = 0;
+    }
+    wave_lds_sync();
+  }
+}
+
+// ---- stage 3: plane stage ---------------------------------------------------------------------------
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+plane_stage_kernel(FieldDev fb, FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
+                   ScratchCaps caps, int* __restrict__ error_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const WaveScratch s = carve_scratch(smem, threadIdx.x >> 6, caps);
+  const unsigned long long count = q.counters[1];
+  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES;
+  for (unsigned long long item = (unsigned long long)blockIdx.x * WAVES + (threadIdx.x >> 6); item < count;
+       item += stride) {
+    const PendingBox rec = q.q1[q.q2[item]];
+    if (valid[rec.state] == 0) continue;
+    BoxHF b;
+    box_from_record(rec, rb, b);
+    const FieldDev& f = rec.kind ? ff : fb;
+    WindowStats w;
+    wave_scan_window(f, b, s, lane, w);
+    const int T = wave_compact_triangles<true>(b, s, lane);
+    if (T < 0) {
+      if (lane == 0) atomicExch(error_flag, 1);
+      continue;
+    }
+    const int result = (T > 0 && wave_plane_stage(f, b, s, lane, T)) ? 1 : 0;
+    if (lane == 0) {
+      const bool ok = rec.kind ? (result != 0) : (result == 0);
+      if (!ok) valid[rec.state] = 0;
+    }
+    wave_lds_sync();
+  }
+}
+
+}  // namespace artp

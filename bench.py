@@ -100,6 +100,9 @@ def main():
     gm = make_map(args.map, args.res, seed=1234)
     ctx = Context(local_rank, "yaml")
     ctx.upload_map(gm)
+    # one explicit stream carries the kernels AND the HIP events that time them
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
     ctx.use_torch_stream()
 
     S, K, W, seed = args.batch, args.steps, args.warmup, 42

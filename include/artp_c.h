@@ -63,7 +63,10 @@ const char* artp_device_arch(const artp_ctx* ctx);
  * validity_checker.cpp:9-15).  Fails with ARTP_ERR_NO_DEVICE when there is no GPU. */
 int artp_create(int device, const artp_params* params, artp_ctx** out);
 void artp_destroy(artp_ctx* ctx);
-int artp_set_stream(artp_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+/* Run the context's work on a caller-provided hipStream_t (NULL = HIP's legacy default stream).
+ * A fresh context uses a private non-blocking stream; artp_use_own_stream switches back to it. */
+int artp_set_stream(artp_ctx* ctx, void* hip_stream);
+int artp_use_own_stream(artp_ctx* ctx);
 int artp_synchronize(artp_ctx* ctx);
 
 /* ---- map upload: HeightMapBoxChecker::setHeightField

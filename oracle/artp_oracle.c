@@ -379,6 +379,8 @@ typedef struct { /* per-thread scratch, grown on demand (ODE keeps these in the 
 } scratch_t;
 
 static _Thread_local scratch_t g_scratch;
+static _Thread_local unsigned g_last_num_tri; /* diagnostics: triangles kept by the last zone call */
+unsigned artp_oracle_last_num_tri(void) { return g_last_num_tri; }
 
 static void scratch_reserve(scratch_t* s, size_t nverts, size_t ntris) {
   if (s->verts_cap < nverts) {
@@ -452,6 +454,7 @@ static int collide_zone(const artp_oracle_field* f, int minX, int maxX, int minZ
   const float cfSampleWidth = f->sample_w;
   const float cfSampleDepth = f->sample_d;
   scratch_t* S = &g_scratch;
+  g_last_num_tri = 0;
   const unsigned numTriMax = (unsigned)((maxX - minX) * (maxZ - minZ) * 2);
   scratch_reserve(S, (size_t)numX * numZ, numTriMax);
   hf_vertex* V = S->verts; /* V[x_local*numZ + z_local] == tempHeightBuffer[x_local][z_local] */
@@ -596,6 +599,7 @@ static int collide_zone(const artp_oracle_field* f, int minX, int maxX, int minZ
     }
   }
 
+  g_last_num_tri = numTri;
   /* (g) pass 1: triangles as planes, :1470-1646 */
   for (unsigned k = 0; k < numTri; k++) {
     hf_triangle* t = &T[k];
