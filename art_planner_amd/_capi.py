@@ -18,6 +18,7 @@ SYMBOLS = [
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_algorithmic_vertices_dev",
+    "artp_debug_pipeline_counters",
 ]
 
 
@@ -84,6 +85,7 @@ def load():
         getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp]
     L.artp_compact_valid_dev.argtypes = [vp, vp, vp, sz, vp, vp]
     L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
+    L.artp_debug_pipeline_counters.argtypes = [vp, C.POINTER(u64 * 8)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("artp_destroy",):

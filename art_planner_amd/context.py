@@ -184,3 +184,8 @@ class Context:
         self._chk(self.L.artp_algorithmic_vertices_dev(self.h, se3_t.data_ptr(), se3_t.shape[0], C.byref(v)),
                   "artp_algorithmic_vertices_dev")
         return v.value
+
+    def pipeline_counters(self):
+        out = (C.c_uint64 * 8)()
+        self._chk(self.L.artp_debug_pipeline_counters(self.h, C.byref(out)), "artp_debug_pipeline_counters")
+        return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1]}

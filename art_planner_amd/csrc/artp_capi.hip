@@ -40,7 +40,8 @@ struct artp_ctx {
   size_t table_elems[2] = {0, 0};
   TablesDev tables[2]{};
   ScratchCaps caps_full{0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
-  ScratchCaps caps_scan{0, 0, 0};  // window tile only (ARTP_WAVES_PER_BLOCK waves / block)
+  ScratchCaps caps_scan{0, 0, 0};  // torso resolve stage: window tile + short triangle list, per wave
+  ScratchCaps caps_feet{0, 0, 0};  // foot resolve stage: per 16-lane group
   int n_cus = 256;
   // device scratch
   int* d_error = nullptr;
@@ -145,7 +146,17 @@ int size_scratch(artp_ctx* c) {
   long tab = 64;
   while (tab < 2 * tris && tab < 4096) tab <<= 1;  // partner-detection fast path up to tab/2 triangles
   c->caps_full = ScratchCaps{(int)verts, (int)tris, (int)tab};
-  c->caps_scan = ScratchCaps{(int)verts, (int)tris, 0};  // window tile + triangle list
+  // resolve stage: window tile + a short triangle list (longer lists take the exact-grouping stage)
+  c->caps_scan = ScratchCaps{(int)verts, (int)(tris < 1024 ? tris : 1024), 0};
+  {
+    int fdim = (int)std::ceil(d_foot / spacing) + 4;
+    if (fdim > max_n) fdim = max_n;
+    if (fdim < 4) fdim = 4;
+    long fv = ((long)fdim * fdim + 3) & ~3L;
+    long ft = (2L * (fdim - 1) * (fdim - 1) + 7) & ~7L;
+    if (ft > 1024) ft = 1024;
+    c->caps_feet = ScratchCaps{(int)fv, (int)ft, 0};
+  }
   if (scratch_bytes_per_wave(c->caps_full) > 160 * 1024 ||
       scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK > 160 * 1024) {
     c->last_error = "box too large for the LDS window tile";
@@ -156,6 +167,7 @@ int size_scratch(artp_ctx* c) {
 
 size_t lds_full(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_full); }
 size_t lds_scan(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK; }
+size_t lds_feet(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_feet) * 4 * ARTP_WAVES_PER_BLOCK; }
 
 int set_kernel_lds(artp_ctx* c) {
   // > 64 KiB of dynamic LDS needs the opt-in attribute
@@ -165,8 +177,10 @@ int set_kernel_lds(artp_ctx* c) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(plane_stage_kernel<1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK>),
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet(c)));
   return ARTP_OK;
 }
 
@@ -179,8 +193,8 @@ int grid_full(const artp_ctx* c, size_t tasks) {
   if (tasks && tasks < g) g = tasks;
   return (int)(g ? g : 1);
 }
-int grid_scan(const artp_ctx* c) {
-  size_t per_cu = (160 * 1024) / (lds_scan(c) ? lds_scan(c) : 1);
+int grid_scan(const artp_ctx* c, size_t lds) {
+  size_t per_cu = (160 * 1024) / (lds ? lds : 1);
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   return (int)((size_t)c->n_cus * per_cu);
@@ -241,12 +255,18 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   q.q1 = static_cast<PendingBox*>(c->tmp[4]);
   q.counters = static_cast<unsigned long long*>(c->tmp[5]);
   q.q2 = reinterpret_cast<unsigned*>(q.counters + 8);
+  q.feet_base = n;
   HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
-  hipLaunchKernelGGL(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK>, dim3(grid_scan(c)),
-                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->field[1],
-                     c->robot, q, valid, c->caps_scan, c->d_error);
+  hipLaunchKernelGGL(feet_vertex_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(256), 0, c->stream, c->field[1],
+                     c->robot, q);
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64>), dim3(grid_scan(c, lds_scan(c))),
+                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->robot, q, valid,
+                     c->caps_scan, c->d_error);
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16>), dim3(grid_scan(c, lds_feet(c))),
+                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_feet(c), c->stream, c->field[1], c->robot, q, valid,
+                     c->caps_feet, c->d_error);
   hipLaunchKernelGGL(plane_stage_kernel<1>, dim3(grid_full(c, 0)), dim3(64), lds_full(c), c->stream,
                      c->field[0], c->field[1], c->robot, q, valid, c->caps_full, c->d_error);
   HIP_TRY(c, hipGetLastError());
@@ -757,6 +777,16 @@ int artp_check_edges_interp(artp_ctx* c, const double* s1, const double* s2, siz
 
 namespace {
 struct Se3Row { double v[7]; };
+}
+
+int artp_debug_pipeline_counters(artp_ctx* c, uint64_t out[8]) {
+  if (!c || !out) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->tmp[5]) return ARTP_ERR_NO_MAP;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(out, c->tmp[5], 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
 }
 
 int artp_compact_valid_dev(artp_ctx* c, const double* se3, const uint8_t* valid, size_t n,

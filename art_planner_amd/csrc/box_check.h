@@ -45,30 +45,89 @@ enum ExitCode : int {
   EXIT_NONE = 8
 };
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const float o = __shfl_xor(v, m, 64);
-    v = (o > v) ? o : v;
+// ---- lane-group primitives ------------------------------------------------------------------------
+// A box is decided by a GROUP of G lanes: G = 64 (a whole wavefront: torso windows, ~1000 samples) or
+// G = 16 (one DPP row: foot windows, ~70 samples, four boxes per wavefront).  All lanes of a group
+// follow the same control flow; different groups of one wavefront may diverge.
+template <int G>
+__device__ __forceinline__ int grp_lane(int lane) { return lane & (G - 1); }
+
+template <int G>
+__device__ __forceinline__ unsigned long long grp_ballot(bool p, int lane) {
+  const unsigned long long bal = __ballot(p);
+  if (G == 64) return bal;
+  return (bal >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1ull);
+}
+template <int G>
+__device__ __forceinline__ bool grp_any(bool p, int lane) { return grp_ballot<G>(p, lane) != 0ull; }
+
+// lanes of the group strictly below this lane
+template <int G>
+__device__ __forceinline__ unsigned long long grp_lt_mask(int lane) {
+  const int gl = lane & (G - 1);
+  return gl == 0 ? 0ull : (~0ull >> (64 - gl));
+}
+
+#define ARTP_DPP_QUAD_XOR1 0xB1        /* quad_perm:[1,0,3,2] */
+#define ARTP_DPP_QUAD_XOR2 0x4E        /* quad_perm:[2,3,0,1] */
+#define ARTP_DPP_ROW_HALF_MIRROR 0x141
+#define ARTP_DPP_ROW_MIRROR 0x140
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+
+// max / min over the group (max and min are idempotent, so butterfly order is irrelevant; values are
+// compared with the same (o > v) ? o : v select the scan uses).  4 DPP steps inside a 16-lane row,
+// then the four row results are combined through scalar readlanes for G = 64.
+template <int G, bool IS_MAX>
+__device__ __forceinline__ float grp_minmax(float v) {
+#define ARTP_STEP(CTRL)                                                  \
+  {                                                                      \
+    const float o = __int_as_float(dpp_i<CTRL>(__float_as_int(v)));      \
+    v = IS_MAX ? ((o > v) ? o : v) : ((o < v) ? o : v);                  \
+  }
+  ARTP_STEP(ARTP_DPP_QUAD_XOR1)
+  ARTP_STEP(ARTP_DPP_QUAD_XOR2)
+  ARTP_STEP(ARTP_DPP_ROW_HALF_MIRROR)
+  ARTP_STEP(ARTP_DPP_ROW_MIRROR)
+#undef ARTP_STEP
+  if (G == 64) {
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    const float a = IS_MAX ? ((r1 > r0) ? r1 : r0) : ((r1 < r0) ? r1 : r0);
+    const float c = IS_MAX ? ((r3 > r2) ? r3 : r2) : ((r3 < r2) ? r3 : r2);
+    v = IS_MAX ? ((c > a) ? c : a) : ((c < a) ? c : a);
   }
   return v;
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const float o = __shfl_xor(v, m, 64);
-    v = (o < v) ? o : v;
+template <int G>
+__device__ __forceinline__ float grp_max(float v) { return grp_minmax<G, true>(v); }
+template <int G>
+__device__ __forceinline__ float grp_min(float v) { return grp_minmax<G, false>(v); }
+
+template <int G>
+__device__ __forceinline__ int grp_max_i(int v) {
+#define ARTP_STEP(CTRL)              \
+  {                                  \
+    const int o = dpp_i<CTRL>(v);    \
+    v = (o > v) ? o : v;             \
+  }
+  ARTP_STEP(ARTP_DPP_QUAD_XOR1)
+  ARTP_STEP(ARTP_DPP_QUAD_XOR2)
+  ARTP_STEP(ARTP_DPP_ROW_HALF_MIRROR)
+  ARTP_STEP(ARTP_DPP_ROW_MIRROR)
+#undef ARTP_STEP
+  if (G == 64) {
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int a = r1 > r0 ? r1 : r0, c = r3 > r2 ? r3 : r2;
+    v = c > a ? c : a;
   }
   return v;
 }
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const int o = __shfl_xor(v, m, 64);
-    v = (o > v) ? o : v;
-  }
-  return v;
-}
+
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
@@ -128,53 +187,72 @@ ARTP_HD bool decide_exits(const BoxHF& b, const WindowStats& w, int& result, int
 }
 
 // (a).  Requires b.on_field and numX*numZ <= s.cap_verts (checked by the caller).
-__device__ __forceinline__ void wave_scan_window(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
-                                                 int lane, WindowStats& w) {
+template <int G>
+__device__ __forceinline__ void grp_scan_window(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
+                                                int lane, WindowStats& w) {
+  const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
   const int total = numX * numZ;
   float lmax = -INFINITY, lmin = INFINITY;
   int lnonfinite = 0;
   int llast_nan = -1;  // ODE scan index (xl*numZ + zl) of this lane's last NaN
-  const int qz = 64 / numX, rx = 64 - qz * numX;  // advance of (xl, zl) per 64 elements
+  const int qz = G / numX, rx = G - qz * numX;  // advance of (xl, zl) per G elements
   {
-    int xl = lane % numX, zl = lane / numX;
+    int xl = gl % numX, zl = gl / numX;
     const float* base = f.data + b.minX + (size_t)b.minZ * f.nW;
-    for (int e = lane; e < total; e += 64) {
-      const float h = base[xl + zl * f.nW];
-      s.h[e] = h;
-      lmax = (h > lmax) ? h : lmax;  // NaN never wins here; handled below
-      if (is_finite(h)) {
-        lmin = (lmin > h) ? h : lmin;
-      } else {
-        lnonfinite = 1;
-        if (is_nan(h)) {
-          const int si = xl * numZ + zl;
-          llast_nan = si > llast_nan ? si : llast_nan;
+    // 8 independent loads in flight per lane before the first use (the window comes from L2: a
+    // dependent load per step would pay the full L2 latency 17 times for a torso window)
+    constexpr int U = 8;
+    for (int e0 = gl; e0 < total; e0 += G * U) {
+      float hv[U];
+      int xs[U], zs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xs[u] = xl;
+        zs[u] = zl;
+        hv[u] = (e0 + G * u < total) ? base[xl + zl * f.nW] : 0.0f;
+        xl += rx;
+        zl += qz;
+        if (xl >= numX) {
+          xl -= numX;
+          zl += 1;
         }
       }
-      xl += rx;
-      zl += qz;
-      if (xl >= numX) {
-        xl -= numX;
-        zl += 1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + G * u;
+        if (e < total) {
+          const float h = hv[u];
+          s.h[e] = h;
+          lmax = (h > lmax) ? h : lmax;  // NaN never wins here; handled below
+          if (is_finite(h)) {
+            lmin = (lmin > h) ? h : lmin;
+          } else {
+            lnonfinite = 1;
+            if (is_nan(h)) {
+              const int si = xs[u] * numZ + zs[u];
+              llast_nan = si > llast_nan ? si : llast_nan;
+            }
+          }
+        }
       }
     }
   }
   wave_lds_sync();
-  w.maxY = wave_max(lmax);
-  w.minY = wave_min(lmin);
-  w.allFinite = !__any(lnonfinite);
+  w.maxY = grp_max<G>(lmax);
+  w.minY = grp_min<G>(lmin);
+  w.allFinite = !grp_any<G>(lnonfinite != 0, lane);
   if (f.has_nan && !w.allFinite) {
-    const int last_nan = wave_max_i(llast_nan);
+    const int last_nan = grp_max_i<G>(llast_nan);
     if (last_nan >= 0) {
       // running dMAX: the maximum restarts after every NaN, and a trailing NaN survives.
       if (last_nan == total - 1) {
         w.maxY = __uint_as_float(0x7fc00000u);
       } else {
         float m2 = -INFINITY;
-        int xl = lane % numX, zl = lane / numX;
-        for (int e = lane; e < total; e += 64) {
+        int xl = gl % numX, zl = gl / numX;
+        for (int e = gl; e < total; e += G) {
           const float h = s.h[e];
           if (xl * numZ + zl > last_nan) m2 = (h > m2) ? h : m2;
           xl += rx;
@@ -184,25 +262,28 @@ __device__ __forceinline__ void wave_scan_window(const FieldDev& f, const BoxHF&
             zl += 1;
           }
         }
-        w.maxY = wave_max(m2);
+        w.maxY = grp_max<G>(m2);
       }
     }
   }
 }
 
 // (f).  Heights must be staged in s.h.
-__device__ __forceinline__ bool wave_vertex_pass(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
-                                                 int lane, bool allFinite) {
+template <int G>
+__device__ __forceinline__ bool grp_vertex_pass(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
+                                                int lane, bool allFinite) {
+  const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
   const int total = numX * numZ;
   const int cellsX = numX - 1, cellsZ = numZ - 1;
   const float minO2 = b.aabb[2];
   bool hit = false;
-  const int qz = 64 / numX, rx = 64 - qz * numX;
-  int xl = lane % numX, zl = lane / numX;
-  for (int e0 = 0; e0 < total; e0 += 64) {
-    const int e = e0 + lane;
+  const int qz = G / numX, rx = G - qz * numX;
+  int xl = gl % numX, zl = gl / numX;
+  int step = 0;
+  for (int e0 = 0; e0 < total; e0 += G, ++step) {
+    const int e = e0 + gl;
     if (e < total) {
       const float h = s.h[e];
       const bool coll = is_finite(h) && (h > minO2);
@@ -239,27 +320,30 @@ __device__ __forceinline__ bool wave_vertex_pass(const FieldDev& f, const BoxHF&
       xl -= numX;
       zl += 1;
     }
-    if (__any(hit)) return true;
+    if ((step & 3) == 3 && grp_any<G>(hit, lane)) return true;  // group-wide poll every 4th step
   }
-  return false;
+  return grp_any<G>(hit, lane);
 }
 
 // Kept triangles of the window in the reference's buffer order (x_local outer, z_local inner, ABC
 // before DBC; :1306-1441).  With WRITE_LIST the ids go to s.tri; returns T, or -1 on list overflow.
-template <bool WRITE_LIST>
-__device__ __forceinline__ int wave_compact_triangles(const BoxHF& b, const WaveScratch& s, int lane) {
+template <int G, bool WRITE_LIST>
+__device__ __forceinline__ int grp_compact_triangles(const BoxHF& b, const WaveScratch& s, int lane) {
+  const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
   const int cellsX = numX - 1, cellsZ = numZ - 1;
   const int ncells = cellsX * cellsZ;
   const float minO2 = b.aabb[2];
   int T = 0;
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int c0 = 0; c0 < ncells; c0 += 64) {
-    const int c = c0 + lane;
+  const unsigned long long lt_mask = grp_lt_mask<G>(lane);
+  const int cz_safe = cellsZ > 0 ? cellsZ : 1;
+  const int qc = G / cz_safe, rc = G - qc * cz_safe;  // advance of (cx, cz) per G cells
+  int cx = gl / cz_safe, cz = gl - cx * cz_safe;
+  for (int c0 = 0; c0 < ncells; c0 += G) {
+    const int c = c0 + gl;
     bool keepUp = false, keepDown = false;
     if (c < ncells) {
-      const int cx = c / cellsZ, cz = c - cx * cellsZ;
       const int e = cz * numX + cx;
       const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
       const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
@@ -268,7 +352,7 @@ __device__ __forceinline__ int wave_compact_triangles(const BoxHF& b, const Wave
       keepUp = (cA || cB || cC) && (fA && fB && fC);
       keepDown = (cB || cC || cD) && (fB && fC && fD);
     }
-    const unsigned long long bu = __ballot(keepUp), bd = __ballot(keepDown);
+    const unsigned long long bu = grp_ballot<G>(keepUp, lane), bd = grp_ballot<G>(keepDown, lane);
     const int n_here = __popcll(bu) + __popcll(bd);
     if (WRITE_LIST) {
       if (T + n_here > s.cap_tris) return -1;
@@ -277,9 +361,29 @@ __device__ __forceinline__ int wave_compact_triangles(const BoxHF& b, const Wave
       if (keepDown) s.tri[w] = (unsigned short)(2 * c + 1);
     }
     T += n_here;
+    cx += qc;
+    cz += rc;
+    if (cz >= cz_safe) {
+      cz -= cz_safe;
+      cx += 1;
+    }
   }
   if (WRITE_LIST) wave_lds_sync();
   return T;
+}
+
+// 64-lane spellings used by the single-call path below
+__device__ __forceinline__ void wave_scan_window(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
+                                                 int lane, WindowStats& w) {
+  grp_scan_window<64>(f, b, s, lane, w);
+}
+__device__ __forceinline__ bool wave_vertex_pass(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
+                                                 int lane, bool allFinite) {
+  return grp_vertex_pass<64>(f, b, s, lane, allFinite);
+}
+template <bool WRITE_LIST>
+__device__ __forceinline__ int wave_compact_triangles(const BoxHF& b, const WaveScratch& s, int lane) {
+  return grp_compact_triangles<64, WRITE_LIST>(b, s, lane);
 }
 
 __device__ __forceinline__ unsigned hash_u64(unsigned long long x) {
@@ -457,96 +561,107 @@ __device__ __forceinline__ bool wave_plane_stage(const FieldDev& f, const BoxHF&
 // among ALL kept triangles is a group of its own in the greedy grouping (:1511-1556), so its base
 // plane is its own plane and it can be decided alone.  Returns 0 / 1 when that settles the check, 2
 // when some candidate has a partner (the caller then runs the exact sequential grouping).
-__device__ __forceinline__ int wave_plane_stage_corners(const FieldDev& f, const BoxHF& b,
-                                                        const WaveScratch& s, int lane, int T) {
+template <int G>
+__device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const BoxHF& b,
+                                                       const WaveScratch& s, int lane, int T) {
+  const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
   const int cellsX = numX - 1, cellsZ = numZ - 1;
   const float minO2 = b.aabb[2];
-  // candidate (lane): corner = lane>>3, cell offset (dx, dz) = (lane&1, (lane>>1)&1), up/down = lane>>2 &1
-  const int corner = lane >> 3;
-  const float s0 = (corner & 1) ? 0.5f : -0.5f, s1 = (corner & 2) ? 0.5f : -0.5f, s2 = (corner & 4) ? 0.5f : -0.5f;
-  const float px = b.pos[0] + s0 * b.side[0] * b.R[0] + s1 * b.side[1] * b.R[1] + s2 * b.side[2] * b.R[2];
-  const float pz = b.pos[2] + s0 * b.side[0] * b.R[6] + s1 * b.side[1] * b.R[7] + s2 * b.side[2] * b.R[8];
   const float margin = 1.0e-3f;
-  const int cxa = (int)floorf((px - margin) * f.inv_w), cxb = (int)floorf((px + margin) * f.inv_w);
-  const int cza = (int)floorf((pz - margin) * f.inv_d), czb = (int)floorf((pz + margin) * f.inv_d);
-  const int dx = lane & 1, dz = (lane >> 1) & 1;
-  const bool c_up = !((lane >> 2) & 1);
-  const int cx = cxa + dx - b.minX, cz = cza + dz - b.minZ;  // window-local cell
-  bool is_cand = (cxa + dx <= cxb) && (cza + dz <= czb) && cx >= 0 && cz >= 0 && cx < cellsX && cz < cellsZ;
-  float cpl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  int cgx = 0, cgz = 0;
-  if (is_cand) {
-    const int e = cz * numX + cx;
-    const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
-    const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
-    const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
-    const bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
-    is_cand = kept;
-    if (kept) {
-      const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
-      const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;
-      if (c_up)
-        triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, cpl);
-      else
-        triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, cpl);
-      cgx = b.minX + cx + (c_up ? 0 : 1);
-      cgz = b.minZ + cz + (c_up ? 0 : 1);
+  float4* cand_pl = reinterpret_cast<float4*>(s.cand);   // [64] candidate planes (compacted)
+  int* cand_id = reinterpret_cast<int*>(s.cand) + 256;    // [64] id | corner-cell info, see below
+  // 64 candidate slots: corner = slot>>3, cell offset (dx, dz) = (slot&1, (slot>>1)&1), down = (slot>>2)&1.
+  // A group of G lanes walks them in 64/G rounds and compacts the kept ones into LDS.
+  int ncand = 0;
+  for (int r = 0; r < 64 / G; ++r) {
+    const int slot = gl + G * r;
+    const int corner = slot >> 3;
+    const float s0 = (corner & 1) ? 0.5f : -0.5f, s1 = (corner & 2) ? 0.5f : -0.5f,
+                s2 = (corner & 4) ? 0.5f : -0.5f;
+    const float px = b.pos[0] + s0 * b.side[0] * b.R[0] + s1 * b.side[1] * b.R[1] + s2 * b.side[2] * b.R[2];
+    const float pz = b.pos[2] + s0 * b.side[0] * b.R[6] + s1 * b.side[1] * b.R[7] + s2 * b.side[2] * b.R[8];
+    const int cxa = (int)floorf((px - margin) * f.inv_w), cxb = (int)floorf((px + margin) * f.inv_w);
+    const int cza = (int)floorf((pz - margin) * f.inv_d), czb = (int)floorf((pz + margin) * f.inv_d);
+    const int dx = slot & 1, dz = (slot >> 1) & 1;
+    const bool c_up = !((slot >> 2) & 1);
+    const int cx = cxa + dx - b.minX, cz = cza + dz - b.minZ;  // window-local cell
+    bool is_cand = (cxa + dx <= cxb) && (cza + dz <= czb) && cx >= 0 && cz >= 0 && cx < cellsX && cz < cellsZ;
+    float cpl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (is_cand) {
+      const int e = cz * numX + cx;
+      const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
+      const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
+      const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
+      const bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
+      is_cand = kept;
+      if (kept) {
+        const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
+        const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;
+        if (c_up)
+          triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, cpl);
+        else
+          triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, cpl);
+      }
     }
+    const unsigned long long m = grp_ballot<G>(is_cand, lane);
+    if (is_cand) {
+      const int w = ncand + __popcll(m & grp_lt_mask<G>(lane));
+      cand_pl[w] = make_float4(cpl[0], cpl[1], cpl[2], cpl[3]);
+      cand_id[w] = 2 * (cx * cellsZ + cz) + (c_up ? 0 : 1);  // same id as the kept-triangle list
+    }
+    ncand += __popcll(m);
   }
-  const unsigned long long cand_mask = __ballot(is_cand);
-  if (cand_mask == 0ull) return 0;  // no kept triangle under any box corner: nothing can accept
-  const int my_id = 2 * (cx * cellsZ + cz) + (c_up ? 0 : 1);
-  // compact candidate planes into LDS (ids alongside, so a triangle does not partner with itself)
-  const int ncand = __popcll(cand_mask);
-  if (is_cand) {
-    const int w = __popcll(cand_mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-    reinterpret_cast<float4*>(s.cand)[w] = make_float4(cpl[0], cpl[1], cpl[2], cpl[3]);
-    reinterpret_cast<int*>(s.cand)[256 + w] = my_id;
-  }
+  if (ncand == 0) return 0;  // no kept triangle under any box corner: nothing can accept a contact
   wave_lds_sync();
   // does any kept triangle have a plane epsilon-equal to a candidate's (other than itself)?
   bool partner = false;
-  const int slots = (T + 63) >> 6;
-  for (int sl = 0; sl < slots; ++sl) {
-    const int j = lane + 64 * sl;
-    if (j < T) {
-      const int id = s.tri[j];
-      const int c = id >> 1;
-      const bool up = !(id & 1);
-      const int tx = c / cellsZ, tz = c - tx * cellsZ;
-      const int e = tz * numX + tx;
-      const float xA = (float)(b.minX + tx) * f.sample_w, xB = (float)(b.minX + tx + 1) * f.sample_w;
-      const float zA = (float)(b.minZ + tz) * f.sample_d, zC = (float)(b.minZ + tz + 1) * f.sample_d;
-      const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
-      float pl[4];
-      if (up)
-        triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, pl);
-      else
-        triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, pl);
-      for (int q = 0; q < ncand; ++q) {
-        const float4 cp = reinterpret_cast<const float4*>(s.cand)[q];  // broadcast read
-        if (fabsf(pl[3] - cp.w) < ARTP_EPS) {
-          const int cid = reinterpret_cast<const int*>(s.cand)[256 + q];
-          if (cid != id && fabsf(pl[1] - cp.y) < ARTP_EPS && fabsf(pl[0] - cp.x) < ARTP_EPS &&
-              fabsf(pl[2] - cp.z) < ARTP_EPS)
-            partner = true;
-        }
+  for (int j = gl; j < T; j += G) {
+    const int id = s.tri[j];
+    const int c = id >> 1;
+    const bool up = !(id & 1);
+    const int tx = c / cellsZ, tz = c - tx * cellsZ;
+    const int e = tz * numX + tx;
+    const float xA = (float)(b.minX + tx) * f.sample_w, xB = (float)(b.minX + tx + 1) * f.sample_w;
+    const float zA = (float)(b.minZ + tz) * f.sample_d, zC = (float)(b.minZ + tz + 1) * f.sample_d;
+    const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
+    float pl[4];
+    if (up)
+      triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, pl);
+    else
+      triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, pl);
+    for (int q = 0; q < ncand; ++q) {
+      const float4 cp = cand_pl[q];  // broadcast read
+      if (fabsf(pl[3] - cp.w) < ARTP_EPS) {
+        if (cand_id[q] != id && fabsf(pl[1] - cp.y) < ARTP_EPS && fabsf(pl[0] - cp.x) < ARTP_EPS &&
+            fabsf(pl[2] - cp.z) < ARTP_EPS)
+          partner = true;
       }
     }
   }
-  if (__any(partner)) return 2;
+  if (grp_any<G>(partner, lane)) return 2;
   // all candidates are singleton groups: own plane, own contacts, own cell
   bool hit = false;
-  if (is_cand) {
+  for (int q = gl; q < ncand; q += G) {
+    const float4 cp = cand_pl[q];
+    const int id = cand_id[q];
+    const int c = id >> 1;
+    const bool up = !(id & 1);
+    const int tx = c / cellsZ, tz = c - tx * cellsZ;
+    const int gx = b.minX + tx + (up ? 0 : 1), gz = b.minZ + tz + (up ? 0 : 1);
     float cpos[4][3];
-    const int nc = box_plane_contacts(b, cpl[0], cpl[1], cpl[2], cpl[3], 10, cpos);
+    const int nc = box_plane_contacts(b, cp.x, cp.y, cp.z, cp.w, 10, cpos);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i < nc) hit = hit || is_on_heightfield2(f, cgx, cgz, cpos[i][0], cpos[i][2], c_up);
+      if (i < nc) hit = hit || is_on_heightfield2(f, gx, gz, cpos[i][0], cpos[i][2], up);
   }
-  return __any(hit) ? 1 : 0;
+  return grp_any<G>(hit, lane) ? 1 : 0;
+}
+
+__device__ __forceinline__ int wave_plane_stage_corners(const FieldDev& f, const BoxHF& b,
+                                                        const WaveScratch& s, int lane, int T) {
+  return grp_plane_stage_corners<64>(f, b, s, lane, T);
 }
 
 // The whole zone test in one call (used at the HeightMapBoxChecker boundary, artp_check_boxes).

@@ -38,7 +38,7 @@ struct SamplerDev {
   const float* plane_fit_std_dev;
 };
 
-#define ARTP_WAVES_PER_BLOCK 4
+#define ARTP_WAVES_PER_BLOCK 2
 
 // ---- per-wave LDS carve --------------------------------------------------------------------------
 struct ScratchCaps {  // sized on the host from the box diagonals / sample spacing
@@ -48,14 +48,14 @@ struct ScratchCaps {  // sized on the host from the box diagonals / sample spaci
 };
 
 __host__ __device__ __forceinline__ size_t scratch_bytes_per_wave(const ScratchCaps& c) {
-  return 2048 /* candidate planes + ids */ + (size_t)c.verts * 4 + (size_t)c.tab * 4 + (size_t)c.tris * 2;
+  return 1280 /* candidate planes + ids */ + (size_t)c.verts * 4 + (size_t)c.tab * 4 + (size_t)c.tris * 2;
 }
 
 __device__ __forceinline__ WaveScratch carve_scratch(char* smem, int wave_in_block, const ScratchCaps& c) {
   char* base = smem + scratch_bytes_per_wave(c) * wave_in_block;
   WaveScratch s;
   s.cand = reinterpret_cast<float*>(base);
-  base += 2048;
+  base += 1280;
   s.h = reinterpret_cast<float*>(base);
   s.tab = reinterpret_cast<unsigned*>(base + (size_t)c.verts * 4);
   s.tri = reinterpret_cast<unsigned short*>(base + (size_t)c.verts * 4 + (size_t)c.tab * 4);

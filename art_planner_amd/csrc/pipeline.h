@@ -148,9 +148,10 @@ struct __attribute__((aligned(16))) PendingBox {  // 96 bytes
 };
 
 struct PipelineQueues {
-  PendingBox* q1;                // undecided boxes
-  unsigned* q2;                  // indices into q1 of boxes that need the plane stage
-  unsigned long long* counters;  // [0] q1 count, [1] q2 count, [2] resolve cursor, [3] plane cursor
+  PendingBox* q1;                // undecided boxes: torso records at [0, n), foot records at [n, 5n)
+  unsigned* q2;                  // indices into q1 of boxes that need the exact-grouping stage
+  unsigned long long* counters;  // [0] torso count, [1] q2 count, [4] foot count
+  unsigned long long feet_base;  // = n
 };
 
 __device__ __forceinline__ void box_from_record(const PendingBox& r, const RobotDev& rb, BoxHF& b) {
@@ -160,9 +161,10 @@ __device__ __forceinline__ void box_from_record(const PendingBox& r, const Robot
   for (int i = 0; i < 9; ++i) b.R[i] = r.R[i];
 #pragma unroll
   for (int i = 0; i < 6; ++i) b.aabb[i] = r.aabb[i];
-  b.side[0] = r.kind ? rb.foot[0] : rb.torso[0];
-  b.side[1] = r.kind ? rb.foot[1] : rb.torso[1];
-  b.side[2] = r.kind ? rb.foot[2] : rb.torso[2];
+  const bool foot = (r.kind & 1u) != 0;
+  b.side[0] = foot ? rb.foot[0] : rb.torso[0];
+  b.side[1] = foot ? rb.foot[1] : rb.torso[1];
+  b.side[2] = foot ? rb.foot[2] : rb.torso[2];
   b.minX = r.minX;
   b.maxX = r.maxX;
   b.minZ = r.minZ;
@@ -192,6 +194,11 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
   }
 }
 
+// record flags (PendingBox::kind, bit 0 = foot)
+#define ARTP_REC_DECIDED 0x100u         // settled by the lane-per-box vertex pass
+#define ARTP_REC_NO_VERTEX_HIT 0x200u   // (f) already evaluated: no terrain vertex inside the box
+#define ARTP_REC_EXITS_NEGATIVE 0x400u  // exits (b)-(e) already evaluated (from the tables): none fired
+
 // ---- stage 1: one lane per state --------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, MapGeom g, RobotDev rb,
@@ -207,6 +214,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   pose3_from_se3(st, t, R);
   int ok = 1;
   unsigned pending = 0;
+  unsigned exits_neg = 0;  // boxes whose exits (b)-(e) were evaluated from the tables and did not fire
   for (int k = 0; k < 5; ++k) {
     const bool body = (k == 0);
     float pose[16];
@@ -226,8 +234,10 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       WindowStats w;
       int ec;
       const TablesDev& tk = body ? tb : tf;
-      if (!(tk.valid && table_window_stats(fk, tk, b, w) && decide_exits(b, w, hit, ec))) {
+      const bool have_stats = tk.valid && table_window_stats(fk, tk, b, w);
+      if (!(have_stats && decide_exits(b, w, hit, ec))) {
         pending |= 1u << k;
+        if (have_stats) exits_neg |= 1u << k;
         continue;
       }
     }
@@ -235,23 +245,27 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   }
   if (!ok || !live) pending = 0;  // a decided box already fails: the label is 0 whatever the others say
   if (live) valid[i] = (uint8_t)ok;
-  // queue slots for the whole wavefront with ONE atomic (a single word sustains only ~88 returning
-  // atomics per microsecond, MI355X_MICROARCH.md "dequeue")
+  // queue slots for the whole wavefront with ONE atomic per queue (a single word sustains only ~88
+  // returning atomics per microsecond, MI355X_MICROARCH.md "dequeue")
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int before = 0, wave_total = 0;
+  const unsigned long long bal_t = __ballot(pending & 1u);
+  int before_f = 0, total_f = 0;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 1; k < 5; ++k) {
     const unsigned long long bal = __ballot((pending >> k) & 1u);
-    before += __popcll(bal & lt_mask);
-    wave_total += __popcll(bal);
+    before_f += __popcll(bal & lt_mask);
+    total_f += __popcll(bal);
   }
-  unsigned long long wave_base = 0;
-  if (wave_total) {
-    if (lane == 0) wave_base = atomicAdd(&q.counters[0], (unsigned long long)wave_total);
-    wave_base = __shfl(wave_base, 0, 64);
+  unsigned long long base_t = 0, base_f = 0;
+  if (lane == 0) {
+    if (bal_t) base_t = atomicAdd(&q.counters[0], (unsigned long long)__popcll(bal_t));
+    if (total_f) base_f = atomicAdd(&q.counters[4], (unsigned long long)total_f);
   }
-  unsigned long long slot = wave_base + (unsigned long long)before;
+  base_t = __shfl(base_t, 0, 64);
+  base_f = __shfl(base_f, 0, 64);
+  const unsigned long long slot_t = base_t + (unsigned long long)__popcll(bal_t & lt_mask);
+  unsigned long long slot_f = q.feet_base + base_f + (unsigned long long)before_f;
   // second sweep: write the undecided boxes (recomputed -- cheaper than keeping five records live)
   for (int k = 0; k < 5; ++k) {
     if (!((pending >> k) & 1u)) continue;
@@ -262,8 +276,8 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     BoxHF b;
     setup_box(fk, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
               body ? rb.torso[2] : rb.foot[2], b);
-    PendingBox* r = q.q1 + slot;
-    ++slot;
+    PendingBox* r = q.q1 + (body ? slot_t : slot_f);
+    if (!body) ++slot_f;
     float4* dst = reinterpret_cast<float4*>(r);
     dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
     dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
@@ -272,7 +286,8 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
     const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
     dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
-    dst[5] = make_float4(__uint_as_float((unsigned)i), __uint_as_float(body ? 0u : 1u), 0.0f, 0.0f);
+    const unsigned kind = (body ? 0u : 1u) | (((exits_neg >> k) & 1u) ? ARTP_REC_EXITS_NEGATIVE : 0u);
+    dst[5] = make_float4(__uint_as_float((unsigned)i), __uint_as_float(kind), 0.0f, 0.0f);
   }
 }
 
@@ -282,56 +297,108 @@ __device__ __forceinline__ unsigned long long wave_fetch_item(unsigned long long
   return __shfl(item, 0, 64);
 }
 
-// ---- stage 2: one wavefront per undecided box ---------------------------------------------------------
-// Static striding over queue 1 (a shared work cursor would serialise on one atomic word).
-template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
-resolve_boxes_kernel(FieldDev fb, FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
-                     ScratchCaps caps, int* __restrict__ error_flag) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const WaveScratch s = carve_scratch(smem, threadIdx.x >> 6, caps);
-  const unsigned long long count = q.counters[0];
-  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES;
-  for (unsigned long long item = (unsigned long long)blockIdx.x * WAVES + (threadIdx.x >> 6); item < count;
-       item += stride) {
-    const PendingBox rec = q.q1[item];
-    if (valid[rec.state] == 0) continue;  // another box of this state already failed
+// ---- stage 1b: (f) for the foot queue, one LANE per box ----------------------------------------------
+// A foot window holds ~70 samples; walking it sequentially in one lane costs ~70 steps shared by 64
+// boxes per instruction, an order of magnitude less issue than a lane group per box.  Same predicate
+// as grp_vertex_pass (any colliding vertex of an all-finite triangle inside the box), so any hit
+// decides the box ("foot touches" = ok).  Boxes without a hit stay queued for stage 2, flagged so
+// that stage does not repeat the pass.
+__global__ void __launch_bounds__(256)
+feet_vertex_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q) {
+  const unsigned long long count = q.counters[4];
+  for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
+       it += (unsigned long long)gridDim.x * blockDim.x) {
+    PendingBox* rp = q.q1 + q.feet_base + it;
+    const PendingBox rec = *rp;
+    // (f) comes after the exits in the reference: only boxes whose exits are known not to fire
+    if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) continue;
     BoxHF b;
     box_from_record(rec, rb, b);
-    const FieldDev& f = rec.kind ? ff : fb;
+    const int numX = b.maxX - b.minX + 1, numZ = b.maxZ - b.minZ + 1;
+    const float minO2 = b.aabb[2];
+    const float* base = ff.data + b.minX + (size_t)b.minZ * ff.nW;
+    bool hit = false;
+    for (int zl = 0; zl < numZ && !hit; ++zl) {
+      const float vz = (float)(b.minZ + zl) * ff.sample_d;
+      for (int xl = 0; xl < numX; ++xl) {
+        const float h = base[xl + zl * ff.nW];
+        if (!(is_finite(h) && h > minO2)) continue;
+        const float vx = (float)(b.minX + xl) * ff.sample_w;
+        if (!point_in_box(b, vx, h, vz)) continue;
+        // member of a triangle whose three vertices are finite? (same six neighbours as grp_vertex_pass)
+        const bool xm = xl > 0, xp = xl < numX - 1, zm = zl > 0, zp = zl < numZ - 1;
+        const float* c = base + xl + zl * ff.nW;
+        const bool f_xp = xp && is_finite(c[1]);
+        const bool f_xm = xm && is_finite(c[-1]);
+        const bool f_zp = zp && is_finite(c[ff.nW]);
+        const bool f_zm = zm && is_finite(c[-ff.nW]);
+        const bool f_xm_zp = xm && zp && is_finite(c[ff.nW - 1]);
+        const bool f_xp_zm = xp && zm && is_finite(c[1 - ff.nW]);
+        const bool member = (f_xp && f_zp) || (f_xm && f_xm_zp) || (f_xm_zp && f_zp) || (f_zm && f_xp_zm) ||
+                            (f_xp_zm && f_xp) || (f_zm && f_xm);
+        if (member) {
+          hit = true;
+          break;
+        }
+      }
+    }
+    rp->kind = rec.kind | (hit ? ARTP_REC_DECIDED : ARTP_REC_NO_VERTEX_HIT);
+  }
+}
+
+// ---- stage 2: one lane group per undecided box ---------------------------------------------------------
+// G = 64: torso queue, one wavefront per box.  G = 16: foot queue, four boxes per wavefront.
+// Static striding over the queue (a shared work cursor would serialise on one atomic word).
+template <int WAVES, int G>
+__global__ void __launch_bounds__(64 * WAVES)
+resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
+                     ScratchCaps caps, int* __restrict__ error_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int GPW = 64 / G;  // groups per wavefront
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
+  const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
+  const bool feet = (G != 64);
+  const unsigned long long count = q.counters[feet ? 4 : 0];
+  const unsigned long long qbase = feet ? q.feet_base : 0ull;
+  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
+  for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
+       it += stride) {
+    const unsigned long long item = qbase + it;
+    const PendingBox rec = q.q1[item];
+    if (rec.kind & ARTP_REC_DECIDED) continue;  // settled by the lane-per-box vertex pass
+    if (valid[rec.state] == 0) continue;        // another box of this state already failed
+    BoxHF b;
+    box_from_record(rec, rb, b);
     const int total = (b.maxX - b.minX + 1) * (b.maxZ - b.minZ + 1);
     if (total > s.cap_verts) {
-      if (lane == 0) atomicExch(error_flag, 1);
+      if (gl == 0) atomicExch(error_flag, 1);
       continue;
     }
     WindowStats w;
-    wave_scan_window(f, b, s, lane, w);
+    grp_scan_window<G>(fld, b, s, lane, w);
     int result = 0, ec;
     bool decided = decide_exits(b, w, result, ec);
     if (!decided) {
-      if (wave_vertex_pass(f, b, s, lane, w.allFinite)) {
+      if (!(rec.kind & ARTP_REC_NO_VERTEX_HIT) && grp_vertex_pass<G>(fld, b, s, lane, w.allFinite)) {
         result = 1;
         decided = true;
       } else {
-        const int T = wave_compact_triangles<true>(b, s, lane);
-        if (T < 0) {
-          if (lane == 0) atomicExch(error_flag, 1);
-          wave_lds_sync();
-          continue;
-        }
-        const int r = (T == 0) ? 0 : wave_plane_stage_corners(f, b, s, lane, T);
+        const int T = grp_compact_triangles<G, true>(b, s, lane);
+        // T < 0: more kept triangles than the short list of this stage holds -> exact-grouping stage
+        const int r = (T == 0) ? 0 : (T < 0 ? 2 : grp_plane_stage_corners<G>(fld, b, s, lane, T));
         if (r != 2) {
           result = r;
           decided = true;
-        } else if (lane == 0) {  // a corner candidate has an epsilon-equal partner: exact grouping
+        } else if (gl == 0) {  // a corner candidate has an epsilon-equal partner: exact grouping
           const unsigned long long slot = atomicAdd(&q.counters[1], 1ull);
           q.q2[slot] = (unsigned)item;
         }
       }
     }
-    if (decided && lane == 0) {
-      const bool ok = rec.kind ? (result != 0) : (result == 0);
+    if (decided && gl == 0) {
+      const bool ok = (rec.kind & 1u) ? (result != 0) : (result == 0);
       if (!ok) valid[rec.state] = 0;
     }
     wave_lds_sync();
@@ -354,7 +421,7 @@ plane_stage_kernel(FieldDev fb, FieldDev ff, RobotDev rb, PipelineQueues q, uint
     if (valid[rec.state] == 0) continue;
     BoxHF b;
     box_from_record(rec, rb, b);
-    const FieldDev& f = rec.kind ? ff : fb;
+    const FieldDev& f = (rec.kind & 1u) ? ff : fb;
     WindowStats w;
     wave_scan_window(f, b, s, lane, w);
     const int T = wave_compact_triangles<true>(b, s, lane);
@@ -364,7 +431,7 @@ plane_stage_kernel(FieldDev fb, FieldDev ff, RobotDev rb, PipelineQueues q, uint
     }
     const int result = (T > 0 && wave_plane_stage(f, b, s, lane, T)) ? 1 : 0;
     if (lane == 0) {
-      const bool ok = rec.kind ? (result != 0) : (result == 0);
+      const bool ok = (rec.kind & 1u) ? (result != 0) : (result == 0);
       if (!ok) valid[rec.state] = 0;
     }
     wave_lds_sync();

@@ -195,6 +195,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     k_ms = ev0.elapsed_time(ev1) / reps
+    pipeline_counts = ctx.pipeline_counters()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -287,7 +288,7 @@ def main():
                                (", compacted valid states all-gathered over RCCL" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts,
         "device": ctx.arch,
     }
     print(json.dumps(out))

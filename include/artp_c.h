@@ -151,6 +151,9 @@ int artp_compact_valid_dev(artp_ctx* ctx, const double* se3, const uint8_t* vali
  * early-outs or short-circuiting, 0 for a box whose centre is outside the map or whose AABB is off
  * the field.  Host result. */
 int artp_algorithmic_vertices_dev(artp_ctx* ctx, const double* se3, size_t n, uint64_t* total_vertices);
+/* Diagnostics of the last validity batch: out[0] = torso boxes queued for the window stage,
+ * out[4] = foot boxes queued, out[1] = boxes that needed the exact plane grouping. */
+int artp_debug_pipeline_counters(artp_ctx* ctx, uint64_t out[8]);
 
 #ifdef __cplusplus
 }
