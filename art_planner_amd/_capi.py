@@ -18,7 +18,8 @@ SYMBOLS = [
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_algorithmic_vertices_dev",
-    "artp_debug_pipeline_counters",
+    "artp_debug_pipeline_counters", "artp_cost_blob_bytes", "artp_cost_load_weights",
+    "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
 
 
@@ -86,9 +87,16 @@ def load():
     L.artp_compact_valid_dev.argtypes = [vp, vp, vp, sz, vp, vp]
     L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
     L.artp_debug_pipeline_counters.argtypes = [vp, C.POINTER(u64 * 8)]
+    L.artp_cost_blob_bytes.argtypes = []
+    L.artp_cost_blob_bytes.restype = sz
+    L.artp_cost_load_weights.argtypes = [vp, vp, sz]
+    L.artp_cost_update_map.argtypes = [vp, vp, i32, i32, dbl, dbl, dbl, dbl, dbl]
+    L.artp_cost_query.argtypes = [vp, vp, sz, vp]
+    L.artp_cost_query_dev.argtypes = [vp, vp, sz, vp]
+    L.artp_cost_get_features.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("artp_destroy",):
+        if fn.restype is C.c_int and name not in ("artp_destroy", "artp_cost_blob_bytes"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -189,3 +189,31 @@ class Context:
         out = (C.c_uint64 * 8)()
         self._chk(self.L.artp_debug_pipeline_counters(self.h, C.byref(out)), "artp_debug_pipeline_counters")
         return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1]}
+
+    # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
+    def cost_load_weights(self, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._chk(self.L.artp_cost_load_weights(self.h, buf, len(blob)), "artp_cost_load_weights")
+
+    def cost_update_map(self, elev_xy, res, len_x, len_y, cx=0.0, cy=0.0):
+        a = np.ascontiguousarray(elev_xy, np.float32)
+        self._chk(self.L.artp_cost_update_map(self.h, a.ctypes.data, a.shape[0], a.shape[1], res, len_x, len_y,
+                                              cx, cy), "artp_cost_update_map")
+
+    def cost_query(self, edges):
+        e = np.ascontiguousarray(edges, np.float32).reshape(-1, 6)
+        out = np.empty((e.shape[0], 3), np.float32)
+        self._chk(self.L.artp_cost_query(self.h, e.ctypes.data, e.shape[0], out.ctypes.data), "artp_cost_query")
+        return out
+
+    def cost_query_dev(self, edges_t, cost_t):
+        self._chk(self.L.artp_cost_query_dev(self.h, edges_t.data_ptr(), edges_t.shape[0], cost_t.data_ptr()),
+                  "artp_cost_query_dev")
+
+    def cost_features(self):
+        fh, fw = C.c_int(0), C.c_int(0)
+        self._chk(self.L.artp_cost_get_features(self.h, None, C.byref(fh), C.byref(fw)), "artp_cost_get_features")
+        out = np.empty((fh.value, fw.value, 48), np.float32)
+        self._chk(self.L.artp_cost_get_features(self.h, out.ctypes.data, C.byref(fh), C.byref(fw)),
+                  "artp_cost_get_features")
+        return out

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pipeline.h"
+#include "cost_kernels.h"
 
 using namespace artp;
 
@@ -50,6 +51,21 @@ struct artp_ctx {
   size_t tmp_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void* cub_tmp = nullptr;
   size_t cub_cap = 0;
+  // motion cost (R8/R9)
+  bool have_weights = false;
+  float* d_conv1_w = nullptr;          // [24][9] + [24]
+  half8* d_convw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // packed B fragments, layers 2..6
+  float* d_convb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* d_fc = nullptr;               // FcWeights::TOTAL floats
+  half_t* d_act[2] = {nullptr, nullptr};
+  size_t act_cap = 0;
+  half_t* d_feat = nullptr;            // NHWC [Fh][Fw][48]
+  size_t feat_cap = 0;
+  float* d_map_f32 = nullptr;
+  size_t map_cap = 0;
+  CostMapGeom cost_geom{};
+  int feat_h = 0, feat_w = 0;
+  bool have_features = false;
   std::string last_error;
   std::string arch;
   std::mutex mu;
@@ -372,6 +388,16 @@ void artp_destroy(artp_ctx* c) {
     if (c->sat_buf[s]) (void)hipFree(c->sat_buf[s]);
   }
   if (c->cub_tmp) (void)hipFree(c->cub_tmp);
+  if (c->d_conv1_w) (void)hipFree(c->d_conv1_w);
+  for (int l = 0; l < 5; ++l) {
+    if (c->d_convw[l]) (void)hipFree(c->d_convw[l]);
+    if (c->d_convb[l]) (void)hipFree(c->d_convb[l]);
+  }
+  if (c->d_fc) (void)hipFree(c->d_fc);
+  for (int l = 0; l < 2; ++l)
+    if (c->d_act[l]) (void)hipFree(c->d_act[l]);
+  if (c->d_feat) (void)hipFree(c->d_feat);
+  if (c->d_map_f32) (void)hipFree(c->d_map_f32);
   if (c->d_error) (void)hipFree(c->d_error);
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -831,6 +857,235 @@ int artp_algorithmic_vertices_dev(artp_ctx* c, const double* se3, size_t n, uint
   HIP_TRY(c, hipMemcpyAsync(&v, c->d_count, sizeof(v), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *total = v;
+  return ARTP_OK;
+}
+
+}  // extern "C"
+
+// ---- learned motion cost (R8 / R9) ------------------------------------------------------------------
+namespace {
+
+struct ConvSpec { int cout, cin, kh, kw, nt; };
+// layers 2..6 of network.CNNpart (network_light.py:23-36)
+const ConvSpec kConv[5] = {{24, 24, 3, 3, 2}, {48, 24, 3, 3, 3}, {48, 48, 3, 3, 3}, {48, 48, 3, 3, 3}, {48, 48, 15, 15, 3}};
+
+size_t cost_blob_floats() {
+  size_t n = 24 * 9 + 24;
+  for (const ConvSpec& s : kConv) n += (size_t)s.cout * s.cin * s.kh * s.kw + s.cout;
+  return n + FcWeights::TOTAL;
+}
+
+inline uint16_t f32_to_f16_bits(float f) {  // round-to-nearest-even, host side
+  _Float16 h = (_Float16)f;
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t artp_cost_blob_bytes(void) { return 8 + cost_blob_floats() * sizeof(float); }
+
+int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
+  if (!c || !blob) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  const unsigned char* p = static_cast<const unsigned char*>(blob);
+  if (bytes != artp_cost_blob_bytes() || std::memcmp(p, "ARMC", 4) != 0 || p[4] != 1) {
+    c->last_error = "motion-cost blob: bad magic, version or size";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const float* w = reinterpret_cast<const float*>(p + 8);
+  if (!c->d_conv1_w) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_conv1_w), (216 + 24) * sizeof(float)));
+  HIP_TRY(c, hipMemcpy(c->d_conv1_w, w, (216 + 24) * sizeof(float), hipMemcpyHostToDevice));
+  w += 216 + 24;
+  for (int l = 0; l < 5; ++l) {
+    const ConvSpec& s = kConv[l];
+    const int krow = s.kw * s.cin, ksteps = (krow + 31) / 32;
+    const size_t nfrag = (size_t)s.kh * ksteps * s.nt * 64;
+    std::vector<uint16_t> packed(nfrag * 8, 0);
+    // B fragment of v_mfma_f32_16x16x32_f16: lane l holds B[k = (l>>4)*8 + j][n = l&15]
+    for (int kh = 0; kh < s.kh; ++kh)
+      for (int ks = 0; ks < ksteps; ++ks)
+        for (int nt = 0; nt < s.nt; ++nt)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+              const int co = nt * 16 + (l & 15);
+              const int kidx = ks * 32 + (l >> 4) * 8 + j;
+              float v = 0.f;
+              if (co < s.cout && kidx < krow) {
+                const int kw = kidx / s.cin, ci = kidx % s.cin;
+                v = w[(((size_t)co * s.cin + ci) * s.kh + kh) * s.kw + kw];  // torch [cout][cin][kh][kw]
+              }
+              packed[((((size_t)kh * ksteps + ks) * s.nt + nt) * 64 + l) * 8 + j] = f32_to_f16_bits(v);
+            }
+    w += (size_t)s.cout * s.cin * s.kh * s.kw;
+    if (c->d_convw[l]) HIP_TRY(c, hipFree(c->d_convw[l]));
+    if (c->d_convb[l]) HIP_TRY(c, hipFree(c->d_convb[l]));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convw[l]), packed.size() * 2));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convb[l]), 64 * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->d_convw[l], packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    float bias[64] = {0};
+    std::memcpy(bias, w, s.cout * sizeof(float));
+    HIP_TRY(c, hipMemcpy(c->d_convb[l], bias, sizeof(bias), hipMemcpyHostToDevice));
+    w += s.cout;
+  }
+  if (!c->d_fc) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_fc), FcWeights::TOTAL * sizeof(float)));
+  HIP_TRY(c, hipMemcpy(c->d_fc, w, FcWeights::TOTAL * sizeof(float), hipMemcpyHostToDevice));
+  c->have_weights = true;
+  return ARTP_OK;
+}
+
+static int cost_run_cnn(artp_ctx* c, int H, int W) {
+  // shapes: network_light.py:84-107
+  const int h1 = H - 2, w1 = W - 2, h2 = h1 - 2, w2 = w1 - 2, hp = h2 / 2, wpp = w2 / 2;
+  const int h3 = hp - 2, w3 = wpp - 2, h4 = h3 - 2, w4 = w3 - 2, hq = h4 - 2, wq = w4 - 2;
+  const int h5 = hq - 2, w5 = wq - 2, hf = h5 - 14, wf = w5 - 14;
+  if (hf < 3 || wf < 3) {
+    c->last_error = "map too small for the motion-cost feature extractor";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  const size_t act_bytes = (size_t)h1 * w1 * 24 * 2 + 8192;
+  if (c->act_cap < act_bytes) {
+    for (int l = 0; l < 2; ++l) {
+      if (c->d_act[l]) HIP_TRY(c, hipFree(c->d_act[l]));
+      c->d_act[l] = nullptr;
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_act[l]), act_bytes));
+      HIP_TRY(c, hipMemset(c->d_act[l], 0, act_bytes));
+    }
+    c->act_cap = act_bytes;
+  }
+  const size_t feat_bytes = (size_t)hf * wf * 48 * 2 + 256;
+  if (c->feat_cap < feat_bytes) {
+    if (c->d_feat) HIP_TRY(c, hipFree(c->d_feat));
+    c->d_feat = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_feat), feat_bytes));
+    c->feat_cap = feat_bytes;
+  }
+  half_t* A = c->d_act[0];
+  half_t* Bf = c->d_act[1];
+  hipStream_t st = c->stream;
+  // input fp16 lives at the tail of buffer B while conv1 writes buffer A
+  half_t* in16 = Bf;
+  {
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const float*)c->d_map_f32, n, in16);
+    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)(((size_t)h1 * w1 + 255) / 256)), dim3(256), 0, st,
+                       (const half_t*)in16, H, W, (const float*)c->d_conv1_w, (const float*)(c->d_conv1_w + 216), A);
+  }
+  auto grid_for = [](int hout, int wout, int mt) {
+    const size_t waves = (size_t)((wout + 16 * mt - 1) / (16 * mt)) * hout;
+    return dim3((unsigned)((waves + 3) / 4));
+  };
+  // conv2 + BN + lrelu (A -> B), maxpool 2/2 (B -> A)
+  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 24, 24, 2, 2, true>), grid_for(h2, w2, 2), dim3(256), 0, st,
+                     (const half_t*)A, h1, w1, (const half8*)c->d_convw[0], (const float*)c->d_convb[0], Bf);
+  hipLaunchKernelGGL((maxpool_kernel<2, 2>), dim3((unsigned)(((size_t)hp * wpp * 24 + 255) / 256)), dim3(256), 0, st,
+                     (const half_t*)Bf, h2, w2, 24, A);
+  // conv3 (A -> B), conv4 (B -> A), maxpool 3/1 (A -> B)
+  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 24, 48, 3, 2, true>), grid_for(h3, w3, 2), dim3(256), 0, st,
+                     (const half_t*)A, hp, wpp, (const half8*)c->d_convw[1], (const float*)c->d_convb[1], Bf);
+  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 48, 48, 3, 2, true>), grid_for(h4, w4, 2), dim3(256), 0, st,
+                     (const half_t*)Bf, h3, w3, (const half8*)c->d_convw[2], (const float*)c->d_convb[2], A);
+  hipLaunchKernelGGL((maxpool_kernel<3, 1>), dim3((unsigned)(((size_t)hq * wq * 48 + 255) / 256)), dim3(256), 0, st,
+                     (const half_t*)A, h4, w4, 48, Bf);
+  // conv5 (B -> A), flatten 15x15 (A -> features)
+  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 48, 48, 3, 2, true>), grid_for(h5, w5, 2), dim3(256), 0, st,
+                     (const half_t*)Bf, hq, wq, (const half8*)c->d_convw[3], (const float*)c->d_convb[3], A);
+  hipLaunchKernelGGL((conv_mfma_kernel<15, 15, 48, 48, 3, 2, true>), grid_for(hf, wf, 2), dim3(256), 0, st,
+                     (const half_t*)A, h5, w5, (const half8*)c->d_convw[4], (const float*)c->d_convb[4], c->d_feat);
+  HIP_TRY(c, hipGetLastError());
+  c->feat_h = hf;
+  c->feat_w = wf;
+  return ARTP_OK;
+}
+
+int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, double res, double len_x,
+                         double len_y, double cx, double cy) {
+  if (!c || !elev_xy || rows < 1 || cols < 1 || !(res > 0)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = (size_t)rows * cols;
+  if (c->map_cap < n) {
+    if (c->d_map_f32) HIP_TRY(c, hipFree(c->d_map_f32));
+    c->d_map_f32 = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_map_f32), n * sizeof(float)));
+    c->map_cap = n;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_map_f32, elev_xy, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  const int rc = cost_run_cnn(c, rows, cols);
+  if (rc) return rc;
+  // CostQuery.setMapParams (cost_query.py:26-35): featureResFactor = 2, mapClip = 24
+  CostMapGeom& g = c->cost_geom;
+  g.F = c->feat_h;  // square maps in the reference; the column extent is feat_w (see fc kernel clamp)
+  g.feat_res = res * 2;
+  g.row_bias = (int)((len_x / res - 2 * 24) / 2 * 0.5);
+  g.col_bias = (int)((len_y / res - 2 * 24) / 2 * 0.5);
+  g.cx = cx;
+  g.cy = cy;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_features = true;
+  return ARTP_OK;
+}
+
+int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) {
+  if (!c || (b && (!edges || !cost))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
+  if (!c->have_features) return ARTP_ERR_NO_MAP;
+  if (b == 0) return ARTP_OK;
+  if (c->feat_h != c->feat_w) {
+    c->last_error = "cost query supports square feature maps";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), FcWeights::TOTAL * sizeof(float),
+                     c->stream, edges, b, (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+int artp_cost_query(artp_ctx* c, const float* edges, size_t b, float* cost) {
+  if (!c || (b && (!edges || !cost))) return ARTP_ERR_INVALID_ARG;
+  if (b == 0) return ARTP_OK;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_tmp(c, 0, b * 6 * sizeof(float));
+    if (rc) return rc;
+    rc = ensure_tmp(c, 1, b * 3 * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], edges, b * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = artp_cost_query_dev(c, static_cast<const float*>(c->tmp[0]), b, static_cast<float*>(c->tmp[1]));
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipMemcpyAsync(cost, c->tmp[1], b * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
+}
+
+// Copy the feature map out (tests / diagnostics): NHWC fp16 -> float [F][F][48]
+int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
+  if (!c || !fh || !fw) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_features) return ARTP_ERR_NO_MAP;
+  *fh = c->feat_h;
+  *fw = c->feat_w;
+  if (!out) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->feat_h * c->feat_w * 48;
+  std::vector<uint16_t> tmp(n);
+  HIP_TRY(c, hipMemcpy(tmp.data(), c->d_feat, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    _Float16 h;
+    std::memcpy(&h, &tmp[i], 2);
+    out[i] = (float)h;
+  }
   return ARTP_OK;
 }
 

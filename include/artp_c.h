@@ -155,6 +155,29 @@ int artp_algorithmic_vertices_dev(artp_ctx* ctx, const double* se3, size_t n, ui
  * out[4] = foot boxes queued, out[1] = boxes that needed the exact plane grouping. */
 int artp_debug_pipeline_counters(artp_ctx* ctx, uint64_t out[8]);
 
+/* ---- learned motion cost: MotionCostObjective::MotionCostFunc
+ *      (art_planner/include/art_planner/objectives/motion_cost_objective.h:22-23; the reference
+ *      implements it as a ROS service to the Python/CUDA node, art_planner_ros/src/planner_ros.cpp:
+ *      283-318 -> art_planner_motion_cost/scripts/cost_query_server.py:145-169) ----------------------
+ * Weights: a flat float32 blob of the n48convNetwork3LR network (network_light.py:19-62) with eval-mode
+ * BatchNorm folded into every convolution: "ARMC", version byte 1, 3 pad bytes, then for the six
+ * convolutions [Cout][Cin][KH][KW] weights + [Cout] bias, then the 1x1 layers tar0, out0, out1_conv1..3
+ * ([Cout][Cin] + [Cout]) and out2_conv1..3 ([Cin] + 1).  tools/convert_weights.py writes it from a
+ * torch state_dict. */
+size_t artp_cost_blob_bytes(void);
+int artp_cost_load_weights(artp_ctx* ctx, const void* blob, size_t bytes);
+/* CostPredictor.updateFeatures (predictor.py:28-36) + CostQuery.setMapParams (cost_query.py:26-35):
+ * elev_xy is the server's map array [rows][cols] row-major with index a growing along world x and b
+ * along world y (cost_query_server.py:66-74), holes already inpainted; (cx, cy) = map centre. */
+int artp_cost_update_map(artp_ctx* ctx, const float* elev_xy, int rows, int cols, double res, double len_x,
+                         double len_y, double cx, double cy);
+/* MotionCostFunc: edges [B][6] = target x y yaw, start x y yaw (prm_motion_cost.cpp:41-52);
+ * cost [B][3] = energy, time, risk (= 1 - prob; cost_query.py:65-69). */
+int artp_cost_query(artp_ctx* ctx, const float* edges, size_t b, float* cost);
+int artp_cost_query_dev(artp_ctx* ctx, const float* edges, size_t b, float* cost);
+/* diagnostics: feature map as float [fh][fw][48]; out may be NULL to query the size */
+int artp_cost_get_features(artp_ctx* ctx, float* out, int* fh, int* fw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,90 @@
+"""Learned motion cost: numpy oracle vs reference golden vectors (CPU suite) and
+the HIP MFMA conv stack + per-edge MLP vs the same vectors (GPU suite)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import common
+
+sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+import motion_cost_oracle as mo  # noqa: E402
+import convert_weights  # noqa: E402
+
+GOLD = np.load(os.path.join(common.GOLDEN_DIR, "motion_cost.npz"))
+
+
+def test_oracle_matches_reference_network_golden():
+    p = mo.random_params(0)
+    crop = GOLD["crop"].astype(np.float32)
+    res = float(GOLD["res"])
+    L = crop.shape[0] * res
+    f = mo.cnn_features(p, crop)
+    assert f.shape == (48, 32, 32)
+    assert np.abs(f - GOLD["features"]).max() < 1e-3
+    c = mo.fc_costs(p, GOLD["features"], GOLD["edges"], res, L, L)
+    assert np.abs(c - GOLD["costs"]).max() < 1e-4
+
+
+def test_blob_layout():
+    blob = convert_weights.to_blob(mo.random_params(0))
+    n_conv = sum(int(np.prod(mo.SHAPES[k])) + mo.SHAPES[k][0] for k in convert_weights.CONVS)
+    n_fc = sum(int(np.prod(mo.SHAPES[k])) + mo.SHAPES[k][0] for k in convert_weights.FC_BN)
+    n_out = sum(int(np.prod(mo.SHAPES[k])) + 1 for k in convert_weights.FC_OUT)
+    assert len(blob) == 8 + 4 * (n_conv + n_fc + n_out)
+    assert blob[:4] == b"ARMC" and blob[4] == 1
+    from art_planner_amd import _capi
+    assert _capi.load().artp_cost_blob_bytes() == len(blob)
+
+
+@pytest.mark.gpu
+def test_gpu_features_and_costs_match_reference_golden():
+    """fp16 activations / fp32 accumulate on the matrix cores vs the reference network in float32:
+    features within 2e-2 absolute (values reach +-5; six fp16-rounded layers, K up to 10800),
+    edge costs within 2e-3 relative + 2e-3 absolute (SURVEY.md 8c tolerance for the fp16 path)."""
+    from art_planner_amd.context import Context
+    ctx = Context(0, "yaml")
+    ctx.cost_load_weights(convert_weights.to_blob(mo.random_params(0)))
+    crop = GOLD["crop"].astype(np.float32)
+    res = float(GOLD["res"])
+    L = crop.shape[0] * res
+    ctx.cost_update_map(crop, res, L, L)
+    f = ctx.cost_features()                      # [F][F][48]
+    ref = np.transpose(GOLD["features"], (1, 2, 0))
+    assert f.shape == ref.shape
+    err = np.abs(f - ref)
+    assert err.max() < 2e-2, (err.max(), err.mean())
+    assert err.mean() < 2e-3
+    c = ctx.cost_query(GOLD["edges"])
+    cerr = np.abs(c - GOLD["costs"])
+    assert (cerr <= 2e-3 * np.abs(GOLD["costs"]) + 2e-3).all(), cerr.max()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cost_full_map_properties(big_map):
+    """C3 size (400x400): feature map 176x176; queries are deterministic, depend only on the start cell
+    and the delta pose, and clamp at the feature-map border like the reference."""
+    from art_planner_amd.context import Context
+    ctx = Context(0, "yaml")
+    p = mo.random_params(0)
+    ctx.cost_load_weights(convert_weights.to_blob(p))
+    elv = np.ascontiguousarray(big_map["elevation"][::-1, ::-1]).astype(np.float32)
+    ctx.cost_update_map(elv, big_map.res, big_map.len_x, big_map.len_y)
+    f = ctx.cost_features()
+    assert f.shape == (176, 176, 48) and np.isfinite(f).all()
+    rng = np.random.default_rng(1)
+    B = 50000
+    s = rng.uniform(-9, 9, (B, 2))      # some starts outside the 16 m map -> clamped rows/cols
+    d = rng.uniform(-0.5, 0.5, (B, 2))
+    e = np.stack([s[:, 0] + d[:, 0], s[:, 1] + d[:, 1], rng.uniform(-3, 3, B), s[:, 0], s[:, 1],
+                  rng.uniform(-3, 3, B)], 1).astype(np.float32)
+    c1 = ctx.cost_query(e)
+    assert np.array_equal(c1, ctx.cost_query(e))
+    assert (c1[:, 0] >= 0).all() and (c1[:, 1] >= 0).all() and ((c1[:, 2] >= 0) & (c1[:, 2] <= 1)).all()
+    # against the numpy oracle fed with the GPU's own feature map (isolates the per-edge MLP, fp32)
+    co = mo.fc_costs(p, np.transpose(f, (2, 0, 1)), e[:4096], big_map.res, big_map.len_x, big_map.len_y)
+    assert np.abs(c1[:4096] - co).max() < 1e-3
+    ctx.close()
