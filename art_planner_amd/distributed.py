@@ -1,0 +1,52 @@
+"""Multi-GPU plumbing of the sampling + validity path: one process per GPU (torch.distributed; backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The path shards over independent sample-index ranges: rank r of W owns the states
+[ (step*W + r)*S, (step*W + r + 1)*S ) of the global counter-based sample stream, so the union over ranks
+and steps is a gap-free, overlap-free prefix of the stream whatever W is.  The only exchange step is the
+all-gather of the ACCEPTED states (every rank's planner front end needs all of them): fixed-capacity
+blocks {count, states[cap]} so the collective has a static shape and can run on a side stream.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+def shard_first_index(step: int, rank: int, world: int, batch: int) -> int:
+    """First global sample index of (step, rank)."""
+    return (step * world + rank) * batch
+
+
+class ValidStateGatherer:
+    """All-gather of compacted valid states with a fixed per-rank capacity."""
+
+    def __init__(self, world: int, cap: int, device, dtype=torch.float64, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.cap, self.group = world, cap, group
+        self.gathered = torch.empty((world, cap, 7), dtype=dtype, device=device)
+        self.counts = torch.empty(world, dtype=torch.int64, device=device)
+
+    def gather(self, compact: torch.Tensor, count: torch.Tensor):
+        """compact: [>=cap, 7] states with the valid ones first; count: int64[1].  Asynchronous on the
+        current stream for NCCL."""
+        self.dist.all_gather_into_tensor(self.counts, count, group=self.group)
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), compact[:self.cap].reshape(-1),
+                                         group=self.group)
+
+    def merged(self) -> Tuple[torch.Tensor, bool]:
+        """Valid states of all ranks in rank order (host sync).  Second value: no block overflowed."""
+        counts = self.counts.tolist()
+        ok = all(c <= self.cap for c in counts)
+        parts = [self.gathered[r, :min(c, self.cap)] for r, c in enumerate(counts)]
+        return torch.cat(parts, 0), ok
+
+
+def agree_capacity(local_max_count: int, batch: int, device, slack: float = 1.1, group=None) -> int:
+    """Common block capacity: max over ranks of the observed valid count, plus slack."""
+    import torch.distributed as dist
+    t = torch.tensor([int(local_max_count * slack) + 1024], device=device, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return min(int(t.item()), batch)

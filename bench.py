@@ -112,28 +112,35 @@ def main():
     comm = torch.cuda.Stream(device=dev) if do_gather else None
 
     def first_index(step):
-        return (step * N + rank) * S
+        from art_planner_amd.distributed import shard_first_index
+        return shard_first_index(step, rank, N, S)
 
     # ---- warmup (also sizes the fixed-capacity all-gather blocks) -----------------------------
     cap = 0
     compact = [None, None]
     counts = [None, None]
-    gathered = gcounts = None
+    gatherer = None
+    gather_error = None
     for i in range(max(W, 1)):
         c = ctx.sample_and_validate_dev(seed, first_index(1000000 + i), S, se3, valid, count=True)
         cap = max(cap, c)
     torch.cuda.synchronize()
     if do_gather:
-        cap_t = torch.tensor([int(cap * 1.1) + 1024], device=dev, dtype=torch.int64)
-        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
-        cap = min(int(cap_t.item()), S)
+        from art_planner_amd.distributed import ValidStateGatherer, agree_capacity
+        cap = agree_capacity(cap, S, dev)
         compact = [torch.zeros((S, 7), dtype=torch.float64, device=dev) for _ in range(2)]
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
-        gathered = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)
-        gcounts = torch.empty(N, dtype=torch.int64, device=dev)
+        gatherer = ValidStateGatherer(N, cap, dev)
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         for e in done_ev:
             e.record()
+        try:  # trial exchange outside the timed region; a failing collective must not lose the whole run
+            ctx.compact_valid_dev(se3, valid, compact[0], counts[0])
+            gatherer.gather(compact[0], counts[0])
+            torch.cuda.synchronize()
+        except Exception as ex:  # pragma: no cover
+            gather_error = repr(ex)
+            do_gather = False
 
     def step(i):
         ctx.sample_and_validate_dev(seed, first_index(i), S, se3, valid)
@@ -145,8 +152,7 @@ def main():
             ready.record()
             comm.wait_event(ready)
             with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(gcounts, counts[b])
-                dist.all_gather_into_tensor(gathered.view(N, -1), compact[b][:cap].reshape(-1))
+                gatherer.gather(compact[b], counts[b])
                 done_ev[b].record()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides -----------------------
@@ -164,7 +170,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        assert int(gcounts.max().item()) <= cap, "all-gather block capacity exceeded"
+        assert (not do_gather) or int(gatherer.counts.max().item()) <= cap, "all-gather block capacity exceeded"
     total_states = N * S * K
     value = total_states / dt
 
@@ -246,6 +252,54 @@ def main():
             edges[name] = {"edges": E, "edges_per_s": E / (ms * 1e-3), "ms": ms,
                            "valid_frac": float(ev.float().mean().item())}
 
+    # ---- C3 extras: learned motion cost (seeded random weights: the trained ones are git-LFS stubs) ----
+    motion_cost = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import convert_weights
+        ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
+        elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)  # cost_query_server.py:66-74
+        ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y)   # H2D of the map + CNN, synchronous
+        cnn_ms = (time.perf_counter() - t0) / 5 * 1e3
+        shp = []
+        h = gm.rows
+        for (k, cin, cout, pool) in ((3, 1, 24, 0), (3, 24, 24, 2), (3, 24, 48, 0), (3, 48, 48, 3), (3, 48, 48, 0),
+                                     (15, 48, 48, 0)):
+            h = h - k + 1
+            shp.append(2.0 * k * k * cin * cout * h * h)
+            if pool == 2:
+                h //= 2
+            elif pool == 3:
+                h -= 2
+        cnn_gflop = sum(shp) / 1e9
+        Bq = 1 << 20
+        if E > 0:
+            reps_e = (Bq + E - 1) // E
+            em = np.concatenate([np.concatenate([b[:, [0, 1]], np.arctan2(2 * (b[:, 6] * b[:, 5] + b[:, 3] * b[:, 4]),
+                                 1 - 2 * (b[:, 4] ** 2 + b[:, 5] ** 2))[:, None],
+                                 a[:, [0, 1]], np.arctan2(2 * (a[:, 6] * a[:, 5] + a[:, 3] * a[:, 4]),
+                                 1 - 2 * (a[:, 4] ** 2 + a[:, 5] ** 2))[:, None]], 1)] * reps_e)[:Bq]
+            edges_t = torch.from_numpy(np.ascontiguousarray(em, dtype=np.float32)).to(dev)
+            cost_t = torch.empty((Bq, 3), dtype=torch.float32, device=dev)
+            ctx.cost_query_dev(edges_t, cost_t)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(5):
+                ctx.cost_query_dev(edges_t, cost_t)
+            ev1.record()
+            torch.cuda.synchronize()
+            q_ms = ev0.elapsed_time(ev1) / 5
+            motion_cost = {"cnn_ms_incl_h2d": cnn_ms, "cnn_gflop": cnn_gflop,
+                           "cnn_tflops": cnn_gflop / cnn_ms, "cnn_frac_of_mfma_f16_peak": cnn_gflop / cnn_ms / 2500.0,
+                           "cost_queries": Bq, "cost_queries_per_s": Bq / (q_ms * 1e-3), "cost_query_ms": q_ms,
+                           "weights": "seeded random (tools/convert_weights.random_params(0))"}
+    except Exception as ex:  # pragma: no cover
+        motion_cost = {"error": repr(ex)}
+
     cpu = None
     if N == 1 and not args.no_cpu_baseline:
         cpu, cpu_labels, _ = cpu_baseline(gm, states)
@@ -288,8 +342,8 @@ def main():
                                (", compacted valid states all-gathered over RCCL" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts,
-        "device": ctx.arch,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost,
+        "device": ctx.arch, "gather_error": gather_error,
     }
     print(json.dumps(out))
     sys.stdout.flush()

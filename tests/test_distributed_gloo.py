@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks shard the sample-index stream, label their shards (CPU oracle as the
+stand-in for the per-GPU kernels), compact, all-gather fixed-capacity blocks -- and every rank ends up
+with exactly the valid set a single process computes for the union range."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import common
+import oracle_py as O
+from art_planner_amd.distributed import ValidStateGatherer, agree_capacity, shard_first_index
+from art_planner_amd.synthetic import make_map
+
+BATCH, STEPS, WORLD = 512, 3, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_valid(gm, rob, step, rank, world):
+    smp = O.OracleSampler(gm)
+    se3, _ = smp.sample(rob, 42, shard_first_index(step, rank, world, BATCH), BATCH)
+    valid = O.OracleMap(gm).states_valid(rob, se3)
+    return se3, valid
+
+
+def _worker(rank, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    gm = make_map(96, 0.04, seed=3)
+    rob = O.robot("yaml")
+    dev = torch.device("cpu")
+    # warm-up step sizes the blocks
+    _, v0 = _shard_valid(gm, rob, 1000, rank, WORLD)
+    cap = agree_capacity(int(v0.sum()), BATCH, dev)
+    g = ValidStateGatherer(WORLD, cap, dev)
+    merged = []
+    for step in range(STEPS):
+        se3, valid = _shard_valid(gm, rob, step, rank, WORLD)
+        comp = torch.zeros((BATCH, 7), dtype=torch.float64)
+        sel = torch.from_numpy(se3[valid != 0])
+        comp[:len(sel)] = sel
+        g.gather(comp, torch.tensor([len(sel)], dtype=torch.int64))
+        m, ok = g.merged()
+        assert ok
+        merged.append(m.numpy().copy())
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate(merged, 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shards_tile_the_stream():
+    seen = []
+    for world in (1, 2, 4, 8):
+        idx = sorted(shard_first_index(s, r, world, BATCH) for s in range(4) for r in range(world))
+        assert idx == [k * BATCH for k in range(4 * world)]
+        seen.append(idx)
+
+
+def test_two_rank_gather_equals_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    r0 = np.load(tmp_path / "rank0.npy")
+    r1 = np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1)          # every rank holds the same gathered set
+    # single process over the union range, in (step, rank) order
+    gm = make_map(96, 0.04, seed=3)
+    rob = O.robot("yaml")
+    ref = []
+    for step in range(STEPS):
+        for rank in range(WORLD):
+            se3, valid = _shard_valid(gm, rob, step, rank, WORLD)
+            ref.append(se3[valid != 0])
+    ref = np.concatenate(ref, 0)
+    assert np.array_equal(r0, ref)
+    assert len(ref) > 0
