@@ -188,7 +188,7 @@ class Context:
     def pipeline_counters(self):
         out = (C.c_uint64 * 8)()
         self._chk(self.L.artp_debug_pipeline_counters(self.h, C.byref(out)), "artp_debug_pipeline_counters")
-        return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1]}
+        return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1], "feet_plane_stage": out[5]}
 
     # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
     def cost_load_weights(self, blob: bytes):

@@ -40,9 +40,9 @@ struct artp_ctx {
   int* sat_buf[2] = {nullptr, nullptr};
   size_t table_elems[2] = {0, 0};
   TablesDev tables[2]{};
-  ScratchCaps caps_full{0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
-  ScratchCaps caps_scan{0, 0, 0};  // torso resolve stage: window tile + short triangle list, per wave
-  ScratchCaps caps_feet{0, 0, 0};  // foot resolve stage: per 16-lane group
+  ScratchCaps caps_full{0, 0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
+  ScratchCaps caps_scan{0, 0, 0, 0};  // torso resolve stage: window tile + short triangle list, per wave
+  ScratchCaps caps_feet{0, 0, 0, 0};  // foot resolve stage: per 16-lane group
   int n_cus = 256;
   // device scratch
   int* d_error = nullptr;
@@ -161,9 +161,13 @@ int size_scratch(artp_ctx* c) {
   tris = (tris + 7) & ~7L;
   long tab = 64;
   while (tab < 2 * tris && tab < 4096) tab <<= 1;  // partner-detection fast path up to tab/2 triangles
-  c->caps_full = ScratchCaps{(int)verts, (int)tris, (int)tab};
+  if (maxdim > 64) {
+    c->last_error = "box window wider than 64 samples: not supported by the packed triangle ids";
+    return ARTP_ERR_CAPACITY;
+  }
+  c->caps_full = ScratchCaps{64 * 36, (int)verts, (int)tris, (int)tab};
   // resolve stage: window tile + a short triangle list (longer lists take the exact-grouping stage)
-  c->caps_scan = ScratchCaps{(int)verts, (int)(tris < 1024 ? tris : 1024), 0};
+  c->caps_scan = ScratchCaps{64 * 36, (int)verts, (int)(tris < 1024 ? tris : 1024), 0};
   {
     int fdim = (int)std::ceil(d_foot / spacing) + 4;
     if (fdim > max_n) fdim = max_n;
@@ -171,7 +175,7 @@ int size_scratch(artp_ctx* c) {
     long fv = ((long)fdim * fdim + 3) & ~3L;
     long ft = (2L * (fdim - 1) * (fdim - 1) + 7) & ~7L;
     if (ft > 1024) ft = 1024;
-    c->caps_feet = ScratchCaps{(int)fv, (int)ft, 0};
+    c->caps_feet = ScratchCaps{32 * 36, (int)fv, (int)ft, 0};
   }
   if (scratch_bytes_per_wave(c->caps_full) > 160 * 1024 ||
       scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK > 160 * 1024) {
@@ -265,18 +269,20 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   }
   int rc = ensure_tmp(c, 4, 5 * n * sizeof(PendingBox));
   if (rc) return rc;
-  rc = ensure_tmp(c, 5, 5 * n * sizeof(unsigned) + 64);
+  rc = ensure_tmp(c, 5, (5 + 4 + 4) * n * sizeof(unsigned) + 64);
   if (rc) return rc;
   PipelineQueues q;
   q.q1 = static_cast<PendingBox*>(c->tmp[4]);
   q.counters = static_cast<unsigned long long*>(c->tmp[5]);
   q.q2 = reinterpret_cast<unsigned*>(q.counters + 8);
+  q.q3 = q.q2 + 5 * n;
+  q.q5 = q.q3 + 4 * n;
   q.feet_base = n;
   HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
-  hipLaunchKernelGGL(feet_vertex_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(256), 0, c->stream, c->field[1],
-                     c->robot, q);
+  hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
+                     c->field[1], c->robot, q, valid);
   hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64>), dim3(grid_scan(c, lds_scan(c))),
                      dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->robot, q, valid,
                      c->caps_scan, c->d_error);
@@ -473,6 +479,16 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
   r_from_2_axes(f.R, -1, 0, 0, 0, 0, 1);  // height_map_box_checker.cpp:22
   orthogonalize_R(f.R);                  // dBodySetRotation, :25
   f.has_nan = has_nan;
+  {
+    // relative spread of the constant cross component (sample_w * sample_d) between cells: the sample
+    // coordinates are products float(index) * spacing, so a coordinate difference carries an absolute
+    // error of ~2 ulp(map length); see DESIGN.md 4.1 for the bound partner_tol = 4 * (delta + 1e-5)
+    const double map_len = std::fmax((double)f.width, (double)f.depth);
+    const double spacing = std::fmin((double)f.sample_w, (double)f.sample_d);
+    const double delta = 2.0 * (2.0 * map_len * 1.1920929e-07) / spacing;
+    const double tol = 4.0 * (delta + 1e-5);
+    f.partner_tol = tol < 0.05 ? (float)std::fmax(tol, 2e-3) : INFINITY;
+  }
   c->have_field[slot] = true;
   c->geom.len_x = len_x;
   c->geom.len_y = len_y;

@@ -36,6 +36,10 @@ struct FieldDev {
   float pos[3];
   float R[12];
   int has_nan;  // any NaN sample in the layer (enables the running-dMAX quirk path)
+  // Partner pre-filter of the plane stage (box_check.h): two triangles whose normalised planes are
+  // epsilon-equal have raw cross products that differ by at most partner_tol * |cross| per component
+  // (derivation in DESIGN.md 4.1); +inf disables the filter.
+  float partner_tol;
 };
 
 // Box in heightfield frame, ready for the zone test.
@@ -339,8 +343,10 @@ ARTP_HD bool is_on_heightfield2(const FieldDev& f, int cx, int cz, float px, flo
 // Plane (n, d) of a heightfield triangle (heightfield.cpp:1474-1501).
 // up:   vertices (A,B,C): Edge1 = C-A, Edge2 = B-A, n = Edge1 x Edge2
 // down: vertices (D,B,C): Edge1 = C-D, Edge2 = B-D, n = Edge2 x Edge1
+// raw (optional) receives the un-normalised cross product.
 ARTP_HD void triangle_plane(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
-                            float v2x, float v2y, float v2z, bool is_up, float pl[4]) {
+                            float v2x, float v2y, float v2z, bool is_up, float pl[4],
+                            float* raw = nullptr) {
   const float e1x = v2x - v0x, e1y = v2y - v0y, e1z = v2z - v0z;
   const float e2x = v1x - v0x, e2y = v1y - v0y, e2z = v1z - v0z;
   float ax, ay, az, bx, by, bz;
@@ -352,6 +358,11 @@ ARTP_HD void triangle_plane(float v0x, float v0y, float v0z, float v1x, float v1
   float t0 = ay * bz - az * by;
   float t1 = az * bx - ax * bz;
   float t2 = ax * by - ay * bx;
+  if (raw) {
+    raw[0] = t0;
+    raw[1] = t1;
+    raw[2] = t2;
+  }
   const float dinv = 1.0f / sqrtf(t0 * t0 + t1 * t1 + t2 * t2);
   t0 *= dinv;
   t1 *= dinv;
@@ -360,6 +371,22 @@ ARTP_HD void triangle_plane(float v0x, float v0y, float v0z, float v1x, float v1
   pl[1] = t1;
   pl[2] = t2;
   pl[3] = dot3(t0, t1, t2, v0x, v0y, v0z);
+}
+
+// Un-normalised cross product of a heightfield triangle: exactly the (t0, t1, t2) of triangle_plane.
+ARTP_HD void triangle_cross(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z, float v2x,
+                            float v2y, float v2z, bool is_up, float raw[3]) {
+  const float e1x = v2x - v0x, e1y = v2y - v0y, e1z = v2z - v0z;
+  const float e2x = v1x - v0x, e2y = v1y - v0y, e2z = v1z - v0z;
+  float ax, ay, az, bx, by, bz;
+  if (is_up) {
+    ax = e1x; ay = e1y; az = e1z; bx = e2x; by = e2y; bz = e2z;
+  } else {
+    ax = e2x; ay = e2y; az = e2z; bx = e1x; by = e1y; bz = e1z;
+  }
+  raw[0] = ay * bz - az * by;
+  raw[1] = az * bx - ax * bz;
+  raw[2] = ax * by - ay * bx;
 }
 
 ARTP_HD bool planes_eps_equal(const float a[4], const float b[4]) {

@@ -145,9 +145,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // Per-wave LDS scratch.  Stages that do not need a member get a null pointer / zero capacity.
 struct WaveScratch {
-  float* cand;          // 64 x float4: planes of the corner-candidate triangles (may be null)
+  float* cand;          // corner-candidate planes, raw cross products and ids (cand bytes, may be null)
   float* h;             // heights tile, z-major rows of numX; capacity cap_verts
-  unsigned short* tri;  // kept-triangle list; id = 2*(cx*(numZ-1)+cz) + (down ? 1 : 0); cap_tris
+  unsigned short* tri;  // kept-triangle list; id = cx | cz << 6 | down << 12 (window-local cell); cap_tris
   unsigned* tab;        // open-addressing hash table of quantised plane offsets; tab_size (pow2)
   int cap_verts;
   int cap_tris;
@@ -357,8 +357,8 @@ __device__ __forceinline__ int grp_compact_triangles(const BoxHF& b, const WaveS
     if (WRITE_LIST) {
       if (T + n_here > s.cap_tris) return -1;
       int w = T + __popcll(bu & lt_mask) + __popcll(bd & lt_mask);
-      if (keepUp) s.tri[w++] = (unsigned short)(2 * c);
-      if (keepDown) s.tri[w] = (unsigned short)(2 * c + 1);
+      if (keepUp) s.tri[w++] = (unsigned short)(cx | (cz << 6));
+      if (keepDown) s.tri[w] = (unsigned short)(cx | (cz << 6) | 4096);
     }
     T += n_here;
     cx += qc;
@@ -397,14 +397,11 @@ __device__ __forceinline__ unsigned hash_u64(unsigned long long x) {
 __device__ __forceinline__ bool wave_plane_stage(const FieldDev& f, const BoxHF& b, const WaveScratch& s,
                                                  int lane, int T) {
   const int numX = b.maxX - b.minX + 1;
-  const int numZ = b.maxZ - b.minZ + 1;
-  const int cellsZ = numZ - 1;
   // Plane of kept triangle `id` from the LDS tile, and the global sample coordinates of its
   // IsOnHeightfield2 corner vertex (A for ABC, D for DBC).
   auto tri_plane = [&](int id, float pl[4], int& gx, int& gz, bool& up) {
-    const int c = id >> 1;
-    up = !(id & 1);
-    const int cx = c / cellsZ, cz = c - cx * cellsZ;
+    up = !(id & 4096);
+    const int cx = id & 63, cz = (id >> 6) & 63;
     const int e = cz * numX + cx;
     const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
     const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;
@@ -561,34 +558,49 @@ __device__ __forceinline__ bool wave_plane_stage(const FieldDev& f, const BoxHF&
 // among ALL kept triangles is a group of its own in the greedy grouping (:1511-1556), so its base
 // plane is its own plane and it can be decided alone.  Returns 0 / 1 when that settles the check, 2
 // when some candidate has a partner (the caller then runs the exact sequential grouping).
+// Packed kept-triangle id: window-local cell (cx, cz) and orientation; cx, cz < 64 (host-checked).
+__device__ __forceinline__ int tri_pack(int cx, int cz, bool down) { return cx | (cz << 6) | (down ? 4096 : 0); }
+
+template <int G>
+struct CandCap { static constexpr int value = (G == 64) ? 64 : 32; };
+
 template <int G>
 __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const BoxHF& b,
                                                        const WaveScratch& s, int lane, int T) {
+  constexpr int CAP = CandCap<G>::value;
   const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
   const int cellsX = numX - 1, cellsZ = numZ - 1;
   const float minO2 = b.aabb[2];
-  const float margin = 1.0e-3f;
-  float4* cand_pl = reinterpret_cast<float4*>(s.cand);   // [64] candidate planes (compacted)
-  int* cand_id = reinterpret_cast<int*>(s.cand) + 256;    // [64] id | corner-cell info, see below
-  // 64 candidate slots: corner = slot>>3, cell offset (dx, dz) = (slot&1, (slot>>1)&1), down = (slot>>2)&1.
-  // A group of G lanes walks them in 64/G rounds and compacts the kept ones into LDS.
+  // Corner positions are a handful of float ops on coordinates of a few tens of metres (rounding
+  // ~1e-5 m at most); the contact positions of dCollideBoxPlane are the same corners computed in another
+  // order.  A 0.1 mm margin around each corner covers both.
+  const float margin = 1.0e-4f;
+  float4* cand_pl = reinterpret_cast<float4*>(s.cand);         // [CAP] candidate planes (compacted)
+  float4* cand_raw = cand_pl + CAP;                             // [CAP] raw cross x, z, tolerance, unused
+  int* cand_id = reinterpret_cast<int*>(cand_raw + CAP);        // [CAP] packed triangle ids
+  // 16 base slots = 8 corners x 2 orientations for the cell under the corner; a corner within the margin
+  // of a cell border also nominates the neighbouring cell(s): offsets (1,0), (0,1), (1,1).
+  // G = 64 walks the four offsets side by side; G = 16 runs an offset round only when some corner needs it.
   int ncand = 0;
-  for (int r = 0; r < 64 / G; ++r) {
-    const int slot = gl + G * r;
-    const int corner = slot >> 3;
-    const float s0 = (corner & 1) ? 0.5f : -0.5f, s1 = (corner & 2) ? 0.5f : -0.5f,
-                s2 = (corner & 4) ? 0.5f : -0.5f;
-    const float px = b.pos[0] + s0 * b.side[0] * b.R[0] + s1 * b.side[1] * b.R[1] + s2 * b.side[2] * b.R[2];
-    const float pz = b.pos[2] + s0 * b.side[0] * b.R[6] + s1 * b.side[1] * b.R[7] + s2 * b.side[2] * b.R[8];
-    const int cxa = (int)floorf((px - margin) * f.inv_w), cxb = (int)floorf((px + margin) * f.inv_w);
-    const int cza = (int)floorf((pz - margin) * f.inv_d), czb = (int)floorf((pz + margin) * f.inv_d);
-    const int dx = slot & 1, dz = (slot >> 1) & 1;
-    const bool c_up = !((slot >> 2) & 1);
+  const int base_slot = gl & 15;
+  const int corner = base_slot >> 1;
+  const bool c_up = !(base_slot & 1);
+  const float s0 = (corner & 1) ? 0.5f : -0.5f, s1 = (corner & 2) ? 0.5f : -0.5f, s2 = (corner & 4) ? 0.5f : -0.5f;
+  const float px = b.pos[0] + s0 * b.side[0] * b.R[0] + s1 * b.side[1] * b.R[1] + s2 * b.side[2] * b.R[2];
+  const float pz = b.pos[2] + s0 * b.side[0] * b.R[6] + s1 * b.side[1] * b.R[7] + s2 * b.side[2] * b.R[8];
+  const int cxa = (int)floorf((px - margin) * f.inv_w), cxb = (int)floorf((px + margin) * f.inv_w);
+  const int cza = (int)floorf((pz - margin) * f.inv_d), czb = (int)floorf((pz + margin) * f.inv_d);
+  for (int r = 0; r < 4; ++r) {
+    const int off = (G == 64) ? (gl >> 4) : r;
+    const int dx = off & 1, dz = off >> 1;
+    const bool wanted = (cxa + dx <= cxb) && (cza + dz <= czb);
+    if (G != 64 && r > 0 && !grp_any<G>(wanted, lane)) continue;
     const int cx = cxa + dx - b.minX, cz = cza + dz - b.minZ;  // window-local cell
-    bool is_cand = (cxa + dx <= cxb) && (cza + dz <= czb) && cx >= 0 && cz >= 0 && cx < cellsX && cz < cellsZ;
+    bool is_cand = wanted && cx >= 0 && cz >= 0 && cx < cellsX && cz < cellsZ;
     float cpl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float craw[3] = {0.0f, 0.0f, 0.0f};
     if (is_cand) {
       const int e = cz * numX + cx;
       const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
@@ -600,43 +612,64 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
         const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
         const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;
         if (c_up)
-          triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, cpl);
+          triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, cpl, craw);
         else
-          triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, cpl);
+          triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, cpl, craw);
       }
     }
     const unsigned long long m = grp_ballot<G>(is_cand, lane);
+    const int n_here = __popcll(m);
+    if (ncand + n_here > CAP) return 2;  // more candidates than the scratch holds: exact grouping stage
     if (is_cand) {
       const int w = ncand + __popcll(m & grp_lt_mask<G>(lane));
       cand_pl[w] = make_float4(cpl[0], cpl[1], cpl[2], cpl[3]);
-      cand_id[w] = 2 * (cx * cellsZ + cz) + (c_up ? 0 : 1);  // same id as the kept-triangle list
+      cand_id[w] = tri_pack(cx, cz, !c_up);  // same id as the kept-triangle list
+      // pre-filter tolerance; near-vertical candidate planes (|ny| < 0.05) are never filtered
+      const float len = sqrtf(craw[0] * craw[0] + craw[1] * craw[1] + craw[2] * craw[2]);
+      const float tol = (fabsf(cpl[1]) >= 0.05f) ? f.partner_tol * len : INFINITY;
+      cand_raw[w] = make_float4(craw[0], craw[2], tol, 0.0f);
     }
-    ncand += __popcll(m);
+    ncand += n_here;
+    if (G == 64) break;  // the four offsets were handled side by side
   }
   if (ncand == 0) return 0;  // no kept triangle under any box corner: nothing can accept a contact
   wave_lds_sync();
   // does any kept triangle have a plane epsilon-equal to a candidate's (other than itself)?
+  // (the same triangle may be nominated by two corners: duplicates are harmless)
   bool partner = false;
   for (int j = gl; j < T; j += G) {
     const int id = s.tri[j];
-    const int c = id >> 1;
-    const bool up = !(id & 1);
-    const int tx = c / cellsZ, tz = c - tx * cellsZ;
+    const bool up = !(id & 4096);
+    const int tx = id & 63, tz = (id >> 6) & 63;
     const int e = tz * numX + tx;
     const float xA = (float)(b.minX + tx) * f.sample_w, xB = (float)(b.minX + tx + 1) * f.sample_w;
     const float zA = (float)(b.minZ + tz) * f.sample_d, zC = (float)(b.minZ + tz + 1) * f.sample_d;
     const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
-    float pl[4];
+    // cheap necessary condition first: the raw cross product (no sqrt / divide) must be close to a
+    // candidate's; only then the normalised plane is computed and compared exactly
+    float raw[3];
     if (up)
-      triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, pl);
+      triangle_cross(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, raw);
     else
-      triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, pl);
+      triangle_cross(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, raw);
+    bool close = false;
     for (int q = 0; q < ncand; ++q) {
-      const float4 cp = cand_pl[q];  // broadcast read
-      if (fabsf(pl[3] - cp.w) < ARTP_EPS) {
-        if (cand_id[q] != id && fabsf(pl[1] - cp.y) < ARTP_EPS && fabsf(pl[0] - cp.x) < ARTP_EPS &&
-            fabsf(pl[2] - cp.z) < ARTP_EPS)
-          partner = true;
+      const float4 cr = cand_raw[q];  // broadcast read
+      close = close || (!(fabsf(raw[0] - cr.x) > cr.z) && !(fabsf(raw[2] - cr.y) > cr.z));
+    }
+    if (close) {
+      float pl[4];
+      if (up)
+        triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, pl);
+      else
+        triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, pl);
+      for (int q = 0; q < ncand; ++q) {
+        const float4 cp = cand_pl[q];
+        if (fabsf(pl[3] - cp.w) < ARTP_EPS) {
+          if (cand_id[q] != id && fabsf(pl[1] - cp.y) < ARTP_EPS && fabsf(pl[0] - cp.x) < ARTP_EPS &&
+              fabsf(pl[2] - cp.z) < ARTP_EPS)
+            partner = true;
+        }
       }
     }
   }
@@ -646,9 +679,8 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
   for (int q = gl; q < ncand; q += G) {
     const float4 cp = cand_pl[q];
     const int id = cand_id[q];
-    const int c = id >> 1;
-    const bool up = !(id & 1);
-    const int tx = c / cellsZ, tz = c - tx * cellsZ;
+    const bool up = !(id & 4096);
+    const int tx = id & 63, tz = (id >> 6) & 63;
     const int gx = b.minX + tx + (up ? 0 : 1), gz = b.minZ + tz + (up ? 0 : 1);
     float cpos[4][3];
     const int nc = box_plane_contacts(b, cp.x, cp.y, cp.z, cp.w, 10, cpos);

@@ -42,20 +42,21 @@ struct SamplerDev {
 
 // ---- per-wave LDS carve --------------------------------------------------------------------------
 struct ScratchCaps {  // sized on the host from the box diagonals / sample spacing
+  int cand;   // bytes for the corner-candidate arrays (36 B per candidate; multiple of 16)
   int verts;  // heights tile, floats (multiple of 4)
   int tris;   // kept-triangle list, u16 (multiple of 8); 0 = stage has no list
   int tab;    // hash table entries, u32 (power of two); 0 = stage has no table
 };
 
 __host__ __device__ __forceinline__ size_t scratch_bytes_per_wave(const ScratchCaps& c) {
-  return 1280 /* candidate planes + ids */ + (size_t)c.verts * 4 + (size_t)c.tab * 4 + (size_t)c.tris * 2;
+  return (size_t)c.cand + (size_t)c.verts * 4 + (size_t)c.tab * 4 + (size_t)c.tris * 2;
 }
 
 __device__ __forceinline__ WaveScratch carve_scratch(char* smem, int wave_in_block, const ScratchCaps& c) {
   char* base = smem + scratch_bytes_per_wave(c) * wave_in_block;
   WaveScratch s;
   s.cand = reinterpret_cast<float*>(base);
-  base += 1280;
+  base += c.cand;
   s.h = reinterpret_cast<float*>(base);
   s.tab = reinterpret_cast<unsigned*>(base + (size_t)c.verts * 4);
   s.tri = reinterpret_cast<unsigned short*>(base + (size_t)c.verts * 4 + (size_t)c.tab * 4);

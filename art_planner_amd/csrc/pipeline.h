@@ -150,7 +150,9 @@ struct __attribute__((aligned(16))) PendingBox {  // 96 bytes
 struct PipelineQueues {
   PendingBox* q1;                // undecided boxes: torso records at [0, n), foot records at [n, 5n)
   unsigned* q2;                  // indices into q1 of boxes that need the exact-grouping stage
-  unsigned long long* counters;  // [0] torso count, [1] q2 count, [4] foot count
+  unsigned* q3;                  // indices into q1 of foot boxes that survive the lane scan stage
+  unsigned* q5;                  // indices into q1 of foot boxes left to the lane-group stage
+  unsigned long long* counters;  // [0] torso, [1] q2, [4] feet, [5] q3, [6] q5 counts
   unsigned long long feet_base;  // = n
 };
 
@@ -195,8 +197,6 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 }
 
 // record flags (PendingBox::kind, bit 0 = foot)
-#define ARTP_REC_DECIDED 0x100u         // settled by the lane-per-box vertex pass
-#define ARTP_REC_NO_VERTEX_HIT 0x200u   // (f) already evaluated: no terrain vertex inside the box
 #define ARTP_REC_EXITS_NEGATIVE 0x400u  // exits (b)-(e) already evaluated (from the tables): none fired
 
 // ---- stage 1: one lane per state --------------------------------------------------------------------
@@ -297,52 +297,88 @@ __device__ __forceinline__ unsigned long long wave_fetch_item(unsigned long long
   return __shfl(item, 0, 64);
 }
 
-// ---- stage 1b: (f) for the foot queue, one LANE per box ----------------------------------------------
-// A foot window holds ~70 samples; walking it sequentially in one lane costs ~70 steps shared by 64
-// boxes per instruction, an order of magnitude less issue than a lane group per box.  Same predicate
-// as grp_vertex_pass (any colliding vertex of an all-finite triangle inside the box), so any hit
-// decides the box ("foot touches" = ok).  Boxes without a hit stay queued for stage 2, flagged so
-// that stage does not repeat the pass.
-__global__ void __launch_bounds__(256)
-feet_vertex_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q) {
+// ---- stage 1b: the foot queue, one LANE per box --------------------------------------------------------
+// A foot window holds ~70 samples.  Walking it sequentially in one lane costs ~70 steps that 64 boxes
+// share per instruction -- an order of magnitude less issue than a lane group per box -- and the
+// sequential walk is literally the reference's loop nest (x outer, z inner), NaN quirk included.
+// Per box: maxY (running dMAX), minY over finite, allFinite and, speculatively, (f) "colliding vertex of
+// an all-finite triangle inside the box"; then exits (b)-(e) (skipped when stage 1 already evaluated
+// them from the tables), then (f).  Boxes still undecided (they need the plane stage) are compacted
+// into queue 3 for the lane-group stage, one atomic per wavefront.
+#define ARTP_LANE_THREADS 256
+
+__global__ void __launch_bounds__(ARTP_LANE_THREADS)
+feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const unsigned long long count = q.counters[4];
-  for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < count;
-       it += (unsigned long long)gridDim.x * blockDim.x) {
-    PendingBox* rp = q.q1 + q.feet_base + it;
-    const PendingBox rec = *rp;
-    // (f) comes after the exits in the reference: only boxes whose exits are known not to fire
-    if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) continue;
-    BoxHF b;
-    box_from_record(rec, rb, b);
-    const int numX = b.maxX - b.minX + 1, numZ = b.maxZ - b.minZ + 1;
-    const float minO2 = b.aabb[2];
-    const float* base = ff.data + b.minX + (size_t)b.minZ * ff.nW;
-    bool hit = false;
-    for (int zl = 0; zl < numZ && !hit; ++zl) {
-      const float vz = (float)(b.minZ + zl) * ff.sample_d;
-      for (int xl = 0; xl < numX; ++xl) {
-        const float h = base[xl + zl * ff.nW];
-        if (!(is_finite(h) && h > minO2)) continue;
-        const float vx = (float)(b.minX + xl) * ff.sample_w;
-        if (!point_in_box(b, vx, h, vz)) continue;
-        // member of a triangle whose three vertices are finite? (same six neighbours as grp_vertex_pass)
-        const bool xm = xl > 0, xp = xl < numX - 1, zm = zl > 0, zp = zl < numZ - 1;
-        const float* c = base + xl + zl * ff.nW;
-        const bool f_xp = xp && is_finite(c[1]);
-        const bool f_xm = xm && is_finite(c[-1]);
-        const bool f_zp = zp && is_finite(c[ff.nW]);
-        const bool f_zm = zm && is_finite(c[-ff.nW]);
-        const bool f_xm_zp = xm && zp && is_finite(c[ff.nW - 1]);
-        const bool f_xp_zm = xp && zm && is_finite(c[1 - ff.nW]);
-        const bool member = (f_xp && f_zp) || (f_xm && f_xm_zp) || (f_xm_zp && f_zp) || (f_zm && f_xp_zm) ||
-                            (f_xp_zm && f_xp) || (f_zm && f_xm);
-        if (member) {
-          hit = true;
-          break;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long rounds = (count + stride - 1) / stride;  // uniform trip count: ballots below
+  for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
+    const unsigned long long it = rnd * stride + (unsigned long long)blockIdx.x * blockDim.x + tid;
+    const bool live = it < count;
+    const unsigned long long item = q.feet_base + (live ? it : 0ull);
+    bool undecided = false;
+    if (live) {
+      const PendingBox rec = q.q1[item];
+      if (valid[rec.state] != 0) {
+        BoxHF b;
+        box_from_record(rec, rb, b);
+        const int numX = b.maxX - b.minX + 1, numZ = b.maxZ - b.minZ + 1;
+        const int cellsX = numX - 1, cellsZ = numZ - 1;
+        const float minO2 = b.aabb[2];
+        const int nW = ff.nW;
+        const float* base = ff.data + b.minX + (size_t)b.minZ * nW;
+        WindowStats w;  // heightfield.cpp:1002-1026
+        w.maxY = -INFINITY;
+        w.minY = INFINITY;
+        w.allFinite = true;
+        bool vhit = false;
+        for (int xl = 0; xl < numX; ++xl) {
+          const float vx = (float)(b.minX + xl) * ff.sample_w;
+          for (int zl = 0; zl < numZ; ++zl) {
+            const float* c = base + xl + zl * nW;
+            const float h = c[0];
+            w.maxY = (w.maxY > h) ? w.maxY : h;  // dMAX(maxY, h): a NaN replaces maxY
+            if (is_finite(h)) {
+              w.minY = (w.minY > h) ? h : w.minY;
+              if (!vhit && h > minO2) {
+                const float vz = (float)(b.minZ + zl) * ff.sample_d;
+                if (point_in_box(b, vx, h, vz)) {
+                  // member of a triangle whose three vertices are finite (the six neighbours of
+                  // grp_vertex_pass)
+                  const bool xm = xl > 0, xp = xl < cellsX, zm = zl > 0, zp = zl < cellsZ;
+                  const bool f_xp = xp && is_finite(c[1]);
+                  const bool f_xm = xm && is_finite(c[-1]);
+                  const bool f_zp = zp && is_finite(c[nW]);
+                  const bool f_zm = zm && is_finite(c[-nW]);
+                  const bool f_xm_zp = xm && zp && is_finite(c[nW - 1]);
+                  const bool f_xp_zm = xp && zm && is_finite(c[1 - nW]);
+                  vhit = (f_xp && f_zp) || (f_xm && f_xm_zp) || (f_xm_zp && f_zp) || (f_zm && f_xp_zm) ||
+                         (f_xp_zm && f_xp) || (f_zm && f_xm);
+                }
+              }
+            } else {
+              w.allFinite = false;
+            }
+          }
         }
+        int result = 0, ec;
+        bool decided = !(rec.kind & ARTP_REC_EXITS_NEGATIVE) && decide_exits(b, w, result, ec);
+        if (!decided && vhit) {
+          result = 1;
+          decided = true;
+        }
+        if (decided && result == 0) valid[rec.state] = 0;  // a foot that touches nothing fails the state
+        undecided = !decided;
       }
     }
-    rp->kind = rec.kind | (hit ? ARTP_REC_DECIDED : ARTP_REC_NO_VERTEX_HIT);
+    const unsigned long long b3 = __ballot(undecided);
+    unsigned long long base3 = 0;
+    if (lane == 0 && b3) base3 = atomicAdd(&q.counters[5], (unsigned long long)__popcll(b3));
+    base3 = __shfl(base3, 0, 64);
+    if (undecided) q.q3[base3 + __popcll(b3 & lt_mask)] = (unsigned)item;
   }
 }
 
@@ -359,15 +395,13 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   const int gl = lane & (G - 1);
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
-  const bool feet = (G != 64);
-  const unsigned long long count = q.counters[feet ? 4 : 0];
-  const unsigned long long qbase = feet ? q.feet_base : 0ull;
+  const bool feet = (G != 64);  // feet: only the boxes the lane-per-box stages handed over (queue 3)
+  const unsigned long long count = q.counters[feet ? 5 : 0];
   const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
   for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
        it += stride) {
-    const unsigned long long item = qbase + it;
+    const unsigned long long item = feet ? (unsigned long long)q.q3[it] : it;
     const PendingBox rec = q.q1[item];
-    if (rec.kind & ARTP_REC_DECIDED) continue;  // settled by the lane-per-box vertex pass
     if (valid[rec.state] == 0) continue;        // another box of this state already failed
     BoxHF b;
     box_from_record(rec, rb, b);
@@ -379,9 +413,10 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
     WindowStats w;
     grp_scan_window<G>(fld, b, s, lane, w);
     int result = 0, ec;
-    bool decided = decide_exits(b, w, result, ec);
+    // queue 5 boxes (feet) already went through exits and (f) in the lane-per-box stage
+    bool decided = !feet && decide_exits(b, w, result, ec);
     if (!decided) {
-      if (!(rec.kind & ARTP_REC_NO_VERTEX_HIT) && grp_vertex_pass<G>(fld, b, s, lane, w.allFinite)) {
+      if (!feet && grp_vertex_pass<G>(fld, b, s, lane, w.allFinite)) {
         result = 1;
         decided = true;
       } else {
