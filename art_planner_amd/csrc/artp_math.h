@@ -84,66 +84,65 @@ ARTP_HD void safe_normalize3(float& a0, float& a1, float& a2) {
     if (!(abs0 > 0.0f)) return;
     idx = 0;
   }
-  if (idx == 0) {
-    const float recip = 1.0f / abs0;
-    const float b1 = a1 * recip, b2 = a2 * recip;
-    const float l = 1.0f / sqrtf(1.0f + b1 * b1 + b2 * b2);
-    a1 = b1 * l;
-    a2 = b2 * l;
-    a0 = copysignf(l, a0);
-  } else if (idx == 1) {
-    const float recip = 1.0f / abs1;
-    const float b0 = a0 * recip, b2 = a2 * recip;
-    const float l = 1.0f / sqrtf(1.0f + b0 * b0 + b2 * b2);
-    a0 = b0 * l;
-    a2 = b2 * l;
-    a1 = copysignf(l, a1);
-  } else {
-    const float recip = 1.0f / abs2;
-    const float b0 = a0 * recip, b1 = a1 * recip;
-    const float l = 1.0f / sqrtf(1.0f + b0 * b0 + b1 * b1);
-    a0 = b0 * l;
-    a1 = b1 * l;
-    a2 = copysignf(l, a2);
-  }
+  // The three branches of the reference differ only in which component is the largest; written with
+  // value selects (not per-branch stores through references, which the compiler turns into a
+  // dynamically indexed scratch array).  "first"/"second" = the other two components in index order, so
+  // 1 + first^2 + second^2 is summed exactly like each branch of dxSafeNormalize3.
+  const float big = idx == 0 ? a0 : (idx == 1 ? a1 : a2);
+  const float first = idx == 0 ? a1 : a0;
+  const float second = idx == 2 ? a1 : a2;
+  const float recip = 1.0f / fabsf(big);
+  const float p1 = first * recip, p2 = second * recip;
+  const float l = 1.0f / sqrtf(1.0f + p1 * p1 + p2 * p2);
+  const float nb = copysignf(l, big), n1 = p1 * l, n2 = p2 * l;
+  a0 = idx == 0 ? nb : n1;
+  a1 = idx == 1 ? nb : (idx == 0 ? n1 : n2);
+  a2 = idx == 2 ? nb : n2;
 }
 
-// dBodySetRotation's dxOrthogonalizeR on a 3x4 row-major matrix m[12] (in place).
-ARTP_HD void orthogonalize_R(float* m) {
-  if (!(m[0] != 0.0f || m[1] != 0.0f || m[2] != 0.0f)) return;
-  const float n0 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
-  const float proj = dot3(m[0], m[1], m[2], m[4], m[5], m[6]);
-  float r0 = m[4], r1 = m[5], r2 = m[6];
+// dBodySetRotation's dxOrthogonalizeR on the 3x3 part of a row-major rotation, all nine entries as
+// scalars (a pointer-to-array version ends up in per-lane scratch memory on the GPU).
+ARTP_HD void orthogonalize_R9(float& m0, float& m1, float& m2, float& m4, float& m5, float& m6, float& m8,
+                              float& m9, float& m10) {
+  if (!(m0 != 0.0f || m1 != 0.0f || m2 != 0.0f)) return;
+  const float n0 = m0 * m0 + m1 * m1 + m2 * m2;
+  const float proj = dot3(m0, m1, m2, m4, m5, m6);
+  float r0 = m4, r1 = m5, r2 = m6;
   const bool in_place = !(proj != 0);
   if (!in_place) {
     const float pd = proj / n0;
-    r0 = m[4] - pd * m[0];
-    r1 = m[5] - pd * m[1];
-    r2 = m[6] - pd * m[2];
+    r0 = m4 - pd * m0;
+    r1 = m5 - pd * m1;
+    r2 = m6 - pd * m2;
   }
   if (!(r0 != 0.0f || r1 != 0.0f || r2 != 0.0f)) return;
-  if (n0 != 1.0f) safe_normalize3(m[0], m[1], m[2]);
+  if (n0 != 1.0f) safe_normalize3(m0, m1, m2);
   const float n1 = r0 * r0 + r1 * r1 + r2 * r2;
   if (n1 != 1.0f) safe_normalize3(r0, r1, r2);
   if (in_place) {  // the Gram-Schmidt temporary aliases row 1 only when proj == 0
-    m[4] = r0;
-    m[5] = r1;
-    m[6] = r2;
+    m4 = r0;
+    m5 = r1;
+    m6 = r2;
   }
-  m[8] = m[1] * r2 - m[2] * r1;
-  m[9] = m[2] * r0 - m[0] * r2;
-  m[10] = m[0] * r1 - m[1] * r0;
-  m[3] = m[7] = m[11] = 0.0f;
+  m8 = m1 * r2 - m2 * r1;
+  m9 = m2 * r0 - m0 * r2;
+  m10 = m0 * r1 - m1 * r0;
+}
+
+// same on a 3x4 row-major matrix m[12] (host side: the field rotation at map upload)
+ARTP_HD void orthogonalize_R(float* m) {
+  orthogonalize_R9(m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]);
+  if (m[0] != 0.0f || m[1] != 0.0f || m[2] != 0.0f) m[3] = m[7] = m[11] = 0.0f;
 }
 
 // HeightMapBoxChecker::checkCollision pose -> box in heightfield frame + index window.
 // pose = dPose{origin[4], rotation[12]}.
 ARTP_HD void setup_box(const FieldDev& f, const float* pose, float sx, float sy, float sz,
                        BoxHF& b) {
-  float Rw[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) Rw[i] = pose[4 + i];
-  orthogonalize_R(Rw);
+  float w0 = pose[4], w1 = pose[5], w2 = pose[6], w4 = pose[8], w5 = pose[9], w6 = pose[10], w8 = pose[12],
+        w9 = pose[13], w10 = pose[14];
+  orthogonalize_R9(w0, w1, w2, w4, w5, w6, w8, w9, w10);
+  const float Rw[12] = {w0, w1, w2, 0.0f, w4, w5, w6, 0.0f, w8, w9, w10, 0.0f};
   const float p0 = pose[0] - f.pos[0];
   const float p1 = pose[1] - f.pos[1];
   const float p2 = pose[2] - f.pos[2];

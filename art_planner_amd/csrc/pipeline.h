@@ -199,6 +199,54 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 // record flags (PendingBox::kind, bit 0 = foot)
 #define ARTP_REC_EXITS_NEGATIVE 0x400u  // exits (b)-(e) already evaluated (from the tables): none fired
 
+// Box k of a state against ITS layer: 0 = decided ok, 1 = decided failing, 2 = undecided (exits known not
+// to fire), 3 = undecided (tables could not answer).  Called with the body layer for k = 0 and the feet
+// layer for k = 1..4 from separate call sites: selecting the FieldDev / TablesDev kernel arguments by a
+// run-time index would force both structs into per-lane scratch memory (240 B/lane of HBM traffic).
+__device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
+                                            const RobotDev& rb, const float t[3], const float R[9], int k) {
+  const bool body = (k == 0);
+  float pose[16];
+  state_box_pose(rb, t, R, k, pose);
+  if (!map_is_inside(g, (double)pose[0], (double)pose[1])) {
+    // body outside -> valid (validity_checker_body.cpp:29-32); foot outside ->
+    // !unknown_space_untraversable (validity_checker_feet.cpp:34-37)
+    return (!body && rb.unknown_space_untraversable) ? 1 : 0;
+  }
+  BoxHF b;
+  setup_box(f, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
+            body ? rb.torso[2] : rb.foot[2], b);
+  int hit = 0;
+  if (b.on_field) {
+    WindowStats w;
+    int ec;
+    const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
+    if (!(have_stats && decide_exits(b, w, hit, ec))) return have_stats ? 2 : 3;
+  }
+  return (body ? hit : !hit) ? 1 : 0;
+}
+
+// Queue record of box k (recomputed) into the LDS staging slot dst[0..5].
+__device__ __forceinline__ void stage_record(const FieldDev& f, const RobotDev& rb, const float t[3],
+                                             const float R[9], int k, unsigned state, bool exits_negative,
+                                             float4* dst) {
+  const bool body = (k == 0);
+  float pose[16];
+  state_box_pose(rb, t, R, k, pose);
+  BoxHF b;
+  setup_box(f, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
+            body ? rb.torso[2] : rb.foot[2], b);
+  dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
+  dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
+  dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
+  dst[3] = make_float4(b.aabb[0], b.aabb[1], b.aabb[2], b.aabb[3]);
+  const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
+  const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
+  dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
+  const unsigned kind = (body ? 0u : 1u) | (exits_negative ? ARTP_REC_EXITS_NEGATIVE : 0u);
+  dst[5] = make_float4(__uint_as_float(state), __uint_as_float(kind), 0.0f, 0.0f);
+}
+
 // ---- stage 1: one lane per state --------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, MapGeom g, RobotDev rb,
@@ -215,79 +263,63 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   int ok = 1;
   unsigned pending = 0;
   unsigned exits_neg = 0;  // boxes whose exits (b)-(e) were evaluated from the tables and did not fire
-  for (int k = 0; k < 5; ++k) {
-    const bool body = (k == 0);
-    float pose[16];
-    state_box_pose(rb, t, R, k, pose);
-    if (!map_is_inside(g, (double)pose[0], (double)pose[1])) {
-      // body outside -> valid (validity_checker_body.cpp:29-32); foot outside ->
-      // !unknown_space_untraversable (validity_checker_feet.cpp:34-37)
-      if (!body && rb.unknown_space_untraversable) ok = 0;
-      continue;
-    }
-    const FieldDev& fk = body ? fb : ff;
-    BoxHF b;
-    setup_box(fk, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
-              body ? rb.torso[2] : rb.foot[2], b);
-    int hit = 0;
-    if (b.on_field) {
-      WindowStats w;
-      int ec;
-      const TablesDev& tk = body ? tb : tf;
-      const bool have_stats = tk.valid && table_window_stats(fk, tk, b, w);
-      if (!(have_stats && decide_exits(b, w, hit, ec))) {
-        pending |= 1u << k;
-        if (have_stats) exits_neg |= 1u << k;
-        continue;
-      }
-    }
-    if (body ? hit : !hit) ok = 0;
+  {
+    const int r = classify_box(fb, tb, g, rb, t, R, 0);
+    if (r == 1) ok = 0;
+    if (r >= 2) pending |= 1u;
+    if (r == 2) exits_neg |= 1u;
+  }
+#pragma unroll 1
+  for (int k = 1; k < 5; ++k) {
+    const int r = classify_box(ff, tf, g, rb, t, R, k);
+    if (r == 1) ok = 0;
+    if (r >= 2) pending |= 1u << k;
+    if (r == 2) exits_neg |= 1u << k;
   }
   if (!ok || !live) pending = 0;  // a decided box already fails: the label is 0 whatever the others say
   if (live) valid[i] = (uint8_t)ok;
   // queue slots for the whole wavefront with ONE atomic per queue (a single word sustains only ~88
-  // returning atomics per microsecond, MI355X_MICROARCH.md "dequeue")
+  // returning atomics per microsecond, MI355X_MICROARCH.md "dequeue").  Within the wavefront's run of the
+  // foot queue the records are ordered box-major (all pending "foot 1" boxes, then "foot 2", ...), so
+  // every sweep below writes ONE contiguous run.
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const unsigned long long bal_t = __ballot(pending & 1u);
-  int before_f = 0, total_f = 0;
+  unsigned long long bal[5];
+  int total_f = 0;
 #pragma unroll
-  for (int k = 1; k < 5; ++k) {
-    const unsigned long long bal = __ballot((pending >> k) & 1u);
-    before_f += __popcll(bal & lt_mask);
-    total_f += __popcll(bal);
+  for (int k = 0; k < 5; ++k) {
+    bal[k] = __ballot((pending >> k) & 1u);
+    if (k > 0) total_f += __popcll(bal[k]);
   }
   unsigned long long base_t = 0, base_f = 0;
   if (lane == 0) {
-    if (bal_t) base_t = atomicAdd(&q.counters[0], (unsigned long long)__popcll(bal_t));
+    if (bal[0]) base_t = atomicAdd(&q.counters[0], (unsigned long long)__popcll(bal[0]));
     if (total_f) base_f = atomicAdd(&q.counters[4], (unsigned long long)total_f);
   }
   base_t = __shfl(base_t, 0, 64);
-  base_f = __shfl(base_f, 0, 64);
-  const unsigned long long slot_t = base_t + (unsigned long long)__popcll(bal_t & lt_mask);
-  unsigned long long slot_f = q.feet_base + base_f + (unsigned long long)before_f;
-  // second sweep: write the undecided boxes (recomputed -- cheaper than keeping five records live)
+  base_f = __shfl(base_f, 0, 64) + q.feet_base;
+  // second sweep: the undecided boxes are recomputed (cheaper than keeping five records live), staged
+  // in LDS and copied out as full, coalesced 16-byte lanes: scattered 16-byte stores into 96-byte
+  // records cost ~7x the bytes in partial-line write traffic (rocprofv3 WRITE_SIZE / FETCH_SIZE).
+  __shared__ float4 stage[(256 / 64)][64 * 6];
+  float4* stg = stage[threadIdx.x >> 6];
+#pragma unroll 1
   for (int k = 0; k < 5; ++k) {
-    if (!((pending >> k) & 1u)) continue;
+    const int cnt = __popcll(bal[k]);
+    if (cnt == 0) continue;  // wave-uniform
     const bool body = (k == 0);
-    float pose[16];
-    state_box_pose(rb, t, R, k, pose);
-    const FieldDev& fk = body ? fb : ff;
-    BoxHF b;
-    setup_box(fk, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
-              body ? rb.torso[2] : rb.foot[2], b);
-    PendingBox* r = q.q1 + (body ? slot_t : slot_f);
-    if (!body) ++slot_f;
-    float4* dst = reinterpret_cast<float4*>(r);
-    dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
-    dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
-    dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
-    dst[3] = make_float4(b.aabb[0], b.aabb[1], b.aabb[2], b.aabb[3]);
-    const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
-    const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
-    dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
-    const unsigned kind = (body ? 0u : 1u) | (((exits_neg >> k) & 1u) ? ARTP_REC_EXITS_NEGATIVE : 0u);
-    dst[5] = make_float4(__uint_as_float((unsigned)i), __uint_as_float(kind), 0.0f, 0.0f);
+    if ((pending >> k) & 1u) {
+      float4* dst = stg + 6 * __popcll(bal[k] & lt_mask);
+      if (body)
+        stage_record(fb, rb, t, R, k, (unsigned)i, (exits_neg >> k) & 1u, dst);
+      else
+        stage_record(ff, rb, t, R, k, (unsigned)i, (exits_neg >> k) & 1u, dst);
+    }
+    wave_lds_sync();
+    float4* out = reinterpret_cast<float4*>(q.q1 + (body ? base_t : base_f));
+    for (int j = lane; j < cnt * 6; j += 64) out[j] = stg[j];
+    if (!body) base_f += (unsigned long long)cnt;
+    wave_lds_sync();
   }
 }
 
@@ -456,15 +488,18 @@ plane_stage_kernel(FieldDev fb, FieldDev ff, RobotDev rb, PipelineQueues q, uint
     if (valid[rec.state] == 0) continue;
     BoxHF b;
     box_from_record(rec, rb, b);
-    const FieldDev& f = (rec.kind & 1u) ? ff : fb;
+    const bool foot = (rec.kind & 1u) != 0;
     WindowStats w;
-    wave_scan_window(f, b, s, lane, w);
+    if (foot)
+      wave_scan_window(ff, b, s, lane, w);
+    else
+      wave_scan_window(fb, b, s, lane, w);
     const int T = wave_compact_triangles<true>(b, s, lane);
     if (T < 0) {
       if (lane == 0) atomicExch(error_flag, 1);
       continue;
     }
-    const int result = (T > 0 && wave_plane_stage(f, b, s, lane, T)) ? 1 : 0;
+    const int result = (T > 0 && (foot ? wave_plane_stage(ff, b, s, lane, T) : wave_plane_stage(fb, b, s, lane, T))) ? 1 : 0;
     if (lane == 0) {
       const bool ok = (rec.kind & 1u) ? (result != 0) : (result == 0);
       if (!ok) valid[rec.state] = 0;

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--res", type=float, default=0.04)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -233,7 +234,7 @@ def main():
     a, b = acc[:-1], acc[1:]
     near = np.hypot(a[:, 0] - b[:, 0], a[:, 1] - b[:, 1]) < 2.0
     a, b = a[near][:args.edges], b[near][:args.edges]
-    E = len(a)
+    E = 0 if args.skip_extras else len(a)
     edges = {}
     if E > 0:
         s1 = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -255,6 +256,8 @@ def main():
     # ---- C3 extras: learned motion cost (seeded random weights: the trained ones are git-LFS stubs) ----
     motion_cost = None
     try:
+        if args.skip_extras:
+            raise RuntimeError("skipped (--skip-extras)")
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import convert_weights
         ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))

@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 rocpd (sqlite) outputs: per-kernel time stats and PMC sums per dispatch.
-Usage: python scripts/prof_summary.py gpurun_out/prof_<tag> > profiles/<name>.txt"""
+"""Summarise rocprofv3 rocpd (sqlite) outputs: per-kernel time stats and PMC values per dispatch.
+Usage: python scripts/prof_summary.py gpurun_out/prof_<tag> [traffic.json] > profiles/<name>.txt
+
+With a second argument it also writes the HBM traffic of the validity pipeline per 2^22-state launch
+(the LARGEST dispatch of every pipeline kernel; FETCH_SIZE / WRITE_SIZE are in KiB)."""
 import glob
+import json
 import os
 import sqlite3
 import sys
+
+PIPELINE = ["classify_states_kernel", "feet_lane_kernel", "resolve_boxes_kernel<2, 64>", "resolve_boxes_kernel<2, 16>",
+            "plane_stage_kernel"]
 
 
 def q(db, sql):
     return db.execute(sql).fetchall()
 
 
-def main(d):
+def main(d, traffic_out=None):
+    traffic = {}
     for path in sorted(glob.glob(os.path.join(d, "*", "*_results.db"))):
         db = sqlite3.connect(path)
         print(f"== {os.path.relpath(path, d)}")
-        cols = [r[1] for r in q(db, "pragma table_info(kernels)")]
         rows = q(db, "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                      "from kernels group by name order by sum(end-start) desc")
         tot = sum(r[2] for r in rows) or 1
@@ -23,25 +30,29 @@ def main(d):
         for name, n, s, a, mn, mx in rows:
             print(f"{name[:70]:70s} {n:6d} {s/1e6:10.3f} {a/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*s/tot:6.1f}")
         try:
-            ccols = [r[1] for r in q(db, "pragma table_info(counters_collection)")]
-            pm = q(db, "select kernel_name, counter_name, count(*), sum(value), avg(value) from counters_collection "
+            pm = q(db, "select kernel_name, counter_name, count(*), avg(value), max(value) from counters_collection "
                        "group by kernel_name, counter_name order by kernel_name, counter_name")
             if pm:
-                print(f"  {'kernel':50s} {'counter':26s} {'dispatches':>10s} {'avg/dispatch':>18s}")
-                for kn, cn, n, s, a in pm:
-                    print(f"  {kn[:50]:50s} {cn:26s} {n:10d} {a:18.1f}")
+                print(f"  {'kernel':50s} {'counter':28s} {'disp':>5s} {'avg/dispatch':>18s} {'max/dispatch':>18s}")
+                for kn, cn, n, a, mx in pm:
+                    print(f"  {kn[:50]:50s} {cn:28s} {n:5d} {a:18.1f} {mx:18.1f}")
+                    if cn in ("FETCH_SIZE", "WRITE_SIZE"):
+                        for pk in PIPELINE:
+                            if pk in kn:
+                                traffic.setdefault(pk, {})[cn] = mx
         except sqlite3.OperationalError as e:
             print("  (no counters:", e, ")")
-        # resources of our kernels
-        try:
-            kc = [r[1] for r in q(db, "pragma table_info(kernels)")]
-            want = [c for c in ("name", "vgpr_count", "accum_vgpr_count", "sgpr_count", "lds_size", "scratch_size",
-                                "workgroup_size", "grid_size") if c in kc]
-            for r in q(db, f"select distinct {','.join(want)} from kernels where name like '%artp%'"):
-                print("  res:", dict(zip(want, r)))
-        except sqlite3.OperationalError:
-            pass
+    if traffic_out and traffic:
+        fetch = sum(v.get("FETCH_SIZE", 0.0) for v in traffic.values()) * 1024
+        write = sum(v.get("WRITE_SIZE", 0.0) for v in traffic.values()) * 1024
+        out = {"per_kernel_KiB_largest_dispatch": traffic, "fetch_bytes_raw": fetch, "write_bytes": write,
+               # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced streaming reads by 2x on gfx950;
+               # narrower patterns are uncalibrated.  WRITE_SIZE was calibrated here on sample_states_kernel
+               # (exactly 7*8*2^22 bytes written -> 229 381 KiB reported = 1.000x).
+               "fetch_bytes_doubled": 2 * fetch,
+               "validate_states_kernel_hbm_bytes_per_launch": 2 * fetch + write}
+        json.dump(out, open(traffic_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
