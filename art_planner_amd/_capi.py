@@ -17,7 +17,8 @@ SYMBOLS = [
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
-    "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_algorithmic_vertices_dev",
+    "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
+    "artp_algorithmic_vertices_dev",
     "artp_debug_pipeline_counters", "artp_cost_blob_bytes", "artp_cost_load_weights",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
@@ -85,6 +86,8 @@ def load():
     for name in ("artp_check_edges_interp", "artp_check_edges_interp_dev"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp]
     L.artp_compact_valid_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.artp_compact_valid_indices_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.artp_sample_states_at_dev.argtypes = [vp, u64, u64, vp, vp, sz, vp]
     L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
     L.artp_debug_pipeline_counters.argtypes = [vp, C.POINTER(u64 * 8)]
     L.artp_cost_blob_bytes.argtypes = []

@@ -217,3 +217,13 @@ class Context:
         self._chk(self.L.artp_cost_get_features(self.h, out.ctypes.data, C.byref(fh), C.byref(fw)),
                   "artp_cost_get_features")
         return out
+
+    def compact_valid_indices_dev(self, valid_t, idx_t, count_t):
+        """idx_t: uint32/int32 device tensor [>= n]; count_t: 1-element int64 device tensor."""
+        self._chk(self.L.artp_compact_valid_indices_dev(self.h, valid_t.data_ptr(), valid_t.shape[0],
+                                                        idx_t.data_ptr(), count_t.data_ptr()),
+                  "artp_compact_valid_indices_dev")
+
+    def sample_states_at_dev(self, seed, base_index, idx_t, count_t, cap, out_t):
+        self._chk(self.L.artp_sample_states_at_dev(self.h, seed, base_index, idx_t.data_ptr(), count_t.data_ptr(),
+                                                   cap, out_t.data_ptr()), "artp_sample_states_at_dev")

@@ -856,6 +856,46 @@ int artp_compact_valid_dev(artp_ctx* c, const double* se3, const uint8_t* valid,
   return ARTP_OK;
 }
 
+int artp_compact_valid_indices_dev(artp_ctx* c, const uint8_t* valid, size_t n, uint32_t* out_idx,
+                                   uint64_t* n_out_dev) {
+  if (!c || (n && (!valid || !out_idx)) || !n_out_dev || n >= (1ull << 32)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n == 0) {
+    HIP_TRY(c, hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), c->stream));
+    return ARTP_OK;
+  }
+  hipcub::CountingInputIterator<uint32_t> in(0u);
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(n_out_dev);
+  size_t need = 0;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, need, in, valid, out_idx, cnt, (int)n, c->stream));
+  if (c->cub_cap < need) {
+    if (c->cub_tmp) HIP_TRY(c, hipFree(c->cub_tmp));
+    c->cub_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->cub_tmp, need + 256));
+    c->cub_cap = need + 256;
+  }
+  size_t cap = c->cub_cap;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->cub_tmp, cap, in, valid, out_idx, cnt, (int)n, c->stream));
+  return ARTP_OK;
+}
+
+int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, const uint32_t* idx,
+                              const uint64_t* count_dev, size_t cap, double* se3_out) {
+  if (!c || !idx || !count_dev || (cap && !se3_out)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_sampler) return ARTP_ERR_NO_MAP;
+  if (cap == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t blocks = (cap + 255) / 256;
+  if (blocks > (size_t)c->n_cus * 16) blocks = (size_t)c->n_cus * 16;
+  hipLaunchKernelGGL(sample_states_at_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler, c->geom,
+                     c->robot, seed, base_index, idx, reinterpret_cast<const unsigned long long*>(count_dev), cap,
+                     se3_out);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
 int artp_algorithmic_vertices_dev(artp_ctx* c, const double* se3, size_t n, uint64_t* total) {
   if (!c || (n && !se3) || !total) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(c->mu);

@@ -326,6 +326,23 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
   }
 }
 
+// States of the global sample stream at explicit indices base + idx[j], j < *count (device counter):
+// how a rank materialises the accepted states of another rank from the 4-byte indices it received
+// (a state is a pure function of (seed, index), so only indices need to cross xGMI).
+__global__ void __launch_bounds__(256)
+sample_states_at_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t base_index,
+                        const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ count,
+                        size_t cap, double* __restrict__ se3_out) {
+  const size_t n = (size_t)(*count) < cap ? (size_t)(*count) : cap;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    double st[7];
+    sample_one(sm, g, rb, seed, base_index + idx[i], st);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) se3_out[7 * i + k] = st[k];
+  }
+}
+
 // ---- R7 ------------------------------------------------------------------------------------------
 #define ARTP_MAX_QUATERNION_NORM_ERROR 1e-9
 

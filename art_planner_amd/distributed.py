@@ -4,8 +4,10 @@
 The path shards over independent sample-index ranges: rank r of W owns the states
 [ (step*W + r)*S, (step*W + r + 1)*S ) of the global counter-based sample stream, so the union over ranks
 and steps is a gap-free, overlap-free prefix of the stream whatever W is.  The only exchange step is the
-all-gather of the ACCEPTED states (every rank's planner front end needs all of them): fixed-capacity
-blocks {count, states[cap]} so the collective has a static shape and can run on a side stream.
+all-gather of the ACCEPTED states (every rank's planner front end needs all of them).  A state is a pure
+function of (seed, sample index), so only the 4-byte in-batch indices cross xGMI (fixed-capacity blocks
+{count, idx[cap]}: static shape, runs on a side stream) and every rank re-materialises the states it needs
+with the sampler (ValidIndexGatherer); ValidStateGatherer moves whole 56-byte states instead.
 """
 from __future__ import annotations
 
@@ -50,3 +52,26 @@ def agree_capacity(local_max_count: int, batch: int, device, slack: float = 1.1,
     t = torch.tensor([int(local_max_count * slack) + 1024], device=device, dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return min(int(t.item()), batch)
+
+
+class ValidIndexGatherer:
+    """All-gather of the in-batch indices (int32) of the accepted states, fixed per-rank capacity."""
+
+    def __init__(self, world: int, cap: int, device, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.cap, self.group = world, cap, group
+        self.gathered = torch.empty((world, cap), dtype=torch.int32, device=device)
+        self.counts = torch.empty(world, dtype=torch.int64, device=device)
+
+    def gather(self, idx: torch.Tensor, count: torch.Tensor):
+        self.dist.all_gather_into_tensor(self.counts, count, group=self.group)
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), idx[:self.cap].reshape(-1), group=self.group)
+
+    def global_indices(self, step: int, batch: int) -> Tuple[torch.Tensor, bool]:
+        """Global sample indices of every accepted state of this step, in rank order (host sync)."""
+        counts = self.counts.tolist()
+        ok = all(c <= self.cap for c in counts)
+        parts = [self.gathered[r, :min(c, self.cap)].to(torch.int64) + shard_first_index(step, r, self.world, batch)
+                 for r, c in enumerate(counts)]
+        return torch.cat(parts, 0), ok

@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the all-gather path even with one rank (self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,9 +92,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if N > 1:
+    if N > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from art_planner_amd.context import Context
@@ -109,11 +112,12 @@ def main():
     S, K, W, seed = args.batch, args.steps, args.warmup, 42
     se3 = torch.empty((S, 7), dtype=torch.float64, device=dev)
     valid = torch.empty(S, dtype=torch.uint8, device=dev)
-    do_gather = N > 1 and not args.no_gather
+    do_gather = (N > 1 or args.force_dist) and not args.no_gather
     comm = torch.cuda.Stream(device=dev) if do_gather else None
 
+    from art_planner_amd.distributed import shard_first_index
+
     def first_index(step):
-        from art_planner_amd.distributed import shard_first_index
         return shard_first_index(step, rank, N, S)
 
     # ---- warmup (also sizes the fixed-capacity all-gather blocks) -----------------------------
@@ -127,17 +131,19 @@ def main():
         cap = max(cap, c)
     torch.cuda.synchronize()
     if do_gather:
-        from art_planner_amd.distributed import ValidStateGatherer, agree_capacity
+        from art_planner_amd.distributed import ValidIndexGatherer, agree_capacity
         cap = agree_capacity(cap, S, dev)
-        compact = [torch.zeros((S, 7), dtype=torch.float64, device=dev) for _ in range(2)]
+        idx_buf = [torch.zeros(S, dtype=torch.int32, device=dev) for _ in range(2)]
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
-        gatherer = ValidStateGatherer(N, cap, dev)
+        gatherers = [ValidIndexGatherer(N, cap, dev), ValidIndexGatherer(N, cap, dev)]  # double-buffered
+        gatherer = gatherers[0]
+        all_states = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)  # every rank's accepted states
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         for e in done_ev:
             e.record()
         try:  # trial exchange outside the timed region; a failing collective must not lose the whole run
-            ctx.compact_valid_dev(se3, valid, compact[0], counts[0])
-            gatherer.gather(compact[0], counts[0])
+            ctx.compact_valid_indices_dev(valid, idx_buf[0], counts[0])
+            gatherers[0].gather(idx_buf[0], counts[0])
             torch.cuda.synchronize()
         except Exception as ex:  # pragma: no cover
             gather_error = repr(ex)
@@ -148,35 +154,48 @@ def main():
         if do_gather:
             b = i & 1
             torch.cuda.current_stream().wait_event(done_ev[b])  # buffer b free again
-            ctx.compact_valid_dev(se3, valid, compact[b], counts[b])
+            ctx.compact_valid_indices_dev(valid, idx_buf[b], counts[b])
             ready = torch.cuda.Event()
             ready.record()
             comm.wait_event(ready)
             with torch.cuda.stream(comm):
-                gatherer.gather(compact[b], counts[b])
+                gatherers[b].gather(idx_buf[b], counts[b])     # 4 B per accepted state over xGMI
                 done_ev[b].record()
+            # materialise the accepted states of every rank for the PREVIOUS step (its gather has had a
+            # whole step to complete): a state is a pure function of (seed, index)
+            if i > 0:
+                materialise(i - 1)
+
+    def materialise(j):
+        gb = gatherers[j & 1]
+        torch.cuda.current_stream().wait_event(done_ev[j & 1])
+        for r in range(N):
+            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), gb.gathered[r], gb.counts[r:r + 1], cap,
+                                     all_states[r])
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides -----------------------
-    if N > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
+    if do_gather:
+        materialise(K - 1)
     torch.cuda.synchronize()
-    if N > 1:
+    if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if N > 1:
+    if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        assert (not do_gather) or int(gatherer.counts.max().item()) <= cap, "all-gather block capacity exceeded"
+        assert (not do_gather) or max(int(g_.counts.max().item()) for g_ in gatherers) <= cap, "all-gather block capacity exceeded"
     total_states = N * S * K
     value = total_states / dt
 
     if rank != 0:
-        if N > 1:
+        if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -342,7 +361,7 @@ def main():
                                "(seed 1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
                    "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}",
                    "sharding": f"sample-index ranges over {N} GPU(s)" +
-                               (", compacted valid states all-gathered over RCCL" if do_gather else "")},
+                               (", accepted-state indices all-gathered over RCCL + states re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
         "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost,
@@ -350,7 +369,7 @@ def main():
     }
     print(json.dumps(out))
     sys.stdout.flush()
-    if N > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -146,6 +146,14 @@ int artp_check_edges_interp_dev(artp_ctx* ctx, const double* s1, const double* s
  * *n_out_dev (device uint64) their number.  out_se3 must hold n states. */
 int artp_compact_valid_dev(artp_ctx* ctx, const double* se3, const uint8_t* valid, size_t n,
                            double* out_se3, uint64_t* n_out_dev);
+/* Multi-GPU exchange helpers.  A state is a pure function of (seed, sample index), so ranks exchange the
+ * 4-byte indices of their accepted states (RCCL all-gather) and materialise remote states locally:
+ * out_idx receives the positions i < n with valid[i] != 0 in order, *n_out_dev their number;
+ * artp_sample_states_at_dev writes the states of indices base_index + idx[j], j < min(*count_dev, cap). */
+int artp_compact_valid_indices_dev(artp_ctx* ctx, const uint8_t* valid, size_t n, uint32_t* out_idx,
+                                   uint64_t* n_out_dev);
+int artp_sample_states_at_dev(artp_ctx* ctx, uint64_t seed, uint64_t base_index, const uint32_t* idx,
+                              const uint64_t* count_dev, size_t cap, double* se3_out);
 /* Measurement helper: the ALGORITHMIC window size of a batch = sum over states of
  * the heightfield vertices (nMaxX-nMinX+1)*(nMaxZ-nMinZ+1) of all five boxes, no credit for
  * early-outs or short-circuiting, 0 for a box whose centre is outside the map or whose AABB is off

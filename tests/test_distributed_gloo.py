@@ -11,7 +11,8 @@ import torch.multiprocessing as mp
 
 import common
 import oracle_py as O
-from art_planner_amd.distributed import ValidStateGatherer, agree_capacity, shard_first_index
+from art_planner_amd.distributed import (ValidIndexGatherer, ValidStateGatherer, agree_capacity,
+                                         shard_first_index)
 from art_planner_amd.synthetic import make_map
 
 BATCH, STEPS, WORLD = 512, 3, 2
@@ -44,6 +45,8 @@ def _worker(rank, port, out_dir):
     _, v0 = _shard_valid(gm, rob, 1000, rank, WORLD)
     cap = agree_capacity(int(v0.sum()), BATCH, dev)
     g = ValidStateGatherer(WORLD, cap, dev)
+    gi = ValidIndexGatherer(WORLD, cap, dev)
+    smp = O.OracleSampler(gm)
     merged = []
     for step in range(STEPS):
         se3, valid = _shard_valid(gm, rob, step, rank, WORLD)
@@ -53,6 +56,15 @@ def _worker(rank, port, out_dir):
         g.gather(comp, torch.tensor([len(sel)], dtype=torch.int64))
         m, ok = g.merged()
         assert ok
+        # the index exchange (4 B per accepted state) + local re-materialisation gives the same states
+        idx = torch.zeros(BATCH, dtype=torch.int32)
+        pos = np.flatnonzero(valid)
+        idx[:len(pos)] = torch.from_numpy(pos.astype(np.int32))
+        gi.gather(idx, torch.tensor([len(pos)], dtype=torch.int64))
+        gidx, ok2 = gi.global_indices(step, BATCH)
+        assert ok2
+        regen = np.stack([smp.sample(rob, 42, int(k), 1)[0][0] for k in gidx.tolist()]) if len(gidx) else np.zeros((0, 7))
+        assert np.array_equal(regen, m.numpy())
         merged.append(m.numpy().copy())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate(merged, 0))
     dist.barrier()

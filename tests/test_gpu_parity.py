@@ -153,3 +153,27 @@ def test_float_primitives_are_correctly_rounded(ctx_yaml):
     ctx_yaml.upload_layer(0, gm[c["layer"]], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
     hit = ctx_yaml.check_boxes(0, c["side"], c["poses"][3000:])  # engineered +-ulp cases
     assert np.array_equal(hit, c["hit"][3000:])
+
+
+def test_index_exchange_rematerialises_the_same_states(big_map, ctx_yaml):
+    """Multi-GPU exchange helpers on one GPU: compact the indices of the accepted states, then rebuild the
+    states from (seed, base + index) -- bit-identical to the sampled ones."""
+    import torch
+    ctx_yaml.upload_map(big_map)
+    n, base = 100000, 5_000_000
+    se3 = torch.empty((n, 7), dtype=torch.float64, device="cuda")
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx_yaml.use_torch_stream()
+    ctx_yaml.sample_and_validate_dev(42, base, n, se3, valid)
+    ctx_yaml.compact_valid_indices_dev(valid, idx, cnt)
+    out = torch.zeros((n, 7), dtype=torch.float64, device="cuda")
+    ctx_yaml.sample_states_at_dev(42, base, idx, cnt, n, out)
+    torch.cuda.synchronize()
+    c = int(cnt.item())
+    v = valid.cpu().numpy()
+    assert c == int(v.sum()) and c > 0
+    pos = np.flatnonzero(v)
+    assert np.array_equal(idx[:c].cpu().numpy(), pos.astype(np.int32))
+    assert np.array_equal(out[:c].cpu().numpy(), se3.cpu().numpy()[pos])
