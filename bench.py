@@ -322,6 +322,31 @@ def main():
     except Exception as ex:  # pragma: no cover
         motion_cost = {"error": repr(ex)}
 
+    # ---- C5 extras: persistent HBM map with incremental updates, one replanning cycle -----------------
+    c5 = None
+    try:
+        if args.skip_extras:
+            raise RuntimeError("skipped (--skip-extras)")
+        rng5 = np.random.default_rng(55)
+        elev0 = gm["elevation"].copy()
+        n5, cyc = 1 << 18, []
+        se5 = torch.empty((n5, 7), dtype=torch.float64, device=dev)
+        va5 = torch.empty(n5, dtype=torch.uint8, device=dev)
+        for c_i in range(10):
+            t0 = time.perf_counter()
+            for _ in range(3):  # 3 rectangles ~ 5 % of the cells
+                r0, c0 = int(rng5.integers(0, gm.rows - 52)), int(rng5.integers(0, gm.cols - 52))
+                patch = (elev0[r0:r0 + 52, c0:c0 + 52] + np.float32(rng5.normal(0, 0.02))).astype(np.float32)
+                ctx.update_layer_rect(0, patch, r0, c0)   # dirty tiles -> HBM + range-table refresh
+            ctx.sample_and_validate_dev(seed, 7_000_000 + c_i * n5, n5, se5, va5)
+            torch.cuda.synchronize()
+            cyc.append((time.perf_counter() - t0) * 1e3)
+        ctx.upload_map(gm)  # restore
+        c5 = {"cycle_ms_median": float(np.median(cyc)), "cycle_ms_max": float(np.max(cyc)),
+              "states_per_cycle": n5, "dirty_rects_per_cycle": 3, "budget_ms_at_10hz": 100.0}
+    except Exception as ex:  # pragma: no cover
+        c5 = {"error": repr(ex)}
+
     cpu = None
     if N == 1 and not args.no_cpu_baseline:
         cpu, cpu_labels, _ = cpu_baseline(gm, states)
@@ -364,7 +389,7 @@ def main():
                                (", accepted-state indices all-gathered over RCCL + states re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5,
         "device": ctx.arch, "gather_error": gather_error,
     }
     print(json.dumps(out))

@@ -177,3 +177,44 @@ def test_index_exchange_rematerialises_the_same_states(big_map, ctx_yaml):
     pos = np.flatnonzero(v)
     assert np.array_equal(idx[:c].cpu().numpy(), pos.astype(np.int32))
     assert np.array_equal(out[:c].cpu().numpy(), se3.cpu().numpy()[pos])
+
+
+def test_c4_map_800_defaults_robot_labels():
+    """BASELINE config C4 size (800x800 @ 0.04 m, 32 m map) with the `Params` default robot: sampler
+    states -> GPU labels == oracle labels; plus the 0.5 m edge interpolation on the same map."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import RobotDims, make_map
+    gm = make_map(800, 0.04, seed=77, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
+    ctx = Context(0, "defaults")
+    ctx.upload_map(gm)
+    rob = O.robot("defaults")
+    se3 = ctx.sample_states(7, 0, 1 << 18)
+    vg = ctx.validate_states(se3)
+    om = O.OracleMap(gm)
+    n_chk = 40000
+    vo = om.states_valid(rob, se3[:n_chk])
+    assert np.array_equal(vg[:n_chk], vo), f"{(vg[:n_chk] != vo).sum()} mismatches"
+    assert 0.02 < vg.mean() < 0.98
+    acc = se3[vg != 0]
+    a, b = acc[:3000], acc[1:3001]
+    near = np.hypot(a[:, 0] - b[:, 0], a[:, 1] - b[:, 1]) < 3.0
+    a, b = a[near], b[near]
+    if len(a):
+        eg, ng = ctx.check_edges_interp(a, b)
+        eo, no = om.edges_interp_valid(rob, a, b)
+        assert np.array_equal(ng, no) and np.array_equal(eg, eo)
+    ctx.close()
+
+
+def test_c1_flat_map_all_exit_paths_decided_by_tables(ctx_yaml):
+    """BASELINE config C1 (flat 100x100 @ 0.1 m): every box is decided by the range tables alone
+    (nothing reaches the window stages), labels equal the oracle's."""
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(100, 0.1, flat=True)
+    ctx_yaml.upload_map(gm)
+    rng = np.random.default_rng(2)
+    se3 = common.random_states(gm, 50000, rng, z_off=(0.0, 0.2), tilt=0.1, spread=0.5)
+    vg = ctx_yaml.validate_states(se3)
+    vo = O.OracleMap(gm).states_valid(O.robot("yaml"), se3)
+    assert np.array_equal(vg, vo)
+    assert 0.05 < vg.mean() < 0.95
