@@ -234,29 +234,21 @@ int build_tables(artp_ctx* c, int slot) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sat_buf[slot]), 2 * sat_elems * sizeof(int)));
     c->table_elems[slot] = elems;
   }
-  float* mx[6];
-  float* mn[6];
-  for (int l = 0; l < 6; ++l) {
-    mx[l] = c->table_buf[slot] + (size_t)(2 * l) * elems;
-    mn[l] = c->table_buf[slot] + (size_t)(2 * l + 1) * elems;
-  }
+  float2* mm[6];
+  for (int l = 0; l < 6; ++l) mm[l] = reinterpret_cast<float2*>(c->table_buf[slot]) + (size_t)l * elems;
   const int n = (int)elems;
-  hipLaunchKernelGGL(table_level0_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, f.data, n, mx[0], mn[0]);
+  hipLaunchKernelGGL(table_level0_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, f.data, n, mm[0]);
   for (int l = 1; l < 6; ++l)
     hipLaunchKernelGGL(table_level_up_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
-                       (const float*)mx[l - 1], (const float*)mn[l - 1], f.nW, f.nD, 1 << (l - 1), mx[l], mn[l]);
-  int* s_nf = c->sat_buf[slot];
-  int* s_nan = f.has_nan ? c->sat_buf[slot] + sat_elems : nullptr;
-  hipLaunchKernelGGL(sat_rows_kernel, dim3((f.nD + 63) / 64), dim3(64), 0, c->stream, f.data, f.nW, f.nD, s_nf, s_nan);
-  hipLaunchKernelGGL(sat_cols_kernel, dim3((f.nW + 1 + 63) / 64), dim3(64), 0, c->stream, f.nW, f.nD, s_nf, s_nan);
+                       (const float2*)mm[l - 1], f.nW, f.nD, 1 << (l - 1), mm[l]);
+  int2* sat = reinterpret_cast<int2*>(c->sat_buf[slot]);
+  hipLaunchKernelGGL(sat_rows_kernel, dim3((f.nD + 63) / 64), dim3(64), 0, c->stream, f.data, f.nW, f.nD, sat);
+  hipLaunchKernelGGL(sat_cols_kernel, dim3((f.nW + 1 + 63) / 64), dim3(64), 0, c->stream, f.nW, f.nD, sat);
   HIP_TRY(c, hipGetLastError());
   TablesDev& t = c->tables[slot];
-  for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) {
-    t.maxT[l] = mx[l + 2];
-    t.minT[l] = mn[l + 2];
-  }
-  t.sat_nonfinite = s_nf;
-  t.sat_nan = s_nan;
+  for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) t.mm[l] = mm[l + 2];
+  t.sat = sat;
+  t.has_nan = f.has_nan;
   t.valid = 1;
   return ARTP_OK;
 }
@@ -279,7 +271,9 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   q.q5 = q.q3 + 4 * n;
   q.feet_base = n;
   HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+  const size_t per_block = 64 * ARTP_CLASSIFY_SUB;
+  hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + per_block - 1) / per_block)),
+                     dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);

@@ -9,7 +9,7 @@
 // lane-parallel work (one lane per STATE, 64 states per wavefront instruction) and leaves the
 // wave-cooperative window work to the boxes that really need it:
 //
-//   classify_states_kernel   1 lane / state : poses, frame change, AABB, window, table statistics,
+//   classify_states_kernel   1 lane / (state, box) : poses, frame change, AABB, window, table statistics,
 //                                             exits (b)-(e); undecided boxes -> queue 1
 //   resolve_boxes_kernel     1 wave / box   : window -> LDS, (re-)decide exits, (f) vertex-in-box,
 //                                             count kept triangles; boxes with triangles -> queue 2
@@ -27,73 +27,66 @@ namespace artp {
 #define ARTP_TABLE_LEVELS 4  // block sizes 4, 8, 16, 32 samples
 
 struct TablesDev {
-  const float* maxT[ARTP_TABLE_LEVELS];  // max over [x, x+B) x [z, z+B), NaN samples count as -inf
-  const float* minT[ARTP_TABLE_LEVELS];  // min over the FINITE samples of the block, +inf if none
-  const int* sat_nonfinite;              // (nW+1) x (nD+1) summed-area table of !isfinite
-  const int* sat_nan;                    // same for NaN; nullptr when the layer has none
+  // {max, min-of-finite} interleaved so one 8-byte gather answers both (the lookups are random
+  // accesses into tables larger than one XCD's L2: cache lines touched, not bytes, are the cost)
+  const float2* mm[ARTP_TABLE_LEVELS];  // .x = max over [x, x+B) x [z, z+B), NaN samples count as -inf
+                                        // .y = min over the FINITE samples of the block, +inf if none
+  const int2* sat;                      // (nW+1) x (nD+1) summed-area tables: .x = !isfinite, .y = NaN
+  int has_nan;                          // the layer holds a NaN somewhere (else .y is all zero)
   int valid;
 };
 
 // ---- table construction (map upload) ---------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-table_level0_kernel(const float* __restrict__ data, int n, float* __restrict__ mx, float* __restrict__ mn) {
+table_level0_kernel(const float* __restrict__ data, int n, float2* __restrict__ mm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const float h = data[i];
-    mx[i] = is_nan(h) ? -INFINITY : h;
-    mn[i] = is_finite(h) ? h : INFINITY;
+    mm[i] = make_float2(is_nan(h) ? -INFINITY : h, is_finite(h) ? h : INFINITY);
   }
 }
 
 // out = combine of the four half-size blocks at offsets (0,0), (h,0), (0,h), (h,h); indices clamp at
 // the border (blocks hanging over the edge are never queried).
 __global__ void __launch_bounds__(256)
-table_level_up_kernel(const float* __restrict__ in_mx, const float* __restrict__ in_mn, int nW, int nD,
-                      int half, float* __restrict__ out_mx, float* __restrict__ out_mn) {
+table_level_up_kernel(const float2* __restrict__ in, int nW, int nD, int half, float2* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nW * nD) return;
   const int x = i % nW, z = i / nW;
   const int x1 = min(x + half, nW - 1), z1 = min(z + half, nD - 1);
-  const float a = in_mx[x + z * nW], b = in_mx[x1 + z * nW], c = in_mx[x + z1 * nW], d = in_mx[x1 + z1 * nW];
-  const float ab = (b > a) ? b : a, cd = (d > c) ? d : c;
-  out_mx[i] = (cd > ab) ? cd : ab;
-  const float e = in_mn[x + z * nW], f = in_mn[x1 + z * nW], g = in_mn[x + z1 * nW], h = in_mn[x1 + z1 * nW];
-  const float ef = (f < e) ? f : e, gh = (h < g) ? h : g;
-  out_mn[i] = (gh < ef) ? gh : ef;
+  const float2 a = in[x + z * nW], b = in[x1 + z * nW], c = in[x + z1 * nW], d = in[x1 + z1 * nW];
+  const float ab = (b.x > a.x) ? b.x : a.x, cd = (d.x > c.x) ? d.x : c.x;
+  const float ef = (b.y < a.y) ? b.y : a.y, gh = (d.y < c.y) ? d.y : c.y;
+  out[i] = make_float2((cd > ab) ? cd : ab, (gh < ef) ? gh : ef);
 }
 
 // Summed-area tables, two passes (rows then columns); S is (nW+1) x (nD+1), row/col 0 are zero.
 __global__ void __launch_bounds__(64)
-sat_rows_kernel(const float* __restrict__ data, int nW, int nD, int* __restrict__ S_nf, int* __restrict__ S_nan) {
+sat_rows_kernel(const float* __restrict__ data, int nW, int nD, int2* __restrict__ S) {
   const int z = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per sample row z
   if (z >= nD) return;
   const int W1 = nW + 1;
   int a = 0, bnan = 0;
-  S_nf[(z + 1) * W1] = 0;
-  if (S_nan) S_nan[(z + 1) * W1] = 0;
+  S[(z + 1) * W1] = make_int2(0, 0);
   for (int x = 0; x < nW; ++x) {
     const float h = data[x + z * nW];
     a += is_finite(h) ? 0 : 1;
     bnan += is_nan(h) ? 1 : 0;
-    S_nf[(x + 1) + (z + 1) * W1] = a;
-    if (S_nan) S_nan[(x + 1) + (z + 1) * W1] = bnan;
+    S[(x + 1) + (z + 1) * W1] = make_int2(a, bnan);
   }
 }
 __global__ void __launch_bounds__(64)
-sat_cols_kernel(int nW, int nD, int* __restrict__ S_nf, int* __restrict__ S_nan) {
+sat_cols_kernel(int nW, int nD, int2* __restrict__ S) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per column x in [0, nW]
   if (x > nW) return;
   const int W1 = nW + 1;
   int a = 0, b = 0;
-  S_nf[x] = 0;
-  if (S_nan) S_nan[x] = 0;
+  S[x] = make_int2(0, 0);
   for (int z = 1; z <= nD; ++z) {
-    a += S_nf[x + z * W1];
-    S_nf[x + z * W1] = a;
-    if (S_nan) {
-      b += S_nan[x + z * W1];
-      S_nan[x + z * W1] = b;
-    }
+    const int2 v = S[x + z * W1];
+    a += v.x;
+    b += v.y;
+    S[x + z * W1] = make_int2(a, b);
   }
 }
 
@@ -106,27 +99,22 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
   if (m < 4) return false;
   const int W1 = f.nW + 1;
   const int x0 = b.minX, x1 = b.maxX + 1, z0 = b.minZ, z1 = b.maxZ + 1;
-  if (t.sat_nan) {
-    const int nn = t.sat_nan[x1 + z1 * W1] - t.sat_nan[x0 + z1 * W1] - t.sat_nan[x1 + z0 * W1] + t.sat_nan[x0 + z0 * W1];
-    if (nn) return false;
-  }
-  const int nf = t.sat_nonfinite[x1 + z1 * W1] - t.sat_nonfinite[x0 + z1 * W1] -
-                 t.sat_nonfinite[x1 + z0 * W1] + t.sat_nonfinite[x0 + z0 * W1];
-  w.allFinite = (nf == 0);
+  const int2 s11 = t.sat[x1 + z1 * W1], s01 = t.sat[x0 + z1 * W1], s10 = t.sat[x1 + z0 * W1],
+             s00 = t.sat[x0 + z0 * W1];
+  if (t.has_nan && (s11.y - s01.y - s10.y + s00.y)) return false;
+  w.allFinite = (s11.x - s01.x - s10.x + s00.x) == 0;
   const int lvl = m >= 32 ? 3 : (m >= 16 ? 2 : (m >= 8 ? 1 : 0));
   const int B = 4 << lvl;
-  const float* __restrict__ mx = t.maxT[lvl];
-  const float* __restrict__ mn = t.minT[lvl];
+  const float2* __restrict__ mm = t.mm[lvl];
   float vmax = -INFINITY, vmin = INFINITY;
   const int lastX = b.maxX - B + 1, lastZ = b.maxZ - B + 1;
   for (int zz = b.minZ;; zz += B) {
     const int zc = zz < lastZ ? zz : lastZ;
     for (int xx = b.minX;; xx += B) {
       const int xc = xx < lastX ? xx : lastX;
-      const float a = mx[xc + zc * f.nW];
-      const float c = mn[xc + zc * f.nW];
-      vmax = (a > vmax) ? a : vmax;
-      vmin = (c < vmin) ? c : vmin;
+      const float2 v = mm[xc + zc * f.nW];
+      vmax = (v.x > vmax) ? v.x : vmax;
+      vmin = (v.y < vmin) ? v.y : vmin;
       if (xx >= lastX) break;
     }
     if (zz >= lastZ) break;
@@ -200,11 +188,13 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 #define ARTP_REC_EXITS_NEGATIVE 0x400u  // exits (b)-(e) already evaluated (from the tables): none fired
 
 // Box k of a state against ITS layer: 0 = decided ok, 1 = decided failing, 2 = undecided (exits known not
-// to fire), 3 = undecided (tables could not answer).  Called with the body layer for k = 0 and the feet
-// layer for k = 1..4 from separate call sites: selecting the FieldDev / TablesDev kernel arguments by a
-// run-time index would force both structs into per-lane scratch memory (240 B/lane of HBM traffic).
+// to fire), 3 = undecided (tables could not answer).  `b` is complete whenever the result is >= 2.
+// Called with the body layer for k = 0 and the feet layer for k = 1..4 from separate call sites:
+// selecting the FieldDev / TablesDev kernel arguments by a per-lane index would force both structs into
+// per-lane scratch memory (240 B/lane of HBM traffic).
 __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
-                                            const RobotDev& rb, const float t[3], const float R[9], int k) {
+                                            const RobotDev& rb, const float t[3], const float R[9], int k,
+                                            BoxHF& b) {
   const bool body = (k == 0);
   float pose[16];
   state_box_pose(rb, t, R, k, pose);
@@ -213,7 +203,6 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     // !unknown_space_untraversable (validity_checker_feet.cpp:34-37)
     return (!body && rb.unknown_space_untraversable) ? 1 : 0;
   }
-  BoxHF b;
   setup_box(f, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
             body ? rb.torso[2] : rb.foot[2], b);
   int hit = 0;
@@ -226,16 +215,9 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
   return (body ? hit : !hit) ? 1 : 0;
 }
 
-// Queue record of box k (recomputed) into the LDS staging slot dst[0..5].
-__device__ __forceinline__ void stage_record(const FieldDev& f, const RobotDev& rb, const float t[3],
-                                             const float R[9], int k, unsigned state, bool exits_negative,
+// Queue record of a box into the LDS staging slot dst[0..5].
+__device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned state, bool exits_negative,
                                              float4* dst) {
-  const bool body = (k == 0);
-  float pose[16];
-  state_box_pose(rb, t, R, k, pose);
-  BoxHF b;
-  setup_box(f, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
-            body ? rb.torso[2] : rb.foot[2], b);
   dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
   dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
   dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
@@ -247,78 +229,80 @@ __device__ __forceinline__ void stage_record(const FieldDev& f, const RobotDev& 
   dst[5] = make_float4(__uint_as_float(state), __uint_as_float(kind), 0.0f, 0.0f);
 }
 
-// ---- stage 1: one lane per state --------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+// ---- stage 1: one lane per (state, box) ---------------------------------------------------------------
+// A workgroup owns SUB x 64 consecutive states and runs 5 x SUB wavefronts: wavefront w handles box
+// k = w / SUB (0 torso, 1..4 feet) of the 64 states of sub-block w % SUB.  The box index is therefore
+// wave-uniform (no divergence between torso and foot geometry, the layer is picked by a uniform branch)
+// and the five table-lookup latency chains of one state run in five different wavefronts instead of
+// back to back in one lane.  The five verdicts meet in LDS; a state with a decided failing box is
+// finished (label 0) and queues nothing.  Queue slots: ONE atomic per queue per workgroup (a single word
+// sustains only ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue"); every wavefront
+// writes one contiguous run of records, staged in LDS and copied out as full coalesced 16-byte lanes
+// (scattered 16-byte stores into 96-byte records cost ~7x the bytes in partial-line write traffic).
+#define ARTP_CLASSIFY_SUB 2
+#define ARTP_CLASSIFY_THREADS (64 * 5 * ARTP_CLASSIFY_SUB)
+
+__global__ void __launch_bounds__(ARTP_CLASSIFY_THREADS)
 classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, MapGeom g, RobotDev rb,
                        const double* __restrict__ se3, size_t n, uint8_t* __restrict__ valid,
                        PipelineQueues q) {
-  const size_t i_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int SUB = ARTP_CLASSIFY_SUB;
+  __shared__ float4 stage[5 * SUB][32 * 6];
+  __shared__ uint8_t codes[SUB][5][64];
+  __shared__ unsigned cnts[5 * SUB];
+  __shared__ unsigned long long bases[2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = wave / SUB, sub = wave % SUB;
+  const bool body = (k == 0);
+  const size_t i_raw = ((size_t)blockIdx.x * SUB + sub) * 64 + lane;
   const bool live = i_raw < n;
   const size_t i = live ? i_raw : n - 1;  // dead lanes shadow the last state and write nothing
   double st[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) st[k] = se3[7 * i + k];
+  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
   float t[3], R[9];
   pose3_from_se3(st, t, R);
-  int ok = 1;
-  unsigned pending = 0;
-  unsigned exits_neg = 0;  // boxes whose exits (b)-(e) were evaluated from the tables and did not fire
-  {
-    const int r = classify_box(fb, tb, g, rb, t, R, 0);
-    if (r == 1) ok = 0;
-    if (r >= 2) pending |= 1u;
-    if (r == 2) exits_neg |= 1u;
-  }
-#pragma unroll 1
-  for (int k = 1; k < 5; ++k) {
-    const int r = classify_box(ff, tf, g, rb, t, R, k);
-    if (r == 1) ok = 0;
-    if (r >= 2) pending |= 1u << k;
-    if (r == 2) exits_neg |= 1u << k;
-  }
-  if (!ok || !live) pending = 0;  // a decided box already fails: the label is 0 whatever the others say
-  if (live) valid[i] = (uint8_t)ok;
-  // queue slots for the whole wavefront with ONE atomic per queue (a single word sustains only ~88
-  // returning atomics per microsecond, MI355X_MICROARCH.md "dequeue").  Within the wavefront's run of the
-  // foot queue the records are ordered box-major (all pending "foot 1" boxes, then "foot 2", ...), so
-  // every sweep below writes ONE contiguous run.
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  unsigned long long bal[5];
-  int total_f = 0;
+  BoxHF b;
+  int code;
+  if (body)
+    code = classify_box(fb, tb, g, rb, t, R, 0, b);
+  else
+    code = classify_box(ff, tf, g, rb, t, R, k, b);
+  codes[sub][k][lane] = (uint8_t)code;
+  __syncthreads();
+  bool ok = true;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    bal[k] = __ballot((pending >> k) & 1u);
-    if (k > 0) total_f += __popcll(bal[k]);
-  }
-  unsigned long long base_t = 0, base_f = 0;
-  if (lane == 0) {
-    if (bal[0]) base_t = atomicAdd(&q.counters[0], (unsigned long long)__popcll(bal[0]));
-    if (total_f) base_f = atomicAdd(&q.counters[4], (unsigned long long)total_f);
-  }
-  base_t = __shfl(base_t, 0, 64);
-  base_f = __shfl(base_f, 0, 64) + q.feet_base;
-  // second sweep: the undecided boxes are recomputed (cheaper than keeping five records live), staged
-  // in LDS and copied out as full, coalesced 16-byte lanes: scattered 16-byte stores into 96-byte
-  // records cost ~7x the bytes in partial-line write traffic (rocprofv3 WRITE_SIZE / FETCH_SIZE).
-  __shared__ float4 stage[(256 / 64)][64 * 6];
-  float4* stg = stage[threadIdx.x >> 6];
-#pragma unroll 1
-  for (int k = 0; k < 5; ++k) {
-    const int cnt = __popcll(bal[k]);
-    if (cnt == 0) continue;  // wave-uniform
-    const bool body = (k == 0);
-    if ((pending >> k) & 1u) {
-      float4* dst = stg + 6 * __popcll(bal[k] & lt_mask);
-      if (body)
-        stage_record(fb, rb, t, R, k, (unsigned)i, (exits_neg >> k) & 1u, dst);
-      else
-        stage_record(ff, rb, t, R, k, (unsigned)i, (exits_neg >> k) & 1u, dst);
+  for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
+  if (body && live) valid[i] = (uint8_t)ok;
+  const bool pending = live && ok && code >= 2;
+  const unsigned long long bal = __ballot(pending);
+  const int cnt = __popcll(bal);
+  if (lane == 0) cnts[wave] = (unsigned)cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot_t = 0, tot_f = 0;
+#pragma unroll
+    for (int w = 0; w < 5 * SUB; ++w) {
+      if (w < SUB) tot_t += cnts[w];
+      else tot_f += cnts[w];
     }
+    bases[0] = tot_t ? atomicAdd(&q.counters[0], (unsigned long long)tot_t) : 0ull;
+    bases[1] = tot_f ? atomicAdd(&q.counters[4], (unsigned long long)tot_f) : 0ull;
+  }
+  __syncthreads();
+  if (cnt == 0) return;  // wave-uniform; no barrier below
+  unsigned long long base = body ? bases[0] : bases[1] + q.feet_base;
+  for (int w = body ? 0 : SUB; w < wave; ++w) base += cnts[w];
+  float4* stg = stage[wave];
+  float4* out = reinterpret_cast<float4*>(q.q1 + base);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int rank = __popcll(bal & lt_mask);
+  // two rounds of up to 32 records: half the staging LDS, twice the resident wavefronts
+  for (int r0 = 0; r0 < cnt; r0 += 32) {
+    if (pending && rank >= r0 && rank < r0 + 32) stage_record(b, body, (unsigned)i, code == 2, stg + 6 * (rank - r0));
     wave_lds_sync();
-    float4* out = reinterpret_cast<float4*>(q.q1 + (body ? base_t : base_f));
-    for (int j = lane; j < cnt * 6; j += 64) out[j] = stg[j];
-    if (!body) base_f += (unsigned long long)cnt;
+    const int m = (cnt - r0 < 32 ? cnt - r0 : 32) * 6;
+    for (int j = lane; j < m; j += 64) out[r0 * 6 + j] = stg[j];
     wave_lds_sync();
   }
 }
