@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libartp.so")
+if os.environ.get("ARTP_LIB"):  # tuning builds (e.g. libartp_timing.so); never a CPU path
+    LIB_PATH = os.path.abspath(os.environ["ARTP_LIB"])
 
 # every symbol include/artp_c.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -19,7 +21,7 @@ SYMBOLS = [
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_algorithmic_vertices_dev",
-    "artp_debug_pipeline_counters", "artp_cost_blob_bytes", "artp_cost_load_weights",
+    "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_cost_blob_bytes", "artp_cost_load_weights",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
 
@@ -90,6 +92,7 @@ def load():
     L.artp_sample_states_at_dev.argtypes = [vp, u64, u64, vp, vp, sz, vp]
     L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
     L.artp_debug_pipeline_counters.argtypes = [vp, C.POINTER(u64 * 8)]
+    L.artp_debug_partner_table.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int)]
     L.artp_cost_blob_bytes.argtypes = []
     L.artp_cost_blob_bytes.restype = sz
     L.artp_cost_load_weights.argtypes = [vp, vp, sz]

@@ -188,7 +188,20 @@ class Context:
     def pipeline_counters(self):
         out = (C.c_uint64 * 8)()
         self._chk(self.L.artp_debug_pipeline_counters(self.h, C.byref(out)), "artp_debug_pipeline_counters")
-        return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1], "feet_plane_stage": out[5]}
+        return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1], "feet_plane_stage": out[5],
+                "feet_partner_pass": out[6]}
+
+    def partner_table(self, slot, shape):
+        """(flags[nD, nW] uint8 in ODE sample layout, radius) of a layer's partner table; (None, 0) if
+        the layer has none."""
+        r = C.c_int(0)
+        self._chk(self.L.artp_debug_partner_table(self.h, slot, None, 0, C.byref(r)), "artp_debug_partner_table")
+        if r.value == 0:
+            return None, 0
+        out = np.empty(shape[0] * shape[1], np.uint8)
+        self._chk(self.L.artp_debug_partner_table(self.h, slot, out.ctypes.data, out.size, C.byref(r)),
+                  "artp_debug_partner_table")
+        return out.reshape(shape[1], shape[0]), r.value
 
     # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
     def cost_load_weights(self, blob: bytes):

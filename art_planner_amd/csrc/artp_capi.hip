@@ -38,6 +38,9 @@ struct artp_ctx {
   // map tables (pipeline.h): per layer 2 x 6 levels of floats + two summed-area tables
   float* table_buf[2] = {nullptr, nullptr};
   int* sat_buf[2] = {nullptr, nullptr};
+  unsigned char* partner_buf[2] = {nullptr, nullptr};
+  int partner_R_built[2] = {-1, -1};
+  float4* tri_raw_buf[2] = {nullptr, nullptr};
   size_t table_elems[2] = {0, 0};
   TablesDev tables[2]{};
   ScratchCaps caps_full{0, 0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
@@ -197,9 +200,11 @@ int set_kernel_lds(artp_ctx* c) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(plane_stage_kernel<1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64>),
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16>),
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 2>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet(c)));
   return ARTP_OK;
 }
@@ -221,15 +226,62 @@ int grid_scan(const artp_ctx* c, size_t lds) {
 }
 
 // Range tables of one layer (pipeline.h).  Levels 0..5 (block 1..32); the kernels use levels 2..5.
-int build_tables(artp_ctx* c, int slot) {
+// Partner table of the foot layer (FieldDev::partner_flags).  Radius = the largest index window a foot box
+// can have: box diagonal / sample spacing, + the window's rounding and dCollideHeightfield's +1 border.
+// dirty = {x0, z0, x1, z1} (inclusive sample range that changed) or nullptr for the whole layer.
+int build_partner_table(artp_ctx* c, int slot, const int* dirty) {
+  FieldDev& f = c->field[slot];
+  f.partner_flags = nullptr;
+  f.partner_R = 0;
+  if (slot != 1) return ARTP_OK;
+  const double diag = std::sqrt((double)c->robot.foot[0] * c->robot.foot[0] + (double)c->robot.foot[1] * c->robot.foot[1] +
+                                (double)c->robot.foot[2] * c->robot.foot[2]);
+  const int R = (int)std::ceil(diag / std::fmin((double)f.sample_w, (double)f.sample_d)) + 3;
+  if (R > 24) return ARTP_OK;  // beyond that the table costs more than it saves: the list path takes every box
+  int cx0 = 0, cz0 = 0, cx1 = f.nW - 1, cz1 = f.nD - 1;
+  if (dirty && c->partner_R_built[slot] == R) {
+    cx0 = std::max(dirty[0] - R - 1, 0);
+    cz0 = std::max(dirty[1] - R - 1, 0);
+    cx1 = std::min(dirty[2] + R + 1, f.nW - 1);
+    cz1 = std::min(dirty[3] + R + 1, f.nD - 1);
+  }
+  const int ncx = cx1 - cx0 + 1, ncz = cz1 - cz0 + 1, ncell = ncx * ncz;
+  hipLaunchKernelGGL(partner_flags_clear_kernel, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, f.nW, cx0, cz0,
+                     ncx, ncz, c->partner_buf[slot]);
+  {
+    // raw cross products of every cell the pass below reads: the rectangle widened by R
+    const int rx0 = std::max(cx0 - R, 0), rz0 = std::max(cz0 - R, 0);
+    const int rx1 = std::min(cx1 + R, f.nW - 1), rz1 = std::min(cz1 + R, f.nD - 1);
+    const int rnx = rx1 - rx0 + 1, rnz = rz1 - rz0 + 1;
+    hipLaunchKernelGGL(tri_raw_kernel, dim3((rnx * rnz + 255) / 256), dim3(256), 0, c->stream, f, rx0, rz0, rnx, rnz,
+                       c->tri_raw_buf[slot]);
+  }
+  hipLaunchKernelGGL(partner_flags_kernel, dim3((ncell + 255) / 256, 2 * R + 1), dim3(256), 0, c->stream, f, R, cx0,
+                     cz0, ncx, ncz, (const float4*)c->tri_raw_buf[slot],
+                     reinterpret_cast<unsigned*>(c->partner_buf[slot]));
+  HIP_TRY(c, hipGetLastError());
+  c->partner_R_built[slot] = R;
+  f.partner_flags = c->partner_buf[slot];
+  f.partner_R = R;
+  return ARTP_OK;
+}
+
+int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
   const FieldDev& f = c->field[slot];
   const size_t elems = (size_t)f.nW * f.nD;
   const size_t sat_elems = (size_t)(f.nW + 1) * (f.nD + 1);
   if (c->table_elems[slot] < elems) {
     if (c->table_buf[slot]) HIP_TRY(c, hipFree(c->table_buf[slot]));
     if (c->sat_buf[slot]) HIP_TRY(c, hipFree(c->sat_buf[slot]));
+    if (c->partner_buf[slot]) HIP_TRY(c, hipFree(c->partner_buf[slot]));
+    if (c->tri_raw_buf[slot]) HIP_TRY(c, hipFree(c->tri_raw_buf[slot]));
+    c->tri_raw_buf[slot] = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tri_raw_buf[slot]), elems * sizeof(float4)));
     c->table_buf[slot] = nullptr;
     c->sat_buf[slot] = nullptr;
+    c->partner_buf[slot] = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->partner_buf[slot]), (elems + 3) / 4 * 4));
+    c->partner_R_built[slot] = -1;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->table_buf[slot]), 12 * elems * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sat_buf[slot]), 2 * sat_elems * sizeof(int)));
     c->table_elems[slot] = elems;
@@ -249,6 +301,8 @@ int build_tables(artp_ctx* c, int slot) {
   for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) t.mm[l] = mm[l + 2];
   t.sat = sat;
   t.has_nan = f.has_nan;
+  const int rc_partner = build_partner_table(c, slot, dirty);
+  if (rc_partner != ARTP_OK) return rc_partner;
   t.valid = 1;
   return ARTP_OK;
 }
@@ -277,10 +331,13 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);
-  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64>), dim3(grid_scan(c, lds_scan(c))),
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_scan(c, lds_scan(c))),
                      dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->robot, q, valid,
                      c->caps_scan, c->d_error);
-  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16>), dim3(grid_scan(c, lds_feet(c))),
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>), dim3(grid_scan(c, lds_feet(c))),
+                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_feet(c), c->stream, c->field[1], c->robot, q, valid,
+                     c->caps_feet, c->d_error);
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 2>), dim3(grid_scan(c, lds_feet(c))),
                      dim3(64 * ARTP_WAVES_PER_BLOCK), lds_feet(c), c->stream, c->field[1], c->robot, q, valid,
                      c->caps_feet, c->d_error);
   hipLaunchKernelGGL(plane_stage_kernel<1>, dim3(grid_full(c, 0)), dim3(64), lds_full(c), c->stream,
@@ -386,6 +443,8 @@ void artp_destroy(artp_ctx* c) {
   for (int s = 0; s < 2; ++s) {
     if (c->table_buf[s]) (void)hipFree(c->table_buf[s]);
     if (c->sat_buf[s]) (void)hipFree(c->sat_buf[s]);
+    if (c->partner_buf[s]) (void)hipFree(c->partner_buf[s]);
+    if (c->tri_raw_buf[s]) (void)hipFree(c->tri_raw_buf[s]);
   }
   if (c->cub_tmp) (void)hipFree(c->cub_tmp);
   if (c->d_conv1_w) (void)hipFree(c->d_conv1_w);
@@ -523,7 +582,10 @@ int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, 
   int has_nan = 0;
   for (float v : host) has_nan |= (v != v);
   c->field[slot].has_nan = has_nan;
-  const int rc = build_tables(c, slot);  // the whole map is ~1 MB: rebuilding beats tracking dirty blocks
+  // range tables: the whole map is ~1 MB, rebuilding beats tracking dirty blocks; the partner table only
+  // recomputes the dirty rectangle plus its margin
+  const int dirty[4] = {row0, cols - (col0 + ncols), row0 + nrows - 1, cols - 1 - col0};
+  const int rc = build_tables(c, slot, dirty);
   if (rc != ARTP_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
@@ -821,6 +883,21 @@ int artp_debug_pipeline_counters(artp_ctx* c, uint64_t out[8]) {
   if (!c->tmp[5]) return ARTP_ERR_NO_MAP;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(out, c->tmp[5], 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ARTP_OK;
+}
+
+int artp_debug_partner_table(artp_ctx* c, int slot, uint8_t* out, size_t out_bytes, int* radius) {
+  if (!c || slot < 0 || slot > 1 || !radius) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
+  const FieldDev& f = c->field[slot];
+  *radius = f.partner_flags ? f.partner_R : 0;
+  if (!out || !f.partner_flags) return ARTP_OK;
+  const size_t need = (size_t)f.nW * f.nD;
+  if (out_bytes < need) return ARTP_ERR_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(out, f.partner_flags, need, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
 }
@@ -1140,3 +1217,15 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 }
 
 }  // extern "C"
+
+#ifdef ARTP_STAGE_TIMING
+extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
+  if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_stage_cycles), 20 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned long long z[20] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_stage_cycles), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

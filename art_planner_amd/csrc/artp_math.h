@@ -40,6 +40,13 @@ struct FieldDev {
   // epsilon-equal have raw cross products that differ by at most partner_tol * |cross| per component
   // (derivation in DESIGN.md 4.1); +inf disables the filter.
   float partner_tol;
+  // Partner table (pipeline.h: partner_flags_kernel), indexed like `data` by the cell's lower vertex:
+  // bit 0 / bit 1 = the ABC / DBC triangle of the cell has ANOTHER all-finite triangle with an
+  // epsilon-equal plane within Chebyshev distance partner_R cells.  Planes depend on the map only, so a
+  // window of at most partner_R x partner_R cells whose corner candidates are all unflagged cannot hold
+  // a partner.  nullptr = not built for this layer.
+  const unsigned char* partner_flags;
+  int partner_R;
 };
 
 // Box in heightfield frame, ready for the zone test.

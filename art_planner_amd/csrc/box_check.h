@@ -566,7 +566,17 @@ struct CandCap { static constexpr int value = (G == 64) ? 64 : 32; };
 
 template <int G>
 __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const BoxHF& b,
-                                                       const WaveScratch& s, int lane, int T) {
+                                                       const WaveScratch& s, int lane, int T, bool fast = false
+#ifdef ARTP_STAGE_TIMING
+                                                       , unsigned long long* t_acc = nullptr
+#endif
+) {
+#ifdef ARTP_STAGE_TIMING
+  long long t_prev = clock64();
+#define ARTP_TC_MARK(slot) do { const long long n_ = clock64(); if (t_acc) t_acc[slot] += (unsigned long long)(n_ - t_prev); t_prev = n_; } while (0)
+#else
+#define ARTP_TC_MARK(slot) do { } while (0)
+#endif
   constexpr int CAP = CandCap<G>::value;
   const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
@@ -583,7 +593,11 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
   // 16 base slots = 8 corners x 2 orientations for the cell under the corner; a corner within the margin
   // of a cell border also nominates the neighbouring cell(s): offsets (1,0), (0,1), (1,1).
   // G = 64 walks the four offsets side by side; G = 16 runs an offset round only when some corner needs it.
+  // fast mode (T unknown, no kept-triangle list): decide from the candidates alone when the map's partner
+  // table rules out a partner for every one of them; 2 = "needs the list" otherwise.
   int ncand = 0;
+  bool maybe_partner = false;
+  const bool window_covered = f.partner_flags != nullptr && cellsX <= f.partner_R && cellsZ <= f.partner_R;
   const int base_slot = gl & 15;
   const int corner = base_slot >> 1;
   const bool c_up = !(base_slot & 1);
@@ -608,6 +622,9 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
       const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
       const bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
       is_cand = kept;
+      if (kept && fast)
+        maybe_partner = maybe_partner || !window_covered ||
+                        ((f.partner_flags[(b.minX + cx) + (size_t)(b.minZ + cz) * f.nW] >> (c_up ? 0 : 1)) & 1);
       if (kept) {
         const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
         const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;
@@ -632,8 +649,12 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
     ncand += n_here;
     if (G == 64) break;  // the four offsets were handled side by side
   }
+  ARTP_TC_MARK(5);
   if (ncand == 0) return 0;  // no kept triangle under any box corner: nothing can accept a contact
   wave_lds_sync();
+  if (fast) {
+    if (grp_any<G>(maybe_partner, lane)) return 2;
+  } else {
   // does any kept triangle have a plane epsilon-equal to a candidate's (other than itself)?
   // (the same triangle may be nominated by two corners: duplicates are harmless)
   bool partner = false;
@@ -673,7 +694,9 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
       }
     }
   }
+  ARTP_TC_MARK(6);
   if (grp_any<G>(partner, lane)) return 2;
+  }
   // all candidates are singleton groups: own plane, own contacts, own cell
   bool hit = false;
   for (int q = gl; q < ncand; q += G) {
@@ -688,6 +711,7 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
     for (int i = 0; i < 4; ++i)
       if (i < nc) hit = hit || is_on_heightfield2(f, gx, gz, cpos[i][0], cpos[i][2], up);
   }
+  ARTP_TC_MARK(7);
   return grp_any<G>(hit, lane) ? 1 : 0;
 }
 

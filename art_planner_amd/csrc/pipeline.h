@@ -90,6 +90,100 @@ sat_cols_kernel(int nW, int nD, int2* __restrict__ S) {
   }
 }
 
+// Partner table (FieldDev::partner_flags): both triangles of a cell against every triangle of the
+// (2R+1)^2 cell neighbourhood, with the very arithmetic of the plane stage (triangle_plane on absolute
+// sample coordinates, the raw-cross pre-filter, the four epsilon compares).
+// Pass 1 (tri_raw_kernel): per cell {raw0, raw2} of the ABC and the DBC triangle (+inf for a triangle
+// with a non-finite vertex: it can never be kept, and +inf fails the pre-filter).
+// Pass 2: one lane per (cell of the rectangle [cx0, cx0+ncx) x [cz0, cz0+ncz), neighbourhood row
+// dz = blockIdx.y - R); the inner loop is one 16-byte load and four pre-filter compares per neighbour cell,
+// the exact planes are only formed on a pre-filter hit.  Hits are OR-ed into the byte table (the caller
+// zeroes the rectangle first).  A changed sample can alter the flags of cells up to R+1 cells away only,
+// so rectangle updates recompute a margin instead of the map.
+__device__ __forceinline__ void cell_triangle(const FieldDev& f, int cx, int cz, bool up, bool& finite,
+                                              float pl[4], float raw[3]) {
+  const int i = cx + cz * f.nW;
+  const float hA = f.data[i], hB = f.data[i + 1], hC = f.data[i + f.nW], hD = f.data[i + f.nW + 1];
+  const float xA = (float)cx * f.sample_w, xB = (float)(cx + 1) * f.sample_w;
+  const float zA = (float)cz * f.sample_d, zC = (float)(cz + 1) * f.sample_d;
+  finite = is_finite(hB) && is_finite(hC) && is_finite(up ? hA : hD);
+  if (up)
+    triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, pl, raw);
+  else
+    triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, pl, raw);
+}
+
+__global__ void __launch_bounds__(256)
+tri_raw_kernel(FieldDev f, int cx0, int cz0, int ncx, int ncz, float4* __restrict__ raw4) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= ncx * ncz) return;
+  const int cx = cx0 + li % ncx, cz = cz0 + li / ncx;
+  float4 o = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+  if (cx < f.nW - 1 && cz < f.nD - 1) {
+    float pl[4], raw[3];
+    bool fin;
+    cell_triangle(f, cx, cz, true, fin, pl, raw);
+    if (fin) { o.x = raw[0]; o.y = raw[2]; }
+    cell_triangle(f, cx, cz, false, fin, pl, raw);
+    if (fin) { o.z = raw[0]; o.w = raw[2]; }
+  }
+  raw4[cx + cz * f.nW] = o;
+}
+
+__global__ void __launch_bounds__(256)
+partner_flags_kernel(FieldDev f, int R, int cx0, int cz0, int ncx, int ncz, const float4* __restrict__ raw4,
+                     unsigned* __restrict__ flags32) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= ncx * ncz) return;
+  const int cx = cx0 + li % ncx, cz = cz0 + li / ncx;
+  if (cx >= f.nW - 1 || cz >= f.nD - 1) return;
+  const int z = cz + (int)blockIdx.y - R;
+  if (z < 0 || z > f.nD - 2) return;
+  const int i = cx + cz * f.nW;
+  float pl[2][4], raw[2][3], tol[2];
+  bool own[2];
+  cell_triangle(f, cx, cz, true, own[0], pl[0], raw[0]);
+  cell_triangle(f, cx, cz, false, own[1], pl[1], raw[1]);
+  if (!(own[0] || own[1])) return;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const float len = sqrtf(raw[o][0] * raw[o][0] + raw[o][1] * raw[o][1] + raw[o][2] * raw[o][2]);
+    tol[o] = !own[o] ? -1.0f : ((fabsf(pl[o][1]) >= 0.05f) ? f.partner_tol * len : INFINITY);
+  }
+  unsigned out = 0;
+  const int x0 = max(cx - R, 0), x1 = min(cx + R, f.nW - 2);
+  for (int x = x0; x <= x1; ++x) {
+    const int e = x + z * f.nW;
+    const float4 r = raw4[e];
+    // pre-filter of own triangle o against the neighbour cell's ABC (r.x, r.y) and DBC (r.z, r.w);
+    // tol = -1 (own triangle not finite) never passes
+    const bool c00 = !(fabsf(r.x - raw[0][0]) > tol[0]) && !(fabsf(r.y - raw[0][2]) > tol[0]);
+    const bool c01 = !(fabsf(r.z - raw[0][0]) > tol[0]) && !(fabsf(r.w - raw[0][2]) > tol[0]);
+    const bool c10 = !(fabsf(r.x - raw[1][0]) > tol[1]) && !(fabsf(r.y - raw[1][2]) > tol[1]);
+    const bool c11 = !(fabsf(r.z - raw[1][0]) > tol[1]) && !(fabsf(r.w - raw[1][2]) > tol[1]);
+    if (!(c00 || c01 || c10 || c11)) continue;
+    const bool same = (e == i);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (!(p == 0 ? (c00 || c10) : (c01 || c11))) continue;
+      float p2[4], r2[3];
+      bool fin;
+      cell_triangle(f, x, z, p == 0, fin, p2, r2);
+      if (!fin) continue;
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+        if (own[o] && !(same && o == p) && planes_eps_equal(pl[o], p2)) out |= 1u << o;
+    }
+  }
+  if (out) atomicOr(&flags32[i >> 2], out << (8 * (i & 3)));
+}
+
+__global__ void __launch_bounds__(256)
+partner_flags_clear_kernel(int nW, int cx0, int cz0, int ncx, int ncz, unsigned char* __restrict__ flags) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li < ncx * ncz) flags[(cx0 + li % ncx) + (size_t)(cz0 + li / ncx) * nW] = 0;
+}
+
 // Exact window statistics from the tables.  Returns false when the tables cannot answer (window
 // thinner than the smallest block, or a NaN in the window -> the running-dMAX quirk needs the scan).
 __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const TablesDev& t, const BoxHF& b,
@@ -398,10 +492,25 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
   }
 }
 
+#ifdef ARTP_STAGE_TIMING
+// tuning aid (never in the shipped build): cycles per stage of resolve_boxes_kernel, summed over boxes
+__device__ unsigned long long g_stage_cycles[2][10];
+#define ARTP_T_MARK(slot)                    \
+  do {                                       \
+    const long long now_ = clock64();        \
+    t_acc[slot] += (unsigned long long)(now_ - t_prev); \
+    t_prev = now_;                           \
+  } while (0)
+#else
+#define ARTP_T_MARK(slot) do { } while (0)
+#endif
+
 // ---- stage 2: one lane group per undecided box ---------------------------------------------------------
 // G = 64: torso queue, one wavefront per box.  G = 16: foot queue, four boxes per wavefront.
 // Static striding over the queue (a shared work cursor would serialise on one atomic word).
-template <int WAVES, int G>
+// PASS 0: torso queue.  PASS 1: foot queue 3, fast -- no kept-triangle list; boxes whose corner candidates
+// might have a partner (partner table) go to queue 5.  PASS 2: queue 5 with the list and the partner search.
+template <int WAVES, int G, int PASS>
 __global__ void __launch_bounds__(64 * WAVES)
 resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
                      ScratchCaps caps, int* __restrict__ error_flag) {
@@ -412,11 +521,18 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
   const bool feet = (G != 64);  // feet: only the boxes the lane-per-box stages handed over (queue 3)
-  const unsigned long long count = q.counters[feet ? 5 : 0];
+  const unsigned long long count = q.counters[PASS == 0 ? 0 : (PASS == 1 ? 5 : 6)];
   const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
+#ifdef ARTP_STAGE_TIMING
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = clock64();
+#endif
   for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
        it += stride) {
-    const unsigned long long item = feet ? (unsigned long long)q.q3[it] : it;
+    const unsigned long long item = PASS == 0 ? it : (unsigned long long)(PASS == 1 ? q.q3[it] : q.q5[it]);
+#ifdef ARTP_STAGE_TIMING
+    long long t_prev = clock64();
+#endif
     const PendingBox rec = q.q1[item];
     if (valid[rec.state] == 0) continue;        // another box of this state already failed
     BoxHF b;
@@ -426,19 +542,39 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
       if (gl == 0) atomicExch(error_flag, 1);
       continue;
     }
+    ARTP_T_MARK(0);
     WindowStats w;
     grp_scan_window<G>(fld, b, s, lane, w);
+    ARTP_T_MARK(1);
     int result = 0, ec;
     // queue 5 boxes (feet) already went through exits and (f) in the lane-per-box stage
     bool decided = !feet && decide_exits(b, w, result, ec);
     if (!decided) {
-      if (!feet && grp_vertex_pass<G>(fld, b, s, lane, w.allFinite)) {
+      const bool vhit = !feet && grp_vertex_pass<G>(fld, b, s, lane, w.allFinite);
+      ARTP_T_MARK(2);
+      if (vhit) {
         result = 1;
         decided = true;
+      } else if (PASS == 1) {
+        const int r = grp_plane_stage_corners<G>(fld, b, s, lane, 0, true);
+        ARTP_T_MARK(4);
+        if (r != 2) {
+          result = r;
+          decided = true;
+        } else if (gl == 0) {
+          const unsigned long long slot = atomicAdd(&q.counters[6], 1ull);
+          q.q5[slot] = (unsigned)item;
+        }
       } else {
         const int T = grp_compact_triangles<G, true>(b, s, lane);
+        ARTP_T_MARK(3);
         // T < 0: more kept triangles than the short list of this stage holds -> exact-grouping stage
+#ifdef ARTP_STAGE_TIMING
+        const int r = (T == 0) ? 0 : (T < 0 ? 2 : grp_plane_stage_corners<G>(fld, b, s, lane, T, false, t_acc));
+#else
         const int r = (T == 0) ? 0 : (T < 0 ? 2 : grp_plane_stage_corners<G>(fld, b, s, lane, T));
+#endif
+        ARTP_T_MARK(4);
         if (r != 2) {
           result = r;
           decided = true;
@@ -454,6 +590,13 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
     }
     wave_lds_sync();
   }
+#ifdef ARTP_STAGE_TIMING
+  if (gl == 0) {
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_stage_cycles[G == 64 ? 0 : 1][k], t_acc[k]);
+    atomicAdd(&g_stage_cycles[G == 64 ? 0 : 1][8], (unsigned long long)(clock64() - t_begin));
+    atomicAdd(&g_stage_cycles[G == 64 ? 0 : 1][9], 1ull);
+  }
+#endif
 }
 
 // ---- stage 3: plane stage ---------------------------------------------------------------------------

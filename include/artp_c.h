@@ -162,6 +162,10 @@ int artp_algorithmic_vertices_dev(artp_ctx* ctx, const double* se3, size_t n, ui
 /* Diagnostics of the last validity batch: out[0] = torso boxes queued for the window stage,
  * out[4] = foot boxes queued, out[1] = boxes that needed the exact plane grouping. */
 int artp_debug_pipeline_counters(artp_ctx* ctx, uint64_t out[8]);
+/* Diagnostics: the partner table of a layer (one byte per sample in ODE sample layout, bit 0 / bit 1 =
+ * the ABC / DBC triangle of the cell has an epsilon-equal plane within *radius cells).
+ * out may be NULL to query the radius only; *radius = 0 when the layer has no table. */
+int artp_debug_partner_table(artp_ctx* ctx, int slot, uint8_t* out, size_t out_bytes, int* radius);
 
 /* ---- learned motion cost: MotionCostObjective::MotionCostFunc
  *      (art_planner/include/art_planner/objectives/motion_cost_objective.h:22-23; the reference

@@ -1,0 +1,34 @@
+"""Per-stage cycle totals of resolve_boxes_kernel (build with `make -C art_planner_amd/csrc timing`,
+which writes libartp_timing.so; the shipped libartp.so carries no instrumentation).
+usage: ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/stage_timing.py"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from art_planner_amd import _capi
+from art_planner_amd.context import Context
+from art_planner_amd.synthetic import make_map
+
+gm = make_map(400, 0.04, seed=1234)
+ctx = Context(0, "yaml")
+ctx.upload_map(gm)
+L = _capi.load()
+n = 1 << 22
+se3 = torch.empty((n, 7), dtype=torch.float64, device="cuda:0")
+va = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+ctx.use_torch_stream()
+ctx.sample_and_validate_dev(1234, 0, n, se3, va)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 20)()
+L.artp_debug_stage_cycles(out, 1)
+ctx.sample_and_validate_dev(1234, n, n, se3, va)
+torch.cuda.synchronize()
+L.artp_debug_stage_cycles(out, 0)
+a = np.array(list(out), dtype=np.float64).reshape(2, 10)
+names = ["record", "scan", "vertex(f)", "compact", "corners"]
+cnt = ctx.pipeline_counters()
+print("counters", cnt)
+for g, nm in ((0, "torso G=64"), (1, "feet G=16")):
+    tot = a[g, :5].sum()
+    print(nm, "stage ticks/lifetime", round(tot / a[g, 8], 3), "groups", int(a[g, 9]), "ticks per group", a[g, 8] / a[g, 9],
+          {names[k]: round(float(a[g, k] / tot), 3) for k in range(5)},
+          "corners split", {n2: round(float(a[g, k] / tot), 3) for k, n2 in ((5, "candidates"), (6, "partners"), (7, "contacts"))})

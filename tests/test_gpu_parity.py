@@ -218,3 +218,69 @@ def test_c1_flat_map_all_exit_paths_decided_by_tables(ctx_yaml):
     vo = O.OracleMap(gm).states_valid(O.robot("yaml"), se3)
     assert np.array_equal(vg, vo)
     assert 0.05 < vg.mean() < 0.95
+
+
+def _terraced(gm, step=0.05):
+    """Quantise both height layers to terraces: large families of exactly coplanar triangles, i.e. the
+    plane stage's grouping (and the partner table that lets most boxes skip it) really matters."""
+    import copy
+    out = copy.deepcopy(gm)
+    for name in ("elevation", "elevation_masked"):
+        a = out[name].astype(np.float64)
+        q = np.where(np.isfinite(a), np.round(a / step) * step, a)
+        out.layers[name] = np.asfortranarray(q.astype(np.float32))
+    return out
+
+
+def test_terraced_map_partner_paths(big_map):
+    """Feet on terraces: many corner candidates have coplanar partners (partner table set -> list pass and
+    exact grouping); labels must still equal the oracle's."""
+    gm = _terraced(common.crop_map(big_map, 60, 90, 200))
+    rob = O.robot("yaml")
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm, sampler=False)
+    rng = np.random.default_rng(21)
+    se3 = common.random_states(gm, 120000, rng, z_off=(0.0, 0.03), tilt=0.15, spread=0.5)
+    vg = ctx.validate_states(se3)
+    cnt = ctx.pipeline_counters()
+    vo = O.OracleMap(gm).states_valid(rob, se3)
+    assert np.array_equal(vg, vo), f"{(vg != vo).sum()} mismatches"
+    assert cnt["feet_partner_pass"] > 1000, cnt  # the flagged path is really exercised
+    assert 0.02 < vg.mean() < 0.98
+    flags, radius = ctx.partner_table(1, (gm.rows, gm.cols))
+    assert radius > 0 and (flags != 0).mean() > 0.2
+    ctx.close()
+
+
+def test_partner_table_incremental_equals_full(big_map):
+    """artp_update_layer_rect recomputes the partner table in the dirty rectangle + margin only: the
+    table must equal the one of a fresh upload of the modified layer; labels equal the oracle's."""
+    gm = _terraced(common.crop_map(big_map, 100, 100, 160), step=0.02)
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm, sampler=False)
+    rng = np.random.default_rng(5)
+    masked = gm["elevation_masked"].copy()
+    elev = gm["elevation"].copy()
+    for (r0, c0, nr, nc) in ((10, 20, 30, 40), (0, 0, 12, 9), (120, 131, 40, 29)):
+        patch = masked[r0:r0 + nr, c0:c0 + nc] + np.float32(0.013) * rng.integers(0, 3, (nr, nc)).astype(np.float32)
+        masked[r0:r0 + nr, c0:c0 + nc] = patch
+        ctx.update_layer_rect(1, patch, r0, c0)
+        patch0 = elev[r0:r0 + nr, c0:c0 + nc] + np.float32(0.01)
+        elev[r0:r0 + nr, c0:c0 + nc] = patch0
+        ctx.update_layer_rect(0, patch0, r0, c0)
+    inc, radius = ctx.partner_table(1, (gm.rows, gm.cols))
+    gm2 = common.crop_map(gm, 0, 0, gm.rows)
+    gm2.pos_x, gm2.pos_y = gm.pos_x, gm.pos_y
+    gm2.layers["elevation_masked"] = np.asfortranarray(masked)
+    gm2.layers["elevation"] = np.asfortranarray(elev)
+    ctx2 = _ctx("yaml")
+    ctx2.upload_map(gm2, sampler=False)
+    full, radius2 = ctx2.partner_table(1, (gm.rows, gm.cols))
+    assert radius == radius2 > 0
+    assert np.array_equal(inc, full), f"{(inc != full).sum()} cells differ"
+    se3 = common.random_states(gm2, 60000, rng, z_off=(0.0, 0.03), tilt=0.15, spread=0.5)
+    vo = O.OracleMap(gm2).states_valid(O.robot("yaml"), se3)
+    assert np.array_equal(ctx.validate_states(se3), vo)
+    assert np.array_equal(ctx2.validate_states(se3), vo)
+    ctx.close()
+    ctx2.close()
