@@ -233,11 +233,10 @@ int build_partner_table(artp_ctx* c, int slot, const int* dirty) {
   FieldDev& f = c->field[slot];
   f.partner_flags = nullptr;
   f.partner_R = 0;
-  if (slot != 1) return ARTP_OK;
-  const double diag = std::sqrt((double)c->robot.foot[0] * c->robot.foot[0] + (double)c->robot.foot[1] * c->robot.foot[1] +
-                                (double)c->robot.foot[2] * c->robot.foot[2]);
+  const float* side = slot == 1 ? c->robot.foot : c->robot.torso;
+  const double diag = std::sqrt((double)side[0] * side[0] + (double)side[1] * side[1] + (double)side[2] * side[2]);
   const int R = (int)std::ceil(diag / std::fmin((double)f.sample_w, (double)f.sample_d)) + 3;
-  if (R > 24) return ARTP_OK;  // beyond that the table costs more than it saves: the list path takes every box
+  if (R > 63) return ARTP_OK;  // larger windows than the stages hold anyway
   int cx0 = 0, cz0 = 0, cx1 = f.nW - 1, cz1 = f.nD - 1;
   if (dirty && c->partner_R_built[slot] == R) {
     cx0 = std::max(dirty[0] - R - 1, 0);

@@ -546,7 +546,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
     WindowStats w;
     grp_scan_window<G>(fld, b, s, lane, w);
     ARTP_T_MARK(1);
-    int result = 0, ec;
+    int result = 0, ec, fast_r = 2;
     // queue 5 boxes (feet) already went through exits and (f) in the lane-per-box stage
     bool decided = !feet && decide_exits(b, w, result, ec);
     if (!decided) {
@@ -565,6 +565,11 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
           const unsigned long long slot = atomicAdd(&q.counters[6], 1ull);
           q.q5[slot] = (unsigned)item;
         }
+      } else if (PASS == 0 && fld.partner_flags != nullptr &&
+                 (fast_r = grp_plane_stage_corners<G>(fld, b, s, lane, 0, true)) != 2) {
+        ARTP_T_MARK(4);
+        result = fast_r;
+        decided = true;
       } else {
         const int T = grp_compact_triangles<G, true>(b, s, lane);
         ARTP_T_MARK(3);
