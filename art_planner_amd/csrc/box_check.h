@@ -325,6 +325,48 @@ __device__ __forceinline__ bool grp_vertex_pass(const FieldDev& f, const BoxHF& 
   return grp_any<G>(hit, lane);
 }
 
+// (f) for an ALL-FINITE window straight from global memory (no LDS tile): every colliding vertex belongs
+// to an all-finite triangle, so the test is order-free and needs no neighbour.  8 loads in flight per lane;
+// the group polls for a hit after every chunk.
+template <int G>
+__device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF& b, int lane) {
+  const int gl = grp_lane<G>(lane);
+  const int numX = b.maxX - b.minX + 1;
+  const int numZ = b.maxZ - b.minZ + 1;
+  const int total = numX * numZ;
+  if (numX < 2 || numZ < 2) return false;  // no cell, no triangle, no member vertex
+  const float minO2 = b.aabb[2];
+  const int qz = G / numX, rx = G - qz * numX;
+  int xl = gl % numX, zl = gl / numX;
+  const float* base = f.data + b.minX + (size_t)b.minZ * f.nW;
+  constexpr int U = 8;
+  bool hit = false;
+  for (int e0 = gl; e0 < total; e0 += G * U) {
+    float hv[U];
+    int xs[U], zs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      xs[u] = xl;
+      zs[u] = zl;
+      hv[u] = (e0 + G * u < total) ? base[xl + zl * f.nW] : -INFINITY;
+      xl += rx;
+      zl += qz;
+      if (xl >= numX) {
+        xl -= numX;
+        zl += 1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float h = hv[u];
+      if (is_finite(h) && h > minO2)
+        hit = hit || point_in_box(b, (float)(b.minX + xs[u]) * f.sample_w, h, (float)(b.minZ + zs[u]) * f.sample_d);
+    }
+    if (grp_any<G>(hit, lane)) return true;
+  }
+  return false;
+}
+
 // Kept triangles of the window in the reference's buffer order (x_local outer, z_local inner, ABC
 // before DBC; :1306-1441).  With WRITE_LIST the ids go to s.tri; returns T, or -1 on list overflow.
 template <int G, bool WRITE_LIST>
@@ -564,7 +606,7 @@ __device__ __forceinline__ int tri_pack(int cx, int cz, bool down) { return cx |
 template <int G>
 struct CandCap { static constexpr int value = (G == 64) ? 64 : 32; };
 
-template <int G>
+template <int G, bool GLOBAL_H = false>
 __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const BoxHF& b,
                                                        const WaveScratch& s, int lane, int T, bool fast = false
 #ifdef ARTP_STAGE_TIMING
@@ -616,8 +658,10 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
     float cpl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float craw[3] = {0.0f, 0.0f, 0.0f};
     if (is_cand) {
-      const int e = cz * numX + cx;
-      const float hA = s.h[e], hB = s.h[e + 1], hC = s.h[e + numX], hD = s.h[e + numX + 1];
+      // GLOBAL_H: no LDS tile was staged (fast mode only), read the four samples of the cell from the map
+      const float* hp = GLOBAL_H ? f.data + (b.minX + cx) + (size_t)(b.minZ + cz) * f.nW : s.h + cz * numX + cx;
+      const int hstride = GLOBAL_H ? f.nW : numX;
+      const float hA = hp[0], hB = hp[1], hC = hp[hstride], hD = hp[hstride + 1];
       const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
       const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
       const bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
@@ -652,8 +696,8 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
   ARTP_TC_MARK(5);
   if (ncand == 0) return 0;  // no kept triangle under any box corner: nothing can accept a contact
   wave_lds_sync();
-  if (fast) {
-    if (grp_any<G>(maybe_partner, lane)) return 2;
+  if (fast || GLOBAL_H) {
+    if (!fast || grp_any<G>(maybe_partner, lane)) return 2;
   } else {
   // does any kept triangle have a plane epsilon-equal to a candidate's (other than itself)?
   // (the same triangle may be nominated by two corners: duplicates are harmless)

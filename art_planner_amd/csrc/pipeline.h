@@ -280,6 +280,7 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 
 // record flags (PendingBox::kind, bit 0 = foot)
 #define ARTP_REC_EXITS_NEGATIVE 0x400u  // exits (b)-(e) already evaluated (from the tables): none fired
+#define ARTP_REC_ALL_FINITE 0x800u      // ... and the window holds no non-finite sample
 
 // Box k of a state against ITS layer: 0 = decided ok, 1 = decided failing, 2 = undecided (exits known not
 // to fire), 3 = undecided (tables could not answer).  `b` is complete whenever the result is >= 2.
@@ -288,7 +289,8 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 // per-lane scratch memory (240 B/lane of HBM traffic).
 __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
                                             const RobotDev& rb, const float t[3], const float R[9], int k,
-                                            BoxHF& b) {
+                                            BoxHF& b, bool& all_finite) {
+  all_finite = false;
   const bool body = (k == 0);
   float pose[16];
   state_box_pose(rb, t, R, k, pose);
@@ -304,6 +306,7 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     WindowStats w;
     int ec;
     const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
+    all_finite = have_stats && w.allFinite;
     if (!(have_stats && decide_exits(b, w, hit, ec))) return have_stats ? 2 : 3;
   }
   return (body ? hit : !hit) ? 1 : 0;
@@ -311,7 +314,7 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
 
 // Queue record of a box into the LDS staging slot dst[0..5].
 __device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned state, bool exits_negative,
-                                             float4* dst) {
+                                             bool all_finite, float4* dst) {
   dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
   dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
   dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
@@ -319,7 +322,8 @@ __device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned
   const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
   const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
   dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
-  const unsigned kind = (body ? 0u : 1u) | (exits_negative ? ARTP_REC_EXITS_NEGATIVE : 0u);
+  const unsigned kind = (body ? 0u : 1u) | (exits_negative ? ARTP_REC_EXITS_NEGATIVE : 0u) |
+                        (exits_negative && all_finite ? ARTP_REC_ALL_FINITE : 0u);
   dst[5] = make_float4(__uint_as_float(state), __uint_as_float(kind), 0.0f, 0.0f);
 }
 
@@ -358,10 +362,11 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   pose3_from_se3(st, t, R);
   BoxHF b;
   int code;
+  bool all_finite;
   if (body)
-    code = classify_box(fb, tb, g, rb, t, R, 0, b);
+    code = classify_box(fb, tb, g, rb, t, R, 0, b, all_finite);
   else
-    code = classify_box(ff, tf, g, rb, t, R, k, b);
+    code = classify_box(ff, tf, g, rb, t, R, k, b, all_finite);
   codes[sub][k][lane] = (uint8_t)code;
   __syncthreads();
   bool ok = true;
@@ -393,7 +398,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   const int rank = __popcll(bal & lt_mask);
   // two rounds of up to 32 records: half the staging LDS, twice the resident wavefronts
   for (int r0 = 0; r0 < cnt; r0 += 32) {
-    if (pending && rank >= r0 && rank < r0 + 32) stage_record(b, body, (unsigned)i, code == 2, stg + 6 * (rank - r0));
+    if (pending && rank >= r0 && rank < r0 + 32) stage_record(b, body, (unsigned)i, code == 2, all_finite, stg + 6 * (rank - r0));
     wave_lds_sync();
     const int m = (cnt - r0 < 32 ? cnt - r0 : 32) * 6;
     for (int j = lane; j < m; j += 64) out[r0 * 6 + j] = stg[j];
@@ -543,12 +548,32 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
       continue;
     }
     ARTP_T_MARK(0);
-    WindowStats w;
-    grp_scan_window<G>(fld, b, s, lane, w);
-    ARTP_T_MARK(1);
     int result = 0, ec, fast_r = 2;
-    // queue 5 boxes (feet) already went through exits and (f) in the lane-per-box stage
-    bool decided = !feet && decide_exits(b, w, result, ec);
+    bool decided = false;
+    if (PASS == 0 && fld.partner_flags != nullptr && (rec.kind & ARTP_REC_ALL_FINITE)) {
+      // Streaming path: the tables already ruled out exits (b)-(e) and found the window all finite, so
+      // (f) runs straight off the map and the corner stage reads its few cells from the map too: no LDS
+      // tile, no list.  Only a box whose candidates may have partners falls through to the staged path.
+      if (grp_vertex_stream<G>(fld, b, lane)) {
+        result = 1;
+        decided = true;
+      } else {
+        ARTP_T_MARK(2);
+        const int r = grp_plane_stage_corners<G, true>(fld, b, s, lane, 0, true);
+        if (r != 2) {
+          result = r;
+          decided = true;
+        }
+      }
+      ARTP_T_MARK(4);
+    }
+    WindowStats w;
+    if (!decided) {
+      grp_scan_window<G>(fld, b, s, lane, w);
+      ARTP_T_MARK(1);
+      // queue 5 boxes (feet) already went through exits and (f) in the lane-per-box stage
+      decided = !feet && decide_exits(b, w, result, ec);
+    }
     if (!decided) {
       const bool vhit = !feet && grp_vertex_pass<G>(fld, b, s, lane, w.allFinite);
       ARTP_T_MARK(2);
