@@ -314,7 +314,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   }
   int rc = ensure_tmp(c, 4, 5 * n * sizeof(PendingBox));
   if (rc) return rc;
-  rc = ensure_tmp(c, 5, (5 + 4 + 4) * n * sizeof(unsigned) + 64);
+  rc = ensure_tmp(c, 5, (5 + 4 + 4 + 4) * n * sizeof(unsigned) + 64);
   if (rc) return rc;
   PipelineQueues q;
   q.q1 = static_cast<PendingBox*>(c->tmp[4]);
@@ -322,12 +322,18 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   q.q2 = reinterpret_cast<unsigned*>(q.counters + 8);
   q.q3 = q.q2 + 5 * n;
   q.q5 = q.q3 + 4 * n;
+  q.q4 = q.q5 + 4 * n;
   q.feet_base = n;
   HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
   const size_t per_block = 64 * ARTP_CLASSIFY_SUB;
   hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + per_block - 1) / per_block)),
                      dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
+  {
+    const size_t lds = (size_t)CandCap<16>::value * 36 * 4 * ARTP_STREAM_WAVES;
+    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3((unsigned)c->n_cus * 4), dim3(64 * ARTP_STREAM_WAVES), lds,
+                       c->stream, c->field[1], c->robot, q, valid);
+  }
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);
   hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_scan(c, lds_scan(c))),

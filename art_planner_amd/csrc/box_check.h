@@ -325,20 +325,23 @@ __device__ __forceinline__ bool grp_vertex_pass(const FieldDev& f, const BoxHF& 
   return grp_any<G>(hit, lane);
 }
 
-// (f) for an ALL-FINITE window straight from global memory (no LDS tile): every colliding vertex belongs
-// to an all-finite triangle, so the test is order-free and needs no neighbour.  8 loads in flight per lane;
-// the group polls for a hit after every chunk.
+// (f) straight from global memory (no LDS tile); the test is order-free.  In an all-finite window every
+// colliding vertex belongs to an all-finite triangle; otherwise the six neighbours that share a triangle
+// with the vertex are looked up (only for colliding vertices inside the box: rare).  8 loads in flight per
+// lane; the group polls for a hit after every chunk.
 template <int G>
-__device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF& b, int lane) {
+__device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF& b, int lane, bool all_finite) {
   const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
   const int total = numX * numZ;
   if (numX < 2 || numZ < 2) return false;  // no cell, no triangle, no member vertex
+  const int cellsX = numX - 1, cellsZ = numZ - 1;
   const float minO2 = b.aabb[2];
   const int qz = G / numX, rx = G - qz * numX;
   int xl = gl % numX, zl = gl / numX;
-  const float* base = f.data + b.minX + (size_t)b.minZ * f.nW;
+  const int nW = f.nW;
+  const float* base = f.data + b.minX + (size_t)b.minZ * nW;
   constexpr int U = 8;
   bool hit = false;
   for (int e0 = gl; e0 < total; e0 += G * U) {
@@ -348,7 +351,7 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
     for (int u = 0; u < U; ++u) {
       xs[u] = xl;
       zs[u] = zl;
-      hv[u] = (e0 + G * u < total) ? base[xl + zl * f.nW] : -INFINITY;
+      hv[u] = (e0 + G * u < total) ? base[xl + zl * nW] : -INFINITY;
       xl += rx;
       zl += qz;
       if (xl >= numX) {
@@ -359,8 +362,23 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float h = hv[u];
-      if (is_finite(h) && h > minO2)
-        hit = hit || point_in_box(b, (float)(b.minX + xs[u]) * f.sample_w, h, (float)(b.minZ + zs[u]) * f.sample_d);
+      if (is_finite(h) && h > minO2 && !hit &&
+          point_in_box(b, (float)(b.minX + xs[u]) * f.sample_w, h, (float)(b.minZ + zs[u]) * f.sample_d)) {
+        if (all_finite) {
+          hit = true;
+        } else {
+          const float* c = base + xs[u] + zs[u] * nW;
+          const bool xm = xs[u] > 0, xp = xs[u] < cellsX, zm = zs[u] > 0, zp = zs[u] < cellsZ;
+          const bool f_xp = xp && is_finite(c[1]);
+          const bool f_xm = xm && is_finite(c[-1]);
+          const bool f_zp = zp && is_finite(c[nW]);
+          const bool f_zm = zm && is_finite(c[-nW]);
+          const bool f_xm_zp = xm && zp && is_finite(c[nW - 1]);
+          const bool f_xp_zm = xp && zm && is_finite(c[1 - nW]);
+          hit = (f_xp && f_zp) || (f_xm && f_xm_zp) || (f_xm_zp && f_zp) || (f_zm && f_xp_zm) ||
+                (f_xp_zm && f_xp) || (f_zm && f_xm);
+        }
+      }
     }
     if (grp_any<G>(hit, lane)) return true;
   }

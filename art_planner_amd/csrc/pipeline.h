@@ -233,8 +233,9 @@ struct PipelineQueues {
   PendingBox* q1;                // undecided boxes: torso records at [0, n), foot records at [n, 5n)
   unsigned* q2;                  // indices into q1 of boxes that need the exact-grouping stage
   unsigned* q3;                  // indices into q1 of foot boxes that survive the lane scan stage
-  unsigned* q5;                  // indices into q1 of foot boxes left to the lane-group stage
-  unsigned long long* counters;  // [0] torso, [1] q2, [4] feet, [5] q3, [6] q5 counts
+  unsigned* q4;                  // foot boxes whose exits the tables could not evaluate (lane-scan path)
+  unsigned* q5;                  // foot boxes whose corner candidates may have partners (list pass)
+  unsigned long long* counters;  // [0] torso, [1] q2, [4] feet, [5] q3, [6] q5, [7] q4 counts
   unsigned long long feet_base;  // = n
 };
 
@@ -282,6 +283,38 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 #define ARTP_REC_EXITS_NEGATIVE 0x400u  // exits (b)-(e) already evaluated (from the tables): none fired
 #define ARTP_REC_ALL_FINITE 0x800u      // ... and the window holds no non-finite sample
 
+// Probe of exit (f) "a colliding terrain vertex lies inside the box" on an N x N lattice of samples under
+// the box (all-finite window, so every window vertex is a member of an all-finite triangle).  (f) is an
+// existence test, hence any vertex found inside decides it; finding none decides nothing.
+template <int N>
+__device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const BoxHF& b, float frac) {
+  if (b.maxX - b.minX < 1 || b.maxZ - b.minZ < 1) return false;
+  float h[N * N];
+  int ix[N * N], iz[N * N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float a = (N == 1) ? 0.0f : frac * ((float)(2 * i) / (float)(N - 1) - 1.0f) * b.side[0];
+      const float c = (N == 1) ? 0.0f : frac * ((float)(2 * j) / (float)(N - 1) - 1.0f) * b.side[1];
+      const float wx = b.pos[0] + a * b.R[0] + c * b.R[1];
+      const float wz = b.pos[2] + a * b.R[6] + c * b.R[7];
+      int x = (int)rintf(wx * f.inv_w), z = (int)rintf(wz * f.inv_d);
+      x = x < b.minX ? b.minX : (x > b.maxX ? b.maxX : x);
+      z = z < b.minZ ? b.minZ : (z > b.maxZ ? b.maxZ : z);
+      ix[j * N + i] = x;
+      iz[j * N + i] = z;
+      h[j * N + i] = f.data[x + (size_t)z * f.nW];
+    }
+  }
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < N * N; ++k)
+    hit = hit || (is_finite(h[k]) && h[k] > b.aabb[2] &&
+                  point_in_box(b, (float)ix[k] * f.sample_w, h[k], (float)iz[k] * f.sample_d));
+  return hit;
+}
+
 // Box k of a state against ITS layer: 0 = decided ok, 1 = decided failing, 2 = undecided (exits known not
 // to fire), 3 = undecided (tables could not answer).  `b` is complete whenever the result is >= 2.
 // Called with the body layer for k = 0 and the feet layer for k = 1..4 from separate call sites:
@@ -307,7 +340,12 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     int ec;
     const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
     all_finite = have_stats && w.allFinite;
-    if (!(have_stats && decide_exits(b, w, hit, ec))) return have_stats ? 2 : 3;
+    if (!(have_stats && decide_exits(b, w, hit, ec))) {
+      // feet only: 3/5 of the undecided foot boxes hold a vertex and the 2 x 2 probe finds most of them;
+      // torso hits sit at the rim of the box (a 3 x 3 probe caught 1 in 4) and do not pay for the probe
+      if (all_finite && !body && probe_vertices_inside<2>(f, b, 0.25f)) return 0;  // exit (f): the foot touches
+      return have_stats ? 2 : 3;
+    }
   }
   return (body ? hit : !hit) ? 1 : 0;
 }
@@ -374,6 +412,17 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
   if (body && live) valid[i] = (uint8_t)ok;
   const bool pending = live && ok && code >= 2;
+#ifdef ARTP_STAGE_TIMING
+  if (!body) {
+    const unsigned long long m2 = __ballot(pending && code == 2 && all_finite), m3 = __ballot(pending && code == 2 && !all_finite),
+                             m7 = __ballot(pending && code == 3);
+    if (lane == 0) {
+      if (m2) atomicAdd(&q.counters[2], (unsigned long long)__popcll(m2));
+      if (m3) atomicAdd(&q.counters[3], (unsigned long long)__popcll(m3));
+      if (m7) atomicAdd(&q.counters[7], (unsigned long long)__popcll(m7));
+    }
+  }
+#endif
   const unsigned long long bal = __ballot(pending);
   const int cnt = __popcll(bal);
   if (lane == 0) cnts[wave] = (unsigned)cnt;
@@ -421,19 +470,20 @@ __device__ __forceinline__ unsigned long long wave_fetch_item(unsigned long long
 // them from the tables), then (f).  Boxes still undecided (they need the plane stage) are compacted
 // into queue 3 for the lane-group stage, one atomic per wavefront.
 #define ARTP_LANE_THREADS 256
+#define ARTP_STREAM_WAVES 4
 
 __global__ void __launch_bounds__(ARTP_LANE_THREADS)
 feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const unsigned long long count = q.counters[4];
+  const unsigned long long count = q.counters[7];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long rounds = (count + stride - 1) / stride;  // uniform trip count: ballots below
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
     const unsigned long long it = rnd * stride + (unsigned long long)blockIdx.x * blockDim.x + tid;
     const bool live = it < count;
-    const unsigned long long item = q.feet_base + (live ? it : 0ull);
+    const unsigned long long item = live ? (unsigned long long)q.q4[it] : q.feet_base;
     bool undecided = false;
     if (live) {
       const PendingBox rec = q.q1[item];
@@ -497,6 +547,46 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
   }
 }
 
+// ---- stage 1c: the foot queue, one 16-lane row per box, straight off the map ---------------------------
+// For the records whose exits (b)-(e) the tables already ruled out (all of them unless the window holds a
+// NaN or is thinner than the smallest table block): (f) streamed from the map, then the list-free corner
+// stage.  Decides everything except boxes whose corner candidates may have partners (-> queue 5, list
+// pass).  Records without table verdict go to queue 4 (sequential lane scan with the running-dMAX quirk).
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = 16, GPW = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
+  const ScratchCaps caps{CandCap<G>::value * 36, 0, 0, 0};
+  const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
+  const unsigned long long count = q.counters[4];
+  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
+  for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
+       it += stride) {
+    const unsigned long long item = q.feet_base + it;
+    const PendingBox rec = q.q1[item];
+    if (valid[rec.state] == 0) continue;  // another box of this state already failed
+    if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) {
+      if (gl == 0) q.q4[atomicAdd(&q.counters[7], 1ull)] = (unsigned)item;
+      continue;
+    }
+    BoxHF b;
+    box_from_record(rec, rb, b);
+    if (grp_vertex_stream<G>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0)) continue;  // it touches
+    const int r = grp_plane_stage_corners<G, true>(ff, b, s, lane, 0, true);
+    if (gl == 0) {
+      if (r == 2)
+        q.q5[atomicAdd(&q.counters[6], 1ull)] = (unsigned)item;
+      else if (r == 0)
+        valid[rec.state] = 0;  // a foot that touches nothing fails the state
+    }
+    wave_lds_sync();
+  }
+}
+
 #ifdef ARTP_STAGE_TIMING
 // tuning aid (never in the shipped build): cycles per stage of resolve_boxes_kernel, summed over boxes
 __device__ unsigned long long g_stage_cycles[2][10];
@@ -554,7 +644,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
       // Streaming path: the tables already ruled out exits (b)-(e) and found the window all finite, so
       // (f) runs straight off the map and the corner stage reads its few cells from the map too: no LDS
       // tile, no list.  Only a box whose candidates may have partners falls through to the staged path.
-      if (grp_vertex_stream<G>(fld, b, lane)) {
+      if (grp_vertex_stream<G>(fld, b, lane, true)) {
         result = 1;
         decided = true;
       } else {
