@@ -37,9 +37,10 @@ struct artp_ctx {
   bool have_z = false;
   // map tables (pipeline.h): per layer 2 x 6 levels of floats + two summed-area tables
   float* table_buf[2] = {nullptr, nullptr};
-  int* sat_buf[2] = {nullptr, nullptr};
+  unsigned char* flag_buf[2] = {nullptr, nullptr};  // per-level non-finite / NaN block flags
   unsigned char* partner_buf[2] = {nullptr, nullptr};
   int partner_R_built[2] = {-1, -1};
+  int layer_has_nonfinite[2] = {1, 1};
   float4* tri_raw_buf[2] = {nullptr, nullptr};
   size_t table_elems[2] = {0, 0};
   TablesDev tables[2]{};
@@ -268,38 +269,42 @@ int build_partner_table(artp_ctx* c, int slot, const int* dirty) {
 int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
   const FieldDev& f = c->field[slot];
   const size_t elems = (size_t)f.nW * f.nD;
-  const size_t sat_elems = (size_t)(f.nW + 1) * (f.nD + 1);
   if (c->table_elems[slot] < elems) {
     if (c->table_buf[slot]) HIP_TRY(c, hipFree(c->table_buf[slot]));
-    if (c->sat_buf[slot]) HIP_TRY(c, hipFree(c->sat_buf[slot]));
+    if (c->flag_buf[slot]) HIP_TRY(c, hipFree(c->flag_buf[slot]));
     if (c->partner_buf[slot]) HIP_TRY(c, hipFree(c->partner_buf[slot]));
     if (c->tri_raw_buf[slot]) HIP_TRY(c, hipFree(c->tri_raw_buf[slot]));
     c->tri_raw_buf[slot] = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tri_raw_buf[slot]), elems * sizeof(float4)));
     c->table_buf[slot] = nullptr;
-    c->sat_buf[slot] = nullptr;
+    c->flag_buf[slot] = nullptr;
     c->partner_buf[slot] = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->partner_buf[slot]), (elems + 3) / 4 * 4));
     c->partner_R_built[slot] = -1;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->table_buf[slot]), 12 * elems * sizeof(float)));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sat_buf[slot]), 2 * sat_elems * sizeof(int)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->flag_buf[slot]), 6 * elems));
     c->table_elems[slot] = elems;
   }
   float2* mm[6];
-  for (int l = 0; l < 6; ++l) mm[l] = reinterpret_cast<float2*>(c->table_buf[slot]) + (size_t)l * elems;
+  unsigned char* fl[6];
+  for (int l = 0; l < 6; ++l) {
+    mm[l] = reinterpret_cast<float2*>(c->table_buf[slot]) + (size_t)l * elems;
+    fl[l] = reinterpret_cast<unsigned char*>(c->flag_buf[slot]) + (size_t)l * elems;
+  }
   const int n = (int)elems;
-  hipLaunchKernelGGL(table_level0_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, f.data, n, mm[0]);
+  hipLaunchKernelGGL(table_level0_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, f.data, n, mm[0], fl[0]);
   for (int l = 1; l < 6; ++l)
     hipLaunchKernelGGL(table_level_up_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
-                       (const float2*)mm[l - 1], f.nW, f.nD, 1 << (l - 1), mm[l]);
-  int2* sat = reinterpret_cast<int2*>(c->sat_buf[slot]);
-  hipLaunchKernelGGL(sat_rows_kernel, dim3((f.nD + 63) / 64), dim3(64), 0, c->stream, f.data, f.nW, f.nD, sat);
-  hipLaunchKernelGGL(sat_cols_kernel, dim3((f.nW + 1 + 63) / 64), dim3(64), 0, c->stream, f.nW, f.nD, sat);
+                       (const float2*)mm[l - 1], (const unsigned char*)fl[l - 1], f.nW, f.nD, 1 << (l - 1), mm[l],
+                       fl[l]);
   HIP_TRY(c, hipGetLastError());
   TablesDev& t = c->tables[slot];
-  for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) t.mm[l] = mm[l + 2];
-  t.sat = sat;
+  for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) {
+    t.mm[l] = mm[l + 2];
+    t.fl[l] = fl[l + 2];
+  }
   t.has_nan = f.has_nan;
+  t.has_nonfinite = c->layer_has_nonfinite[slot];
   const int rc_partner = build_partner_table(c, slot, dirty);
   if (rc_partner != ARTP_OK) return rc_partner;
   t.valid = 1;
@@ -447,7 +452,7 @@ void artp_destroy(artp_ctx* c) {
     if (c->tmp[s]) (void)hipFree(c->tmp[s]);
   for (int s = 0; s < 2; ++s) {
     if (c->table_buf[s]) (void)hipFree(c->table_buf[s]);
-    if (c->sat_buf[s]) (void)hipFree(c->sat_buf[s]);
+    if (c->flag_buf[s]) (void)hipFree(c->flag_buf[s]);
     if (c->partner_buf[s]) (void)hipFree(c->partner_buf[s]);
     if (c->tri_raw_buf[s]) (void)hipFree(c->tri_raw_buf[s]);
   }
@@ -500,13 +505,15 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
   // layer(x, cols-1-z), stored x-fastest.
   std::vector<float>& host = c->field_host[slot];
   host.resize(elems);
-  int has_nan = 0;
+  int has_nan = 0, has_nonfinite = 0;
   for (int j = 0; j < cols; ++j)
     for (int i = 0; i < rows; ++i) {
       const float v = layer[(size_t)i + (size_t)(cols - 1 - j) * rows];
       host[(size_t)i + (size_t)j * rows] = v;
       has_nan |= (v != v);
+      has_nonfinite |= !std::isfinite(v);
     }
+  c->layer_has_nonfinite[slot] = has_nonfinite;
   if (c->field_elems[slot] < elems) {
     if (c->field_data[slot]) HIP_TRY(c, hipFree(c->field_data[slot]));
     c->field_data[slot] = nullptr;
@@ -584,9 +591,13 @@ int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, 
     HIP_TRY(c, hipMemcpyAsync(c->field_data[slot] + (size_t)row0 + (size_t)z * rows, dst,
                               sizeof(float) * nrows, hipMemcpyHostToDevice, c->stream));
   }
-  int has_nan = 0;
-  for (float v : host) has_nan |= (v != v);
+  int has_nan = 0, has_nonfinite = 0;
+  for (float v : host) {
+    has_nan |= (v != v);
+    has_nonfinite |= !std::isfinite(v);
+  }
   c->field[slot].has_nan = has_nan;
+  c->layer_has_nonfinite[slot] = has_nonfinite;
   // range tables: the whole map is ~1 MB, rebuilding beats tracking dirty blocks; the partner table only
   // recomputes the dirty rectangle plus its margin
   const int dirty[4] = {row0, cols - (col0 + ncols), row0 + nrows - 1, cols - 1 - col0};

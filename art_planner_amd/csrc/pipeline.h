@@ -31,25 +31,28 @@ struct TablesDev {
   // accesses into tables larger than one XCD's L2: cache lines touched, not bytes, are the cost)
   const float2* mm[ARTP_TABLE_LEVELS];  // .x = max over [x, x+B) x [z, z+B), NaN samples count as -inf
                                         // .y = min over the FINITE samples of the block, +inf if none
-  const int2* sat;                      // (nW+1) x (nD+1) summed-area tables: .x = !isfinite, .y = NaN
-  int has_nan;                          // the layer holds a NaN somewhere (else .y is all zero)
+  const unsigned char* fl[ARTP_TABLE_LEVELS];  // bit 0: the block holds a non-finite sample, bit 1: a NaN
+  int has_nan;                          // the layer holds a NaN somewhere
+  int has_nonfinite;                    // the layer holds a NaN or an infinity somewhere (else fl is all zero)
   int valid;
 };
 
 // ---- table construction (map upload) ---------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-table_level0_kernel(const float* __restrict__ data, int n, float2* __restrict__ mm) {
+table_level0_kernel(const float* __restrict__ data, int n, float2* __restrict__ mm, unsigned char* __restrict__ fl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const float h = data[i];
     mm[i] = make_float2(is_nan(h) ? -INFINITY : h, is_finite(h) ? h : INFINITY);
+    fl[i] = (unsigned char)((is_finite(h) ? 0 : 1) | (is_nan(h) ? 2 : 0));
   }
 }
 
 // out = combine of the four half-size blocks at offsets (0,0), (h,0), (0,h), (h,h); indices clamp at
 // the border (blocks hanging over the edge are never queried).
 __global__ void __launch_bounds__(256)
-table_level_up_kernel(const float2* __restrict__ in, int nW, int nD, int half, float2* __restrict__ out) {
+table_level_up_kernel(const float2* __restrict__ in, const unsigned char* __restrict__ fin, int nW, int nD, int half,
+                      float2* __restrict__ out, unsigned char* __restrict__ fout) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nW * nD) return;
   const int x = i % nW, z = i / nW;
@@ -58,36 +61,7 @@ table_level_up_kernel(const float2* __restrict__ in, int nW, int nD, int half, f
   const float ab = (b.x > a.x) ? b.x : a.x, cd = (d.x > c.x) ? d.x : c.x;
   const float ef = (b.y < a.y) ? b.y : a.y, gh = (d.y < c.y) ? d.y : c.y;
   out[i] = make_float2((cd > ab) ? cd : ab, (gh < ef) ? gh : ef);
-}
-
-// Summed-area tables, two passes (rows then columns); S is (nW+1) x (nD+1), row/col 0 are zero.
-__global__ void __launch_bounds__(64)
-sat_rows_kernel(const float* __restrict__ data, int nW, int nD, int2* __restrict__ S) {
-  const int z = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per sample row z
-  if (z >= nD) return;
-  const int W1 = nW + 1;
-  int a = 0, bnan = 0;
-  S[(z + 1) * W1] = make_int2(0, 0);
-  for (int x = 0; x < nW; ++x) {
-    const float h = data[x + z * nW];
-    a += is_finite(h) ? 0 : 1;
-    bnan += is_nan(h) ? 1 : 0;
-    S[(x + 1) + (z + 1) * W1] = make_int2(a, bnan);
-  }
-}
-__global__ void __launch_bounds__(64)
-sat_cols_kernel(int nW, int nD, int2* __restrict__ S) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;  // one lane per column x in [0, nW]
-  if (x > nW) return;
-  const int W1 = nW + 1;
-  int a = 0, b = 0;
-  S[x] = make_int2(0, 0);
-  for (int z = 1; z <= nD; ++z) {
-    const int2 v = S[x + z * W1];
-    a += v.x;
-    b += v.y;
-    S[x + z * W1] = make_int2(a, b);
-  }
+  fout[i] = fin[x + z * nW] | fin[x1 + z * nW] | fin[x + z1 * nW] | fin[x1 + z1 * nW];
 }
 
 // Partner table (FieldDev::partner_flags): both triangles of a cell against every triangle of the
@@ -191,28 +165,27 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int m = wX < wZ ? wX : wZ;
   if (m < 4) return false;
-  const int W1 = f.nW + 1;
-  const int x0 = b.minX, x1 = b.maxX + 1, z0 = b.minZ, z1 = b.maxZ + 1;
-  const int2 s11 = t.sat[x1 + z1 * W1], s01 = t.sat[x0 + z1 * W1], s10 = t.sat[x1 + z0 * W1],
-             s00 = t.sat[x0 + z0 * W1];
-  if (t.has_nan && (s11.y - s01.y - s10.y + s00.y)) return false;
-  w.allFinite = (s11.x - s01.x - s10.x + s00.x) == 0;
   const int lvl = m >= 32 ? 3 : (m >= 16 ? 2 : (m >= 8 ? 1 : 0));
   const int B = 4 << lvl;
   const float2* __restrict__ mm = t.mm[lvl];
+  const unsigned char* __restrict__ fl = t.fl[lvl];
   float vmax = -INFINITY, vmin = INFINITY;
+  unsigned flags = 0;
   const int lastX = b.maxX - B + 1, lastZ = b.maxZ - B + 1;
   for (int zz = b.minZ;; zz += B) {
     const int zc = zz < lastZ ? zz : lastZ;
     for (int xx = b.minX;; xx += B) {
       const int xc = xx < lastX ? xx : lastX;
       const float2 v = mm[xc + zc * f.nW];
+      if (t.has_nonfinite) flags |= fl[xc + zc * f.nW];  // uniform: a fully finite layer skips the lookup
       vmax = (v.x > vmax) ? v.x : vmax;
       vmin = (v.y < vmin) ? v.y : vmin;
       if (xx >= lastX) break;
     }
     if (zz >= lastZ) break;
   }
+  if (flags & 2u) return false;  // a NaN in the window: the running-dMAX quirk needs the ordered scan
+  w.allFinite = !(flags & 1u);
   w.maxY = vmax;
   w.minY = vmin;
   return true;
