@@ -1238,7 +1238,12 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_stage_cycles), 20 * sizeof(unsigned long long)) != hipSuccess)
     return -1;
+  if (out20 && reset >= 2 &&
+      hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_classify_cycles), 16 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
   if (reset) {
+    unsigned long long z16[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_classify_cycles), z16, sizeof(z16)) != hipSuccess) return -1;
     unsigned long long z[20] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_stage_cycles), z, sizeof(z)) != hipSuccess) return -1;
   }

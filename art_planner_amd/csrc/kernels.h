@@ -285,10 +285,13 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
   double rpy0 = pi * (-2.0 * uniform01(seed, index, 3) + 1.0);
   double rpy1 = acos(1.0 - 2.0 * uniform01(seed, index, 4)) - pi / 2.0;
   const double rpy2 = pi * (-2.0 * uniform01(seed, index, 5) + 1.0);
+  // sin and cos of yaw/2 are needed twice (the yaw quaternion here, setSO3FromRPY below): one sincos
+  double sy2s, sy2c, qw, qz;
+  sincos(0.5 * rpy2, &sy2s, &sy2c);
   {
     // normal_b = Quaterniond(AngleAxisd(yaw, Z)).inverse() * normal_w (sampler.cpp:120-123)
-    const double ha = 0.5 * rpy2;
-    const double qw = cos(ha), qz = sin(ha);
+    qw = sy2c;
+    qz = sy2s;
     const double n2 = qw * qw + qz * qz;
     const double iw = qw / n2, ix = -0.0 / n2, iy = -0.0 / n2, iz = -qz / n2;
     double uv0 = iy * nwz - iz * nwy;
@@ -304,9 +307,10 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
     rpy1 = atan2(nbx, nbz) + rpy1 * rb.max_pitch_pert / 0.78539816339744830962;
   }
   {  // setSO3FromRPY (utils.h:101-115)
-    const double r2 = rpy0 * 0.5, p2 = rpy1 * 0.5, y2 = rpy2 * 0.5;
-    const double cr = cos(r2), cp = cos(p2), cy = cos(y2);
-    const double sr = sin(r2), sp = sin(p2), sy = sin(y2);
+    double cr, cp, sr, sp;
+    sincos(rpy0 * 0.5, &sr, &cr);
+    sincos(rpy1 * 0.5, &sp, &cp);
+    const double cy = sy2c, sy = sy2s;
     out[6] = cy * cp * cr + sy * sp * sr;
     out[3] = cy * cp * sr - sy * sp * cr;
     out[4] = sy * cp * sr + cy * sp * cr;

@@ -349,6 +349,12 @@ __device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned
 // writes one contiguous run of records, staged in LDS and copied out as full coalesced 16-byte lanes
 // (scattered 16-byte stores into 96-byte records cost ~7x the bytes in partial-line write traffic).
 #define ARTP_CLASSIFY_SUB 2
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_classify_cycles[2][8];  // [torso waves | foot waves][phase]
+#define ARTP_C_MARK(slot) do { const long long n_ = clock64(); c_acc[slot] = (unsigned long long)(n_ - c_prev); c_prev = n_; } while (0)
+#else
+#define ARTP_C_MARK(slot) do { } while (0)
+#endif
 #define ARTP_CLASSIFY_THREADS (64 * 5 * ARTP_CLASSIFY_SUB)
 
 __global__ void __launch_bounds__(ARTP_CLASSIFY_THREADS)
@@ -366,11 +372,16 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   const size_t i_raw = ((size_t)blockIdx.x * SUB + sub) * 64 + lane;
   const bool live = i_raw < n;
   const size_t i = live ? i_raw : n - 1;  // dead lanes shadow the last state and write nothing
+#ifdef ARTP_STAGE_TIMING
+  unsigned long long c_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long c_prev = clock64();
+#endif
   double st[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
   float t[3], R[9];
   pose3_from_se3(st, t, R);
+  ARTP_C_MARK(0);
   BoxHF b;
   int code;
   bool all_finite;
@@ -378,24 +389,15 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     code = classify_box(fb, tb, g, rb, t, R, 0, b, all_finite);
   else
     code = classify_box(ff, tf, g, rb, t, R, k, b, all_finite);
+  ARTP_C_MARK(1);
   codes[sub][k][lane] = (uint8_t)code;
   __syncthreads();
+  ARTP_C_MARK(2);
   bool ok = true;
 #pragma unroll
   for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
   if (body && live) valid[i] = (uint8_t)ok;
   const bool pending = live && ok && code >= 2;
-#ifdef ARTP_STAGE_TIMING
-  if (!body) {
-    const unsigned long long m2 = __ballot(pending && code == 2 && all_finite), m3 = __ballot(pending && code == 2 && !all_finite),
-                             m7 = __ballot(pending && code == 3);
-    if (lane == 0) {
-      if (m2) atomicAdd(&q.counters[2], (unsigned long long)__popcll(m2));
-      if (m3) atomicAdd(&q.counters[3], (unsigned long long)__popcll(m3));
-      if (m7) atomicAdd(&q.counters[7], (unsigned long long)__popcll(m7));
-    }
-  }
-#endif
   const unsigned long long bal = __ballot(pending);
   const int cnt = __popcll(bal);
   if (lane == 0) cnts[wave] = (unsigned)cnt;
@@ -411,6 +413,16 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     bases[1] = tot_f ? atomicAdd(&q.counters[4], (unsigned long long)tot_f) : 0ull;
   }
   __syncthreads();
+  ARTP_C_MARK(3);
+#ifdef ARTP_STAGE_TIMING
+  if (cnt == 0) {
+    if (lane == 0) {
+      for (int p = 0; p < 4; ++p) atomicAdd(&g_classify_cycles[body ? 0 : 1][p], c_acc[p]);
+      atomicAdd(&g_classify_cycles[body ? 0 : 1][7], 1ull);
+    }
+    return;
+  }
+#endif
   if (cnt == 0) return;  // wave-uniform; no barrier below
   unsigned long long base = body ? bases[0] : bases[1] + q.feet_base;
   for (int w = body ? 0 : SUB; w < wave; ++w) base += cnts[w];
@@ -426,6 +438,13 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     for (int j = lane; j < m; j += 64) out[r0 * 6 + j] = stg[j];
     wave_lds_sync();
   }
+#ifdef ARTP_STAGE_TIMING
+  ARTP_C_MARK(4);
+  if (lane == 0) {
+    for (int p = 0; p < 5; ++p) atomicAdd(&g_classify_cycles[body ? 0 : 1][p], c_acc[p]);
+    atomicAdd(&g_classify_cycles[body ? 0 : 1][7], 1ull);
+  }
+#endif
 }
 
 __device__ __forceinline__ unsigned long long wave_fetch_item(unsigned long long* cursor, int lane) {

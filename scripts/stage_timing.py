@@ -27,9 +27,13 @@ a = np.array(list(out), dtype=np.float64).reshape(2, 10)
 names = ["record", "scan", "vertex(f)", "compact", "corners"]
 cnt = ctx.pipeline_counters()
 print("counters", cnt)
-raw = (C.c_uint64 * 8)()
-L.artp_debug_pipeline_counters(ctx.h, C.byref(raw))
-print("feet pending: tables ok & all finite", raw[2], " tables ok & some non-finite", raw[3], " tables could not answer", raw[7])
+cc = (C.c_ulonglong * 20)()
+L.artp_debug_stage_cycles(cc, 2)  # reset >= 2: read the classify phase counters instead (and reset all)
+c = np.array(list(cc)[:16], dtype=np.float64).reshape(2, 8)
+for g, nm in ((0, "classify torso waves"), (1, "classify foot waves")):
+    tot = c[g, :5].sum()
+    print(nm, int(c[g, 7]), "waves, ticks/wave", round(tot / max(c[g, 7], 1)),
+          {k: round(float(c[g, j] / tot), 3) for j, k in enumerate(["load+pose", "classify_box", "barrier1", "atomic+barriers", "records"])})
 for g, nm in ((0, "torso G=64"), (1, "feet G=16")):
     tot = a[g, :5].sum()
     print(nm, "stage ticks/lifetime", round(tot / a[g, 8], 3), "groups", int(a[g, 9]), "ticks per group", a[g, 8] / a[g, 9],
