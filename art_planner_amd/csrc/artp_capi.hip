@@ -40,6 +40,7 @@ struct artp_ctx {
   unsigned char* flag_buf[2] = {nullptr, nullptr};  // per-level non-finite / NaN block flags
   unsigned char* partner_buf[2] = {nullptr, nullptr};
   int partner_R_built[2] = {-1, -1};
+  bool conv_lds_attr_set = false;
   int layer_has_nonfinite[2] = {1, 1};
   float4* tri_raw_buf[2] = {nullptr, nullptr};
   size_t table_elems[2] = {0, 0};
@@ -1138,8 +1139,19 @@ static int cost_run_cnn(artp_ctx* c, int H, int W) {
   // conv5 (B -> A), flatten 15x15 (A -> features)
   hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 48, 48, 3, 2, true>), grid_for(h5, w5, 2), dim3(256), 0, st,
                      (const half_t*)Bf, hq, wq, (const half8*)c->d_convw[3], (const float*)c->d_convb[3], A);
-  hipLaunchKernelGGL((conv_mfma_kernel<15, 15, 48, 48, 3, 2, true>), grid_for(hf, wf, 2), dim3(256), 0, st,
-                     (const half_t*)A, h5, w5, (const half8*)c->d_convw[4], (const float*)c->d_convb[4], c->d_feat);
+  {
+    using Cfg = ConvLdsCfg<15, 15, 48, 48, 3, true>;
+    using KCfg = ConvKsplitCfg<15, 15, 48, 48, 3, true>;
+    auto kfn = conv_ksplit_kernel<15, 15, 48, 48, 3, true>;
+    if (!c->conv_lds_attr_set) {
+      HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     KCfg::LDS_BYTES));
+      c->conv_lds_attr_set = true;
+    }
+    const unsigned blocks = (unsigned)(((wf + Cfg::TP - 1) / Cfg::TP) * ((hf + Cfg::TR - 1) / Cfg::TR));
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), KCfg::LDS_BYTES, st, (const half_t*)A, h5, w5,
+                       (const half8*)c->d_convw[4], (const float*)c->d_convb[4], c->d_feat);
+  }
   HIP_TRY(c, hipGetLastError());
   c->feat_h = hf;
   c->feat_w = wf;

@@ -121,6 +121,167 @@ conv_mfma_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* _
   }
 }
 
+// ---- the same implicit GEMM for large kernels (the 15 x 15 flatten layer): LDS-staged input patch ---------
+// A workgroup of 4 wavefronts computes an 8-row x 16-pixel output tile for all channels from a
+// (8+KH-1) x (16+KW) pixel input patch staged once in LDS (NHWC, 2*CIN bytes per pixel: with CIN = 48 the 16
+// lanes of a ds_read_b128 group fall into 16 distinct bank quads, no padding needed; PMC: 0 conflicts).
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU>
+struct ConvLdsCfg {
+  static constexpr int KROW = KW * CIN;
+  static constexpr int KSTEPS = (KROW + 31) / 32;
+  static constexpr int TR = 8, TP = 16;
+  static constexpr int PR = TR + KH - 1;
+  static constexpr int XPAD = (KSTEPS * 32 - KROW + CIN - 1) / CIN;  // pixels the zero-padded K tail reaches into
+  static constexpr int PPX = TP + KW - 1 + XPAD;
+  static constexpr int PIX_B = CIN * 2;
+  static constexpr int ROW_B = PPX * PIX_B;
+  static constexpr int A_BYTES = PR * ROW_B;
+  static_assert(ROW_B % 16 == 0 && A_BYTES % 16 == 0, "16-byte chunks");
+};
+
+// ---- K-split variant: the workgroup's four wavefronts split the k-steps, not the pixels -------------------
+// Every wavefront accumulates the WHOLE 8-row x 16-pixel x COUT tile (8 x NT accumulators) over the
+// k-steps ks = wave, wave+4, ... of every kernel row; the four partial tiles meet in LDS at the end.
+//  * B fragments are used by exactly one wavefront of the group: they go global -> VGPR (prefetched two
+//    steps ahead), never through LDS: no staging stores, no barrier inside the main loop.
+//  * For a fixed ks the A fragments of kernel row kh are patch rows kh .. kh+7 -- kernel row kh+1 needs
+//    ONE new row.  A register ring of 8 fragments turns 8 LDS reads per step into 1.
+//  * Per step: 1 ds_read_b128 + NT global loads feed 8*NT MFMAs (384 cycles for NT = 3).
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU>
+struct ConvKsplitCfg {
+  using P = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU>;
+  static constexpr int RED_BYTES = 4 * P::TR * NT * 1024;  // four partial tiles of floatx4 per lane
+  static constexpr int STAGE_BYTES = P::TR * P::TP * COUT * 2;  // finished NHWC tile
+  static constexpr int LDS_BYTES = (P::A_BYTES > RED_BYTES ? P::A_BYTES : RED_BYTES) + STAGE_BYTES;
+  static_assert((COUT * 2) % 16 == 0, "a pixel is a whole number of 16-byte chunks");
+};
+
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU>
+__global__ void __launch_bounds__(256)
+conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
+                   const float* __restrict__ bias, half_t* __restrict__ out) {
+  using Cfg = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU>;
+  static_assert(Cfg::TR == 8, "the fragment ring below holds 8 rows");
+  constexpr int KSTEPS = Cfg::KSTEPS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  const int Hout = Hin - KH + 1, Wout = Win - KW + 1;
+  const int tiles_x = (Wout + Cfg::TP - 1) / Cfg::TP;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int oy0 = by * Cfg::TR, ox0 = bx * Cfg::TP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+
+  // input patch -> LDS (rows are contiguous byte runs of the NHWC image; out-of-image chunks are zero).
+  // All of a thread's loads are in flight before the first LDS store (one memory round trip, not 16).
+  {
+    constexpr int CPR = Cfg::ROW_B / 16;  // 16-byte chunks per patch row
+    constexpr int NIT = (Cfg::PR * CPR + 255) / 256;
+    const long row_bytes = (long)Win * Cfg::PIX_B;
+    half8 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * 256;
+      const int r = c / CPR, cc = c - r * CPR;
+      const long off = (long)ox0 * Cfg::PIX_B + (long)cc * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = (half_t)0;
+      if (c < Cfg::PR * CPR && oy0 + r < Hin && off + 16 <= row_bytes)
+        v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + r) * row_bytes + off);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * 256;
+      const int r = c / CPR, cc = c - r * CPR;
+      if (c < Cfg::PR * CPR) *reinterpret_cast<half8*>(As + r * Cfg::ROW_B + cc * 16) = v[it];
+    }
+  }
+  __syncthreads();
+
+  floatx4 acc[8][NT];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const char* a_lane = As + li * Cfg::PIX_B + kg * 16;
+  for (int ks = wave; ks < KSTEPS; ks += 4) {
+    const char* a_ks = a_lane + ks * 64;
+    const half8* b_ks = wp + (size_t)ks * NT * 64 + lane;  // + kh * KSTEPS * NT * 64
+    half8 a[8];      // ring: slot (r & 7) holds patch row r
+    half8 b[3][NT];  // ring over kernel rows, two ahead
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      b[0][n] = b_ks[n * 64];
+      if (KH > 1) b[1][n] = b_ks[(size_t)KSTEPS * NT * 64 + n * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) a[r] = *reinterpret_cast<const half8*>(a_ks + r * Cfg::ROW_B);
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      a[(kh + 7) & 7] = *reinterpret_cast<const half8*>(a_ks + (kh + 7) * Cfg::ROW_B);
+      if (kh + 2 < KH) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[(kh + 2) % 3][n] = b_ks[(size_t)(kh + 2) * KSTEPS * NT * 64 + n * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 8; ++m)  // m = 7 uses the row requested just above: it goes last
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(kh + m) & 7], b[kh % 3][n], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // the four partial tiles -> LDS (the patch is dead), wavefront w finishes rows 2w, 2w+1
+  __syncthreads();
+  floatx4* red = reinterpret_cast<floatx4*>(smem);
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) red[((wave * 8 + m) * NT + n) * 64 + lane] = acc[m][n];
+  __syncthreads();
+  // C/D layout of 16x16 MFMA: column (channel in tile) = lane & 15, row (pixel) = (lane >> 4) * 4 + r.
+  // The finished halfs are staged as the NHWC tile [8][16][COUT] behind the partial tiles, then leave as
+  // whole 16-byte lanes (a tile row is one contiguous 16*COUT*2-byte run of the output image).
+  half_t* stage = reinterpret_cast<half_t*>(smem + ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU>::RED_BYTES);
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    const int m = 2 * wave + mm;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      floatx4 v = red[((0 * 8 + m) * NT + n) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const floatx4 p = red[((w * 8 + m) * NT + n) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p[r];
+      }
+      const int ch = n * 16 + li;
+      if (ch >= COUT) continue;
+      const float bv = bias[ch];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = v[r] + bv;
+        if (LRELU) y = y > 0.f ? y : 0.3f * y;
+        stage[(m * 16 + kg * 4 + r) * COUT + ch] = (half_t)y;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = 16 * COUT * 2 / 16;  // 16-byte chunks per tile row
+    for (int c = tid; c < 8 * CPR; c += 256) {
+      const int m = c / CPR, cc = c - m * CPR;
+      const int px = (cc * 16) / (COUT * 2);
+      if (oy0 + m < Hout && ox0 + px < Wout)
+        *reinterpret_cast<half8*>(reinterpret_cast<char*>(out) + ((size_t)(oy0 + m) * Wout + ox0) * COUT * 2 + cc * 16) =
+            *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(stage) + m * CPR * 16 + cc * 16);
+    }
+  }
+}
+
 // max_pool2d NHWC, window P, stride S (network_light.py:89,97)
 template <int P, int S>
 __global__ void __launch_bounds__(256)
