@@ -21,7 +21,9 @@ SYMBOLS = [
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_algorithmic_vertices_dev",
-    "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_cost_blob_bytes", "artp_cost_load_weights",
+    "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_roadmap_params_defaults",
+    "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
+    "artp_cost_blob_bytes", "artp_cost_load_weights",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
 
@@ -39,6 +41,12 @@ class Params(C.Structure):
 
 
 _lib = None
+
+
+class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n_milestones", C.c_uint32),
+                ("k_neighbors", C.c_uint32), ("objective", C.c_int32), ("max_replans", C.c_uint32),
+                ("max_lon_vel", C.c_double), ("max_lat_vel", C.c_double), ("max_ang_vel", C.c_double)]
 
 
 def load():
@@ -93,6 +101,14 @@ def load():
     L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
     L.artp_debug_pipeline_counters.argtypes = [vp, C.POINTER(u64 * 8)]
     L.artp_debug_partner_table.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int)]
+    L.artp_roadmap_params_defaults.argtypes = [C.POINTER(RoadmapParams)]
+    L.artp_roadmap_params_defaults.restype = None
+    L.artp_roadmap_build.argtypes = [vp, C.POINTER(RoadmapParams), vp, vp, C.POINTER(vp)]
+    L.artp_roadmap_stats.argtypes = [vp, C.POINTER(u64 * 8)]
+    L.artp_roadmap_export.argtypes = [vp] + [vp] * 8
+    L.artp_roadmap_solve.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(dbl), C.POINTER(i32)]
+    L.artp_roadmap_destroy.argtypes = [vp]
+    L.artp_roadmap_destroy.restype = None
     L.artp_cost_blob_bytes.argtypes = []
     L.artp_cost_blob_bytes.restype = sz
     L.artp_cost_load_weights.argtypes = [vp, vp, sz]
@@ -102,7 +118,8 @@ def load():
     L.artp_cost_get_features.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("artp_destroy", "artp_cost_blob_bytes"):
+        if fn.restype is C.c_int and name not in ("artp_destroy", "artp_cost_blob_bytes", "artp_roadmap_destroy",
+                                                  "artp_roadmap_params_defaults"):
             fn.restype = C.c_int
     _lib = L
     return L

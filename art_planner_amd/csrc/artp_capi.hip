@@ -1246,6 +1246,8 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 
 }  // extern "C"
 
+#include "roadmap.h"
+
 #ifdef ARTP_STAGE_TIMING
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_stage_cycles), 20 * sizeof(unsigned long long)) != hipSuccess)

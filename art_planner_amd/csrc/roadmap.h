@@ -1,0 +1,606 @@
+// roadmap.h -- "next" row N1: the batched planner front end that turns the state / edge
+// kernels into plans.  It follows the reference's PRM front ends
+//   PRMMotionCostMaintainer::sampleGraph   art_planner/src/planners/prm_motion_cost.cpp:145-219
+//   PRMMotionCost::addValidMilestone       prm_motion_cost.cpp:325-390  (k nearest, 0.5 m interpolation)
+//   PRMMotionCost::constructSolution       prm_motion_cost.cpp:536-673  (A*, lazy checkMotion of the path)
+//   PathLengthObjective                    art_planner/src/objectives/path_length_objective.cpp:26-70
+// as ONE batch per stage instead of one milestone at a time:
+//   1. milestones = the first n accepted states of the (seed, index) sample stream
+//   2. k nearest neighbours of every vertex under OMPL's SE3 distance (|dp| + SO3 arc), k = the PRM* rule
+//      ceil(e (1 + 1/6) ln n) of OMPL's KStarStrategy for a 6-dimensional space
+//   3. candidate edges = the symmetrised k-NN pairs, validated by the 0.5 m interpolation rule of
+//      addValidMilestone (the edge kernels of R7)
+//   4. edge costs: the chain of interpolated sub-edges the reference would have put into its graph
+//   5. host: CSR graph, A* (exact heap search), the final path's edges re-checked with the discrete motion
+//      validator; an invalid one is removed and the search repeated (LazyPRM's loop)
+// The reference inserts milestones one by one (each sees only its predecessors, interpolated states become
+// vertices and neighbours themselves), so graphs differ by construction; what is kept is every predicate
+// (validity, interpolation rule, costs, search).  OMPL is not available here: parity for this row is
+// unpinned, the tests check the stage results against brute force / the oracle / scipy.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <queue>
+#include <vector>
+
+namespace artp {
+
+// OMPL CompoundStateSpace::distance for SE3: RealVectorStateSpace L2 + SO3StateSpace::distance (arc length)
+__device__ __forceinline__ double se3_distance(const double* a, const double* b) {
+  const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return sqrt(dx * dx + dy * dy + dz * dz) + so3_arc_length(a + 3, b + 3);
+}
+
+// One lane per query vertex; candidates stream through an LDS tile; the lane's k best live in LDS
+// (entry e of lane l at [e * 64 + l]: conflict-free).  The R^3 term alone rejects most candidates before
+// the arc length (an acos) is needed.  Output: neighbours by ascending (distance, index).
+#define ARTP_KNN_TILE 128
+__global__ void __launch_bounds__(64)
+knn_kernel(const double* __restrict__ verts, int nv, int k, uint32_t* __restrict__ out_idx,
+           double* __restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* tile = reinterpret_cast<double*>(smem);                 // [TILE][7]
+  double* bd = tile + ARTP_KNN_TILE * 7;                          // [k][64]
+  uint32_t* bi = reinterpret_cast<uint32_t*>(bd + (size_t)k * 64);  // [k][64]
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < nv;
+  double q[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) q[c] = live ? verts[(size_t)i * 7 + c] : 0.0;
+  int count = 0;
+  double thr = INFINITY;  // current k-th best distance once the list is full
+  int arg = 0;            // its slot
+  for (int t0 = 0; t0 < nv; t0 += ARTP_KNN_TILE) {
+    const int tn = min(ARTP_KNN_TILE, nv - t0);
+    __syncthreads();
+    for (int e = lane; e < tn * 7; e += 64) tile[e] = verts[(size_t)t0 * 7 + e];
+    __syncthreads();
+    if (!live) continue;
+    for (int jj = 0; jj < tn; ++jj) {
+      const int j = t0 + jj;
+      if (j == i) continue;
+      const double* c = tile + jj * 7;
+      const double dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+      const double dp = sqrt(dx * dx + dy * dy + dz * dz);
+      if (count == k && !(dp < thr)) continue;
+      const double d = dp + so3_arc_length(q + 3, c + 3);
+      if (count < k) {
+        bd[count * 64 + lane] = d;
+        bi[count * 64 + lane] = (uint32_t)j;
+        ++count;
+        if (count == k) {
+          thr = -1.0;
+          for (int e = 0; e < k; ++e)
+            if (bd[e * 64 + lane] > thr) {
+              thr = bd[e * 64 + lane];
+              arg = e;
+            }
+        }
+      } else if (d < thr) {
+        bd[arg * 64 + lane] = d;
+        bi[arg * 64 + lane] = (uint32_t)j;
+        thr = -1.0;
+        for (int e = 0; e < k; ++e)
+          if (bd[e * 64 + lane] > thr) {
+            thr = bd[e * 64 + lane];
+            arg = e;
+          }
+      }
+    }
+  }
+  if (!live) return;
+  // selection sort by (distance, index); unused slots (fewer than k candidates) are marked
+  for (int a = 0; a < k; ++a) {
+    if (a >= count) {
+      out_idx[(size_t)i * k + a] = 0xffffffffu;
+      out_dist[(size_t)i * k + a] = INFINITY;
+      continue;
+    }
+    int best = a;
+    for (int e = a + 1; e < count; ++e) {
+      const double de = bd[e * 64 + lane], db = bd[best * 64 + lane];
+      if (de < db || (de == db && bi[e * 64 + lane] < bi[best * 64 + lane])) best = e;
+    }
+    const double dbest = bd[best * 64 + lane];
+    const uint32_t ibest = bi[best * 64 + lane];
+    bd[best * 64 + lane] = bd[a * 64 + lane];
+    bi[best * 64 + lane] = bi[a * 64 + lane];
+    bd[a * 64 + lane] = dbest;
+    bi[a * 64 + lane] = ibest;
+    out_idx[(size_t)i * k + a] = ibest;
+    out_dist[(size_t)i * k + a] = dbest;
+  }
+}
+
+// undirected candidate edge of (i, j in knn(i)) as the key min << 32 | max
+__global__ void __launch_bounds__(256)
+knn_edge_keys_kernel(const uint32_t* __restrict__ knn, int nv, int k, unsigned long long* __restrict__ keys) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)nv * k) return;
+  const uint32_t i = (uint32_t)(t / k), j = knn[t];
+  unsigned long long key = ~0ull;  // sorts last, dropped
+  if (j != 0xffffffffu) key = ((unsigned long long)(i < j ? i : j) << 32) | (unsigned long long)(i < j ? j : i);
+  keys[t] = key;
+}
+
+__global__ void __launch_bounds__(256)
+gather_edge_states_kernel(const double* __restrict__ verts, const unsigned long long* __restrict__ keys, size_t ne,
+                          double* __restrict__ s1, double* __restrict__ s2) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const uint32_t u = (uint32_t)(keys[e] >> 32), v = (uint32_t)(keys[e] & 0xffffffffu);
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    s1[e * 7 + c] = verts[(size_t)u * 7 + c];
+    s2[e * 7 + c] = verts[(size_t)v * 7 + c];
+  }
+}
+
+struct PathLengthParams {  // Params::objectives.custom_path_length (params.h:69-73)
+  int directional;
+  double max_lon_vel, max_lat_vel, max_ang_vel;
+};
+
+// getYawFromSO3 (utils.h:78-86): Scalar = float result of the double atan2
+__device__ __forceinline__ double yaw_from_quat(const double* q) {  // q = x y z w
+  return (double)(float)atan2(2.0 * (q[3] * q[2] + q[0] * q[1]), 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]));
+}
+
+// PathLengthObjective::motionCost / motionCostHeuristic (path_length_objective.cpp:26-70)
+__device__ __forceinline__ double path_length_cost(const PathLengthParams& p, const double* a, const double* b) {
+  const double x_dif = b[0] - a[0], y_dif = b[1] - a[1], z_dif = b[2] - a[2];
+  if (!p.directional) return sqrt(x_dif * x_dif + y_dif * y_dif + z_dif * z_dif) / p.max_lon_vel;
+  const double yaw1 = yaw_from_quat(a + 3), yaw2 = yaw_from_quat(b + 3);
+  const double d = fabs(yaw1 - yaw2);
+  const double yaw_dif = (d > 3.14159265358979323846) ? 2.0 * 3.14159265358979323846 - d : d;
+  const double lon_dif = cos(yaw1) * x_dif + sin(yaw1) * y_dif;
+  const double lat_dif = -sin(yaw1) * x_dif + cos(yaw1) * y_dif;
+  const double t_yaw = fabs(yaw_dif) / p.max_ang_vel;
+  const double t_lon = fabs(lon_dif) / p.max_lon_vel;
+  const double t_lat = fabs(lat_dif) / p.max_lat_vel;
+  return fmax(fmax(t_lon, t_lat), t_yaw);
+}
+
+// Cost of a roadmap edge = the sum over the chain the reference's addValidMilestone builds
+// (prm_motion_cost.cpp:340-377): n_interp interior states at step / (n_interp + 1), sub-edges in order.
+__global__ void __launch_bounds__(256)
+edge_chain_cost_kernel(PathLengthParams p, const double* __restrict__ s1, const double* __restrict__ s2,
+                       const uint32_t* __restrict__ n_interp, size_t ne, double* __restrict__ cost) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  double a[7], b[7], prev[7], cur[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    a[c] = s1[e * 7 + c];
+    b[c] = s2[e * 7 + c];
+    prev[c] = a[c];
+  }
+  const unsigned ni = n_interp[e];
+  const double div = 1.0 / (double)(ni + 1);
+  double total = 0.0;
+  for (unsigned step = 1; step <= ni; ++step) {
+    se3_interpolate(a, b, (double)step * div, cur);
+    total += path_length_cost(p, prev, cur);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) prev[c] = cur[c];
+  }
+  total += path_length_cost(p, prev, b);
+  cost[e] = total;
+}
+
+}  // namespace artp
+
+// -------------------------------------------------------------------------------------------------------
+struct artp_roadmap {
+  artp_ctx* ctx = nullptr;
+  artp_roadmap_params params{};
+  int k = 0;
+  uint64_t samples_drawn = 0;
+  std::vector<double> verts;       // nv x 7; vertex 0 = start, 1 = goal
+  std::vector<uint32_t> knn;       // nv x k (0xffffffff = none)
+  std::vector<double> knn_dist;    // nv x k
+  std::vector<uint32_t> eu, ev;    // candidate edges (u < v), sorted by (u, v)
+  std::vector<uint8_t> evalid;     // interpolation rule verdict
+  std::vector<uint32_t> einterp;   // interior states of the chain
+  std::vector<double> ecost;
+  std::vector<uint8_t> eremoved;   // removed by the lazy path check
+  // CSR over the valid, not removed edges
+  std::vector<uint32_t> row, adj, adj_edge;
+  bool csr_dirty = true;
+  size_t nv() const { return verts.size() / 7; }
+};
+
+namespace {
+
+void roadmap_build_csr(artp_roadmap* rm) {
+  const size_t nv = rm->nv(), ne = rm->eu.size();
+  rm->row.assign(nv + 1, 0);
+  for (size_t e = 0; e < ne; ++e)
+    if (rm->evalid[e] && !rm->eremoved[e]) {
+      ++rm->row[rm->eu[e] + 1];
+      ++rm->row[rm->ev[e] + 1];
+    }
+  for (size_t v = 0; v < nv; ++v) rm->row[v + 1] += rm->row[v];
+  rm->adj.assign(rm->row[nv], 0);
+  rm->adj_edge.assign(rm->row[nv], 0);
+  std::vector<uint32_t> fill(rm->row.begin(), rm->row.end() - 1);
+  for (size_t e = 0; e < ne; ++e)
+    if (rm->evalid[e] && !rm->eremoved[e]) {
+      const uint32_t u = rm->eu[e], v = rm->ev[e];
+      rm->adj[fill[u]] = v;
+      rm->adj_edge[fill[u]++] = (uint32_t)e;
+      rm->adj[fill[v]] = u;
+      rm->adj_edge[fill[v]++] = (uint32_t)e;
+    }
+  rm->csr_dirty = false;
+}
+
+// A* from vertex 0 to vertex 1 (boost::astar_search with PathLengthObjective::motionCostHeuristic for
+// the Euclidean objective, which is consistent; zero heuristic otherwise).  Returns false if unreachable.
+bool roadmap_astar(artp_roadmap* rm, std::vector<uint32_t>* path, double* cost) {
+  if (rm->csr_dirty) roadmap_build_csr(rm);
+  const size_t nv = rm->nv();
+  const double* V = rm->verts.data();
+  const bool use_h = rm->params.objective == 0;
+  auto h = [&](uint32_t v) {
+    if (!use_h) return 0.0;
+    const double dx = V[7 + 0] - V[(size_t)v * 7 + 0], dy = V[7 + 1] - V[(size_t)v * 7 + 1],
+                 dz = V[7 + 2] - V[(size_t)v * 7 + 2];
+    return std::sqrt(dx * dx + dy * dy + dz * dz) / rm->params.max_lon_vel;
+  };
+  std::vector<double> g(nv, INFINITY);
+  std::vector<uint32_t> prev(nv, 0xffffffffu);
+  std::vector<uint8_t> closed(nv, 0);
+  using Item = std::pair<double, uint32_t>;
+  std::priority_queue<Item, std::vector<Item>, std::greater<Item>> open;
+  g[0] = 0.0;
+  open.push({h(0), 0});
+  while (!open.empty()) {
+    const uint32_t u = open.top().second;
+    open.pop();
+    if (closed[u]) continue;
+    closed[u] = 1;
+    if (u == 1) break;
+    for (uint32_t a = rm->row[u]; a < rm->row[u + 1]; ++a) {
+      const uint32_t v = rm->adj[a];
+      const double w = rm->ecost[rm->adj_edge[a]];
+      if (!std::isfinite(w)) continue;
+      const double ng = g[u] + w;
+      if (ng < g[v]) {
+        g[v] = ng;
+        prev[v] = u;
+        open.push({ng + h(v), v});
+      }
+    }
+  }
+  if (!closed[1]) return false;
+  path->clear();
+  for (uint32_t v = 1; v != 0xffffffffu; v = prev[v]) path->push_back(v);
+  std::reverse(path->begin(), path->end());
+  *cost = g[1];
+  return true;
+}
+
+#define RM_TRY(expr)          \
+  do {                        \
+    const int rc_ = (expr);   \
+    if (rc_ != ARTP_OK) {     \
+      cleanup();              \
+      return rc_;             \
+    }                         \
+  } while (0)
+#define RM_HIP(expr)                                                                   \
+  do {                                                                                 \
+    const hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                            \
+      c->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+      cleanup();                                                                       \
+      return ARTP_ERR_HIP;                                                             \
+    }                                                                                  \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+void artp_roadmap_params_defaults(artp_roadmap_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->seed = 42;
+  p->first_index = 0;
+  p->n_milestones = 10000;         // Params::planner.prm_motion_cost.max_n_vertices (params.h:51)
+  p->k_neighbors = 0;              // PRM* rule
+  p->objective = 0;                // use_directional_cost{false} (params.h:70)
+  p->max_lon_vel = 0.5;            // params.h:71-73
+  p->max_lat_vel = 0.1;
+  p->max_ang_vel = 0.5;
+  p->max_replans = 1000;
+}
+
+void artp_roadmap_destroy(artp_roadmap* rm) { delete rm; }
+
+int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
+                       artp_roadmap** out) {
+  if (!c || !prm || !start7 || !goal7 || !out || prm->n_milestones < 1 || prm->objective < 0 ||
+      prm->objective > 1 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0))
+    return ARTP_ERR_INVALID_ARG;
+  *out = nullptr;
+  const size_t nm = prm->n_milestones, nv = nm + 2;
+  double* d_verts = nullptr;     // nv x 7
+  double* d_batch = nullptr;     // sample batch
+  uint8_t* d_valid = nullptr;
+  double* d_compact = nullptr;
+  uint64_t* d_cnt = nullptr;
+  uint32_t* d_knn = nullptr;
+  double* d_knn_dist = nullptr;
+  unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr, *d_keys_unique = nullptr;
+  double *d_s1 = nullptr, *d_s2 = nullptr, *d_cost = nullptr;
+  uint8_t* d_evalid = nullptr;
+  uint32_t* d_einterp = nullptr;
+  void* d_cub = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_verts, (void*)d_batch, (void*)d_valid, (void*)d_compact, (void*)d_cnt, (void*)d_knn,
+                    (void*)d_knn_dist, (void*)d_keys, (void*)d_keys_sorted, (void*)d_keys_unique, (void*)d_s1,
+                    (void*)d_s2, (void*)d_cost, (void*)d_evalid, (void*)d_einterp, d_cub})
+      if (p) (void)hipFree(p);
+  };
+  RM_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_verts), nv * 7 * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(uint64_t)));
+
+  // start and goal must be valid states (baseSolve: INVALID_START / INVALID_GOAL, prm_motion_cost.cpp:452-476)
+  {
+    double sg[14];
+    std::memcpy(sg, start7, 7 * sizeof(double));
+    std::memcpy(sg + 7, goal7, 7 * sizeof(double));
+    uint8_t ok[2] = {0, 0};
+    RM_TRY(artp_validate_states(c, sg, 2, ok, nullptr));
+    if (!ok[0] || !ok[1]) {
+      c->last_error = !ok[0] ? "start state is not valid" : "goal state is not valid";
+      cleanup();
+      return ARTP_ERR_INVALID_ARG;
+    }
+    RM_HIP(hipMemcpyAsync(d_verts, sg, sizeof(sg), hipMemcpyHostToDevice, st));
+  }
+
+  // 1. milestones: accepted states of the sample stream, in index order
+  size_t have = 0;
+  uint64_t next = prm->first_index;
+  {
+    size_t batch = std::max<size_t>(4 * nm, 1u << 16);
+    if (batch > (1u << 22)) batch = 1u << 22;
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_batch), batch * 7 * sizeof(double)));
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_compact), batch * 7 * sizeof(double)));
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_valid), batch));
+    int rounds = 0;
+    while (have < nm) {
+      RM_TRY(artp_sample_and_validate_dev(c, prm->seed, next, batch, d_batch, d_valid, nullptr));
+      RM_TRY(artp_compact_valid_dev(c, d_batch, d_valid, batch, d_compact, d_cnt));
+      uint64_t got = 0;
+      RM_HIP(hipMemcpyAsync(&got, d_cnt, sizeof(got), hipMemcpyDeviceToHost, st));
+      RM_HIP(hipStreamSynchronize(st));
+      const size_t take = std::min<size_t>((size_t)got, nm - have);
+      RM_HIP(hipMemcpyAsync(d_verts + (2 + have) * 7, d_compact, take * 7 * sizeof(double), hipMemcpyDeviceToDevice, st));
+      have += take;
+      next += batch;
+      if (++rounds > 256 || (got == 0 && rounds > 8)) {
+        c->last_error = "sampler produced too few valid states for the requested roadmap";
+        cleanup();
+        return ARTP_ERR_CAPACITY;
+      }
+    }
+  }
+
+  // 2. k nearest neighbours
+  int k = (int)prm->k_neighbors;
+  if (k <= 0) k = (int)std::ceil(2.718281828459045 * (1.0 + 1.0 / 6.0) * std::log((double)nv));  // KStarStrategy
+  if (k > (int)nv - 1) k = (int)nv - 1;
+  if (k < 1) k = 1;
+  if (k > 128) k = 128;
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_knn), nv * k * sizeof(uint32_t)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_knn_dist), nv * k * sizeof(double)));
+  {
+    const size_t lds = (size_t)ARTP_KNN_TILE * 7 * 8 + (size_t)k * 64 * 12;
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(artp::knn_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(artp::knn_kernel, dim3((unsigned)((nv + 63) / 64)), dim3(64), lds, st, (const double*)d_verts,
+                       (int)nv, k, d_knn, d_knn_dist);
+    RM_HIP(hipGetLastError());
+  }
+
+  // 3. candidate edges: symmetrised, unique
+  const size_t nk = nv * (size_t)k;
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_keys), nk * 8));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_keys_sorted), nk * 8));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_keys_unique), nk * 8));
+  hipLaunchKernelGGL(artp::knn_edge_keys_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t*)d_knn, (int)nv, k, d_keys);
+  RM_HIP(hipGetLastError());
+  size_t ne = 0;
+  {
+    size_t need1 = 0, need2 = 0;
+    RM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, need1, d_keys, d_keys_sorted, (int)nk, 0, 64, st));
+    RM_HIP(hipcub::DeviceSelect::Unique(nullptr, need2, d_keys_sorted, d_keys_unique,
+                                        reinterpret_cast<unsigned long long*>(d_cnt), (int)nk, st));
+    const size_t need = std::max(need1, need2) + 256;
+    RM_HIP(hipMalloc(&d_cub, need));
+    size_t cap = need;
+    RM_HIP(hipcub::DeviceRadixSort::SortKeys(d_cub, cap, d_keys, d_keys_sorted, (int)nk, 0, 64, st));
+    cap = need;
+    RM_HIP(hipcub::DeviceSelect::Unique(d_cub, cap, d_keys_sorted, d_keys_unique,
+                                        reinterpret_cast<unsigned long long*>(d_cnt), (int)nk, st));
+    uint64_t nu = 0;
+    RM_HIP(hipMemcpyAsync(&nu, d_cnt, sizeof(nu), hipMemcpyDeviceToHost, st));
+    RM_HIP(hipStreamSynchronize(st));
+    ne = (size_t)nu;
+    // the all-ones key (missing neighbour slots) sorts last
+    unsigned long long last = 0;
+    if (ne) {
+      RM_HIP(hipMemcpy(&last, d_keys_unique + (ne - 1), 8, hipMemcpyDeviceToHost));
+      if (last == ~0ull) --ne;
+    }
+  }
+
+  auto rm = new artp_roadmap();
+  rm->ctx = c;
+  rm->params = *prm;
+  rm->k = k;
+  rm->samples_drawn = next - prm->first_index;
+  rm->verts.resize(nv * 7);
+  rm->knn.resize(nk);
+  rm->knn_dist.resize(nk);
+  auto fail = [&](int rc) {
+    delete rm;
+    cleanup();
+    return rc;
+  };
+  if (hipMemcpy(rm->verts.data(), d_verts, nv * 7 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(rm->knn.data(), d_knn, nk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(rm->knn_dist.data(), d_knn_dist, nk * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(ARTP_ERR_HIP);
+
+  // 4. edge verdicts (0.5 m interpolation rule) and chain costs
+  rm->eu.resize(ne);
+  rm->ev.resize(ne);
+  rm->evalid.assign(ne, 0);
+  rm->einterp.assign(ne, 0);
+  rm->ecost.assign(ne, 0.0);
+  rm->eremoved.assign(ne, 0);
+  if (ne) {
+    if (hipMalloc(reinterpret_cast<void**>(&d_s1), ne * 7 * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_s2), ne * 7 * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_cost), ne * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_evalid), ne) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_einterp), ne * sizeof(uint32_t)) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+    hipLaunchKernelGGL(artp::gather_edge_states_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
+                       (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2);
+    int rc = artp_check_edges_interp_dev(c, d_s1, d_s2, ne, d_evalid, d_einterp);
+    if (rc != ARTP_OK) return fail(rc);
+    artp::PathLengthParams pl{prm->objective == 1, prm->max_lon_vel, prm->max_lat_vel, prm->max_ang_vel};
+    hipLaunchKernelGGL(artp::edge_chain_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, pl,
+                       (const double*)d_s1, (const double*)d_s2, (const uint32_t*)d_einterp, ne, d_cost);
+    std::vector<unsigned long long> keys(ne);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+        hipMemcpy(keys.data(), d_keys_unique, ne * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(rm->evalid.data(), d_evalid, ne, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(rm->einterp.data(), d_einterp, ne * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(rm->ecost.data(), d_cost, ne * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+    for (size_t e = 0; e < ne; ++e) {
+      rm->eu[e] = (uint32_t)(keys[e] >> 32);
+      rm->ev[e] = (uint32_t)(keys[e] & 0xffffffffu);
+    }
+    rc = check_error_flag(c);
+    if (rc != ARTP_OK) return fail(rc);
+  }
+  cleanup();
+  *out = rm;
+  return ARTP_OK;
+}
+
+int artp_roadmap_stats(const artp_roadmap* rm, uint64_t out[8]) {
+  if (!rm || !out) return ARTP_ERR_INVALID_ARG;
+  uint64_t nvalid = 0, nrem = 0;
+  for (size_t e = 0; e < rm->eu.size(); ++e) {
+    nvalid += rm->evalid[e] ? 1 : 0;
+    nrem += rm->eremoved[e] ? 1 : 0;
+  }
+  out[0] = rm->nv();
+  out[1] = rm->eu.size();
+  out[2] = nvalid;
+  out[3] = nrem;
+  out[4] = (uint64_t)rm->k;
+  out[5] = rm->samples_drawn;
+  out[6] = out[7] = 0;
+  return ARTP_OK;
+}
+
+int artp_roadmap_export(const artp_roadmap* rm, double* verts, uint32_t* knn, double* knn_dist, uint32_t* edges_uv,
+                        uint8_t* edge_valid, uint32_t* edge_interp, double* edge_cost, uint8_t* edge_removed) {
+  if (!rm) return ARTP_ERR_INVALID_ARG;
+  const size_t ne = rm->eu.size();
+  if (verts) std::memcpy(verts, rm->verts.data(), rm->verts.size() * sizeof(double));
+  if (knn) std::memcpy(knn, rm->knn.data(), rm->knn.size() * sizeof(uint32_t));
+  if (knn_dist) std::memcpy(knn_dist, rm->knn_dist.data(), rm->knn_dist.size() * sizeof(double));
+  if (edges_uv)
+    for (size_t e = 0; e < ne; ++e) {
+      edges_uv[2 * e] = rm->eu[e];
+      edges_uv[2 * e + 1] = rm->ev[e];
+    }
+  if (edge_valid) std::memcpy(edge_valid, rm->evalid.data(), ne);
+  if (edge_interp) std::memcpy(edge_interp, rm->einterp.data(), ne * sizeof(uint32_t));
+  if (edge_cost) std::memcpy(edge_cost, rm->ecost.data(), ne * sizeof(double));
+  if (edge_removed) std::memcpy(edge_removed, rm->eremoved.data(), ne);
+  return ARTP_OK;
+}
+
+int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
+                       int* n_replans) {
+  if (!rm || !n_path || !cost) return ARTP_ERR_INVALID_ARG;
+  artp_ctx* c = rm->ctx;
+  *n_path = 0;
+  *cost = INFINITY;
+  int replans = 0;
+  std::vector<uint32_t> path;
+  std::vector<double> s1, s2;
+  std::vector<uint8_t> ok;
+  for (;;) {
+    double cst = INFINITY;
+    if (!roadmap_astar(rm, &path, &cst)) {
+      if (n_replans) *n_replans = replans;
+      return ARTP_OK;  // *n_path == 0: start and goal are not connected (PlannerStatus::TIMEOUT)
+    }
+    // discrete motion check of the path's edges (constructSolution, prm_motion_cost.cpp:628-661); the
+    // first invalid edge is removed and the search repeated
+    const size_t np = path.size();
+    s1.resize((np - 1) * 7);
+    s2.resize((np - 1) * 7);
+    ok.assign(np - 1, 0);
+    for (size_t i = 0; i + 1 < np; ++i) {
+      std::memcpy(&s1[i * 7], &rm->verts[(size_t)path[i] * 7], 7 * sizeof(double));
+      std::memcpy(&s2[i * 7], &rm->verts[(size_t)path[i + 1] * 7], 7 * sizeof(double));
+    }
+    if (np > 1) {
+      const int rc = artp_check_motions(c, s1.data(), s2.data(), np - 1, ok.data());
+      if (rc != ARTP_OK) return rc;
+      (void)hipStreamSynchronize(c->stream);
+    }
+    size_t bad = np;
+    for (size_t i = np - 1; i-- > 0;)  // the reference walks from the goal backwards
+      if (!ok[i]) {
+        bad = i;
+        break;
+      }
+    if (bad == np) {
+      if (path_se3) {
+        if (cap_states < np) {
+          c->last_error = "path buffer too small";
+          *n_path = np;
+          return ARTP_ERR_CAPACITY;
+        }
+        for (size_t i = 0; i < np; ++i)
+          std::memcpy(path_se3 + i * 7, &rm->verts[(size_t)path[i] * 7], 7 * sizeof(double));
+      }
+      *n_path = np;
+      *cost = cst;
+      if (n_replans) *n_replans = replans;
+      return ARTP_OK;
+    }
+    // remove edge (path[bad], path[bad+1])
+    const uint32_t a = std::min(path[bad], path[bad + 1]), b = std::max(path[bad], path[bad + 1]);
+    for (uint32_t t = rm->row[a]; t < rm->row[a + 1]; ++t)
+      if (rm->adj[t] == b) rm->eremoved[rm->adj_edge[t]] = 1;
+    rm->csr_dirty = true;
+    if (++replans > (int)rm->params.max_replans) {
+      c->last_error = "too many lazy edge removals";
+      if (n_replans) *n_replans = replans;
+      return ARTP_ERR_CAPACITY;
+    }
+  }
+}
+
+}  // extern "C"

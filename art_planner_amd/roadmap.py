@@ -1,0 +1,69 @@
+"""ctypes wrapper of the batched roadmap front end (include/artp_c.h: artp_roadmap_*), "next" row N1.
+
+Mirrors how the reference's planners are driven (Planner::plan -> PRMMotionCost::solve,
+art_planner/src/planners/prm_motion_cost.cpp:289-297): build = sampleGraph + the connection loop of
+addValidMilestone as batches, solve = baseSolve / constructSolution."""
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+
+
+class Roadmap:
+    def __init__(self, ctx, start, goal, n_milestones=10000, seed=42, first_index=0, k_neighbors=0,
+                 objective=0, max_lon_vel=0.5, max_lat_vel=0.1, max_ang_vel=0.5, max_replans=1000):
+        self.ctx = ctx
+        self.L = _capi.load()
+        p = _capi.RoadmapParams()
+        self.L.artp_roadmap_params_defaults(C.byref(p))
+        p.seed, p.first_index, p.n_milestones, p.k_neighbors = seed, first_index, n_milestones, k_neighbors
+        p.objective, p.max_replans = objective, max_replans
+        p.max_lon_vel, p.max_lat_vel, p.max_ang_vel = max_lon_vel, max_lat_vel, max_ang_vel
+        s = np.ascontiguousarray(start, np.float64).reshape(7)
+        g = np.ascontiguousarray(goal, np.float64).reshape(7)
+        h = C.c_void_p()
+        ctx._chk(self.L.artp_roadmap_build(ctx.h, C.byref(p), s.ctypes.data, g.ctypes.data, C.byref(h)),
+                 "artp_roadmap_build")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.artp_roadmap_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self) -> dict:
+        out = (C.c_uint64 * 8)()
+        self.ctx._chk(self.L.artp_roadmap_stats(self.h, C.byref(out)), "artp_roadmap_stats")
+        return {"vertices": out[0], "candidate_edges": out[1], "valid_edges": out[2], "removed_edges": out[3],
+                "k": out[4], "samples_drawn": out[5]}
+
+    def export(self) -> dict:
+        st = self.stats()
+        nv, ne, k = st["vertices"], st["candidate_edges"], st["k"]
+        d = {"verts": np.empty((nv, 7), np.float64), "knn": np.empty((nv, k), np.uint32),
+             "knn_dist": np.empty((nv, k), np.float64), "edges": np.empty((ne, 2), np.uint32),
+             "edge_valid": np.empty(ne, np.uint8), "edge_interp": np.empty(ne, np.uint32),
+             "edge_cost": np.empty(ne, np.float64), "edge_removed": np.empty(ne, np.uint8)}
+        self.ctx._chk(self.L.artp_roadmap_export(self.h, *(d[k_].ctypes.data for k_ in
+                                                          ("verts", "knn", "knn_dist", "edges", "edge_valid",
+                                                           "edge_interp", "edge_cost", "edge_removed"))),
+                      "artp_roadmap_export")
+        return d
+
+    def solve(self, cap_states=4096) -> Tuple[Optional[np.ndarray], float, int]:
+        """(path n x 7 or None when start and goal are not connected, cost, lazy edge removals)."""
+        path = np.empty((cap_states, 7), np.float64)
+        n, cost, rep = C.c_size_t(0), C.c_double(0.0), C.c_int(0)
+        self.ctx._chk(self.L.artp_roadmap_solve(self.h, path.ctypes.data, cap_states, C.byref(n), C.byref(cost),
+                                                C.byref(rep)), "artp_roadmap_solve")
+        if n.value == 0:
+            return None, float("inf"), rep.value
+        return path[:n.value].copy(), cost.value, rep.value

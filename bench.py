@@ -347,6 +347,34 @@ def main():
     except Exception as ex:  # pragma: no cover
         c5 = {"error": repr(ex)}
 
+    # ---- N1 extras: batched roadmap front end (sample -> k-NN -> edge rule -> costs -> A* + lazy check) -----
+    roadmap = None
+    try:
+        if args.skip_extras:
+            raise RuntimeError("skipped (--skip-extras)")
+        from art_planner_amd.roadmap import Roadmap
+        probe = ctx.sample_states(seed, 9_000_000, 1 << 15)
+        okp = probe[ctx.validate_states(probe) != 0]
+        s_state = okp[np.argmin(np.hypot(okp[:, 0] - (gm.pos_x - 0.4 * gm.len_x), okp[:, 1] - (gm.pos_y - 0.4 * gm.len_y)))]
+        g_state = okp[np.argmin(np.hypot(okp[:, 0] - (gm.pos_x + 0.4 * gm.len_x), okp[:, 1] - (gm.pos_y + 0.4 * gm.len_y)))]
+        roadmap = {}
+        for n_m in (10_000, 100_000):  # 10 000 = Params::planner.prm_motion_cost.max_n_vertices
+            Roadmap(ctx, s_state, g_state, n_milestones=1000, seed=seed).close()  # warm the allocators
+            t0 = time.perf_counter()
+            rm = Roadmap(ctx, s_state, g_state, n_milestones=n_m, seed=seed)
+            t1 = time.perf_counter()
+            path, cost, rep = rm.solve()
+            t2 = time.perf_counter()
+            st = rm.stats()
+            rm.close()
+            roadmap[f"milestones_{n_m}"] = {
+                "build_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "k": int(st["k"]),
+                "candidate_edges": int(st["candidate_edges"]), "valid_edges": int(st["valid_edges"]),
+                "path_states": None if path is None else int(len(path)), "path_cost_s": cost, "lazy_removals": rep,
+                "straight_line_cost_s": float(np.linalg.norm(g_state[:3] - s_state[:3]) / 0.5)}
+    except Exception as ex:  # pragma: no cover
+        roadmap = {"error": repr(ex)}
+
     cpu = None
     if N == 1 and not args.no_cpu_baseline:
         cpu, cpu_labels, _ = cpu_baseline(gm, states)
@@ -389,7 +417,7 @@ def main():
                                (", accepted-state indices all-gathered over RCCL + states re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap,
         "device": ctx.arch, "gather_error": gather_error,
     }
     print(json.dumps(out))

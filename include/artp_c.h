@@ -167,6 +167,44 @@ int artp_debug_pipeline_counters(artp_ctx* ctx, uint64_t out[8]);
  * out may be NULL to query the radius only; *radius = 0 when the layer has no table. */
 int artp_debug_partner_table(artp_ctx* ctx, int slot, uint8_t* out, size_t out_bytes, int* radius);
 
+/* ---- "next" row N1: batched roadmap front end ------------------------------------------
+ * Replaces, as one batch per stage, the sampling / connection / search loops of the reference planners:
+ *   PRMMotionCostMaintainer::sampleGraph  art_planner/src/planners/prm_motion_cost.cpp:145-219
+ *   PRMMotionCost::addValidMilestone      prm_motion_cost.cpp:325-390 (k nearest, 0.5 m interpolation rule)
+ *   PRMMotionCost::constructSolution      prm_motion_cost.cpp:536-673 (A*, lazy checkMotion of the path)
+ *   PathLengthObjective                   art_planner/src/objectives/path_length_objective.cpp:26-70
+ * Vertex 0 = start, vertex 1 = goal, vertices 2.. = the first n_milestones accepted states of the
+ * (seed, index) sample stream.  Needs both height layers, the sampler layers and artp_set_z_bounds. */
+typedef struct artp_roadmap artp_roadmap;
+typedef struct artp_roadmap_params {
+  uint64_t seed, first_index;  /* sample stream */
+  uint32_t n_milestones;       /* Params::planner.prm_motion_cost.max_n_vertices (params.h:51) */
+  uint32_t k_neighbors;        /* 0 = OMPL KStarStrategy: ceil(e (1 + 1/6) ln n_vertices) */
+  int32_t objective;           /* 0 = PathLengthObjective::motionCostHeuristic (Euclidean / max_lon_vel),
+                                  1 = directional time cost (use_directional_cost, params.h:70) */
+  uint32_t max_replans;        /* bound on lazy edge removals in artp_roadmap_solve */
+  double max_lon_vel, max_lat_vel, max_ang_vel; /* params.h:71-73 */
+} artp_roadmap_params;
+void artp_roadmap_params_defaults(artp_roadmap_params* p);
+/* Samples, connects and validates.  ARTP_ERR_INVALID_ARG (artp_last_error says which) when start or goal
+ * is not a valid state (OMPL: INVALID_START / INVALID_GOAL, prm_motion_cost.cpp:452-476). */
+int artp_roadmap_build(artp_ctx* ctx, const artp_roadmap_params* params, const double* start_se3,
+                       const double* goal_se3, artp_roadmap** out);
+/* out[0] vertices, [1] candidate edges, [2] edges passing the interpolation rule, [3] edges removed by
+ * the lazy path check so far, [4] k, [5] samples drawn. */
+int artp_roadmap_stats(const artp_roadmap* rm, uint64_t out[8]);
+/* Any pointer may be NULL.  verts: n_vertices x 7; knn / knn_dist: n_vertices x k (0xffffffff = none);
+ * edges_uv: n_edges x 2 (u < v, sorted); edge_*: n_edges. */
+int artp_roadmap_export(const artp_roadmap* rm, double* verts, uint32_t* knn, double* knn_dist,
+                        uint32_t* edges_uv, uint8_t* edge_valid, uint32_t* edge_interp, double* edge_cost,
+                        uint8_t* edge_removed);
+/* Cheapest start -> goal path whose edges also pass the discrete motion validator (artp_check_motions).
+ * *n_path = 0 when start and goal are not connected; ARTP_ERR_CAPACITY (with *n_path = needed) when
+ * path_se3 (cap_states x 7, may be NULL) is too small. */
+int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
+                       int* n_replans);
+void artp_roadmap_destroy(artp_roadmap* rm);
+
 /* ---- learned motion cost: MotionCostObjective::MotionCostFunc
  *      (art_planner/include/art_planner/objectives/motion_cost_objective.h:22-23; the reference
  *      implements it as a ROS service to the Python/CUDA node, art_planner_ros/src/planner_ros.cpp:

@@ -1,0 +1,170 @@
+"""'Next' row N1: the batched roadmap front end.  OMPL is not available here, so there is
+no reference run to compare plans with (parity unpinned); every stage is checked against an
+independent restatement instead: k-NN vs numpy brute force, edge verdicts and the final path vs the CPU
+oracle, edge costs vs a numpy restatement of PathLengthObjective, the search vs scipy's Dijkstra."""
+import numpy as np
+import pytest
+
+import common
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _se3_distance(a, b):
+    """OMPL SE3StateSpace::distance: R^3 L2 + SO3 arc length (SO3StateSpace.cpp arcLength)."""
+    dp = np.sqrt(((a[:, None, :3] - b[None, :, :3]) ** 2).sum(-1))
+    dq = np.abs((a[:, None, 3:] * b[None, :, 3:]).sum(-1))
+    arc = np.where(dq > 1.0 - 1e-9, 0.0, np.arccos(np.minimum(dq, 1.0)))
+    return dp + arc
+
+
+def _valid_state_near(ctx, gm, xy, rng, tries=4000):
+    """A valid state near (x, y): sampler states filtered by distance."""
+    se3 = ctx.sample_states(99, 0, 1 << 16)
+    ok = ctx.validate_states(se3) != 0
+    cand = se3[ok]
+    d = np.hypot(cand[:, 0] - xy[0], cand[:, 1] - xy[1])
+    return cand[np.argmin(d)]
+
+
+@pytest.fixture(scope="module")
+def planning_setup():
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(200, 0.04, seed=5)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    rng = np.random.default_rng(3)
+    start = _valid_state_near(ctx, gm, (gm.pos_x - 2.6, gm.pos_y - 2.6), rng)
+    goal = _valid_state_near(ctx, gm, (gm.pos_x + 2.6, gm.pos_y + 2.6), rng)
+    yield gm, ctx, start, goal
+    ctx.close()
+
+
+def test_knn_matches_bruteforce(planning_setup):
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    rm = Roadmap(ctx, start, goal, n_milestones=3000, seed=7)
+    st, d = rm.stats(), rm.export()
+    nv, k = st["vertices"], st["k"]
+    assert nv == 3002 and k == int(np.ceil(np.e * (1 + 1 / 6) * np.log(nv)))
+    V = d["verts"]
+    assert np.array_equal(V[0], start) and np.array_equal(V[1], goal)
+    # milestones are exactly the first accepted states of the sample stream
+    se3 = ctx.sample_states(7, 0, int(st["samples_drawn"]))
+    acc = se3[ctx.validate_states(se3) != 0]
+    assert np.array_equal(V[2:], acc[:3000])
+    D = _se3_distance(V, V)
+    np.fill_diagonal(D, np.inf)
+    order = np.argsort(D, axis=1, kind="stable")[:, :k]
+    ref_d = np.take_along_axis(D, order, axis=1)
+    assert np.abs(d["knn_dist"] - ref_d).max() < 1e-9
+    same = d["knn"] == order
+    # a different neighbour is only acceptable on a (near-)tie of the distances
+    assert np.abs(np.take_along_axis(D, d["knn"].astype(np.int64), axis=1) - ref_d)[~same].max(initial=0.0) < 1e-9
+    assert same.mean() > 0.999
+    # candidate edges = symmetrised k-NN pairs, unique, sorted
+    pairs = set()
+    for i in range(nv):
+        for j in d["knn"][i]:
+            pairs.add((min(i, int(j)), max(i, int(j))))
+    assert sorted(pairs) == [tuple(e) for e in d["edges"].tolist()]
+    rm.close()
+
+
+def test_edges_costs_and_path_against_oracle_and_scipy(planning_setup):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    rob = O.robot("yaml")
+    om = O.OracleMap(gm)
+    rm = Roadmap(ctx, start, goal, n_milestones=4000, seed=11)
+    d0 = rm.export()
+    V, E = d0["verts"], d0["edges"].astype(np.int64)
+    # edge verdicts: the 0.5 m interpolation rule of addValidMilestone, by the CPU oracle
+    sub = np.random.default_rng(0).choice(len(E), 20000, replace=False)
+    vo, no = om.edges_interp_valid(rob, V[E[sub, 0]], V[E[sub, 1]])
+    assert np.array_equal(d0["edge_valid"][sub], vo) and np.array_equal(d0["edge_interp"][sub], no)
+    assert 0.05 < d0["edge_valid"].mean() < 0.999
+    # Euclidean objective: a chain of interpolated sub-edges on a straight segment sums to its length / v
+    eu = np.sqrt(((V[E[:, 0], :3] - V[E[:, 1], :3]) ** 2).sum(-1)) / 0.5
+    assert np.abs(d0["edge_cost"] - eu).max() < 1e-9
+    path, cost, replans = rm.solve()
+    assert path is not None and np.array_equal(path[0], start) and np.array_equal(path[-1], goal)
+    d1 = rm.export()
+    keep = (d1["edge_valid"] != 0) & (d1["edge_removed"] == 0)
+    n = len(V)
+    W = csr_matrix((d1["edge_cost"][keep], (E[keep, 0], E[keep, 1])), shape=(n, n))
+    ref = dijkstra(W, directed=False, indices=0)[1]
+    assert abs(cost - ref) < 1e-9 * max(1.0, ref)
+    # the path: consecutive vertices are roadmap edges; cost = sum of their costs; every edge passes the
+    # oracle's discrete motion validator (constructSolution's final check)
+    seg = np.sqrt(((path[1:, :3] - path[:-1, :3]) ** 2).sum(-1)) / 0.5
+    assert abs(seg.sum() - cost) < 1e-9 * max(1.0, cost)
+    assert om.check_motions(rob, path[:-1], path[1:])[0].all()
+    assert cost >= np.linalg.norm(goal[:3] - start[:3]) / 0.5 - 1e-12
+    assert replans == int(d1["edge_removed"].sum())
+    rm.close()
+
+
+def test_directional_cost_and_invalid_endpoints(planning_setup):
+    from art_planner_amd.roadmap import Roadmap
+    from art_planner_amd._capi import ArtpError
+    gm, ctx, start, goal = planning_setup
+    rm = Roadmap(ctx, start, goal, n_milestones=1500, seed=3, objective=1)
+    d = rm.export()
+    V, E = d["verts"], d["edges"].astype(np.int64)
+
+    def yaw(q):
+        return np.float32(np.arctan2(2 * (q[:, 3] * q[:, 2] + q[:, 0] * q[:, 1]),
+                                     1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2))).astype(np.float64)
+
+    def cost(a, b):  # PathLengthObjective::motionCost with use_directional_cost
+        dx, dy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1]
+        y1, y2 = yaw(a[:, 3:]), yaw(b[:, 3:])
+        dd = np.abs(y1 - y2)
+        dyaw = np.where(dd > np.pi, 2 * np.pi - dd, dd)
+        lon = np.cos(y1) * dx + np.sin(y1) * dy
+        lat = -np.sin(y1) * dx + np.cos(y1) * dy
+        return np.maximum(np.maximum(np.abs(lon) / 0.5, np.abs(lat) / 0.1), np.abs(dyaw) / 0.5)
+
+    direct = d["edge_interp"] == 0  # no interior states: the chain is the edge itself
+    assert direct.sum() > 100
+    assert np.abs(d["edge_cost"][direct] - cost(V[E[direct, 0]], V[E[direct, 1]])).max() < 1e-9
+    # chains: interpolate like OMPL and add the sub-edge costs
+    idx = np.nonzero(~direct)[0][:300]
+    for e in idx:
+        a, b, ni = V[E[e, 0]], V[E[e, 1]], int(d["edge_interp"][e])
+        pts = [a] + [O.interpolate(a, b, s / (ni + 1)) for s in range(1, ni + 1)] + [b]
+        pts = np.array(pts)
+        assert abs(cost(pts[:-1], pts[1:]).sum() - d["edge_cost"][e]) < 1e-8
+    path, c, _ = rm.solve()
+    assert path is not None and c > 0
+    rm.close()
+    bad = start.copy()
+    bad[2] -= 5.0  # under the terrain: not a valid state
+    with pytest.raises(ArtpError):
+        Roadmap(ctx, bad, goal, n_milestones=100)
+
+
+def test_flat_map_path_is_near_the_straight_line():
+    """BASELINE config C1 (flat 100 x 100 @ 0.1 m): with no obstacles the PRM* path converges to the
+    straight segment; the cost is bounded below by it and, at this density, within 10 %."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(100, 0.1, flat=True)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    se3 = ctx.sample_states(1, 0, 4096)
+    ok = se3[ctx.validate_states(se3) != 0]
+    start = ok[np.argmin(np.hypot(ok[:, 0] + 3.0, ok[:, 1] + 3.0))]
+    goal = ok[np.argmin(np.hypot(ok[:, 0] - 3.0, ok[:, 1] - 3.0))]
+    rm = Roadmap(ctx, start, goal, n_milestones=5000, seed=2)
+    path, cost, _ = rm.solve()
+    lb = np.linalg.norm(goal[:3] - start[:3]) / 0.5
+    assert path is not None and lb - 1e-12 <= cost < 1.10 * lb
+    rm.close()
+    ctx.close()
