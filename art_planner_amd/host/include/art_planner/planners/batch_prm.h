@@ -1,0 +1,85 @@
+// art_planner::BatchPRM -- the batched counterpart of the reference's PRM planners
+// (PRMMotionCost, art_planner/include/art_planner/planners/prm_motion_cost.h:39-120; driven by
+// Planner::plan, art_planner/src/planner.cpp:218-330): sampleGraph + addValidMilestone's connection rule
+// + baseSolve / constructSolution, each as one batch on the MI355X (include/artp_c.h: artp_roadmap_*).
+// Reads the same Params members the reference planners read (planner.prm_motion_cost.max_n_vertices,
+// objectives.custom_path_length.*).  The caller keeps the map current through StateValidityChecker /
+// SE3FromSE2Sampler / BatchMotionValidator::setZBounds exactly as for the per-state interfaces.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#include "art_planner/gpu_context.h"
+#include "art_planner/ompl_min.h"
+#include "art_planner/params.h"
+
+namespace art_planner {
+
+class BatchPRM {
+ public:
+  using StateArray = std::array<double, 7>;  // x y z qx qy qz qw (OMPL SE3 state, flattened)
+
+  BatchPRM(const ParamsConstPtr& params, const GpuContextPtr& gpu) : params_(params), gpu_(gpu) {}
+  ~BatchPRM() { clear(); }
+  BatchPRM(const BatchPRM&) = delete;
+  BatchPRM& operator=(const BatchPRM&) = delete;
+
+  void setSeed(uint64_t seed) { seed_ = seed; }
+  void clear() {
+    if (rm_) artp_roadmap_destroy(rm_);
+    rm_ = nullptr;
+  }
+
+  // PRMMotionCostMaintainer::sampleGraph + the connection loop: (re)build the roadmap for start / goal.
+  // Throws on an invalid start or goal, like the reference's INVALID_START / INVALID_GOAL statuses.
+  void sampleGraph(const ob::SE3StateSpace::StateType& start, const ob::SE3StateSpace::StateType& goal) {
+    clear();
+    artp_roadmap_params p;
+    artp_roadmap_params_defaults(&p);
+    p.seed = seed_;
+    p.n_milestones = params_->planner.prm_motion_cost.max_n_vertices;
+    p.objective = params_->objectives.custom_path_length.use_directional_cost ? 1 : 0;
+    p.max_lon_vel = params_->objectives.custom_path_length.max_lon_vel;
+    p.max_lat_vel = params_->objectives.custom_path_length.max_lat_vel;
+    p.max_ang_vel = params_->objectives.custom_path_length.max_ang_vel;
+    const StateArray s = flatten(start), g = flatten(goal);
+    throwOnError(gpu_->get(), artp_roadmap_build(gpu_->get(), &p, s.data(), g.data(), &rm_), "artp_roadmap_build");
+  }
+
+  // baseSolve / constructSolution: false = start and goal are not connected (PlannerStatus::TIMEOUT).
+  bool solve(std::vector<StateArray>* path, double* cost = nullptr) {
+    if (!rm_) throw std::runtime_error("BatchPRM::solve before sampleGraph");
+    size_t n = 0;
+    double c = 0.0;
+    int replans = 0;
+    int rc = artp_roadmap_solve(rm_, nullptr, 0, &n, &c, &replans);  // length first
+    if (rc != ARTP_OK) throwOnError(gpu_->get(), rc, "artp_roadmap_solve");
+    if (n == 0) return false;
+    path->resize(n);
+    rc = artp_roadmap_solve(rm_, (*path)[0].data(), n, &n, &c, &replans);
+    throwOnError(gpu_->get(), rc, "artp_roadmap_solve");
+    if (cost) *cost = c;
+    return true;
+  }
+
+  size_t numVertices() const { return stat(0); }
+  size_t numEdges() const { return stat(2); }
+
+ private:
+  static StateArray flatten(const ob::SE3StateSpace::StateType& s) {
+    return {s.getX(), s.getY(), s.getZ(), s.rotation().x, s.rotation().y, s.rotation().z, s.rotation().w};
+  }
+  size_t stat(int i) const {
+    uint64_t out[8] = {};
+    if (rm_) artp_roadmap_stats(rm_, out);
+    return static_cast<size_t>(out[i]);
+  }
+  ParamsConstPtr params_;
+  GpuContextPtr gpu_;
+  artp_roadmap* rm_{nullptr};
+  uint64_t seed_{42};
+};
+
+}  // namespace art_planner

@@ -11,6 +11,7 @@
 
 #include "art_planner/objectives/motion_cost_objective.h"
 #include "art_planner/sampler.h"
+#include "art_planner/planners/batch_prm.h"
 #include "art_planner/validity_checker/height_map_box_checker.h"
 #include "art_planner/validity_checker/validity_checker.h"
 
@@ -74,6 +75,21 @@ int main(int argc, char** argv) {
   HeightMapBoxChecker::dPose high;
   high.origin = {0.f, 0.f, 50.f, 0.f};
   bad += box.checkCollision({high}) != 0;
+  // BatchPRM compiles against the same Params; it needs the sampler layers, which this fixture does not
+  // carry: building a roadmap must fail loudly, not fall back to anything
+  {
+    BatchPRM prm(params, gpu);
+    ob::SE3StateSpace::StateType a;
+    a.setXYZ(se3[0], se3[1], se3[2]);
+    a.rotation().x = se3[3]; a.rotation().y = se3[4]; a.rotation().z = se3[5]; a.rotation().w = se3[6];
+    bool threw = false;
+    try {
+      prm.sampleGraph(a, a);
+    } catch (const std::exception&) {
+      threw = true;
+    }
+    bad += threw ? 0 : 1;
+  }
   std::printf("host mirror: %d states batch + %d single, %d mismatches\n", n, n_single, bad);
   return bad == 0 ? 0 : 1;
 }
