@@ -46,7 +46,9 @@ _lib = None
 class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n_milestones", C.c_uint32),
                 ("k_neighbors", C.c_uint32), ("objective", C.c_int32), ("max_replans", C.c_uint32),
-                ("max_lon_vel", C.c_double), ("max_lat_vel", C.c_double), ("max_ang_vel", C.c_double)]
+                ("max_lon_vel", C.c_double), ("max_lat_vel", C.c_double), ("max_ang_vel", C.c_double),
+                ("w_energy", C.c_float), ("w_time", C.c_float), ("w_risk", C.c_float),
+                ("risk_threshold", C.c_float)]
 
 
 def load():

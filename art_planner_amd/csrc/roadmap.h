@@ -190,6 +190,69 @@ edge_chain_cost_kernel(PathLengthParams p, const double* __restrict__ s1, const 
   cost[e] = total;
 }
 
+// Learned-cost objective (PRMMotionCostMaintainer::updateEdges, prm_motion_cost.cpp:27-73): every sub-edge of
+// a chain is one row of the EdgeMatrix -- target (x, y, yaw) then start (x, y, yaw), as floats.
+__global__ void __launch_bounds__(256)
+chain_edge_matrix_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                         const uint32_t* __restrict__ n_interp, const uint32_t* __restrict__ row_off, size_t ne,
+                         float* __restrict__ edge_matrix) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  double a[7], b[7], prev[7], cur[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    a[c] = s1[e * 7 + c];
+    b[c] = s2[e * 7 + c];
+    prev[c] = a[c];
+  }
+  const unsigned ni = n_interp[e];
+  const double div = 1.0 / (double)(ni + 1);
+  float* row = edge_matrix + (size_t)row_off[e] * 6;
+  for (unsigned step = 1; step <= ni + 1; ++step) {
+    if (step <= ni) {
+      se3_interpolate(a, b, (double)step * div, cur);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) cur[c] = b[c];
+    }
+    row[0] = (float)cur[0];
+    row[1] = (float)cur[1];
+    row[2] = (float)yaw_from_quat(cur + 3);
+    row[3] = (float)prev[0];
+    row[4] = (float)prev[1];
+    row[5] = (float)yaw_from_quat(prev + 3);
+    row += 6;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) prev[c] = cur[c];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+chain_rows_kernel(const uint32_t* __restrict__ n_interp, size_t ne, uint32_t* __restrict__ rows) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) rows[e] = n_interp[e] + 1;
+  if (e == ne) rows[e] = 0;
+}
+
+// MotionCostObjective::getCost / isFeasible (motion_cost_objective.h:54-66) summed over the chain; one
+// infeasible sub-edge (risk above the threshold) makes the connection unusable (infinite cost).
+__global__ void __launch_bounds__(256)
+chain_motion_cost_kernel(const float* __restrict__ cost3, const uint32_t* __restrict__ row_off,
+                         const uint32_t* __restrict__ n_interp, size_t ne, float w_energy, float w_time,
+                         float w_risk, float risk_threshold, double* __restrict__ cost) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const float* c = cost3 + (size_t)row_off[e] * 3;
+  double total = 0.0;
+  bool feasible = true;
+  for (unsigned s = 0; s <= n_interp[e]; ++s, c += 3) {
+    const double en = c[0], ti = c[1], ri = c[2];
+    feasible = feasible && (ri <= (double)risk_threshold);
+    total += en * w_energy + ti * w_time + ri * w_risk;
+  }
+  cost[e] = feasible ? total : INFINITY;
+}
+
 }  // namespace artp
 
 // -------------------------------------------------------------------------------------------------------
@@ -317,6 +380,10 @@ void artp_roadmap_params_defaults(artp_roadmap_params* p) {
   p->max_lat_vel = 0.1;
   p->max_ang_vel = 0.5;
   p->max_replans = 1000;
+  p->w_energy = 0.0f;              // Params::planner.prm_motion_cost.cost_weights (params.h:58-62)
+  p->w_time = 1.0f;
+  p->w_risk = 5.0f;
+  p->risk_threshold = 0.1f;        // params.h:55
 }
 
 void artp_roadmap_destroy(artp_roadmap* rm) { delete rm; }
@@ -324,7 +391,7 @@ void artp_roadmap_destroy(artp_roadmap* rm) { delete rm; }
 int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
                        artp_roadmap** out) {
   if (!c || !prm || !start7 || !goal7 || !out || prm->n_milestones < 1 || prm->objective < 0 ||
-      prm->objective > 1 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0))
+      prm->objective > 2 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0))
     return ARTP_ERR_INVALID_ARG;
   *out = nullptr;
   const size_t nm = prm->n_milestones, nv = nm + 2;
@@ -480,9 +547,59 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
                        (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2);
     int rc = artp_check_edges_interp_dev(c, d_s1, d_s2, ne, d_evalid, d_einterp);
     if (rc != ARTP_OK) return fail(rc);
-    artp::PathLengthParams pl{prm->objective == 1, prm->max_lon_vel, prm->max_lat_vel, prm->max_ang_vel};
-    hipLaunchKernelGGL(artp::edge_chain_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, pl,
-                       (const double*)d_s1, (const double*)d_s2, (const uint32_t*)d_einterp, ne, d_cost);
+    if (prm->objective <= 1) {
+      artp::PathLengthParams pl{prm->objective == 1, prm->max_lon_vel, prm->max_lat_vel, prm->max_ang_vel};
+      hipLaunchKernelGGL(artp::edge_chain_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, pl,
+                         (const double*)d_s1, (const double*)d_s2, (const uint32_t*)d_einterp, ne, d_cost);
+    } else {
+      // learned cost: one EdgeMatrix row per sub-edge, one batched query, per-chain reduction
+      uint32_t *d_rows = nullptr, *d_off = nullptr;
+      float *d_em = nullptr, *d_c3 = nullptr;
+      void* d_cub2 = nullptr;
+      auto cleanup2 = [&]() {
+        for (void* p : {(void*)d_rows, (void*)d_off, (void*)d_em, (void*)d_c3, d_cub2})
+          if (p) (void)hipFree(p);
+      };
+      bool okk = hipMalloc(reinterpret_cast<void**>(&d_rows), (ne + 1) * 4) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&d_off), (ne + 1) * 4) == hipSuccess;
+      size_t need = 0;
+      uint32_t total = 0;
+      if (okk) {
+        hipLaunchKernelGGL(artp::chain_rows_kernel, dim3((unsigned)((ne + 256) / 256)), dim3(256), 0, st,
+                           (const uint32_t*)d_einterp, ne, d_rows);
+        okk = hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_rows, d_off, (int)(ne + 1), st) == hipSuccess &&
+              hipMalloc(&d_cub2, need + 256) == hipSuccess;
+      }
+      if (okk) {
+        size_t cap2 = need + 256;
+        okk = hipcub::DeviceScan::ExclusiveSum(d_cub2, cap2, d_rows, d_off, (int)(ne + 1), st) == hipSuccess &&
+              hipMemcpyAsync(&total, d_off + ne, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipStreamSynchronize(st) == hipSuccess;
+      }
+      if (okk)
+        okk = hipMalloc(reinterpret_cast<void**>(&d_em), (size_t)total * 6 * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&d_c3), (size_t)total * 3 * 4) == hipSuccess;
+      if (!okk) {
+        cleanup2();
+        return fail(ARTP_ERR_HIP);
+      }
+      hipLaunchKernelGGL(artp::chain_edge_matrix_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
+                         (const double*)d_s1, (const double*)d_s2, (const uint32_t*)d_einterp, (const uint32_t*)d_off,
+                         ne, d_em);
+      rc = artp_cost_query_dev(c, d_em, total, d_c3);
+      if (rc != ARTP_OK) {
+        cleanup2();
+        return fail(rc);
+      }
+      hipLaunchKernelGGL(artp::chain_motion_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
+                         (const float*)d_c3, (const uint32_t*)d_off, (const uint32_t*)d_einterp, ne, prm->w_energy,
+                         prm->w_time, prm->w_risk, prm->risk_threshold, d_cost);
+      if (hipStreamSynchronize(st) != hipSuccess) {
+        cleanup2();
+        return fail(ARTP_ERR_HIP);
+      }
+      cleanup2();
+    }
     std::vector<unsigned long long> keys(ne);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
         hipMemcpy(keys.data(), d_keys_unique, ne * 8, hipMemcpyDeviceToHost) != hipSuccess ||

@@ -40,7 +40,15 @@ class BatchPRM {
     artp_roadmap_params_defaults(&p);
     p.seed = seed_;
     p.n_milestones = params_->planner.prm_motion_cost.max_n_vertices;
-    p.objective = params_->objectives.custom_path_length.use_directional_cost ? 1 : 0;
+    // planner.name selects the objective like Planner::Planner (planner.cpp:108-127): the learned motion
+    // cost for "prm_motion_cost", PathLengthObjective otherwise
+    p.objective = params_->planner.name == "prm_motion_cost"
+                      ? 2
+                      : (params_->objectives.custom_path_length.use_directional_cost ? 1 : 0);
+    p.w_energy = params_->planner.prm_motion_cost.cost_weights.energy;
+    p.w_time = params_->planner.prm_motion_cost.cost_weights.time;
+    p.w_risk = params_->planner.prm_motion_cost.cost_weights.risk;
+    p.risk_threshold = params_->planner.prm_motion_cost.risk_threshold;
     p.max_lon_vel = params_->objectives.custom_path_length.max_lon_vel;
     p.max_lat_vel = params_->objectives.custom_path_length.max_lat_vel;
     p.max_ang_vel = params_->objectives.custom_path_length.max_ang_vel;

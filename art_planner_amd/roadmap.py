@@ -13,7 +13,8 @@ from . import _capi
 
 class Roadmap:
     def __init__(self, ctx, start, goal, n_milestones=10000, seed=42, first_index=0, k_neighbors=0,
-                 objective=0, max_lon_vel=0.5, max_lat_vel=0.1, max_ang_vel=0.5, max_replans=1000):
+                 objective=0, max_lon_vel=0.5, max_lat_vel=0.1, max_ang_vel=0.5, max_replans=1000,
+                 cost_weights=None, risk_threshold=None):
         self.ctx = ctx
         self.L = _capi.load()
         p = _capi.RoadmapParams()
@@ -21,6 +22,10 @@ class Roadmap:
         p.seed, p.first_index, p.n_milestones, p.k_neighbors = seed, first_index, n_milestones, k_neighbors
         p.objective, p.max_replans = objective, max_replans
         p.max_lon_vel, p.max_lat_vel, p.max_ang_vel = max_lon_vel, max_lat_vel, max_ang_vel
+        if cost_weights is not None:
+            p.w_energy, p.w_time, p.w_risk = cost_weights
+        if risk_threshold is not None:
+            p.risk_threshold = risk_threshold
         s = np.ascontiguousarray(start, np.float64).reshape(7)
         g = np.ascontiguousarray(goal, np.float64).reshape(7)
         h = C.c_void_p()

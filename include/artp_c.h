@@ -181,9 +181,14 @@ typedef struct artp_roadmap_params {
   uint32_t n_milestones;       /* Params::planner.prm_motion_cost.max_n_vertices (params.h:51) */
   uint32_t k_neighbors;        /* 0 = OMPL KStarStrategy: ceil(e (1 + 1/6) ln n_vertices) */
   int32_t objective;           /* 0 = PathLengthObjective::motionCostHeuristic (Euclidean / max_lon_vel),
-                                  1 = directional time cost (use_directional_cost, params.h:70) */
+                                  1 = directional time cost (use_directional_cost, params.h:70),
+                                  2 = learned motion cost: PRMMotionCostMaintainer::updateEdges
+                                      (prm_motion_cost.cpp:27-73) over artp_cost_query; needs
+                                      artp_cost_load_weights + artp_cost_update_map */
   uint32_t max_replans;        /* bound on lazy edge removals in artp_roadmap_solve */
   double max_lon_vel, max_lat_vel, max_ang_vel; /* params.h:71-73 */
+  float w_energy, w_time, w_risk; /* MotionCostObjective::getCost weights (params.h:58-62) */
+  float risk_threshold;           /* MotionCostObjective::isFeasible (params.h:55) */
 } artp_roadmap_params;
 void artp_roadmap_params_defaults(artp_roadmap_params* p);
 /* Samples, connects and validates.  ARTP_ERR_INVALID_ARG (artp_last_error says which) when start or goal

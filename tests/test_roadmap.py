@@ -168,3 +168,53 @@ def test_flat_map_path_is_near_the_straight_line():
     assert path is not None and lb - 1e-12 <= cost < 1.10 * lb
     rm.close()
     ctx.close()
+
+
+def test_learned_cost_objective_matches_per_subedge_queries(planning_setup):
+    """objective 2 = PRMMotionCostMaintainer::updateEdges: every sub-edge of a chain is one EdgeMatrix row
+    (target x y yaw, start x y yaw); chain cost = sum of getCost over its rows, infinite as soon as one
+    row's risk exceeds the threshold.  Checked against artp_cost_query on rows rebuilt in numpy."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import motion_cost_oracle as mo
+    import convert_weights
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    ctx.cost_load_weights(convert_weights.to_blob(mo.random_params(0)))
+    elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)
+    ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+    w = (0.25, 1.0, 5.0)
+    thr = 0.55  # random weights: risks spread around 0.5, so both feasible and infeasible chains occur
+    rm = Roadmap(ctx, start, goal, n_milestones=1200, seed=5, k_neighbors=60, objective=2, cost_weights=w,
+                 risk_threshold=thr)
+    d = rm.export()
+    V, E = d["verts"], d["edges"].astype(np.int64)
+
+    def yaw(q):
+        return np.float32(np.arctan2(2 * (q[3] * q[2] + q[0] * q[1]), 1 - 2 * (q[1] ** 2 + q[2] ** 2)))
+
+    rows, owner = [], []
+    sel = np.concatenate([np.nonzero(d["edge_interp"] > 0)[0][:400], np.nonzero(d["edge_interp"] == 0)[0][:400]])
+    assert (d["edge_interp"][sel] > 0).sum() > 50
+    for e in sel:
+        a, b, ni = V[E[e, 0]], V[E[e, 1]], int(d["edge_interp"][e])
+        pts = [a] + [O.interpolate(a, b, s / (ni + 1)) for s in range(1, ni + 1)] + [b]
+        for s0, s1 in zip(pts[:-1], pts[1:]):
+            rows.append([s1[0], s1[1], yaw(s1[3:]), s0[0], s0[1], yaw(s0[3:])])
+            owner.append(e)
+    c3 = ctx.cost_query(np.array(rows, np.float32)).astype(np.float64)
+    owner = np.array(owner)
+    for e in sel:
+        r = c3[owner == e]
+        ref = np.inf if (r[:, 2] > np.float32(thr)).any() else (r[:, 0] * np.float32(w[0]) + r[:, 1] * np.float32(w[1])
+                                                                + r[:, 2] * np.float32(w[2])).sum()
+        got = d["edge_cost"][e]
+        assert (np.isinf(ref) and np.isinf(got)) or abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (e, got, ref)
+    fin = np.isfinite(d["edge_cost"])
+    assert 0.02 < fin.mean() < 0.98
+    path, cost, _ = rm.solve()
+    if path is not None:  # every edge of the plan is feasible and the cost adds up
+        assert np.isfinite(cost) and cost > 0
+    rm.close()
