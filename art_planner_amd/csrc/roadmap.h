@@ -32,70 +32,126 @@ __device__ __forceinline__ double se3_distance(const double* a, const double* b)
   return sqrt(dx * dx + dy * dy + dz * dz) + so3_arc_length(a + 3, b + 3);
 }
 
-// One lane per query vertex; candidates stream through an LDS tile; the lane's k best live in LDS
-// (entry e of lane l at [e * 64 + l]: conflict-free).  The R^3 term alone rejects most candidates before
-// the arc length (an acos) is needed.  Output: neighbours by ascending (distance, index).
-#define ARTP_KNN_TILE 128
+// ---- k nearest neighbours on a uniform xy grid ----------------------------------------------------------
+// Vertices are bucketed by the grid cell of their (x, y) (cell ids sorted with hipcub, vertex rows permuted
+// into cell order).  One lane per query walks square rings of cells around its own cell; the k best live in
+// LDS (entry e of lane l at [e * 64 + l]: conflict-free).  The SE3 distance is at least the planar
+// distance, and every cell of ring r+1 is at least r cell sizes away in the plane, so the walk stops
+// -- exactly -- once the list is full and r * h >= the current k-th distance (or the grid is exhausted).
+// The R^3 term alone rejects most candidates before the arc length (an acos) is needed.
+// Output: neighbours by ascending (distance, original index).
+struct KnnGrid {
+  double x0, y0, inv_h, h;
+  int gx, gy;
+};
+
+__device__ __forceinline__ int knn_cell_coord(double v, double v0, double inv_h, int g) {
+  int c = (int)floor((v - v0) * inv_h);
+  return c < 0 ? 0 : (c >= g ? g - 1 : c);
+}
+
+__global__ void __launch_bounds__(256)
+knn_cell_ids_kernel(const double* __restrict__ verts, int nv, KnnGrid g, uint32_t* __restrict__ cell,
+                    uint32_t* __restrict__ ident) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nv) return;
+  cell[i] = (uint32_t)(knn_cell_coord(verts[(size_t)i * 7 + 1], g.y0, g.inv_h, g.gy) * g.gx +
+                       knn_cell_coord(verts[(size_t)i * 7 + 0], g.x0, g.inv_h, g.gx));
+  ident[i] = (uint32_t)i;
+}
+
+// rows of verts in cell order + first sorted position of every cell (cell_start[ncell] = nv)
+__global__ void __launch_bounds__(256)
+knn_permute_kernel(const double* __restrict__ verts, const uint32_t* __restrict__ sorted_cell,
+                   const uint32_t* __restrict__ sorted_id, int nv, int ncell, double* __restrict__ verts_sorted,
+                   uint32_t* __restrict__ cell_start) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nv) return;
+  const uint32_t id = sorted_id[p];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) verts_sorted[(size_t)p * 7 + c] = verts[(size_t)id * 7 + c];
+  const uint32_t cc = sorted_cell[p];
+  const uint32_t prev = p == 0 ? 0xffffffffu : sorted_cell[p - 1];
+  if (p == 0 || prev != cc)
+    for (uint32_t c2 = (p == 0 ? 0u : prev + 1u); c2 <= cc; ++c2) cell_start[c2] = (uint32_t)p;
+  if (p == nv - 1)
+    for (uint32_t c2 = cc + 1; c2 <= (uint32_t)ncell; ++c2) cell_start[c2] = (uint32_t)nv;
+}
+
 __global__ void __launch_bounds__(64)
-knn_kernel(const double* __restrict__ verts, int nv, int k, uint32_t* __restrict__ out_idx,
+knn_kernel(const double* __restrict__ verts_sorted, const uint32_t* __restrict__ sorted_id,
+           const uint32_t* __restrict__ cell_start, KnnGrid g, int nv, int k, uint32_t* __restrict__ out_idx,
            double* __restrict__ out_dist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* tile = reinterpret_cast<double*>(smem);                 // [TILE][7]
-  double* bd = tile + ARTP_KNN_TILE * 7;                          // [k][64]
-  uint32_t* bi = reinterpret_cast<uint32_t*>(bd + (size_t)k * 64);  // [k][64]
+  double* bd = reinterpret_cast<double*>(smem);                      // [k][64]
+  uint32_t* bi = reinterpret_cast<uint32_t*>(bd + (size_t)k * 64);  // [k][64] original indices
   const int lane = threadIdx.x;
-  const int i = blockIdx.x * 64 + lane;
-  const bool live = i < nv;
+  const int p = blockIdx.x * 64 + lane;  // query = sorted position p: neighbouring lanes share cells
+  if (p >= nv) return;
   double q[7];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) q[c] = live ? verts[(size_t)i * 7 + c] : 0.0;
+  for (int c = 0; c < 7; ++c) q[c] = verts_sorted[(size_t)p * 7 + c];
+  const int cx = knn_cell_coord(q[0], g.x0, g.inv_h, g.gx), cy = knn_cell_coord(q[1], g.y0, g.inv_h, g.gy);
   int count = 0;
   double thr = INFINITY;  // current k-th best distance once the list is full
   int arg = 0;            // its slot
-  for (int t0 = 0; t0 < nv; t0 += ARTP_KNN_TILE) {
-    const int tn = min(ARTP_KNN_TILE, nv - t0);
-    __syncthreads();
-    for (int e = lane; e < tn * 7; e += 64) tile[e] = verts[(size_t)t0 * 7 + e];
-    __syncthreads();
-    if (!live) continue;
-    for (int jj = 0; jj < tn; ++jj) {
-      const int j = t0 + jj;
-      if (j == i) continue;
-      const double* c = tile + jj * 7;
-      const double dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
-      const double dp = sqrt(dx * dx + dy * dy + dz * dz);
-      if (count == k && !(dp < thr)) continue;
-      const double d = dp + so3_arc_length(q + 3, c + 3);
-      if (count < k) {
-        bd[count * 64 + lane] = d;
-        bi[count * 64 + lane] = (uint32_t)j;
-        ++count;
-        if (count == k) {
-          thr = -1.0;
-          for (int e = 0; e < k; ++e)
-            if (bd[e * 64 + lane] > thr) {
-              thr = bd[e * 64 + lane];
-              arg = e;
-            }
+  const int rmax = max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy));
+  for (int r = 0; r <= rmax; ++r) {
+    if (count == k && (double)(r - 1) * g.h >= thr) break;  // ring r is at least (r-1)*h away
+    for (int yy = cy - r; yy <= cy + r; ++yy) {
+      if (yy < 0 || yy >= g.gy) continue;
+      const bool edge_row = (yy == cy - r) || (yy == cy + r);
+      // edge rows: the whole run of cells cx-r .. cx+r (contiguous in the sorted order); inner rows: the two
+      // end cells
+      for (int part = 0; part < (edge_row || r == 0 ? 1 : 2); ++part) {
+        int xa, xb;
+        if (edge_row || r == 0) {
+          xa = max(cx - r, 0);
+          xb = min(cx + r, g.gx - 1);
+        } else {
+          xa = xb = part == 0 ? cx - r : cx + r;
+          if (xa < 0 || xa >= g.gx) continue;
         }
-      } else if (d < thr) {
-        bd[arg * 64 + lane] = d;
-        bi[arg * 64 + lane] = (uint32_t)j;
-        thr = -1.0;
-        for (int e = 0; e < k; ++e)
-          if (bd[e * 64 + lane] > thr) {
-            thr = bd[e * 64 + lane];
-            arg = e;
+        const uint32_t j0 = cell_start[yy * g.gx + xa], j1 = cell_start[yy * g.gx + xb + 1];
+        for (uint32_t j = j0; j < j1; ++j) {
+          if ((int)j == p) continue;
+          const double* c = verts_sorted + (size_t)j * 7;
+          const double dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+          const double dp = sqrt(dx * dx + dy * dy + dz * dz);
+          if (count == k && !(dp < thr)) continue;
+          const double d = dp + so3_arc_length(q + 3, c + 3);
+          if (count < k) {
+            bd[count * 64 + lane] = d;
+            bi[count * 64 + lane] = sorted_id[j];
+            ++count;
+            if (count == k) {
+              thr = -1.0;
+              for (int e = 0; e < k; ++e)
+                if (bd[e * 64 + lane] > thr) {
+                  thr = bd[e * 64 + lane];
+                  arg = e;
+                }
+            }
+          } else if (d < thr) {
+            bd[arg * 64 + lane] = d;
+            bi[arg * 64 + lane] = sorted_id[j];
+            thr = -1.0;
+            for (int e = 0; e < k; ++e)
+              if (bd[e * 64 + lane] > thr) {
+                thr = bd[e * 64 + lane];
+                arg = e;
+              }
           }
+        }
       }
     }
   }
-  if (!live) return;
   // selection sort by (distance, index); unused slots (fewer than k candidates) are marked
+  const size_t i = sorted_id[p];
   for (int a = 0; a < k; ++a) {
     if (a >= count) {
-      out_idx[(size_t)i * k + a] = 0xffffffffu;
-      out_dist[(size_t)i * k + a] = INFINITY;
+      out_idx[i * k + a] = 0xffffffffu;
+      out_dist[i * k + a] = INFINITY;
       continue;
     }
     int best = a;
@@ -109,8 +165,8 @@ knn_kernel(const double* __restrict__ verts, int nv, int k, uint32_t* __restrict
     bi[best * 64 + lane] = bi[a * 64 + lane];
     bd[a * 64 + lane] = dbest;
     bi[a * 64 + lane] = ibest;
-    out_idx[(size_t)i * k + a] = ibest;
-    out_dist[(size_t)i * k + a] = dbest;
+    out_idx[i * k + a] = ibest;
+    out_dist[i * k + a] = dbest;
   }
 }
 
@@ -328,7 +384,9 @@ bool roadmap_astar(artp_roadmap* rm, std::vector<uint32_t>* path, double* cost) 
     if (u == 1) break;
     for (uint32_t a = rm->row[u]; a < rm->row[u + 1]; ++a) {
       const uint32_t v = rm->adj[a];
-      const double w = rm->ecost[rm->adj_edge[a]];
+      const uint32_t e = rm->adj_edge[a];
+      if (rm->eremoved[e]) continue;  // removed by the lazy path check since the CSR was built
+      const double w = rm->ecost[e];
       if (!std::isfinite(w)) continue;
       const double ng = g[u] + w;
       if (ng < g[v]) {
@@ -470,12 +528,64 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_knn), nv * k * sizeof(uint32_t)));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_knn_dist), nv * k * sizeof(double)));
   {
-    const size_t lds = (size_t)ARTP_KNN_TILE * 7 * 8 + (size_t)k * 64 * 12;
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(artp::knn_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(artp::knn_kernel, dim3((unsigned)((nv + 63) / 64)), dim3(64), lds, st, (const double*)d_verts,
-                       (int)nv, k, d_knn, d_knn_dist);
-    RM_HIP(hipGetLastError());
+    // grid over the map: about three vertices per cell
+    artp::KnnGrid g;
+    {
+      std::lock_guard<std::mutex> lock(c->mu);
+      g.x0 = c->geom.pos_x - 0.5 * c->geom.len_x;
+      g.y0 = c->geom.pos_y - 0.5 * c->geom.len_y;
+      const double area = c->geom.len_x * c->geom.len_y;
+      g.h = std::sqrt(area * 3.0 / (double)nv);
+      const double hmin = std::max(c->geom.len_x, c->geom.len_y) / 2048.0;
+      if (g.h < hmin) g.h = hmin;
+      g.inv_h = 1.0 / g.h;
+      g.gx = std::max(1, (int)std::ceil(c->geom.len_x * g.inv_h));
+      g.gy = std::max(1, (int)std::ceil(c->geom.len_y * g.inv_h));
+    }
+    const int ncell = g.gx * g.gy;
+    uint32_t *d_cell = nullptr, *d_id = nullptr, *d_cell_s = nullptr, *d_id_s = nullptr, *d_start = nullptr;
+    double* d_vs = nullptr;
+    void* d_cub1 = nullptr;
+    auto cleanup_knn = [&]() {
+      for (void* p : {(void*)d_cell, (void*)d_id, (void*)d_cell_s, (void*)d_id_s, (void*)d_start, (void*)d_vs, d_cub1})
+        if (p) (void)hipFree(p);
+    };
+    size_t need = 0;
+    bool okk = hipMalloc(reinterpret_cast<void**>(&d_cell), nv * 4) == hipSuccess &&
+               hipMalloc(reinterpret_cast<void**>(&d_id), nv * 4) == hipSuccess &&
+               hipMalloc(reinterpret_cast<void**>(&d_cell_s), nv * 4) == hipSuccess &&
+               hipMalloc(reinterpret_cast<void**>(&d_id_s), nv * 4) == hipSuccess &&
+               hipMalloc(reinterpret_cast<void**>(&d_start), ((size_t)ncell + 1) * 4) == hipSuccess &&
+               hipMalloc(reinterpret_cast<void**>(&d_vs), nv * 7 * sizeof(double)) == hipSuccess &&
+               hipcub::DeviceRadixSort::SortPairs(nullptr, need, d_cell, d_cell_s, d_id, d_id_s, (int)nv, 0, 32, st) ==
+                   hipSuccess &&
+               hipMalloc(&d_cub1, need + 256) == hipSuccess;
+    if (okk) {
+      hipLaunchKernelGGL(artp::knn_cell_ids_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st,
+                         (const double*)d_verts, (int)nv, g, d_cell, d_id);
+      size_t cap1 = need + 256;
+      okk = hipcub::DeviceRadixSort::SortPairs(d_cub1, cap1, d_cell, d_cell_s, d_id, d_id_s, (int)nv, 0, 32, st) ==
+            hipSuccess;
+    }
+    if (okk) {
+      hipLaunchKernelGGL(artp::knn_permute_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st,
+                         (const double*)d_verts, (const uint32_t*)d_cell_s, (const uint32_t*)d_id_s, (int)nv, ncell,
+                         d_vs, d_start);
+      const size_t lds = (size_t)k * 64 * 12;
+      okk = hipFuncSetAttribute(reinterpret_cast<const void*>(artp::knn_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      if (okk) {
+        hipLaunchKernelGGL(artp::knn_kernel, dim3((unsigned)((nv + 63) / 64)), dim3(64), lds, st, (const double*)d_vs,
+                           (const uint32_t*)d_id_s, (const uint32_t*)d_start, g, (int)nv, k, d_knn, d_knn_dist);
+        okk = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+      }
+    }
+    cleanup_knn();
+    if (!okk) {
+      c->last_error = "k-NN stage failed";
+      cleanup();
+      return ARTP_ERR_HIP;
+    }
   }
 
   // 3. candidate edges: symmetrised, unique
@@ -710,8 +820,7 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
     // remove edge (path[bad], path[bad+1])
     const uint32_t a = std::min(path[bad], path[bad + 1]), b = std::max(path[bad], path[bad + 1]);
     for (uint32_t t = rm->row[a]; t < rm->row[a + 1]; ++t)
-      if (rm->adj[t] == b) rm->eremoved[rm->adj_edge[t]] = 1;
-    rm->csr_dirty = true;
+      if (rm->adj[t] == b) rm->eremoved[rm->adj_edge[t]] = 1;  // the search skips removed edges
     if (++replans > (int)rm->params.max_replans) {
       c->last_error = "too many lazy edge removals";
       if (n_replans) *n_replans = replans;
