@@ -23,6 +23,8 @@ SYMBOLS = [
     "artp_algorithmic_vertices_dev",
     "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_roadmap_params_defaults",
     "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
+    "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
+    "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
     "artp_cost_blob_bytes", "artp_cost_load_weights",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
@@ -41,6 +43,13 @@ class Params(C.Structure):
 
 
 _lib = None
+
+
+class PreprocessParams(C.Structure):  # artp_preprocess_params (include/artp_c.h)
+    _fields_ = [("traversability_thres", C.c_float), ("foothold_margin", C.c_double),
+                ("foothold_margin_max_hole_size", C.c_double), ("foothold_margin_max_drop", C.c_double),
+                ("foothold_margin_max_drop_search_radius", C.c_double), ("foothold_margin_min_step", C.c_double),
+                ("foothold_size", C.c_double)]
 
 
 class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
@@ -111,6 +120,15 @@ def load():
     L.artp_roadmap_solve.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(dbl), C.POINTER(i32)]
     L.artp_roadmap_destroy.argtypes = [vp]
     L.artp_roadmap_destroy.restype = None
+    for name in ("artp_preprocess_params_defaults", "artp_preprocess_params_yaml"):
+        getattr(L, name).argtypes = [C.POINTER(PreprocessParams)]
+        getattr(L, name).restype = None
+    L.artp_preprocess_map.argtypes = [vp, vp, vp, i32, i32, dbl, dbl, dbl, dbl, C.POINTER(PreprocessParams),
+                                      C.POINTER(vp)]
+    L.artp_preprocessed_get_layer.argtypes = [vp, vp, C.c_char_p, vp]
+    L.artp_preprocessed_install.argtypes = [vp, vp]
+    L.artp_preprocessed_destroy.argtypes = [vp]
+    L.artp_preprocessed_destroy.restype = None
     L.artp_cost_blob_bytes.argtypes = []
     L.artp_cost_blob_bytes.restype = sz
     L.artp_cost_load_weights.argtypes = [vp, vp, sz]
@@ -121,7 +139,8 @@ def load():
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("artp_destroy", "artp_cost_blob_bytes", "artp_roadmap_destroy",
-                                                  "artp_roadmap_params_defaults"):
+                                                  "artp_roadmap_params_defaults", "artp_preprocess_params_defaults",
+                                                  "artp_preprocess_params_yaml", "artp_preprocessed_destroy"):
             fn.restype = C.c_int
     _lib = L
     return L

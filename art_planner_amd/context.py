@@ -203,6 +203,22 @@ class Context:
                   "artp_debug_partner_table")
         return out.reshape(shape[1], shape[0]), r.value
 
+    # ---- device-side map preprocessing (N2) -----------------------------------------------------
+    def preprocess_map(self, elevation, len_x, len_y, pos_x=0.0, pos_y=0.0, traversability=None, kind="yaml",
+                       **overrides):
+        """processors::Basic + estimateNormals + the CDF on the device; returns a PreprocessedMap."""
+        p = _capi.PreprocessParams()
+        (self.L.artp_preprocess_params_yaml if kind == "yaml" else self.L.artp_preprocess_params_defaults)(C.byref(p))
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        e = _f32F(elevation)
+        t = _f32F(traversability) if traversability is not None else None
+        h = C.c_void_p()
+        self._chk(self.L.artp_preprocess_map(self.h, e.ctypes.data, t.ctypes.data if t is not None else None,
+                                             e.shape[0], e.shape[1], len_x, len_y, pos_x, pos_y, C.byref(p),
+                                             C.byref(h)), "artp_preprocess_map")
+        return PreprocessedMap(self, h, e.shape)
+
     # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
     def cost_load_weights(self, blob: bytes):
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
@@ -240,3 +256,25 @@ class Context:
     def sample_states_at_dev(self, seed, base_index, idx_t, count_t, cap, out_t):
         self._chk(self.L.artp_sample_states_at_dev(self.h, seed, base_index, idx_t.data_ptr(), count_t.data_ptr(),
                                                    cap, out_t.data_ptr()), "artp_sample_states_at_dev")
+
+
+class PreprocessedMap:
+    """Device-resident result of Context.preprocess_map (artp_preprocessed)."""
+
+    def __init__(self, ctx, handle, shape):
+        self.ctx, self.h, self.shape = ctx, handle, shape
+
+    def layer(self, name):
+        n = self.shape[0] if name == "cum_prob_rowwise" else self.shape[0] * self.shape[1]
+        out = np.empty(n, np.float32)
+        self.ctx._chk(self.ctx.L.artp_preprocessed_get_layer(self.ctx.h, self.h, name.encode(), out.ctypes.data),
+                      "artp_preprocessed_get_layer")
+        return out if name == "cum_prob_rowwise" else out.reshape(self.shape[1], self.shape[0]).T
+
+    def install(self):
+        self.ctx._chk(self.ctx.L.artp_preprocessed_install(self.ctx.h, self.h), "artp_preprocessed_install")
+
+    def close(self):
+        if self.h:
+            self.ctx.L.artp_preprocessed_destroy(self.h)
+            self.h = None

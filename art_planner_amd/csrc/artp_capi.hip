@@ -1247,6 +1247,7 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 }  // extern "C"
 
 #include "roadmap.h"
+#include "preprocess.h"
 
 #ifdef ARTP_STAGE_TIMING
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {

@@ -1,0 +1,402 @@
+// preprocess.h -- "next" row N2: the per-map preprocessing chain on the device.
+// The reference runs it on the CPU with OpenCV on every map update (Map::setMap -> processors::Basic,
+// art_planner/src/map/processors/basic.cpp:42-143; estimateNormals, art_planner/src/utils.cpp:213-326;
+// computeCumulativeProbabilityDistribution, processors/probability_distribution.cpp:20-46); its outputs are
+// exactly the hot path's inputs: elevation_masked, the normals + plane_fit_std_dev, the sampling CDFs.
+// All layers are grid_map matrices: float32, column-major rows x cols, element (i, j) at i + j * rows.
+//
+// Stencils, one lane per cell: estimateNormals (cross products along the axes and the diagonals, in the
+// reference's accumulation order), grey erosion / dilation with a disk footprint, the select chain of
+// setMaskedElevationAndTraversability / setTraversabilityFilter, and the row / column scans of the CDF.
+// OpenCV is not available here: the disk is the set x^2 + y^2 <= (size/2)^2 on a size x size window with
+// replicated borders (cv::circle's rasterisation and cv::erode's border value may differ in single border
+// pixels) and inpainting is left to the caller -- parity for this row is unpinned; the tests compare with
+// the numpy restatement that also generates the benchmark maps (art_planner_amd/synthetic.py).
+#pragma once
+
+namespace artp {
+
+struct PreGeom {
+  int rows, cols;
+  float res;
+  double pos_x, pos_y, len_x, len_y;
+};
+
+// grid_map getPosition as stored in the reference's float position matrix (utils.cpp:238-247)
+__device__ __forceinline__ float pre_cell_x(const PreGeom& g, int i) {
+  return (float)((g.pos_x + (0.5 * g.len_x - 0.5 * (double)g.res)) - (double)g.res * (double)i);
+}
+__device__ __forceinline__ float pre_cell_y(const PreGeom& g, int j) {
+  return (float)((g.pos_y + (0.5 * g.len_y - 0.5 * (double)g.res)) - (double)g.res * (double)j);
+}
+
+struct NormalAcc {
+  float sx, sy, sz, max_dz;
+  int n;
+};
+
+// vec_sum += (a - c).cross(b - c).normalized(); max_z_diff; ++n_vec  (utils.cpp:262-266)
+__device__ __forceinline__ void normal_accumulate(NormalAcc& acc, float cx, float cy, float cz, float ax, float ay,
+                                                  float az, float bx, float by, float bz) {
+  const float ux = ax - cx, uy = ay - cy, uz = az - cz;
+  const float vx = bx - cx, vy = by - cy, vz = bz - cz;
+  float tx = uy * vz - uz * vy, ty = uz * vx - ux * vz, tz = ux * vy - uy * vx;
+  const float nrm = sqrtf(tx * tx + ty * ty + tz * tz);
+  if (nrm > 0.f) {
+    tx /= nrm;
+    ty /= nrm;
+    tz /= nrm;
+  }
+  acc.sx += tx;
+  acc.sy += ty;
+  acc.sz += tz;
+  acc.max_dz = fmaxf(acc.max_dz, fmaxf(fabsf(uz), fabsf(vz)));
+  ++acc.n;
+}
+
+__global__ void __launch_bounds__(256)
+estimate_normals_kernel(const float* __restrict__ elev, PreGeom g, int n_r, int n_d, float* __restrict__ nx,
+                        float* __restrict__ ny, float* __restrict__ nz, float* __restrict__ stdv) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.rows * g.cols) return;
+  const int i = t % g.rows, j = t / g.rows;
+  auto Z = [&](int a, int b) { return elev[a + (size_t)b * g.rows]; };
+  const float cx = pre_cell_x(g, i), cy = pre_cell_y(g, j), cz = Z(i, j);
+  NormalAcc acc{0.f, 0.f, 0.f, 0.f, 0};
+  for (int o = 1; o < n_r; ++o) {  // +x / +y neighbours, both must exist
+    if (i + o >= g.rows || j + o >= g.cols) continue;
+    normal_accumulate(acc, cx, cy, cz, pre_cell_x(g, i + o), cy, Z(i + o, j), cx, pre_cell_y(g, j + o), Z(i, j + o));
+  }
+  for (int o = 1; o < n_r; ++o) {  // -x / -y
+    if (i - o < 0 || j - o < 0) continue;
+    normal_accumulate(acc, cx, cy, cz, pre_cell_x(g, i - o), cy, Z(i - o, j), cx, pre_cell_y(g, j - o), Z(i, j - o));
+  }
+  for (int o = 1; o < n_d; ++o) {  // diagonals (+,+) and (-,+)
+    if (i + o >= g.rows || j + o >= g.cols || i - o < 0) continue;
+    normal_accumulate(acc, cx, cy, cz, pre_cell_x(g, i + o), pre_cell_y(g, j + o), Z(i + o, j + o),
+                      pre_cell_x(g, i - o), pre_cell_y(g, j + o), Z(i - o, j + o));
+  }
+  for (int o = 1; o < n_d; ++o) {  // diagonals (-,-) and (+,-)
+    if (i - o < 0 || j - o < 0 || i + o >= g.rows) continue;
+    normal_accumulate(acc, cx, cy, cz, pre_cell_x(g, i - o), pre_cell_y(g, j - o), Z(i - o, j - o),
+                      pre_cell_x(g, i + o), pre_cell_y(g, j - o), Z(i + o, j - o));
+  }
+  float sx = acc.sx, sy = acc.sy, sz = acc.sz;
+  if (acc.n > 0) {
+    sx /= (float)acc.n;
+    sy /= (float)acc.n;
+    sz /= (float)acc.n;
+  }
+  const float nrm = sqrtf(sx * sx + sy * sy + sz * sz);
+  if (nrm > 0.f) {
+    sx /= nrm;
+    sy /= nrm;
+    sz /= nrm;
+  }
+  nx[t] = sx;
+  ny[t] = sy;
+  nz[t] = sz;
+  stdv[t] = acc.max_dz;
+}
+
+// grey erosion (min) / dilation (max) with the disk footprint of `size`, replicated borders
+template <bool DILATE>
+__global__ void __launch_bounds__(256)
+morph_kernel(const float* __restrict__ in, int rows, int cols, int size, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cols) return;
+  const int i = t % rows, j = t / rows;
+  if (size <= 0) {
+    out[t] = in[t];
+    return;
+  }
+  const int r = size / 2;
+  float v = DILATE ? -INFINITY : INFINITY;
+  for (int dj = -r; dj < size - r; ++dj) {
+    const int jj = min(max(j + dj, 0), cols - 1);
+    for (int di = -r; di < size - r; ++di) {
+      if (di * di + dj * dj > r * r) continue;
+      const int ii = min(max(i + di, 0), rows - 1);
+      const float x = in[ii + (size_t)jj * rows];
+      v = DILATE ? fmaxf(v, x) : fminf(v, x);
+    }
+  }
+  out[t] = v;
+}
+
+// the select chain of setMaskedElevationAndTraversability (basic.cpp:57-106), one elementwise stage each
+__global__ void __launch_bounds__(256)
+pre_threshold_kernel(const float* __restrict__ trav, int n, float thres, float* __restrict__ trav_filter) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) trav_filter[t] = (trav ? trav[t] : 1.0f) > thres ? 1.0f : 0.0f;
+}
+// safety = hole_mask ? trav_filter : closed;  then  wall_mask ? 1 : safety      (basic.cpp:75-88)
+__global__ void __launch_bounds__(256)
+pre_masks_kernel(const float* __restrict__ elev, const float* __restrict__ elev_eroded,
+                 const float* __restrict__ elev_dilated, const float* __restrict__ trav_filter,
+                 const float* __restrict__ closed, int n, float max_drop, float min_step, float* __restrict__ safety,
+                 float* __restrict__ wall_mask) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const bool hole = (elev[t] - elev_eroded[t]) > max_drop;
+  const bool wall = (elev_dilated[t] - elev[t]) > min_step;
+  float s = hole ? trav_filter[t] : closed[t];
+  s = wall ? 1.0f : s;
+  safety[t] = s;
+  wall_mask[t] = wall ? 1.0f : 0.0f;
+}
+// (trav_filter < 0.5 || wall) ? trav_filter : eroded      (basic.cpp:91-93)
+__global__ void __launch_bounds__(256)
+pre_keep_unsafe_kernel(const float* __restrict__ trav_filter, const float* __restrict__ wall_mask,
+                       const float* __restrict__ eroded, int n, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = (trav_filter[t] < 0.5f || (wall_mask && wall_mask[t] > 0.5f)) ? trav_filter[t] : eroded[t];
+}
+// elevation_masked = safety > 0.5 ? elevation : -inf      (basic.cpp:101-105)
+__global__ void __launch_bounds__(256)
+pre_masked_elevation_kernel(const float* __restrict__ elev, const float* __restrict__ safety, int n,
+                            float* __restrict__ masked) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) masked[t] = safety[t] > 0.5f ? elev[t] : -INFINITY;
+}
+
+// CDF (probability_distribution.cpp:20-46): one lane per row walks its columns in order
+__global__ void __launch_bounds__(64)
+cdf_rows_kernel(const float* __restrict__ prob, int rows, int cols, float* __restrict__ cum_prob,
+                float* __restrict__ row_sum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  float s = 0.f;
+  for (int j = 0; j < cols; ++j) s += prob[i + (size_t)j * rows];
+  row_sum[i] = s;
+  float c = 0.f;
+  for (int j = 0; j < cols; ++j) {
+    c += prob[i + (size_t)j * rows] / s;
+    cum_prob[i + (size_t)j * rows] = c;
+  }
+}
+__global__ void cdf_rowwise_kernel(const float* __restrict__ row_sum, int rows, float* __restrict__ cum_rowwise,
+                                   float* __restrict__ any_prob) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float total = 0.f;
+  for (int i = 0; i < rows; ++i) total += row_sum[i];
+  float c = 0.f;
+  for (int i = 0; i < rows; ++i) {
+    c += row_sum[i] / total;
+    cum_rowwise[i] = c;
+  }
+  *any_prob = total;
+}
+__global__ void __launch_bounds__(256)
+pre_fill_kernel(float* __restrict__ out, int n, float v) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = v;
+}
+
+}  // namespace artp
+
+// -------------------------------------------------------------------------------------------------------
+namespace {
+
+enum PreLayer {
+  PRE_ELEV = 0, PRE_TRAV, PRE_NX, PRE_NY, PRE_NZ, PRE_STD, PRE_TRAV_FILTER, PRE_SAFETY, PRE_MASKED, PRE_SAMPLE_PROB,
+  PRE_CUM_PROB, PRE_T0, PRE_T1, PRE_T2, PRE_T3, PRE_COUNT
+};
+
+const char* const kPreLayerNames[] = {"elevation", "traversability", "normal_x", "normal_y", "normal_z",
+                                      "plane_fit_std_dev", "traversability_thresholded_no_safety",
+                                      "traversability_thresholded", "elevation_masked", "sample_probability",
+                                      "cum_prob"};
+
+}  // namespace
+
+struct artp_preprocessed {
+  int rows = 0, cols = 0;
+  double len_x = 0, len_y = 0, pos_x = 0, pos_y = 0;
+  float* buf = nullptr;          // PRE_COUNT layers + cum_prob_rowwise (rows) + 1 scalar
+  float* layer(int k) const { return buf + (size_t)k * rows * cols; }
+  float* rowwise() const { return buf + (size_t)PRE_COUNT * rows * cols; }
+};
+
+extern "C" {
+
+void artp_preprocess_params_defaults(artp_preprocess_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->traversability_thres = 0.5f;  // Params::planner.traversability_thres (params.h:24)
+  // Params::planner.safety defaults are all zero (params.h:27-34): no morphology
+}
+
+void artp_preprocess_params_yaml(artp_preprocess_params* p) {  // art_planner_ros/config/params.yaml
+  artp_preprocess_params_defaults(p);
+  if (!p) return;
+  p->traversability_thres = 0.15f;
+  p->foothold_margin = 0.3;
+  p->foothold_margin_max_hole_size = 0.3;
+  p->foothold_margin_max_drop = 0.3;
+  p->foothold_margin_max_drop_search_radius = 0.16;
+  p->foothold_margin_min_step = 0.3;
+  p->foothold_size = 0.1;
+}
+
+void artp_preprocessed_destroy(artp_preprocessed* pp) {
+  if (!pp) return;
+  if (pp->buf) (void)hipFree(pp->buf);
+  delete pp;
+}
+
+int artp_preprocess_map(artp_ctx* c, const float* elevation, const float* traversability, int rows, int cols,
+                        double len_x, double len_y, double pos_x, double pos_y, const artp_preprocess_params* prm,
+                        artp_preprocessed** out) {
+  if (!c || !elevation || !prm || !out || rows < 2 || cols < 2) return ARTP_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unique_lock<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int n = rows * cols;
+  auto pp = new artp_preprocessed();
+  pp->rows = rows;
+  pp->cols = cols;
+  pp->len_x = len_x;
+  pp->len_y = len_y;
+  pp->pos_x = pos_x;
+  pp->pos_y = pos_y;
+  if (hipMalloc(reinterpret_cast<void**>(&pp->buf), ((size_t)PRE_COUNT * n + rows + 4) * sizeof(float)) != hipSuccess) {
+    delete pp;
+    c->last_error = "hipMalloc failed in artp_preprocess_map";
+    return ARTP_ERR_HIP;
+  }
+  hipStream_t st = c->stream;
+  const double res = len_x / rows;
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  auto L = [&](int k) { return pp->layer(k); };
+  bool ok = hipMemcpyAsync(L(PRE_ELEV), elevation, (size_t)n * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (traversability)
+    ok = ok && hipMemcpyAsync(L(PRE_TRAV), traversability, (size_t)n * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  else
+    hipLaunchKernelGGL(artp::pre_fill_kernel, grid, blk, 0, st, L(PRE_TRAV), n, 1.0f);  // checkTraversability
+
+  // estimateNormals(map, (torso.length + torso.width) * 0.25)      basic.cpp:47
+  {
+    const double radius = (c->params.torso_length + c->params.torso_width) * 0.25;
+    artp::PreGeom g{rows, cols, (float)res, pos_x, pos_y, len_x, len_y};
+    hipLaunchKernelGGL(artp::estimate_normals_kernel, grid, blk, 0, st, (const float*)L(PRE_ELEV), g,
+                       (int)(radius / res), (int)(radius * 0.70710678118 / res), L(PRE_NX), L(PRE_NY), L(PRE_NZ),
+                       L(PRE_STD));
+  }
+  // setMaskedElevationAndTraversability                            basic.cpp:57-106
+  auto erode = [&](const float* in, int size, float* o) {
+    hipLaunchKernelGGL(artp::morph_kernel<false>, grid, blk, 0, st, in, rows, cols, size, o);
+  };
+  auto dilate = [&](const float* in, int size, float* o) {
+    hipLaunchKernelGGL(artp::morph_kernel<true>, grid, blk, 0, st, in, rows, cols, size, o);
+  };
+  const int fh = (int)std::ceil(prm->foothold_size / res);
+  const int margin = (int)std::ceil(2 * prm->foothold_margin / res);
+  const int hole = (int)std::floor(prm->foothold_margin_max_hole_size / res);
+  const int search = (int)std::ceil(2 * prm->foothold_margin_max_drop_search_radius / res);
+  hipLaunchKernelGGL(artp::pre_threshold_kernel, grid, blk, 0, st, (const float*)L(PRE_TRAV), n,
+                     prm->traversability_thres, L(PRE_TRAV_FILTER));
+  dilate(L(PRE_TRAV_FILTER), hole, L(PRE_T0));
+  erode(L(PRE_T0), hole, L(PRE_T1));                 // T1 = closed holes
+  erode(L(PRE_ELEV), search, L(PRE_T0));             // T0 = eroded elevation
+  dilate(L(PRE_ELEV), margin, L(PRE_T2));            // T2 = dilated elevation
+  hipLaunchKernelGGL(artp::pre_masks_kernel, grid, blk, 0, st, (const float*)L(PRE_ELEV), (const float*)L(PRE_T0),
+                     (const float*)L(PRE_T2), (const float*)L(PRE_TRAV_FILTER), (const float*)L(PRE_T1), n,
+                     (float)prm->foothold_margin_max_drop, (float)prm->foothold_margin_min_step, L(PRE_SAFETY),
+                     L(PRE_T3));                     // T3 = wall mask
+  erode(L(PRE_SAFETY), margin, L(PRE_T0));
+  hipLaunchKernelGGL(artp::pre_keep_unsafe_kernel, grid, blk, 0, st, (const float*)L(PRE_TRAV_FILTER),
+                     (const float*)L(PRE_T3), (const float*)L(PRE_T0), n, L(PRE_T1));
+  erode(L(PRE_T1), fh, L(PRE_T0));
+  dilate(L(PRE_T0), fh, L(PRE_T1));
+  hipLaunchKernelGGL(artp::pre_keep_unsafe_kernel, grid, blk, 0, st, (const float*)L(PRE_TRAV_FILTER),
+                     (const float*)nullptr, (const float*)L(PRE_T1), n, L(PRE_SAFETY));
+  hipLaunchKernelGGL(artp::pre_masked_elevation_kernel, grid, blk, 0, st, (const float*)L(PRE_ELEV),
+                     (const float*)L(PRE_SAFETY), n, L(PRE_MASKED));
+  // setTraversabilityFilter                                        basic.cpp:110-125
+  {
+    const double total_reach = std::sqrt(c->params.reach_x * c->params.reach_x + c->params.reach_y * c->params.reach_y);
+    const double min_wall = std::min((c->params.torso_length - c->params.reach_x) * 0.5,
+                                     (c->params.torso_width - c->params.reach_y) * 0.5);
+    dilate(L(PRE_SAFETY), (int)(total_reach / res), L(PRE_T0));
+    erode(L(PRE_T0), (int)(total_reach / res), L(PRE_T1));
+    erode(L(PRE_T1), (int)(min_wall / res), L(PRE_SAMPLE_PROB));  // applyBaseSampleDistribution: 1 * filter
+  }
+  // computeCumulativeProbabilityDistribution                       probability_distribution.cpp:20-46
+  float* row_sum = L(PRE_T0);
+  float* total = pp->rowwise() + rows;
+  hipLaunchKernelGGL(artp::cdf_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st,
+                     (const float*)L(PRE_SAMPLE_PROB), rows, cols, L(PRE_CUM_PROB), row_sum);
+  hipLaunchKernelGGL(artp::cdf_rowwise_kernel, dim3(1), dim3(1), 0, st, (const float*)row_sum, rows, pp->rowwise(),
+                     total);
+  ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  if (!ok) {
+    c->last_error = "device preprocessing failed";
+    lock.unlock();
+    artp_preprocessed_destroy(pp);
+    return ARTP_ERR_HIP;
+  }
+  *out = pp;
+  return ARTP_OK;
+}
+
+int artp_preprocessed_get_layer(artp_ctx* c, const artp_preprocessed* pp, const char* name, float* out) {
+  if (!c || !pp || !name || !out) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (std::strcmp(name, "cum_prob_rowwise") == 0) {
+    HIP_TRY(c, hipMemcpy(out, pp->rowwise(), (size_t)pp->rows * 4, hipMemcpyDeviceToHost));
+    return ARTP_OK;
+  }
+  for (int k = 0; k < (int)(sizeof(kPreLayerNames) / sizeof(kPreLayerNames[0])); ++k)
+    if (std::strcmp(name, kPreLayerNames[k]) == 0) {
+      HIP_TRY(c, hipMemcpy(out, pp->layer(k), (size_t)pp->rows * pp->cols * 4, hipMemcpyDeviceToHost));
+      return ARTP_OK;
+    }
+  c->last_error = std::string("unknown layer ") + name;
+  return ARTP_ERR_INVALID_ARG;
+}
+
+// Planner::setMap (planner.cpp:135-163): make the preprocessed layers the context's current map -- both
+// height fields (with their range / partner tables), the sampler layers and the z bounds.
+int artp_preprocessed_install(artp_ctx* c, const artp_preprocessed* pp) {
+  if (!c || !pp) return ARTP_ERR_INVALID_ARG;
+  const size_t n = (size_t)pp->rows * pp->cols;
+  std::vector<float> h[7];
+  std::vector<float> rowwise(pp->rows);
+  float total = 0.f;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int ks[7] = {PRE_ELEV, PRE_MASKED, PRE_CUM_PROB, PRE_NX, PRE_NY, PRE_NZ, PRE_STD};
+    for (int k = 0; k < 7; ++k) {
+      h[k].resize(n);
+      HIP_TRY(c, hipMemcpyAsync(h[k].data(), pp->layer(ks[k]), n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(rowwise.data(), pp->rowwise(), (size_t)pp->rows * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&total, pp->rowwise() + pp->rows, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (!(total > 0.f)) {
+    c->last_error = "sample_probability is zero everywhere: nothing can be sampled on this map";
+    return ARTP_ERR_NO_MAP;
+  }
+  int rc = artp_upload_layer(c, ARTP_SLOT_BODY, h[0].data(), pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+  if (rc) return rc;
+  rc = artp_upload_layer(c, ARTP_SLOT_FEET, h[1].data(), pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+  if (rc) return rc;
+  rc = artp_upload_sampler_layers(c, h[2].data(), rowwise.data(), h[0].data(), h[3].data(), h[4].data(), h[5].data(),
+                                  h[6].data(), pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+  if (rc) return rc;
+  // bounds.low[2] / high[2] = min / max finite elevation -/+ reach.z / 2 (planner.cpp:146-156)
+  float lo = INFINITY, hi = -INFINITY;
+  for (float v : h[0])
+    if (std::isfinite(v)) {
+      lo = std::min(lo, v);
+      hi = std::max(hi, v);
+    }
+  if (!(lo <= hi)) lo = hi = 0.f;
+  return artp_set_z_bounds(c, (double)lo - c->params.reach_z / 2, (double)hi + c->params.reach_z / 2);
+}
+
+}  // extern "C"

@@ -108,11 +108,13 @@ def _disk(size: int) -> np.ndarray:
 
 
 def _dilate(m, size):
-    return ndimage.grey_dilation(m, footprint=_disk(size), mode="nearest") if size > 0 else m
+    # cv::dilate: max over the kernel placed with its anchor (size // 2) on the pixel, no reflection of the
+    # kernel (scipy's grey_dilation would reflect it, which differs for even sizes)
+    return ndimage.maximum_filter(m, footprint=_disk(size), mode="nearest") if size > 0 else m
 
 
 def _erode(m, size):
-    return ndimage.grey_erosion(m, footprint=_disk(size), mode="nearest") if size > 0 else m
+    return ndimage.minimum_filter(m, footprint=_disk(size), mode="nearest") if size > 0 else m
 
 
 def estimate_normals(gm: GridMap, elevation: np.ndarray, radius_m: float):

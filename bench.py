@@ -375,6 +375,28 @@ def main():
     except Exception as ex:  # pragma: no cover
         roadmap = {"error": repr(ex)}
 
+    # ---- N2 extras: the per-map preprocessing chain on the device ------------------------------------------
+    preprocess = None
+    try:
+        if args.skip_extras:
+            raise RuntimeError("skipped (--skip-extras)")
+        pre_ms, inst_ms = [], []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pp = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
+                                    traversability=gm["traversability"])
+            t1 = time.perf_counter()
+            pp.install()
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            pp.close()
+            pre_ms.append((t1 - t0) * 1e3)
+            inst_ms.append((t2 - t1) * 1e3)
+        preprocess = {"preprocess_ms_incl_h2d": float(np.median(pre_ms)),
+                      "install_ms_incl_tables": float(np.median(inst_ms)), "map": f"{gm.rows}x{gm.cols}"}
+    except Exception as ex:  # pragma: no cover
+        preprocess = {"error": repr(ex)}
+
     cpu = None
     if N == 1 and not args.no_cpu_baseline:
         cpu, cpu_labels, _ = cpu_baseline(gm, states)
@@ -417,7 +439,7 @@ def main():
                                (", accepted-state indices all-gathered over RCCL + states re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess,
         "device": ctx.arch, "gather_error": gather_error,
     }
     print(json.dumps(out))

@@ -210,6 +210,39 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
                        int* n_replans);
 void artp_roadmap_destroy(artp_roadmap* rm);
 
+/* ---- "next" row N2: the per-map preprocessing chain on the device -----------------------
+ * Replaces processors::Basic (art_planner/src/map/processors/basic.cpp:42-143: traversability threshold,
+ * safety morphology, elevation_masked, sample filter), estimateNormals (art_planner/src/utils.cpp:213-326)
+ * and computeCumulativeProbabilityDistribution (processors/probability_distribution.cpp:20-46), which the
+ * reference runs on the CPU (OpenCV) on every map update.  Layers are grid_map matrices (float32,
+ * column-major rows x cols).  Inpainting (inpaintMatrix, utils.cpp:13-64) stays with the caller: the
+ * input layers must be hole-free. */
+typedef struct artp_preprocessed artp_preprocessed;
+typedef struct artp_preprocess_params {
+  float traversability_thres;                    /* Params::planner.traversability_thres (params.h:24) */
+  double foothold_margin;                        /* Params::planner.safety.* (params.h:27-34) */
+  double foothold_margin_max_hole_size;
+  double foothold_margin_max_drop;
+  double foothold_margin_max_drop_search_radius;
+  double foothold_margin_min_step;
+  double foothold_size;
+} artp_preprocess_params;
+void artp_preprocess_params_defaults(artp_preprocess_params* p); /* params.h defaults */
+void artp_preprocess_params_yaml(artp_preprocess_params* p);     /* art_planner_ros/config/params.yaml */
+/* elevation: required; traversability: NULL = all 1 (Basic::checkTraversability, basic.cpp:13-22).
+ * The robot numbers (normal estimation radius, reach) come from the context's artp_params. */
+int artp_preprocess_map(artp_ctx* ctx, const float* elevation, const float* traversability, int rows, int cols,
+                        double len_x, double len_y, double pos_x, double pos_y,
+                        const artp_preprocess_params* params, artp_preprocessed** out);
+/* name: elevation, traversability, normal_x/_y/_z, plane_fit_std_dev, traversability_thresholded_no_safety,
+ * traversability_thresholded, elevation_masked, sample_probability, cum_prob (rows x cols floats each) or
+ * cum_prob_rowwise (rows floats). */
+int artp_preprocessed_get_layer(artp_ctx* ctx, const artp_preprocessed* pp, const char* name, float* out);
+/* Planner::setMap (planner.cpp:135-163): make the result the context's map -- both height fields with
+ * their tables, the sampler layers and the z bounds. */
+int artp_preprocessed_install(artp_ctx* ctx, const artp_preprocessed* pp);
+void artp_preprocessed_destroy(artp_preprocessed* pp);
+
 /* ---- learned motion cost: MotionCostObjective::MotionCostFunc
  *      (art_planner/include/art_planner/objectives/motion_cost_objective.h:22-23; the reference
  *      implements it as a ROS service to the Python/CUDA node, art_planner_ros/src/planner_ros.cpp:
