@@ -422,6 +422,85 @@ bool roadmap_astar(artp_roadmap* rm, std::vector<uint32_t>* path, double* cost) 
     }                                                                                  \
   } while (0)
 
+// Verdict (0.5 m interpolation rule), interior-state count and chain cost of ne edges whose endpoint states
+// are on the device; results to the host arrays.
+int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const double* d_s1, const double* d_s2,
+                           size_t ne, uint8_t* evalid, uint32_t* einterp, double* ecost) {
+  if (ne == 0) return ARTP_OK;
+  hipStream_t st = c->stream;
+  double* d_cost = nullptr;
+  uint8_t* d_evalid = nullptr;
+  uint32_t *d_einterp = nullptr, *d_rows = nullptr, *d_off = nullptr;
+  float *d_em = nullptr, *d_c3 = nullptr;
+  void* d_cub2 = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_cost, (void*)d_evalid, (void*)d_einterp, (void*)d_rows, (void*)d_off, (void*)d_em,
+                    (void*)d_c3, d_cub2})
+      if (p) (void)hipFree(p);
+  };
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cost), ne * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_evalid), ne));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_einterp), ne * sizeof(uint32_t)));
+  RM_TRY(artp_check_edges_interp_dev(c, d_s1, d_s2, ne, d_evalid, d_einterp));
+  if (prm->objective <= 1) {
+    artp::PathLengthParams pl{prm->objective == 1, prm->max_lon_vel, prm->max_lat_vel, prm->max_ang_vel};
+    hipLaunchKernelGGL(artp::edge_chain_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, pl, d_s1,
+                       d_s2, (const uint32_t*)d_einterp, ne, d_cost);
+  } else {
+    // learned cost: one EdgeMatrix row per sub-edge, one batched query, per-chain reduction
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_rows), (ne + 1) * 4));
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_off), (ne + 1) * 4));
+    size_t need = 0;
+    uint32_t total = 0;
+    hipLaunchKernelGGL(artp::chain_rows_kernel, dim3((unsigned)((ne + 256) / 256)), dim3(256), 0, st,
+                       (const uint32_t*)d_einterp, ne, d_rows);
+    RM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_rows, d_off, (int)(ne + 1), st));
+    RM_HIP(hipMalloc(&d_cub2, need + 256));
+    size_t cap2 = need + 256;
+    RM_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub2, cap2, d_rows, d_off, (int)(ne + 1), st));
+    RM_HIP(hipMemcpyAsync(&total, d_off + ne, 4, hipMemcpyDeviceToHost, st));
+    RM_HIP(hipStreamSynchronize(st));
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_em), (size_t)total * 6 * 4));
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_c3), (size_t)total * 3 * 4));
+    hipLaunchKernelGGL(artp::chain_edge_matrix_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, d_s1, d_s2,
+                       (const uint32_t*)d_einterp, (const uint32_t*)d_off, ne, d_em);
+    RM_TRY(artp_cost_query_dev(c, d_em, total, d_c3));
+    hipLaunchKernelGGL(artp::chain_motion_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
+                       (const float*)d_c3, (const uint32_t*)d_off, (const uint32_t*)d_einterp, ne, prm->w_energy,
+                       prm->w_time, prm->w_risk, prm->risk_threshold, d_cost);
+  }
+  RM_HIP(hipGetLastError());
+  RM_HIP(hipStreamSynchronize(st));
+  RM_HIP(hipMemcpy(evalid, d_evalid, ne, hipMemcpyDeviceToHost));
+  RM_HIP(hipMemcpy(einterp, d_einterp, ne * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  RM_HIP(hipMemcpy(ecost, d_cost, ne * sizeof(double), hipMemcpyDeviceToHost));
+  RM_TRY(check_error_flag(c));
+  cleanup();
+  return ARTP_OK;
+}
+
+// same for edges (eu[e], ev[e]) of host vertices: gathers the endpoint states on the host first
+int roadmap_eval_edges_host(artp_ctx* c, const artp_roadmap_params* prm, const std::vector<double>& verts,
+                            const uint32_t* eu, const uint32_t* ev, size_t ne, uint8_t* evalid, uint32_t* einterp,
+                            double* ecost) {
+  if (ne == 0) return ARTP_OK;
+  std::vector<double> s(2 * ne * 7);
+  for (size_t e = 0; e < ne; ++e) {
+    std::memcpy(&s[e * 7], &verts[(size_t)eu[e] * 7], 7 * sizeof(double));
+    std::memcpy(&s[(ne + e) * 7], &verts[(size_t)ev[e] * 7], 7 * sizeof(double));
+  }
+  double* d_s = nullptr;
+  auto cleanup = [&]() {
+    if (d_s) (void)hipFree(d_s);
+  };
+  RM_HIP(hipSetDevice(c->device));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_s), s.size() * sizeof(double)));
+  RM_HIP(hipMemcpy(d_s, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice));
+  RM_TRY(roadmap_eval_edges_dev(c, prm, d_s, d_s + ne * 7, ne, evalid, einterp, ecost));
+  cleanup();
+  return ARTP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -461,14 +540,12 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   uint32_t* d_knn = nullptr;
   double* d_knn_dist = nullptr;
   unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr, *d_keys_unique = nullptr;
-  double *d_s1 = nullptr, *d_s2 = nullptr, *d_cost = nullptr;
-  uint8_t* d_evalid = nullptr;
-  uint32_t* d_einterp = nullptr;
+  double *d_s1 = nullptr, *d_s2 = nullptr;
   void* d_cub = nullptr;
   auto cleanup = [&]() {
     for (void* p : {(void*)d_verts, (void*)d_batch, (void*)d_valid, (void*)d_compact, (void*)d_cnt, (void*)d_knn,
                     (void*)d_knn_dist, (void*)d_keys, (void*)d_keys_sorted, (void*)d_keys_unique, (void*)d_s1,
-                    (void*)d_s2, (void*)d_cost, (void*)d_evalid, (void*)d_einterp, d_cub})
+                    (void*)d_s2, d_cub})
       if (p) (void)hipFree(p);
   };
   RM_HIP(hipSetDevice(c->device));
@@ -648,84 +725,137 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   rm->eremoved.assign(ne, 0);
   if (ne) {
     if (hipMalloc(reinterpret_cast<void**>(&d_s1), ne * 7 * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_s2), ne * 7 * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_cost), ne * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_evalid), ne) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_einterp), ne * sizeof(uint32_t)) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&d_s2), ne * 7 * sizeof(double)) != hipSuccess)
       return fail(ARTP_ERR_HIP);
     hipLaunchKernelGGL(artp::gather_edge_states_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
                        (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2);
-    int rc = artp_check_edges_interp_dev(c, d_s1, d_s2, ne, d_evalid, d_einterp);
+    const int rc = roadmap_eval_edges_dev(c, prm, d_s1, d_s2, ne, rm->evalid.data(), rm->einterp.data(),
+                                          rm->ecost.data());
     if (rc != ARTP_OK) return fail(rc);
-    if (prm->objective <= 1) {
-      artp::PathLengthParams pl{prm->objective == 1, prm->max_lon_vel, prm->max_lat_vel, prm->max_ang_vel};
-      hipLaunchKernelGGL(artp::edge_chain_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, pl,
-                         (const double*)d_s1, (const double*)d_s2, (const uint32_t*)d_einterp, ne, d_cost);
-    } else {
-      // learned cost: one EdgeMatrix row per sub-edge, one batched query, per-chain reduction
-      uint32_t *d_rows = nullptr, *d_off = nullptr;
-      float *d_em = nullptr, *d_c3 = nullptr;
-      void* d_cub2 = nullptr;
-      auto cleanup2 = [&]() {
-        for (void* p : {(void*)d_rows, (void*)d_off, (void*)d_em, (void*)d_c3, d_cub2})
-          if (p) (void)hipFree(p);
-      };
-      bool okk = hipMalloc(reinterpret_cast<void**>(&d_rows), (ne + 1) * 4) == hipSuccess &&
-                 hipMalloc(reinterpret_cast<void**>(&d_off), (ne + 1) * 4) == hipSuccess;
-      size_t need = 0;
-      uint32_t total = 0;
-      if (okk) {
-        hipLaunchKernelGGL(artp::chain_rows_kernel, dim3((unsigned)((ne + 256) / 256)), dim3(256), 0, st,
-                           (const uint32_t*)d_einterp, ne, d_rows);
-        okk = hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_rows, d_off, (int)(ne + 1), st) == hipSuccess &&
-              hipMalloc(&d_cub2, need + 256) == hipSuccess;
-      }
-      if (okk) {
-        size_t cap2 = need + 256;
-        okk = hipcub::DeviceScan::ExclusiveSum(d_cub2, cap2, d_rows, d_off, (int)(ne + 1), st) == hipSuccess &&
-              hipMemcpyAsync(&total, d_off + ne, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
-              hipStreamSynchronize(st) == hipSuccess;
-      }
-      if (okk)
-        okk = hipMalloc(reinterpret_cast<void**>(&d_em), (size_t)total * 6 * 4) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&d_c3), (size_t)total * 3 * 4) == hipSuccess;
-      if (!okk) {
-        cleanup2();
-        return fail(ARTP_ERR_HIP);
-      }
-      hipLaunchKernelGGL(artp::chain_edge_matrix_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
-                         (const double*)d_s1, (const double*)d_s2, (const uint32_t*)d_einterp, (const uint32_t*)d_off,
-                         ne, d_em);
-      rc = artp_cost_query_dev(c, d_em, total, d_c3);
-      if (rc != ARTP_OK) {
-        cleanup2();
-        return fail(rc);
-      }
-      hipLaunchKernelGGL(artp::chain_motion_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
-                         (const float*)d_c3, (const uint32_t*)d_off, (const uint32_t*)d_einterp, ne, prm->w_energy,
-                         prm->w_time, prm->w_risk, prm->risk_threshold, d_cost);
-      if (hipStreamSynchronize(st) != hipSuccess) {
-        cleanup2();
-        return fail(ARTP_ERR_HIP);
-      }
-      cleanup2();
-    }
     std::vector<unsigned long long> keys(ne);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
-        hipMemcpy(keys.data(), d_keys_unique, ne * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(rm->evalid.data(), d_evalid, ne, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(rm->einterp.data(), d_einterp, ne * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(rm->ecost.data(), d_cost, ne * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-      return fail(ARTP_ERR_HIP);
+    if (hipMemcpy(keys.data(), d_keys_unique, ne * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(ARTP_ERR_HIP);
     for (size_t e = 0; e < ne; ++e) {
       rm->eu[e] = (uint32_t)(keys[e] >> 32);
       rm->ev[e] = (uint32_t)(keys[e] & 0xffffffffu);
     }
-    rc = check_error_flag(c);
-    if (rc != ARTP_OK) return fail(rc);
   }
   cleanup();
   *out = rm;
+  return ARTP_OK;
+}
+
+// LazyPRMStarMinUpdate keeps its roadmap across map updates and re-checks what changed
+// (lazy_prm_star_min_update.cpp:18-217).  Batched: after the map changed, re-validate EVERY vertex and
+// re-evaluate EVERY edge against the current layers (10^4 vertices + 10^5 edges are one small batch);
+// edges with an invalid endpoint go, earlier lazy removals are forgotten.
+int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
+  if (!rm) return ARTP_ERR_INVALID_ARG;
+  artp_ctx* c = rm->ctx;
+  const size_t nv = rm->nv(), ne = rm->eu.size();
+  std::vector<uint8_t> vok(nv, 0);
+  int rc = artp_validate_states(c, rm->verts.data(), nv, vok.data(), nullptr);
+  if (rc != ARTP_OK) return rc;
+  uint64_t before = 0, after = 0, vbad = 0;
+  for (size_t e = 0; e < ne; ++e) before += rm->evalid[e] ? 1 : 0;
+  rc = roadmap_eval_edges_host(c, &rm->params, rm->verts, rm->eu.data(), rm->ev.data(), ne, rm->evalid.data(),
+                               rm->einterp.data(), rm->ecost.data());
+  if (rc != ARTP_OK) return rc;
+  for (size_t v = 0; v < nv; ++v) vbad += vok[v] ? 0 : 1;
+  for (size_t e = 0; e < ne; ++e) {
+    if (!vok[rm->eu[e]] || !vok[rm->ev[e]]) rm->evalid[e] = 0;
+    after += rm->evalid[e] ? 1 : 0;
+  }
+  std::fill(rm->eremoved.begin(), rm->eremoved.end(), 0);
+  rm->csr_dirty = true;
+  if (out) {
+    out[0] = vbad;
+    out[1] = before;
+    out[2] = after;
+    out[3] = (uint64_t)((vok[0] ? 1 : 0) | (vok[1] ? 2 : 0));  // bit 0: start still valid, bit 1: goal
+  }
+  return ARTP_OK;
+}
+
+// New start / goal on the kept roadmap (every OMPL query adds its start and goal as milestones,
+// prm_motion_cost.cpp:452-476): vertices 0 and 1 are replaced and connected to their k nearest vertices.
+int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double* goal7) {
+  if (!rm || !start7 || !goal7) return ARTP_ERR_INVALID_ARG;
+  artp_ctx* c = rm->ctx;
+  {
+    double sg[14];
+    std::memcpy(sg, start7, 7 * sizeof(double));
+    std::memcpy(sg + 7, goal7, 7 * sizeof(double));
+    uint8_t ok[2] = {0, 0};
+    const int rc = artp_validate_states(c, sg, 2, ok, nullptr);
+    if (rc != ARTP_OK) return rc;
+    if (!ok[0] || !ok[1]) {
+      c->last_error = !ok[0] ? "start state is not valid" : "goal state is not valid";
+      return ARTP_ERR_INVALID_ARG;
+    }
+    std::memcpy(&rm->verts[0], sg, sizeof(sg));
+  }
+  const size_t nv = rm->nv();
+  const int k = rm->k;
+  // edges are sorted by (u, v) with u < v: everything that touches vertex 0 or 1 is a prefix
+  size_t first_keep = 0;
+  while (first_keep < rm->eu.size() && rm->eu[first_keep] < 2) ++first_keep;
+  auto arc = [](const double* a, const double* b) {
+    const double dq = std::fabs(a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]);
+    return dq > 1.0 - 1e-9 ? 0.0 : std::acos(dq);
+  };
+  std::vector<uint32_t> nu, nvx;
+  for (uint32_t q = 0; q < 2; ++q) {
+    const double* a = &rm->verts[(size_t)q * 7];
+    std::vector<std::pair<double, uint32_t>> cand;
+    cand.reserve(nv);
+    for (uint32_t j = 0; j < nv; ++j) {
+      if (j == q) continue;
+      const double* b = &rm->verts[(size_t)j * 7];
+      const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+      cand.push_back({std::sqrt(dx * dx + dy * dy + dz * dz) + arc(a + 3, b + 3), j});
+    }
+    const size_t kk = std::min<size_t>((size_t)k, cand.size());
+    std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
+    std::vector<uint32_t> nb;
+    for (size_t t = 0; t < (size_t)k; ++t) {
+      rm->knn[(size_t)q * k + t] = t < kk ? cand[t].second : 0xffffffffu;
+      rm->knn_dist[(size_t)q * k + t] = t < kk ? cand[t].first : INFINITY;
+      if (t < kk) nb.push_back(cand[t].second);
+    }
+    std::sort(nb.begin(), nb.end());
+    for (uint32_t j : nb) {
+      nu.push_back(std::min(q, j));
+      nvx.push_back(std::max(q, j));
+    }
+  }
+  // (0, 1) belongs to the u = 0 block: re-sort the new prefix by (u, v) and drop duplicates
+  std::vector<std::pair<uint32_t, uint32_t>> pre;
+  for (size_t e = 0; e < nu.size(); ++e) pre.push_back({nu[e], nvx[e]});
+  std::sort(pre.begin(), pre.end());
+  pre.erase(std::unique(pre.begin(), pre.end()), pre.end());
+  const size_t np = pre.size();
+  std::vector<uint32_t> pu(np), pv(np), pinterp(np);
+  std::vector<uint8_t> pvalid(np);
+  std::vector<double> pcost(np);
+  for (size_t e = 0; e < np; ++e) {
+    pu[e] = pre[e].first;
+    pv[e] = pre[e].second;
+  }
+  const int rc = roadmap_eval_edges_host(c, &rm->params, rm->verts, pu.data(), pv.data(), np, pvalid.data(),
+                                         pinterp.data(), pcost.data());
+  if (rc != ARTP_OK) return rc;
+  auto splice = [&](auto& vec, const auto& head) {
+    vec.erase(vec.begin(), vec.begin() + first_keep);
+    vec.insert(vec.begin(), head.begin(), head.end());
+  };
+  splice(rm->eu, pu);
+  splice(rm->ev, pv);
+  splice(rm->evalid, pvalid);
+  splice(rm->einterp, pinterp);
+  splice(rm->ecost, pcost);
+  std::vector<uint8_t> zeros(np, 0);
+  splice(rm->eremoved, zeros);
+  rm->csr_dirty = true;
   return ARTP_OK;
 }
 

@@ -63,6 +63,18 @@ class Roadmap:
                       "artp_roadmap_export")
         return d
 
+    def revalidate(self) -> dict:
+        """Re-check every vertex and edge against the context's current map (after a map update)."""
+        out = (C.c_uint64 * 4)()
+        self.ctx._chk(self.L.artp_roadmap_revalidate(self.h, C.byref(out)), "artp_roadmap_revalidate")
+        return {"invalid_vertices": out[0], "valid_edges_before": out[1], "valid_edges_after": out[2],
+                "start_valid": bool(out[3] & 1), "goal_valid": bool(out[3] & 2)}
+
+    def set_query(self, start, goal):
+        s = np.ascontiguousarray(start, np.float64).reshape(7)
+        g = np.ascontiguousarray(goal, np.float64).reshape(7)
+        self.ctx._chk(self.L.artp_roadmap_set_query(self.h, s.ctypes.data, g.ctypes.data), "artp_roadmap_set_query")
+
     def solve(self, cap_states=4096) -> Tuple[Optional[np.ndarray], float, int]:
         """(path n x 7 or None when start and goal are not connected, cost, lazy edge removals)."""
         path = np.empty((cap_states, 7), np.float64)

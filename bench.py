@@ -365,9 +365,15 @@ def main():
             path, cost, rep = rm.solve()
             t2 = time.perf_counter()
             st = rm.stats()
+            t3 = time.perf_counter()
+            rm.revalidate()          # the kept roadmap after a map update: every vertex and edge re-checked
+            t4 = time.perf_counter()
+            rm.solve()
+            t5 = time.perf_counter()
             rm.close()
             roadmap[f"milestones_{n_m}"] = {
-                "build_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "k": int(st["k"]),
+                "build_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "revalidate_ms": (t4 - t3) * 1e3,
+                "resolve_ms": (t5 - t4) * 1e3, "k": int(st["k"]),
                 "candidate_edges": int(st["candidate_edges"]), "valid_edges": int(st["valid_edges"]),
                 "path_states": None if path is None else int(len(path)), "path_cost_s": cost, "lazy_removals": rep,
                 "straight_line_cost_s": float(np.linalg.norm(g_state[:3] - s_state[:3]) / 0.5)}

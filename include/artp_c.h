@@ -208,6 +208,15 @@ int artp_roadmap_export(const artp_roadmap* rm, double* verts, uint32_t* knn, do
  * path_se3 (cap_states x 7, may be NULL) is too small. */
 int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
                        int* n_replans);
+/* After the map changed (artp_upload_layer / artp_update_layer_rect / artp_preprocessed_install): re-validate
+ * every vertex and re-evaluate every edge against the current layers, forget earlier lazy removals -- the
+ * batched form of LazyPRMStarMinUpdate's roadmap maintenance (lazy_prm_star_min_update.cpp:18-217).
+ * out (may be NULL): [0] vertices now invalid, [1] / [2] edges passing the rule before / after,
+ * [3] bit 0 = start still valid, bit 1 = goal still valid. */
+int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]);
+/* New start / goal on the kept roadmap: vertices 0 and 1 are replaced and connected to their k nearest
+ * vertices (every OMPL query adds its start and goal as milestones, prm_motion_cost.cpp:452-476). */
+int artp_roadmap_set_query(artp_roadmap* rm, const double* start_se3, const double* goal_se3);
 void artp_roadmap_destroy(artp_roadmap* rm);
 
 /* ---- "next" row N2: the per-map preprocessing chain on the device -----------------------

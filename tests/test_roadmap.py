@@ -218,3 +218,86 @@ def test_learned_cost_objective_matches_per_subedge_queries(planning_setup):
     if path is not None:  # every edge of the plan is feasible and the cost adds up
         assert np.isfinite(cost) and cost > 0
     rm.close()
+
+
+def test_revalidate_after_map_update_and_new_query(planning_setup):
+    """The kept roadmap after a map change (LazyPRMStarMinUpdate's use case): a wall is raised across the
+    plan; revalidate must equal a from-scratch evaluation of the same vertices / edges on the new map, the
+    new plan avoids the wall; then a new start / goal are attached to the kept roadmap."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    rob = O.robot("yaml")
+    rm = Roadmap(ctx, start, goal, n_milestones=4000, seed=13)
+    path0, cost0, _ = rm.solve()
+    assert path0 is not None
+    # raise a block of terrain under the middle of the plan (both layers, like a new obstacle)
+    mid = path0[len(path0) // 2]
+    ix = int((gm.pos_x + 0.5 * gm.len_x - mid[0]) / gm.res)
+    iy = int((gm.pos_y + 0.5 * gm.len_y - mid[1]) / gm.res)
+    r0, c0 = max(ix - 6, 0), max(iy - 6, 0)
+    layers = {}
+    for slot, name in ((0, "elevation"), (1, "elevation_masked")):
+        lay = gm[name].copy()
+        patch = lay[r0:r0 + 12, c0:c0 + 12]
+        if slot == 0:
+            patch = np.where(np.isfinite(patch), patch, np.float32(0)) + np.float32(0.6)
+        else:
+            patch = np.full_like(patch, -np.inf)
+        lay[r0:r0 + 12, c0:c0 + 12] = patch
+        layers[name] = lay
+        ctx.update_layer_rect(slot, np.asfortranarray(patch), r0, c0)
+    info = rm.revalidate()
+    assert info["invalid_vertices"] > 0 and info["valid_edges_after"] < info["valid_edges_before"]
+    d = rm.export()
+    V, E = d["verts"], d["edges"].astype(np.int64)
+    import copy
+    gm2 = copy.deepcopy(gm)
+    gm2.layers["elevation"] = np.asfortranarray(layers["elevation"])
+    gm2.layers["elevation_masked"] = np.asfortranarray(layers["elevation_masked"])
+    om2 = O.OracleMap(gm2)
+    vok = om2.states_valid(rob, V) != 0
+    sub = np.random.default_rng(1).choice(len(E), 15000, replace=False)
+    eo, _ = om2.edges_interp_valid(rob, V[E[sub, 0]], V[E[sub, 1]])
+    expect = (eo != 0) & vok[E[sub, 0]] & vok[E[sub, 1]]
+    assert np.array_equal(d["edge_valid"][sub] != 0, expect)
+    assert info["invalid_vertices"] == int((~vok).sum())
+    assert info["start_valid"] and info["goal_valid"]
+    path1, cost1, _ = rm.solve()
+    d1 = rm.export()
+    keep1 = (d1["edge_valid"] != 0) & (d1["edge_removed"] == 0)
+    W1 = csr_matrix((d1["edge_cost"][keep1], (E[keep1, 0], E[keep1, 1])), shape=(len(V),) * 2)
+    ref1 = dijkstra(W1, directed=False, indices=0)[1]
+    assert (path1 is None) == bool(np.isinf(ref1))
+    if path1 is not None:
+        assert abs(cost1 - ref1) < 1e-9 * max(1.0, ref1) and cost1 >= cost0 - 1e-12
+        assert om2.states_valid(rob, path1).all() and om2.check_motions(rob, path1[:-1], path1[1:])[0].all()
+    # new query on the kept roadmap
+    se3 = ctx.sample_states(77, 0, 1 << 14)
+    okv = se3[ctx.validate_states(se3) != 0]
+    s2 = okv[np.argmin(np.hypot(okv[:, 0] - (gm.pos_x + 2.5), okv[:, 1] - (gm.pos_y - 2.5)))]
+    g2 = okv[np.argmin(np.hypot(okv[:, 0] - (gm.pos_x - 2.5), okv[:, 1] - (gm.pos_y + 2.5)))]
+    rm.set_query(s2, g2)
+    d2 = rm.export()
+    V2, E2 = d2["verts"], d2["edges"].astype(np.int64)
+    assert np.array_equal(V2[0], s2) and np.array_equal(V2[1], g2) and np.array_equal(V2[2:], V[2:])
+    assert np.array_equal(E2[E2[:, 0] >= 2], E[E[:, 0] >= 2])           # the rest of the roadmap is untouched
+    D = _se3_distance(V2[:2], V2)
+    D[0, 0] = D[1, 1] = np.inf
+    k = rm.stats()["k"]
+    for q in (0, 1):
+        ref = set(np.argsort(D[q], kind="stable")[:k].tolist())
+        got = set(int(v) if u == q else int(u) for u, v in E2[(E2[:, 0] == q) | (E2[:, 1] == q)])
+        assert ref <= got                                                # its own k nearest (plus the other's pick)
+    head = E2[:, 0] < 2
+    ho, hn = om2.edges_interp_valid(rob, V2[E2[head, 0]], V2[E2[head, 1]])
+    assert np.array_equal(d2["edge_valid"][head], ho) and np.array_equal(d2["edge_interp"][head], hn)
+    path2, cost2, _ = rm.solve()
+    keep = (d2["edge_valid"] != 0)
+    rem = rm.export()["edge_removed"] != 0
+    W = csr_matrix((d2["edge_cost"][keep & ~rem], (E2[keep & ~rem, 0], E2[keep & ~rem, 1])), shape=(len(V2),) * 2)
+    ref_cost = dijkstra(W, directed=False, indices=0)[1]
+    assert (path2 is None and np.isinf(ref_cost)) or abs(cost2 - ref_cost) < 1e-9 * max(1.0, ref_cost)
+    rm.close()
+    ctx.upload_map(gm)  # restore the module fixture's map
