@@ -328,6 +328,9 @@ struct artp_roadmap {
   // CSR over the valid, not removed edges
   std::vector<uint32_t> row, adj, adj_edge;
   bool csr_dirty = true;
+  // endpoint states of all edges, resident in HBM for artp_roadmap_revalidate (s1 rows, then s2 rows)
+  double* d_edge_states = nullptr;
+  bool d_edge_states_stale = true;
   size_t nv() const { return verts.size() / 7; }
 };
 
@@ -523,7 +526,11 @@ void artp_roadmap_params_defaults(artp_roadmap_params* p) {
   p->risk_threshold = 0.1f;        // params.h:55
 }
 
-void artp_roadmap_destroy(artp_roadmap* rm) { delete rm; }
+void artp_roadmap_destroy(artp_roadmap* rm) {
+  if (!rm) return;
+  if (rm->d_edge_states) (void)hipFree(rm->d_edge_states);
+  delete rm;
+}
 
 int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
                        artp_roadmap** out) {
@@ -544,8 +551,7 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   void* d_cub = nullptr;
   auto cleanup = [&]() {
     for (void* p : {(void*)d_verts, (void*)d_batch, (void*)d_valid, (void*)d_compact, (void*)d_cnt, (void*)d_knn,
-                    (void*)d_knn_dist, (void*)d_keys, (void*)d_keys_sorted, (void*)d_keys_unique, (void*)d_s1,
-                    (void*)d_s2, d_cub})
+                    (void*)d_knn_dist, (void*)d_keys, (void*)d_keys_sorted, (void*)d_keys_unique, (void*)d_s1, d_cub})
       if (p) (void)hipFree(p);
   };
   RM_HIP(hipSetDevice(c->device));
@@ -724,9 +730,8 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   rm->ecost.assign(ne, 0.0);
   rm->eremoved.assign(ne, 0);
   if (ne) {
-    if (hipMalloc(reinterpret_cast<void**>(&d_s1), ne * 7 * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_s2), ne * 7 * sizeof(double)) != hipSuccess)
-      return fail(ARTP_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void**>(&d_s1), 2 * ne * 7 * sizeof(double)) != hipSuccess) return fail(ARTP_ERR_HIP);
+    d_s2 = d_s1 + ne * 7;
     hipLaunchKernelGGL(artp::gather_edge_states_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
                        (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2);
     const int rc = roadmap_eval_edges_dev(c, prm, d_s1, d_s2, ne, rm->evalid.data(), rm->einterp.data(),
@@ -738,6 +743,9 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
       rm->eu[e] = (uint32_t)(keys[e] >> 32);
       rm->ev[e] = (uint32_t)(keys[e] & 0xffffffffu);
     }
+    rm->d_edge_states = d_s1;  // stays resident (freed by artp_roadmap_destroy)
+    rm->d_edge_states_stale = false;
+    d_s1 = d_s2 = nullptr;
   }
   cleanup();
   *out = rm;
@@ -757,9 +765,27 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
   if (rc != ARTP_OK) return rc;
   uint64_t before = 0, after = 0, vbad = 0;
   for (size_t e = 0; e < ne; ++e) before += rm->evalid[e] ? 1 : 0;
-  rc = roadmap_eval_edges_host(c, &rm->params, rm->verts, rm->eu.data(), rm->ev.data(), ne, rm->evalid.data(),
-                               rm->einterp.data(), rm->ecost.data());
-  if (rc != ARTP_OK) return rc;
+  if (ne) {
+    if (rm->d_edge_states_stale) {  // the query vertices changed since the states were staged
+      if (rm->d_edge_states) (void)hipFree(rm->d_edge_states);
+      rm->d_edge_states = nullptr;
+      std::vector<double> sbuf(2 * ne * 7);
+      for (size_t e = 0; e < ne; ++e) {
+        std::memcpy(&sbuf[e * 7], &rm->verts[(size_t)rm->eu[e] * 7], 7 * sizeof(double));
+        std::memcpy(&sbuf[(ne + e) * 7], &rm->verts[(size_t)rm->ev[e] * 7], 7 * sizeof(double));
+      }
+      if (hipSetDevice(c->device) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&rm->d_edge_states), sbuf.size() * sizeof(double)) != hipSuccess ||
+          hipMemcpy(rm->d_edge_states, sbuf.data(), sbuf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        c->last_error = "staging the edge states failed";
+        return ARTP_ERR_HIP;
+      }
+      rm->d_edge_states_stale = false;
+    }
+    rc = roadmap_eval_edges_dev(c, &rm->params, rm->d_edge_states, rm->d_edge_states + ne * 7, ne, rm->evalid.data(),
+                                rm->einterp.data(), rm->ecost.data());
+    if (rc != ARTP_OK) return rc;
+  }
   for (size_t v = 0; v < nv; ++v) vbad += vok[v] ? 0 : 1;
   for (size_t e = 0; e < ne; ++e) {
     if (!vok[rm->eu[e]] || !vok[rm->ev[e]]) rm->evalid[e] = 0;
@@ -856,6 +882,7 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
   std::vector<uint8_t> zeros(np, 0);
   splice(rm->eremoved, zeros);
   rm->csr_dirty = true;
+  rm->d_edge_states_stale = true;
   return ARTP_OK;
 }
 

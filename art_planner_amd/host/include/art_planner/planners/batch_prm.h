@@ -72,6 +72,23 @@ class BatchPRM {
     return true;
   }
 
+  // LazyPRMStarMinUpdate's roadmap maintenance (lazy_prm_star_min_update.cpp:18-217), batched: after the map
+  // changed, re-check every vertex and edge of the kept roadmap.  Returns false when start or goal became
+  // invalid (the caller then re-queries with new ones).
+  bool revalidate() {
+    if (!rm_) throw std::runtime_error("BatchPRM::revalidate before sampleGraph");
+    uint64_t out[4] = {};
+    throwOnError(gpu_->get(), artp_roadmap_revalidate(rm_, out), "artp_roadmap_revalidate");
+    return (out[3] & 3u) == 3u;
+  }
+
+  // new start / goal on the kept roadmap (every OMPL query adds them as milestones)
+  void setQuery(const ob::SE3StateSpace::StateType& start, const ob::SE3StateSpace::StateType& goal) {
+    if (!rm_) throw std::runtime_error("BatchPRM::setQuery before sampleGraph");
+    const StateArray s = flatten(start), g = flatten(goal);
+    throwOnError(gpu_->get(), artp_roadmap_set_query(rm_, s.data(), g.data()), "artp_roadmap_set_query");
+  }
+
   size_t numVertices() const { return stat(0); }
   size_t numEdges() const { return stat(2); }
 
