@@ -5,15 +5,19 @@
 // (ode/ode/src/heightfield.cpp:1027-1064,1139-1160) -- but only after scanning the whole window.
 // max / min are idempotent, so exact 2-D range-max / range-min-of-finite tables over power-of-two
 // blocks (built once per map upload, resident in HBM/L2) give bit-identical statistics from a handful
-// of loads; non-finite / NaN counts come from summed-area tables.  That turns the common case into
-// lane-parallel work (one lane per STATE, 64 states per wavefront instruction) and leaves the
-// wave-cooperative window work to the boxes that really need it:
+// of loads; "holds a non-finite / a NaN sample" comes from per-block flag bytes.  That turns the common
+// case into lane-parallel work and leaves the cooperative window work to the boxes that really need it
+// (DESIGN.md 4.1 has the exactness argument of every shortcut):
 //
-//   classify_states_kernel   1 lane / (state, box) : poses, frame change, AABB, window, table statistics,
-//                                             exits (b)-(e); undecided boxes -> queue 1
-//   resolve_boxes_kernel     1 wave / box   : window -> LDS, (re-)decide exits, (f) vertex-in-box,
-//                                             count kept triangles; boxes with triangles -> queue 2
-//   plane_stage_kernel       1 wave / box   : window -> LDS, kept-triangle list, (g) plane stage
+//   classify_states_kernel      1 lane / (state, box): poses, frame change, AABB, window, table statistics,
+//                               exits (b)-(e), 2 x 2 vertex probe of (f) for feet; undecided -> queue 1
+//   feet_stream_kernel          16 lanes / foot box  : (f) streamed off the map, list-free corner stage
+//   resolve_boxes_kernel<.,64,0>  1 wave / torso box : the same for the ~900-sample torso windows
+//   resolve_boxes_kernel<.,16,2> 16 lanes / box      : candidates with possible partners: LDS tile,
+//                               kept-triangle list, partner search (queue 5)
+//   plane_stage_kernel          1 wave / box         : exact greedy plane grouping (queue 2)
+//   feet_lane_kernel + resolve_boxes_kernel<.,16,1>  : boxes the tables cannot answer (a NaN in the window,
+//                               windows thinner than 4 samples): ordered scan with ODE's running-dMAX quirk
 //
 // A state's label is the AND over its boxes of "torso does not touch" / "foot touches", so boxes can
 // be decided in any order and in different kernels; a failing box stores 0 into the state's label.
@@ -447,20 +451,13 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 #endif
 }
 
-__device__ __forceinline__ unsigned long long wave_fetch_item(unsigned long long* cursor, int lane) {
-  unsigned long long item = 0;
-  if (lane == 0) item = atomicAdd(cursor, 1ull);
-  return __shfl(item, 0, 64);
-}
-
-// ---- stage 1b: the foot queue, one LANE per box --------------------------------------------------------
-// A foot window holds ~70 samples.  Walking it sequentially in one lane costs ~70 steps that 64 boxes
-// share per instruction -- an order of magnitude less issue than a lane group per box -- and the
-// sequential walk is literally the reference's loop nest (x outer, z inner), NaN quirk included.
-// Per box: maxY (running dMAX), minY over finite, allFinite and, speculatively, (f) "colliding vertex of
-// an all-finite triangle inside the box"; then exits (b)-(e) (skipped when stage 1 already evaluated
-// them from the tables), then (f).  Boxes still undecided (they need the plane stage) are compacted
-// into queue 3 for the lane-group stage, one atomic per wavefront.
+// ---- fallback stage: foot boxes without a table verdict (queue 4), one LANE per box ---------------------
+// The tables cannot answer when the window holds a NaN (ODE's running dMAX makes the maximum depend on
+// the scan order) or is thinner than the smallest block.  Such a window (~100 samples) is walked
+// sequentially by one lane -- literally the reference's loop nest (x outer, z inner), NaN quirk included:
+// maxY (running dMAX), minY over finite, allFinite and, speculatively, (f) "colliding vertex of an
+// all-finite triangle inside the box"; then exits (b)-(e), then (f).  Boxes still undecided (they need the
+// plane stage) are compacted into queue 3 for the lane-group stage, one atomic per wavefront.
 #define ARTP_LANE_THREADS 256
 #define ARTP_STREAM_WAVES 4
 
