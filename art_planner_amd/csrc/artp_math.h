@@ -191,25 +191,21 @@ ARTP_HD void setup_box(const FieldDev& f, const float* pose, float sx, float sy,
   }
 }
 
-// dGeomBoxPointDepth(...) > dEpsilon
+// dGeomBoxPointDepth(...) > dEpsilon  (ode/ode/src/box.cpp:109-173).
+// The reference forms the six face distances d = h -+ q, "inside" = none negative, and the depth = the
+// smallest of them (started from (dReal)(unsigned)-1).  For a point inside, depth > eps is min(d) > eps, and
+// min(h - q, h + q) = h - |q| in exact IEEE arithmetic (the same single subtraction either way), so the
+// whole test is  min_i (h_i - |q_i|) > eps.  For a point outside some d is negative: the reference returns
+// a non-positive depth, and the minimum here is negative too.
 ARTP_HD bool point_in_box(const BoxHF& b, float x, float y, float z) {
   const float p0 = x - b.pos[0], p1 = y - b.pos[1], p2 = z - b.pos[2];
   const float q0 = dot3(b.R[0], b.R[3], b.R[6], p0, p1, p2);
   const float q1 = dot3(b.R[1], b.R[4], b.R[7], p0, p1, p2);
   const float q2 = dot3(b.R[2], b.R[5], b.R[8], p0, p1, p2);
-  const float h0 = b.side[0] * 0.5f, h1 = b.side[1] * 0.5f, h2 = b.side[2] * 0.5f;
-  const float d0 = h0 - q0, d3 = h0 + q0;
-  const float d1 = h1 - q1, d4 = h1 + q1;
-  const float d2 = h2 - q2, d5 = h2 + q2;
-  const bool inside = !((d0 < 0) || (d3 < 0) || (d1 < 0) || (d4 < 0) || (d2 < 0) || (d5 < 0));
-  float smallest = 4294967296.0f;  // (dReal)(unsigned)-1
-  if (d0 < smallest) smallest = d0;
-  if (d1 < smallest) smallest = d1;
-  if (d2 < smallest) smallest = d2;
-  if (d3 < smallest) smallest = d3;
-  if (d4 < smallest) smallest = d4;
-  if (d5 < smallest) smallest = d5;
-  return inside && (smallest > ARTP_EPS);
+  const float m0 = b.side[0] * 0.5f - fabsf(q0);
+  const float m1 = b.side[1] * 0.5f - fabsf(q1);
+  const float m2 = b.side[2] * 0.5f - fabsf(q2);
+  return fminf(fminf(m0, m1), m2) > ARTP_EPS;
 }
 
 // dCollideBoxPlane: up to maxc (<= 4) contact positions; returns their number.
