@@ -663,7 +663,13 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
   const bool c_up = !(base_slot & 1);
   const float s0 = (corner & 1) ? 0.5f : -0.5f, s1 = (corner & 2) ? 0.5f : -0.5f, s2 = (corner & 4) ? 0.5f : -0.5f;
   const float px = b.pos[0] + s0 * b.side[0] * b.R[0] + s1 * b.side[1] * b.R[1] + s2 * b.side[2] * b.R[2];
+  const float py = b.pos[1] + s0 * b.side[0] * b.R[3] + s1 * b.side[1] * b.R[4] + s2 * b.side[2] * b.R[5];
   const float pz = b.pos[2] + s0 * b.side[0] * b.R[6] + s1 * b.side[1] * b.R[7] + s2 * b.side[2] * b.R[8];
+  // A contact of dCollideBoxPlane sits on a box corner whose depth below the plane is >= 0.  The plane of a
+  // triangle, extended over its whole cell (+ the margin), stays below `top + spread * reach`: a corner
+  // higher than that (1 mm slack for the roundings of depth and of this corner) cannot be a contact of
+  // that triangle's plane -- nor of a partner's epsilon-equal plane -- so the pair is no candidate.
+  const float reach = 2.0f * margin * fmaxf(f.inv_w, f.inv_d);
   const int cxa = (int)floorf((px - margin) * f.inv_w), cxb = (int)floorf((px + margin) * f.inv_w);
   const int cza = (int)floorf((pz - margin) * f.inv_d), czb = (int)floorf((pz + margin) * f.inv_d);
   for (int r = 0; r < 4; ++r) {
@@ -682,7 +688,15 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
       const float hA = hp[0], hB = hp[1], hC = hp[hstride], hD = hp[hstride + 1];
       const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
       const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
-      const bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
+      bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
+      if (kept) {
+        // plane height at the cell's fourth corner: hB + hC - hA (ABC), hB + hC - hD (DBC)
+        const float h0 = c_up ? hA : hD;
+        const float h4 = (hB + hC) - h0;
+        const float top = fmaxf(fmaxf(h0, h4), fmaxf(hB, hC));
+        const float spread = fabsf(hB - h0) + fabsf(hC - h0);
+        kept = !(py > top + spread * reach + 1.0e-3f);
+      }
       is_cand = kept;
       if (kept && fast)
         maybe_partner = maybe_partner || !window_covered ||
