@@ -162,6 +162,30 @@ partner_flags_clear_kernel(int nW, int cx0, int cz0, int ncx, int ncz, unsigned 
   if (li < ncx * ncz) flags[(cx0 + li % ncx) + (size_t)(cz0 + li / ncx) * nW] = 0;
 }
 
+// One block of a coarser level that CONTAINS the window (anchored at the window's corner) bounds the window's
+// statistics from outside: max_c >= maxY, min_c <= minY, and "block all finite" implies "window all finite".
+// That decides most boxes with a single gather, exactly:
+//   (b) above : minO2 - max_c > -eps  =>  minO2 - maxY > -eps                       -> no contact
+//   (c) under : min_c - maxO2 > -eps  =>  minY - maxO2 > -eps (whether (b) fired first or not: both say 0)
+//   (d) spans : block finite, min_c - minO2 >= eps and maxO2 - max_c >= eps  =>  (b) and (c) cannot fire
+//               (maxY >= min_c >= minO2 + eps, minY <= max_c <= maxO2 - eps) and (d)'s own tests hold
+// Returns 0 / 1 = decided result, -1 = undecided (the precise statistics below take over).
+__device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
+  const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
+  const int wmax = wX > wZ ? wX : wZ;
+  if (wmax > (4 << (ARTP_TABLE_LEVELS - 1))) return -1;
+  const int lc = wmax <= 4 ? 0 : (wmax <= 8 ? 1 : (wmax <= 16 ? 2 : 3));
+  const int at = b.minX + b.minZ * f.nW;
+  const float2 v = t.mm[lc][at];
+  const unsigned fc = t.has_nonfinite ? t.fl[lc][at] : 0u;
+  if (fc & 2u) return -1;  // a NaN nearby: ODE's running dMAX needs the precise path
+  const float minO2 = b.aabb[2], maxO2 = b.aabb[3];
+  if (minO2 - v.x > -ARTP_EPS) return 0;
+  if (v.y - maxO2 > -ARTP_EPS) return 0;
+  if (!(fc & 1u) && v.y - minO2 >= ARTP_EPS && maxO2 - v.x >= ARTP_EPS) return 1;
+  return -1;
+}
+
 // Exact window statistics from the tables.  Returns false when the tables cannot answer (window
 // thinner than the smallest block, or a NaN in the window -> the running-dMAX quirk needs the scan).
 __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const TablesDev& t, const BoxHF& b,
@@ -315,6 +339,10 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
   if (b.on_field) {
     WindowStats w;
     int ec;
+    if (tab.valid) {
+      const int coarse = coarse_block_exit(f, tab, b);
+      if (coarse >= 0) return (body ? coarse : !coarse) ? 1 : 0;
+    }
     const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
     all_finite = have_stats && w.allFinite;
     if (!(have_stats && decide_exits(b, w, hit, ec))) {
