@@ -284,3 +284,52 @@ def test_partner_table_incremental_equals_full(big_map):
     assert np.array_equal(ctx2.validate_states(se3), vo)
     ctx.close()
     ctx2.close()
+
+
+def test_empty_ragged_and_error_inputs(big_map):
+    """Edge cases of the batch interfaces: empty batches, batches that are not a multiple of any tile size,
+    states far outside the map, calls before a map was uploaded, and a robot too large for the window tile."""
+    from art_planner_amd._capi import ArtpError
+    from art_planner_amd.context import Context
+    rob = O.robot("yaml")
+    ctx = _ctx("yaml")
+    z7 = np.zeros((0, 7))
+    with pytest.raises(ArtpError):          # no map yet: the reference's hasMap() == false
+        ctx.validate_states(np.zeros((1, 7)) + [0, 0, 0, 0, 0, 0, 1])
+    ctx.upload_map(big_map)
+    assert ctx.validate_states(z7).shape == (0,)
+    assert ctx.check_boxes(0, rob.torso, np.zeros((0, 16), np.float32)).shape == (0,)
+    v, n = ctx.check_edges_interp(z7, z7)
+    assert v.shape == (0,) and n.shape == (0,)
+    assert ctx.check_motions(z7, z7).shape == (0,)
+    assert ctx.sample_states(1, 0, 0).shape == (0, 7)
+    om = O.OracleMap(big_map)
+    se3 = ctx.sample_states(5, 0, 4099)      # prime-ish, crosses every tile / wave boundary
+    for n in (1, 2, 63, 64, 65, 127, 129, 4099):
+        assert np.array_equal(ctx.validate_states(se3[:n]), om.states_valid(rob, se3[:n])), n
+    # states outside the map: body outside -> valid, feet outside -> !unknown_space_untraversable
+    far = se3[:256].copy()
+    far[:, 0] += 100.0
+    assert np.array_equal(ctx.validate_states(far), om.states_valid(rob, far))
+    edge = se3[:512].copy()                  # straddling the border: some boxes in, some out
+    edge[:, 0] = big_map.pos_x + 0.5 * big_map.len_x - np.linspace(-0.8, 0.8, 512)
+    assert np.array_equal(ctx.validate_states(edge), om.states_valid(rob, edge))
+    # degenerate edges: both end points equal
+    v1, n1 = ctx.check_edges_interp(se3[:100], se3[:100])
+    vo, no = om.edges_interp_valid(rob, se3[:100], se3[:100])
+    assert np.array_equal(v1, vo) and np.array_equal(n1, no)
+    assert np.array_equal(ctx.check_motions(se3[:100], se3[:100]), om.check_motions(rob, se3[:100], se3[:100])[0])
+    ctx.close()
+    # a torso whose window exceeds the 64-sample tile of the packed triangle ids
+    from art_planner_amd import _capi
+    import ctypes as C
+    big = Context(0, "yaml")
+    big.params.torso_length = 4.0
+    L = _capi.load()
+    h = C.c_void_p()
+    assert L.artp_create(0, C.byref(big.params), C.byref(h)) == 0
+    lay = np.asfortranarray(big_map["elevation"], np.float32)
+    rc = L.artp_upload_layer(h, 0, lay.ctypes.data, lay.shape[0], lay.shape[1], big_map.len_x, big_map.len_y, 0.0, 0.0)
+    assert rc == -5                           # ARTP_ERR_CAPACITY, not a wrong answer
+    L.artp_destroy(h)
+    big.close()
