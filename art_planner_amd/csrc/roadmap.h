@@ -886,6 +886,70 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
   return ARTP_OK;
 }
 
+// Planner::getSolutionPath simplifies the solution (params.planner.simplify_solution, planner.cpp:266-280, OMPL's
+// randomised PathSimplifier::reduceVertices / shortcutPath).  Batched and deterministic instead: EVERY pair
+// (i, j) of path states is tried as a shortcut in one batch -- the 0.5 m interpolation rule, the discrete
+// motion validator and the objective's cost -- and the cheapest chain of valid shortcuts from the first to the
+// last state is taken (a shortest path in a DAG).  Never worse than the input path under the objective.
+int artp_roadmap_simplify_path(artp_roadmap* rm, const double* path_se3, size_t n, double* out_se3, size_t* n_out,
+                               double* cost) {
+  if (!rm || !path_se3 || !out_se3 || !n_out || n < 1) return ARTP_ERR_INVALID_ARG;
+  artp_ctx* c = rm->ctx;
+  if (n <= 2) {
+    std::memcpy(out_se3, path_se3, n * 7 * sizeof(double));
+    *n_out = n;
+  }
+  std::vector<double> verts(path_se3, path_se3 + n * 7);
+  std::vector<uint32_t> eu, ev;
+  for (uint32_t i = 0; i + 1 < n; ++i)
+    for (uint32_t j = i + 1; j < n; ++j) {
+      eu.push_back(i);
+      ev.push_back(j);
+    }
+  const size_t ne = eu.size();
+  std::vector<uint8_t> ok1(ne, 0), ok2(ne, 0);
+  std::vector<uint32_t> ni(ne, 0);
+  std::vector<double> ec(ne, 0.0);
+  if (ne) {
+    int rc = roadmap_eval_edges_host(c, &rm->params, verts, eu.data(), ev.data(), ne, ok1.data(), ni.data(), ec.data());
+    if (rc != ARTP_OK) return rc;
+    std::vector<double> s1(ne * 7), s2(ne * 7);
+    for (size_t e = 0; e < ne; ++e) {
+      std::memcpy(&s1[e * 7], &verts[(size_t)eu[e] * 7], 7 * sizeof(double));
+      std::memcpy(&s2[e * 7], &verts[(size_t)ev[e] * 7], 7 * sizeof(double));
+    }
+    rc = artp_check_motions(c, s1.data(), s2.data(), ne, ok2.data());
+    if (rc != ARTP_OK) return rc;
+    (void)hipStreamSynchronize(c->stream);
+  }
+  // DAG shortest path 0 -> n-1 (edges only go forward)
+  std::vector<double> best(n, INFINITY);
+  std::vector<uint32_t> from(n, 0xffffffffu);
+  best[0] = 0.0;
+  size_t e = 0;
+  for (uint32_t i = 0; i + 1 < n; ++i)
+    for (uint32_t j = i + 1; j < n; ++j, ++e) {
+      if (!ok1[e] || !ok2[e] || !std::isfinite(ec[e]) || !std::isfinite(best[i])) continue;
+      if (best[i] + ec[e] < best[j]) {
+        best[j] = best[i] + ec[e];
+        from[j] = i;
+      }
+    }
+  if (n > 1 && !std::isfinite(best[n - 1])) {  // the input path itself does not pass: hand it back unchanged
+    std::memcpy(out_se3, path_se3, n * 7 * sizeof(double));
+    *n_out = n;
+    if (cost) *cost = INFINITY;
+    return ARTP_OK;
+  }
+  std::vector<uint32_t> keep;
+  for (uint32_t v = (uint32_t)n - 1; v != 0xffffffffu; v = from[v]) keep.push_back(v);
+  std::reverse(keep.begin(), keep.end());
+  for (size_t k = 0; k < keep.size(); ++k) std::memcpy(out_se3 + k * 7, &verts[(size_t)keep[k] * 7], 7 * sizeof(double));
+  *n_out = keep.size();
+  if (cost) *cost = best[n - 1];
+  return ARTP_OK;
+}
+
 int artp_roadmap_stats(const artp_roadmap* rm, uint64_t out[8]) {
   if (!rm || !out) return ARTP_ERR_INVALID_ARG;
   uint64_t nvalid = 0, nrem = 0;

@@ -89,6 +89,20 @@ class BatchPRM {
     throwOnError(gpu_->get(), artp_roadmap_set_query(rm_, s.data(), g.data()), "artp_roadmap_set_query");
   }
 
+  // Planner::getSolutionPath(simplify = true) (planner.cpp:266-280): deterministic batched shortcutting
+  void simplify(std::vector<StateArray>* path, double* cost = nullptr) {
+    if (!rm_ || path->empty()) return;
+    std::vector<StateArray> out(path->size());
+    size_t n = 0;
+    double c = 0.0;
+    throwOnError(gpu_->get(),
+                 artp_roadmap_simplify_path(rm_, (*path)[0].data(), path->size(), out[0].data(), &n, &c),
+                 "artp_roadmap_simplify_path");
+    out.resize(n);
+    path->swap(out);
+    if (cost) *cost = c;
+  }
+
   size_t numVertices() const { return stat(0); }
   size_t numEdges() const { return stat(2); }
 

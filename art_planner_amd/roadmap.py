@@ -75,6 +75,15 @@ class Roadmap:
         g = np.ascontiguousarray(goal, np.float64).reshape(7)
         self.ctx._chk(self.L.artp_roadmap_set_query(self.h, s.ctypes.data, g.ctypes.data), "artp_roadmap_set_query")
 
+    def simplify(self, path):
+        """Cheapest chain of valid shortcuts through the states of `path` (deterministic PathSimplifier)."""
+        p = np.ascontiguousarray(path, np.float64).reshape(-1, 7)
+        out = np.empty_like(p)
+        n, cost = C.c_size_t(0), C.c_double(0.0)
+        self.ctx._chk(self.L.artp_roadmap_simplify_path(self.h, p.ctypes.data, p.shape[0], out.ctypes.data,
+                                                        C.byref(n), C.byref(cost)), "artp_roadmap_simplify_path")
+        return out[:n.value].copy(), cost.value
+
     def solve(self, cap_states=4096) -> Tuple[Optional[np.ndarray], float, int]:
         """(path n x 7 or None when start and goal are not connected, cost, lazy edge removals)."""
         path = np.empty((cap_states, 7), np.float64)

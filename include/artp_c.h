@@ -217,6 +217,12 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]);
 /* New start / goal on the kept roadmap: vertices 0 and 1 are replaced and connected to their k nearest
  * vertices (every OMPL query adds its start and goal as milestones, prm_motion_cost.cpp:452-476). */
 int artp_roadmap_set_query(artp_roadmap* rm, const double* start_se3, const double* goal_se3);
+/* Solution simplification (Params::planner.simplify_solution; the reference calls OMPL's randomised
+ * PathSimplifier through ss_->simplifySolution(), planner.cpp:266-280): every pair of path states is tried as a shortcut in one batch
+ * (interpolation rule + discrete motion validator + the objective's cost) and the cheapest chain of valid
+ * shortcuts is returned -- deterministic, never worse than the input.  out_se3 holds up to n states. */
+int artp_roadmap_simplify_path(artp_roadmap* rm, const double* path_se3, size_t n, double* out_se3,
+                               size_t* n_out, double* cost);
 void artp_roadmap_destroy(artp_roadmap* rm);
 
 /* ---- "next" row N2: the per-map preprocessing chain on the device -----------------------

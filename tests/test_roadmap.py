@@ -301,3 +301,37 @@ def test_revalidate_after_map_update_and_new_query(planning_setup):
     assert (path2 is None and np.isinf(ref_cost)) or abs(cost2 - ref_cost) < 1e-9 * max(1.0, ref_cost)
     rm.close()
     ctx.upload_map(gm)  # restore the module fixture's map
+
+
+def test_simplify_path_is_valid_and_never_worse(planning_setup):
+    """The batched shortcutting: the result is a subsequence of the plan from start to goal, every edge of
+    it passes the oracle's interpolation rule and discrete motion validator, and its cost is <= the plan's
+    (and equal to brute-force DP over the oracle-validated shortcut graph)."""
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    rob = O.robot("yaml")
+    om = O.OracleMap(gm)
+    rm = Roadmap(ctx, start, goal, n_milestones=4000, seed=11)
+    path, cost, _ = rm.solve()
+    assert path is not None and len(path) > 4
+    simp, scost = rm.simplify(path)
+    assert np.array_equal(simp[0], path[0]) and np.array_equal(simp[-1], path[-1])
+    idx = [int(np.nonzero((path == s).all(axis=1))[0][0]) for s in simp]
+    assert idx == sorted(idx) and len(set(idx)) == len(idx)      # a subsequence
+    assert scost <= cost + 1e-9 and len(simp) <= len(path)
+    seg = np.sqrt(((simp[1:, :3] - simp[:-1, :3]) ** 2).sum(-1)) / 0.5
+    assert abs(seg.sum() - scost) < 1e-9 * max(1.0, scost)
+    assert om.edges_interp_valid(rob, simp[:-1], simp[1:])[0].all()
+    assert om.check_motions(rob, simp[:-1], simp[1:])[0].all()
+    # brute force: DP over all pairs validated by the oracle
+    n = len(path)
+    ii, jj = np.triu_indices(n, 1)
+    ok = (om.edges_interp_valid(rob, path[ii], path[jj])[0] != 0) & (om.check_motions(rob, path[ii], path[jj])[0] != 0)
+    w = np.sqrt(((path[jj, :3] - path[ii, :3]) ** 2).sum(-1)) / 0.5
+    best = np.full(n, np.inf)
+    best[0] = 0.0
+    for a, b, o, ww in zip(ii, jj, ok, w):   # (i, j) in lexicographic order: all edges into j come before j's out-edges
+        if o and best[a] + ww < best[b]:
+            best[b] = best[a] + ww
+    assert abs(best[-1] - scost) < 1e-9 * max(1.0, scost)
+    rm.close()
