@@ -402,6 +402,31 @@ def main():
     except Exception as ex:  # pragma: no cover
         preprocess = {"error": repr(ex)}
 
+    # ---- C4 extras: 800 x 800 @ 0.04 m map, Params-default robot ---------------------------------------------
+    c4 = None
+    try:
+        if args.skip_extras:
+            raise RuntimeError("skipped (--skip-extras)")
+        from art_planner_amd.synthetic import RobotDims
+        gm4 = make_map(800, 0.04, seed=77, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
+        ctx4 = Context(local_rank, "defaults")
+        ctx4.upload_map(gm4)
+        ctx4.use_torch_stream()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx4.sample_and_validate_dev(seed, 0, S, se3, valid)
+        ev0.record()
+        for i4 in range(3):
+            ctx4.sample_and_validate_dev(seed, (i4 + 1) * S, S, se3, valid)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms4 = ev0.elapsed_time(ev1) / 3
+        c4 = {"states_per_s": S / (ms4 * 1e-3), "ms_per_batch": ms4, "valid_frac": float(valid.float().mean().item()),
+              "map": "800x800@0.04", "robot": "Params defaults"}
+        ctx4.close()
+        ctx.use_torch_stream()
+    except Exception as ex:  # pragma: no cover
+        c4 = {"error": repr(ex)}
+
     cpu = None
     if N == 1 and not args.no_cpu_baseline:
         cpu, cpu_labels, _ = cpu_baseline(gm, states)
@@ -444,7 +469,7 @@ def main():
                                (", accepted-state indices all-gathered over RCCL + states re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess, "c4_800_defaults": c4,
         "device": ctx.arch, "gather_error": gather_error,
     }
     print(json.dumps(out))
