@@ -40,7 +40,8 @@ class Params(C.Structure):
                 ("torso_length", "torso_width", "torso_height", "torso_off_x", "torso_off_y",
                  "torso_off_z", "feet_off_x", "feet_off_y", "feet_off_z", "reach_x", "reach_y",
                  "reach_z")] + [("unknown_space_untraversable", C.c_int),
-                                ("max_pitch_pert", C.c_double), ("max_roll_pert", C.c_double)]
+                                ("max_pitch_pert", C.c_double), ("max_roll_pert", C.c_double),
+                                ("sample_from_distribution", C.c_int)]
 
 
 _lib = None

@@ -381,6 +381,7 @@ void artp_params_defaults(artp_params* p) {  // art_planner/include/art_planner/
   p->unknown_space_untraversable = 1;
   p->max_pitch_pert = 10.0 / 180 * M_PI;
   p->max_roll_pert = 3.33 / 180 * M_PI;
+  p->sample_from_distribution = 1;
 }
 
 void artp_params_yaml(artp_params* p) {  // art_planner_ros/config/params.yaml:44-45,55-71
@@ -391,6 +392,7 @@ void artp_params_yaml(artp_params* p) {  // art_planner_ros/config/params.yaml:4
   p->unknown_space_untraversable = 1;
   p->max_pitch_pert = 10 * M_PI / 180;
   p->max_roll_pert = 3.33 * M_PI / 180;
+  p->sample_from_distribution = 1;
 }
 
 const char* artp_status_string(int s) {
@@ -716,6 +718,7 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
     c->geom.rows = rows; c->geom.cols = cols; c->geom.res = len_x / rows;
     c->have_geom = true;
   }
+  c->sampler.from_distribution = c->params.sample_from_distribution;
   c->have_sampler = true;
   return ARTP_OK;
 }

@@ -29,6 +29,7 @@ struct MapGeom {  // grid_map geometry (doubles, as grid_map stores them)
 };
 
 struct SamplerDev {
+  int from_distribution;          // Params::sampler.sample_from_distribution
   const float* cum_prob;          // col-major rows x cols
   const float* cum_prob_rowwise;  // rows
   const float* elevation;
@@ -245,24 +246,37 @@ ARTP_HD double uniform01(uint64_t seed, uint64_t index, unsigned k) {
 // same "first index whose cumulative value exceeds u, else the last index".
 __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& g, const RobotDev& rb,
                                            uint64_t seed, uint64_t index, double out[7]) {
-  const double samp_col = uniform01(seed, index, 0);
-  const double samp_row = uniform01(seed, index, 1);
-  int lo = 0, hi = g.rows - 1;  // answer in [0, rows-1]
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((double)sm.cum_prob_rowwise[mid] > samp_row) hi = mid; else lo = mid + 1;
+  double px, py;
+  if (sm.from_distribution) {  // samplePositionInMapFromDist (sampler.cpp:56-78)
+    const double samp_col = uniform01(seed, index, 0);
+    const double samp_row = uniform01(seed, index, 1);
+    int lo = 0, hi = g.rows - 1;  // answer in [0, rows-1]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((double)sm.cum_prob_rowwise[mid] > samp_row) hi = mid; else lo = mid + 1;
+    }
+    const int row = lo;
+    lo = 0;
+    hi = g.cols - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((double)sm.cum_prob[(size_t)row + (size_t)mid * g.rows] > samp_col) hi = mid; else lo = mid + 1;
+    }
+    const int col = lo;
+    // grid_map getPosition: (c + (L/2 - res/2)) + res * (-i)
+    px = (g.pos_x + (0.5 * g.len_x - 0.5 * g.res)) + g.res * (double)(-row);
+    py = (g.pos_y + (0.5 * g.len_y - 0.5 * g.res)) + g.res * (double)(-col);
+  } else {
+    // samplePositionInMap (sampler.cpp:38-50): uniform over the SE3 bounds pos -+ length
+    // (planner.cpp:146-156), three draws per attempt (z unused), until map_->isInside(pos)
+    const double lx = g.pos_x - g.len_x, hx = g.pos_x + g.len_x;
+    const double ly = g.pos_y - g.len_y, hy = g.pos_y + g.len_y;
+    for (unsigned a = 0;; ++a) {
+      px = (hx - lx) * uniform01(seed, index, 8 + 3 * a) + lx;
+      py = (hy - ly) * uniform01(seed, index, 8 + 3 * a + 1) + ly;
+      if (map_is_inside(g, px, py) || a >= 255) break;
+    }
   }
-  const int row = lo;
-  lo = 0;
-  hi = g.cols - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((double)sm.cum_prob[(size_t)row + (size_t)mid * g.rows] > samp_col) hi = mid; else lo = mid + 1;
-  }
-  const int col = lo;
-  // grid_map getPosition: (c + (L/2 - res/2)) + res * (-i)
-  const double px = (g.pos_x + (0.5 * g.len_x - 0.5 * g.res)) + g.res * (double)(-row);
-  const double py = (g.pos_y + (0.5 * g.len_y - 0.5 * g.res)) + g.res * (double)(-col);
   // getIndexOfPosition (sampler.cpp:95) -- reproduces (row, col)
   const int ri = (int)(-(((px - 0.5 * g.len_x) - g.pos_x) / g.res));
   const int ci = (int)(-(((py - 0.5 * g.len_y) - g.pos_y) / g.res));

@@ -30,6 +30,7 @@ class GpuContext {
     p.unknown_space_untraversable = params->planner.unknown_space_untraversable ? 1 : 0;
     p.max_pitch_pert = params->sampler.max_pitch_pert;
     p.max_roll_pert = params->sampler.max_roll_pert;
+    p.sample_from_distribution = params->sampler.sample_from_distribution ? 1 : 0;
     const int rc = artp_create(device, &p, &ctx_);
     if (rc != ARTP_OK) throw std::runtime_error(std::string("artp_create: ") + artp_status_string(rc));
   }

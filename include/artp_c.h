@@ -49,6 +49,8 @@ typedef struct {
   double reach_x, reach_y, reach_z;                 /* params.h:113-117 */
   int unknown_space_untraversable;                  /* params.h:26 */
   double max_pitch_pert, max_roll_pert;             /* params.h:80-81 */
+  int sample_from_distribution;                     /* params.h:81: 1 = samplePositionInMapFromDist (default),
+                                                       0 = samplePositionInMap (uniform in the map) */
 } artp_params;
 
 void artp_params_defaults(artp_params* p);          /* params.h defaults */

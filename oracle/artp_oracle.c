@@ -1004,17 +1004,33 @@ double artp_oracle_uniform01(uint64_t seed, uint64_t index, unsigned k) {
 
 void artp_oracle_sample(const artp_oracle_sampler_map* m, const artp_oracle_robot* r, uint64_t seed,
                         uint64_t index, double se3[7], int rowcol[2]) {
-  /* samplePositionInMapFromDist, sampler.cpp:56-78 */
-  const double samp_col = artp_oracle_uniform01(seed, index, 0);
-  const double samp_row = artp_oracle_uniform01(seed, index, 1);
-  int row, col;
-  for (row = 0; row < m->rows - 1; ++row)
-    if (m->cum_prob_rowwise[row] > samp_row) break; /* float promoted to double */
-  for (col = 0; col < m->cols - 1; ++col)
-    if (m->cum_prob[(size_t)row + (size_t)col * m->rows] > samp_col) break;
-  /* grid_map getPosition: c + (L/2 - res/2) - res*i  (grid_map_core GridMapMath.cpp) */
-  const double px = (m->pos_x + (0.5 * m->len_x - 0.5 * m->res)) + m->res * (double)(-row);
-  const double py = (m->pos_y + (0.5 * m->len_y - 0.5 * m->res)) + m->res * (double)(-col);
+  double px, py;
+  if (!m->sample_uniform) {
+    /* samplePositionInMapFromDist, sampler.cpp:56-78 */
+    const double samp_col = artp_oracle_uniform01(seed, index, 0);
+    const double samp_row = artp_oracle_uniform01(seed, index, 1);
+    int row, col;
+    for (row = 0; row < m->rows - 1; ++row)
+      if (m->cum_prob_rowwise[row] > samp_row) break; /* float promoted to double */
+    for (col = 0; col < m->cols - 1; ++col)
+      if (m->cum_prob[(size_t)row + (size_t)col * m->rows] > samp_col) break;
+    /* grid_map getPosition: c + (L/2 - res/2) - res*i  (grid_map_core GridMapMath.cpp) */
+    px = (m->pos_x + (0.5 * m->len_x - 0.5 * m->res)) + m->res * (double)(-row);
+    py = (m->pos_y + (0.5 * m->len_y - 0.5 * m->res)) + m->res * (double)(-col);
+  } else {
+    /* samplePositionInMap, sampler.cpp:38-50: RealVectorStateSampler::sampleUniform over the SE3 bounds
+     * (pos -+ length, planner.cpp:146-156; three uniformReal draws per attempt, z unused) until
+     * map_->isInside(pos).  Attempt a uses the draws k = 8 + 3a .. 8 + 3a + 2. */
+    const double lx = m->pos_x - m->len_x, hx = m->pos_x + m->len_x;
+    const double ly = m->pos_y - m->len_y, hy = m->pos_y + m->len_y;
+    unsigned a = 0;
+    for (;; ++a) {
+      px = (hx - lx) * artp_oracle_uniform01(seed, index, 8 + 3 * a) + lx;
+      py = (hy - ly) * artp_oracle_uniform01(seed, index, 8 + 3 * a + 1) + ly;
+      const double tx = -((px - m->pos_x) - 0.5 * m->len_x), ty = -((py - m->pos_y) - 0.5 * m->len_y);
+      if ((tx >= 0.0 && ty >= 0.0 && tx < m->len_x && ty < m->len_y) || a >= 255) break;
+    }
+  }
   /* getIndexOfPosition (sampler.cpp:95): i = (int)(-((p - L/2 - c)/res)); equals (row,col). */
   const int ri = (int)(-(((px - 0.5 * m->len_x) - m->pos_x) / m->res));
   const int ci = (int)(-(((py - 0.5 * m->len_y) - m->pos_y) / m->res));

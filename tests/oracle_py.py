@@ -50,7 +50,7 @@ class SamplerMap(C.Structure):
                 ("pos_x", C.c_double), ("pos_y", C.c_double), ("res", C.c_double),
                 ("cum_prob", C.c_void_p), ("cum_prob_rowwise", C.c_void_p), ("elevation", C.c_void_p),
                 ("normal_x", C.c_void_p), ("normal_y", C.c_void_p), ("normal_z", C.c_void_p),
-                ("plane_fit_std_dev", C.c_void_p)]
+                ("plane_fit_std_dev", C.c_void_p), ("sample_uniform", C.c_int)]
 
 
 def build_oracle(force: bool = False) -> str:
@@ -207,13 +207,13 @@ class OracleMap:
 
 
 class OracleSampler:
-    def __init__(self, gm, elevation_layer="elevation"):
+    def __init__(self, gm, elevation_layer="elevation", sample_uniform=False):
         self.gm = gm
         self.keep = [_f32F(gm["cum_prob"]), np.ascontiguousarray(gm["cum_prob_rowwise"], np.float32),
                      _f32F(gm[elevation_layer]), _f32F(gm["normal_x"]), _f32F(gm["normal_y"]),
                      _f32F(gm["normal_z"]), _f32F(gm["plane_fit_std_dev"])]
         self.m = SamplerMap(gm.rows, gm.cols, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y, gm.res,
-                            *[a.ctypes.data for a in self.keep])
+                            *[a.ctypes.data for a in self.keep], 1 if sample_uniform else 0)
 
     def sample(self, rob, seed, first, n):
         se3 = np.empty((n, 7), np.float64)

@@ -333,3 +333,28 @@ def test_empty_ragged_and_error_inputs(big_map):
     assert rc == -5                           # ARTP_ERR_CAPACITY, not a wrong answer
     L.artp_destroy(h)
     big.close()
+
+
+def test_uniform_position_sampler_branch(big_map):
+    """Params::sampler.sample_from_distribution = false: samplePositionInMap (sampler.cpp:38-50), uniform in
+    the SE3 bounds (pos -+ length) with rejection until inside the map -- GPU == oracle, every sample inside
+    the map, the continuous position is kept (no snapping to cell centres)."""
+    from art_planner_amd.context import Context, make_params
+    prm = make_params("yaml")
+    prm.sample_from_distribution = 0
+    ctx = Context(0, prm)
+    ctx.upload_map(big_map)
+    rob = O.robot("yaml")
+    so, rc = O.OracleSampler(big_map, sample_uniform=True).sample(rob, 42, 1000, 20000)
+    sg = ctx.sample_states(42, 1000, 20000)
+    assert np.abs(sg - so).max() < 1e-12
+    half = 0.5 * big_map.len_x
+    cx = sg[:, 0] - big_map.pos_x
+    assert (np.abs(cx) < half + 0.3).all()          # inside the map (+ the normal perturbation)
+    cell = (cx + half) / big_map.res
+    assert np.abs(cell - np.round(cell)).mean() > 0.1   # not on a lattice
+    h, _ = np.histogram(cx, bins=8, range=(-half, half))
+    assert h.min() > 0.8 * h.mean()                  # uniform over the map
+    vg = ctx.validate_states(sg)
+    assert np.array_equal(vg, O.OracleMap(big_map).states_valid(rob, sg))
+    ctx.close()
