@@ -166,6 +166,19 @@ def test_flat_map_path_is_near_the_straight_line():
     path, cost, _ = rm.solve()
     lb = np.linalg.norm(goal[:3] - start[:3]) / 0.5
     assert path is not None and lb - 1e-12 <= cost < 1.10 * lb
+    # simplify_solution: on an obstacle-free map the cheapest chain of shortcuts is the segment itself
+    simp, scost = rm.simplify(path)
+    assert len(simp) == 2 and abs(scost - lb) < 1e-12
+    rm.close()
+    # the C1 query of SURVEY.md 8d: start (-4, -4, yaw 0) -> goal (4, 4); optimum = 8*sqrt(2) m / 0.5 m/s
+    z0 = float(ok[0, 2])
+    s1 = np.array([-4.0, -4.0, z0, 0, 0, 0, 1.0])
+    g1 = np.array([4.0, 4.0, z0, 0, 0, 0, 1.0])
+    assert ctx.validate_states(np.stack([s1, g1])).all()
+    rm = Roadmap(ctx, s1, g1, n_milestones=10000, seed=42)
+    p1, c1, _ = rm.solve()
+    q1, d1 = rm.simplify(p1)
+    assert abs(d1 - 8 * np.sqrt(2) / 0.5) < 1e-4 and c1 < 1.05 * d1
     rm.close()
     ctx.close()
 
