@@ -1,0 +1,73 @@
+"""One-off randomized label-parity campaign (GPU pipeline vs CPU oracle) over map families the unit tests
+only sample: NaN-riddled, terraced, steps, tiny and huge robots, near-vertical walls.  Usage (GPU box):
+python scripts/parity_campaign.py [states_per_case]"""
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+import oracle_py as O  # noqa: E402
+from art_planner_amd.context import Context, make_params  # noqa: E402
+from art_planner_amd.synthetic import make_map  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
+rng = np.random.default_rng(2024)
+base = make_map(240, 0.04, seed=31)
+
+
+def variant(name):
+    gm = copy.deepcopy(base)
+    e, m = gm["elevation"].copy(), gm["elevation_masked"].copy()
+    if name == "nan":
+        holes = rng.random(e.shape) < 0.01
+        e[holes] = np.nan
+        m[rng.random(e.shape) < 0.01] = np.nan
+    elif name == "terraced":
+        e = (np.round(e / 0.05) * 0.05).astype(np.float32)
+        m = np.where(np.isfinite(m), e, m).astype(np.float32)
+    elif name == "steps":
+        e = (e + 0.4 * ((np.arange(e.shape[0])[:, None] // 17) % 2)).astype(np.float32)
+        m = np.where(np.isfinite(m), e, m).astype(np.float32)
+    elif name == "inf":
+        m[rng.random(e.shape) < 0.05] = np.inf
+        e[rng.random(e.shape) < 0.002] = -np.inf
+    gm.layers["elevation"] = np.asfortranarray(e)
+    gm.layers["elevation_masked"] = np.asfortranarray(m)
+    return gm
+
+
+cases = [("plain", "yaml"), ("nan", "yaml"), ("terraced", "yaml"), ("steps", "defaults"), ("inf", "yaml"),
+         ("plain", "tiny"), ("terraced", "defaults")]
+bad_total = 0
+for mapname, robot in cases:
+    gm = variant(mapname)
+    if robot == "tiny":
+        prm = make_params("yaml")
+        prm.torso_length, prm.torso_width, prm.torso_height = 0.3, 0.2, 0.1
+        prm.feet_off_x, prm.feet_off_y = 0.1, 0.06
+        prm.reach_x = prm.reach_y = prm.reach_z = 0.06
+        ctx = Context(0, prm)
+        rob = O.Robot()
+        for f, _ in O.Robot._fields_:
+            if hasattr(prm, f):
+                setattr(rob, f, getattr(prm, f))
+    else:
+        ctx = Context(0, robot)
+        rob = O.robot(robot)
+    ctx.upload_map(gm, sampler=False)
+    se3 = common.random_states(gm, n, rng, z_off=(0.0, 0.06), tilt=0.25, spread=0.53)
+    t0 = time.time()
+    vg = ctx.validate_states(se3)
+    vo = O.OracleMap(gm).states_valid(rob, se3)
+    bad = int((vg != vo).sum())
+    bad_total += bad
+    print(f"{mapname:9s} {robot:8s} valid={vg.mean():.3f} mismatches={bad} counters={ctx.pipeline_counters()} ({time.time() - t0:.1f}s)")
+    ctx.close()
+print("TOTAL MISMATCHES", bad_total)
+sys.exit(1 if bad_total else 0)
