@@ -35,7 +35,8 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
-  // map tables (pipeline.h): per layer 2 x 6 levels of floats + two summed-area tables
+  // map tables (pipeline.h): per layer 6 levels of {max, min} + 6 levels of non-finite / NaN flag bytes, the
+  // partner table and the raw cross products it is built from
   float* table_buf[2] = {nullptr, nullptr};
   unsigned char* flag_buf[2] = {nullptr, nullptr};  // per-level non-finite / NaN block flags
   unsigned char* partner_buf[2] = {nullptr, nullptr};
