@@ -499,34 +499,48 @@ int artp_synchronize(artp_ctx* c) {
   return ARTP_OK;
 }
 
-int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int cols, double len_x,
-                      double len_y, double pos_x, double pos_y) {
-  if (!c || !layer || slot < 0 || slot > 1 || rows < 2 || cols < 2) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
-  HIP_TRY(c, hipSetDevice(c->device));
-  const size_t elems = (size_t)rows * cols;
-  // field_.mat = layer.rowwise().reverse() (height_map_box_checker.cpp:44): ODE sample (x, z) =
-  // layer(x, cols-1-z), stored x-fastest.
-  std::vector<float>& host = c->field_host[slot];
-  host.resize(elems);
-  int has_nan = 0, has_nonfinite = 0;
-  for (int j = 0; j < cols; ++j)
-    for (int i = 0; i < rows; ++i) {
-      const float v = layer[(size_t)i + (size_t)(cols - 1 - j) * rows];
-      host[(size_t)i + (size_t)j * rows] = v;
-      has_nan |= (v != v);
-      has_nonfinite |= !std::isfinite(v);
-    }
-  c->layer_has_nonfinite[slot] = has_nonfinite;
-  if (c->field_elems[slot] < elems) {
-    if (c->field_data[slot]) HIP_TRY(c, hipFree(c->field_data[slot]));
-    c->field_data[slot] = nullptr;
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->field_data[slot]), elems * sizeof(float)));
-    c->field_elems[slot] = elems;
+namespace {
+
+// layer(i, j) column-major rows x cols  ->  ODE sample layout data[x + z * rows] = layer(x, cols-1-z)
+// (field_.mat = layer.rowwise().reverse(), height_map_box_checker.cpp:44), with the layer's non-finite /
+// NaN presence OR-ed into flags[0] / flags[1]
+__global__ void __launch_bounds__(256)
+flip_to_ode_layout_kernel(const float* __restrict__ layer, int rows, int cols, float* __restrict__ data,
+                          int* __restrict__ flags) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cols) return;
+  const int x = t % rows, z = t / rows;
+  const float v = layer[(size_t)x + (size_t)(cols - 1 - z) * rows];
+  data[t] = v;
+  if (!artp::is_finite(v)) atomicOr(&flags[0], 1);
+  if (v != v) atomicOr(&flags[1], 1);
+}
+
+// min / max over the finite samples (order-preserving integer keys), for the z bounds of planner.cpp:146-156
+__device__ __forceinline__ int float_order_key(float v) {
+  const int i = __float_as_int(v);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__global__ void __launch_bounds__(256)
+finite_min_max_kernel(const float* __restrict__ layer, int n, int* __restrict__ keys) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo = 0x7fffffff, hi = (int)0x80000000;
+  if (t < n && artp::is_finite(layer[t])) lo = hi = float_order_key(layer[t]);
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
   }
-  HIP_TRY(c, hipMemcpyAsync(c->field_data[slot], host.data(), elems * sizeof(float),
-                            hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&keys[0], lo);
+    atomicMax(&keys[1], hi);
+  }
+}
+
+// Everything of artp_upload_layer that follows the sample data being in c->field_data[slot] (ODE layout) and
+// mirrored in c->field_host[slot]: dxHeightfieldData::SetData, the checker's frame, scratch sizing, tables.
+int finish_layer(artp_ctx* c, int slot, int rows, int cols, double len_x, double len_y, double pos_x, double pos_y,
+                 int has_nan, int has_nonfinite) {
+  c->layer_has_nonfinite[slot] = has_nonfinite;
   FieldDev& f = c->field[slot];
   f.data = c->field_data[slot];
   // dxHeightfieldData::SetData (ode/ode/src/heightfield.cpp:130-169), single precision
@@ -575,6 +589,67 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
   if (rc != ARTP_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
+}
+
+int ensure_field_storage(artp_ctx* c, int slot, size_t elems) {
+  if (c->field_elems[slot] < elems) {
+    if (c->field_data[slot]) HIP_TRY(c, hipFree(c->field_data[slot]));
+    c->field_data[slot] = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->field_data[slot]), elems * sizeof(float)));
+    c->field_elems[slot] = elems;
+  }
+  return ARTP_OK;
+}
+
+}  // namespace
+
+int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int cols, double len_x,
+                      double len_y, double pos_x, double pos_y) {
+  if (!c || !layer || slot < 0 || slot > 1 || rows < 2 || cols < 2) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t elems = (size_t)rows * cols;
+  // field_.mat = layer.rowwise().reverse() (height_map_box_checker.cpp:44): ODE sample (x, z) =
+  // layer(x, cols-1-z), stored x-fastest.
+  std::vector<float>& host = c->field_host[slot];
+  host.resize(elems);
+  int has_nan = 0, has_nonfinite = 0;
+  for (int j = 0; j < cols; ++j)
+    for (int i = 0; i < rows; ++i) {
+      const float v = layer[(size_t)i + (size_t)(cols - 1 - j) * rows];
+      host[(size_t)i + (size_t)j * rows] = v;
+      has_nan |= (v != v);
+      has_nonfinite |= !std::isfinite(v);
+    }
+  int rc = ensure_field_storage(c, slot, elems);
+  if (rc != ARTP_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->field_data[slot], host.data(), elems * sizeof(float),
+                            hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, has_nan, has_nonfinite);
+}
+
+// Same from a layer that already lives in HBM (column-major, this context's device): the layout flip runs
+// on the device; only the 640 kB host mirror that rectangle updates patch comes back.
+static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer, int rows, int cols, double len_x,
+                             double len_y, double pos_x, double pos_y) {
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t elems = (size_t)rows * cols;
+  int rc = ensure_field_storage(c, slot, elems);
+  if (rc != ARTP_OK) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
+  int* d_flags = reinterpret_cast<int*>(c->d_count);
+  hipLaunchKernelGGL(flip_to_ode_layout_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream, d_layer,
+                     rows, cols, c->field_data[slot], d_flags);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<float>& host = c->field_host[slot];
+  host.resize(elems);
+  int flags[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(host.data(), c->field_data[slot], elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, flags[1], flags[0]);
 }
 
 int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, int col0, int nrows,
@@ -721,6 +796,64 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
   }
   c->sampler.from_distribution = c->params.sample_from_distribution;
   c->have_sampler = true;
+  return ARTP_OK;
+}
+
+// artp_upload_sampler_layers from layers that already live in HBM (device-to-device copies)
+static int upload_sampler_layers_from_device(artp_ctx* c, const float* cum_prob, const float* cum_prob_rowwise,
+                                      const float* elevation, const float* normal_x, const float* normal_y,
+                                      const float* normal_z, const float* plane_fit_std_dev, int rows, int cols,
+                                      double len_x, double len_y, double pos_x, double pos_y) {
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t e = (size_t)rows * cols;
+  if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
+  c->sampler_buf = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_buf), (6 * e + rows) * sizeof(float)));
+  float* p = c->sampler_buf;
+  const float* src[6] = {cum_prob, elevation, normal_x, normal_y, normal_z, plane_fit_std_dev};
+  const float** dst[6] = {&c->sampler.cum_prob, &c->sampler.elevation, &c->sampler.normal_x,
+                          &c->sampler.normal_y, &c->sampler.normal_z, &c->sampler.plane_fit_std_dev};
+  for (int k = 0; k < 6; ++k) {
+    HIP_TRY(c, hipMemcpyAsync(p, src[k], e * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    *dst[k] = p;
+    p += e;
+  }
+  HIP_TRY(c, hipMemcpyAsync(p, cum_prob_rowwise, rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->sampler.cum_prob_rowwise = p;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->have_geom) {
+    c->geom.len_x = len_x; c->geom.len_y = len_y; c->geom.pos_x = pos_x; c->geom.pos_y = pos_y;
+    c->geom.rows = rows; c->geom.cols = cols; c->geom.res = len_x / rows;
+    c->have_geom = true;
+  }
+  c->sampler.from_distribution = c->params.sample_from_distribution;
+  c->have_sampler = true;
+  return ARTP_OK;
+}
+
+// min / max of the finite samples of a device layer (host result); false if there is none
+static int finite_min_max_dev(artp_ctx* c, const float* d_layer, size_t n, float* lo, float* hi, bool* any) {
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int init[2] = {0x7fffffff, (int)0x80000000};
+  int* d_keys = reinterpret_cast<int*>(c->d_count);
+  HIP_TRY(c, hipMemcpyAsync(d_keys, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(finite_min_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_layer, (int)n,
+                     d_keys);
+  HIP_TRY(c, hipGetLastError());
+  int keys[2];
+  HIP_TRY(c, hipMemcpyAsync(keys, d_keys, sizeof(keys), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *any = keys[0] <= keys[1];
+  auto unkey = [](int k) {
+    const int i = k >= 0 ? k : k ^ 0x7fffffff;
+    float v;
+    std::memcpy(&v, &i, 4);
+    return v;
+  };
+  *lo = unkey(keys[0]);
+  *hi = unkey(keys[1]);
   return ARTP_OK;
 }
 

@@ -362,40 +362,33 @@ int artp_preprocessed_get_layer(artp_ctx* c, const artp_preprocessed* pp, const 
 int artp_preprocessed_install(artp_ctx* c, const artp_preprocessed* pp) {
   if (!c || !pp) return ARTP_ERR_INVALID_ARG;
   const size_t n = (size_t)pp->rows * pp->cols;
-  std::vector<float> h[7];
-  std::vector<float> rowwise(pp->rows);
   float total = 0.f;
   {
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
-    const int ks[7] = {PRE_ELEV, PRE_MASKED, PRE_CUM_PROB, PRE_NX, PRE_NY, PRE_NZ, PRE_STD};
-    for (int k = 0; k < 7; ++k) {
-      h[k].resize(n);
-      HIP_TRY(c, hipMemcpyAsync(h[k].data(), pp->layer(ks[k]), n * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(c, hipMemcpyAsync(rowwise.data(), pp->rowwise(), (size_t)pp->rows * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&total, pp->rowwise() + pp->rows, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(&total, pp->rowwise() + pp->rows, 4, hipMemcpyDeviceToHost));
   }
   if (!(total > 0.f)) {
     c->last_error = "sample_probability is zero everywhere: nothing can be sampled on this map";
     return ARTP_ERR_NO_MAP;
   }
-  int rc = artp_upload_layer(c, ARTP_SLOT_BODY, h[0].data(), pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+  // everything stays in HBM: layout flips, copies and the z-bound reduction run on the device
+  int rc = upload_layer_from_device(c, ARTP_SLOT_BODY, pp->layer(PRE_ELEV), pp->rows, pp->cols, pp->len_x, pp->len_y,
+                                    pp->pos_x, pp->pos_y);
   if (rc) return rc;
-  rc = artp_upload_layer(c, ARTP_SLOT_FEET, h[1].data(), pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+  rc = upload_layer_from_device(c, ARTP_SLOT_FEET, pp->layer(PRE_MASKED), pp->rows, pp->cols, pp->len_x, pp->len_y,
+                                pp->pos_x, pp->pos_y);
   if (rc) return rc;
-  rc = artp_upload_sampler_layers(c, h[2].data(), rowwise.data(), h[0].data(), h[3].data(), h[4].data(), h[5].data(),
-                                  h[6].data(), pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+  rc = upload_sampler_layers_from_device(c, pp->layer(PRE_CUM_PROB), pp->rowwise(), pp->layer(PRE_ELEV),
+                                         pp->layer(PRE_NX), pp->layer(PRE_NY), pp->layer(PRE_NZ), pp->layer(PRE_STD),
+                                         pp->rows, pp->cols, pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
   if (rc) return rc;
   // bounds.low[2] / high[2] = min / max finite elevation -/+ reach.z / 2 (planner.cpp:146-156)
-  float lo = INFINITY, hi = -INFINITY;
-  for (float v : h[0])
-    if (std::isfinite(v)) {
-      lo = std::min(lo, v);
-      hi = std::max(hi, v);
-    }
-  if (!(lo <= hi)) lo = hi = 0.f;
+  float lo = 0.f, hi = 0.f;
+  bool any = false;
+  rc = finite_min_max_dev(c, pp->layer(PRE_ELEV), n, &lo, &hi, &any);
+  if (rc) return rc;
+  if (!any) lo = hi = 0.f;
   return artp_set_z_bounds(c, (double)lo - c->params.reach_z / 2, (double)hi + c->params.reach_z / 2);
 }
 
