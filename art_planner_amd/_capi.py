@@ -25,6 +25,7 @@ SYMBOLS = [
     "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
     "artp_roadmap_revalidate", "artp_roadmap_set_query", "artp_roadmap_simplify_path",
     "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
+    "artp_preprocess_map_ex", "artp_preprocessed_change",
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
     "artp_cost_blob_bytes", "artp_cost_load_weights",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
@@ -51,7 +52,14 @@ class PreprocessParams(C.Structure):  # artp_preprocess_params (include/artp_c.h
     _fields_ = [("traversability_thres", C.c_float), ("foothold_margin", C.c_double),
                 ("foothold_margin_max_hole_size", C.c_double), ("foothold_margin_max_drop", C.c_double),
                 ("foothold_margin_max_drop_search_radius", C.c_double), ("foothold_margin_min_step", C.c_double),
-                ("foothold_size", C.c_double)]
+                ("foothold_size", C.c_double), ("use_inverse_vertex_density", C.c_int),
+                ("use_max_prob_unknown_samples", C.c_int), ("max_prob_unknown_samples", C.c_double)]
+
+
+class PreprocessInputs(C.Structure):  # artp_preprocess_inputs
+    _fields_ = [("elevation", C.c_void_p), ("traversability", C.c_void_p), ("observed", C.c_void_p),
+                ("vertex_se3", C.c_void_p), ("n_vertices", C.c_size_t), ("rows", C.c_int), ("cols", C.c_int),
+                ("len_x", C.c_double), ("len_y", C.c_double), ("pos_x", C.c_double), ("pos_y", C.c_double)]
 
 
 class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
@@ -130,6 +138,8 @@ def load():
         getattr(L, name).restype = None
     L.artp_preprocess_map.argtypes = [vp, vp, vp, i32, i32, dbl, dbl, dbl, dbl, C.POINTER(PreprocessParams),
                                       C.POINTER(vp)]
+    L.artp_preprocess_map_ex.argtypes = [vp, C.POINTER(PreprocessInputs), C.POINTER(PreprocessParams), C.POINTER(vp)]
+    L.artp_preprocessed_change.argtypes = [vp, vp, vp, C.c_float, vp, C.POINTER(i32 * 4), C.POINTER(u64)]
     L.artp_preprocessed_get_layer.argtypes = [vp, vp, C.c_char_p, vp]
     L.artp_preprocessed_install.argtypes = [vp, vp]
     L.artp_preprocessed_destroy.argtypes = [vp]

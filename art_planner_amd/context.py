@@ -205,19 +205,26 @@ class Context:
 
     # ---- device-side map preprocessing (N2) -----------------------------------------------------
     def preprocess_map(self, elevation, len_x, len_y, pos_x=0.0, pos_y=0.0, traversability=None, kind="yaml",
-                       **overrides):
-        """processors::Basic + estimateNormals + the CDF on the device; returns a PreprocessedMap."""
+                       observed=None, vertices=None, **overrides):
+        """The new-map processor chain (Basic, [inverse vertex density], base distribution, [unknown cap], CDF)
+        on the device; returns a PreprocessedMap."""
         p = _capi.PreprocessParams()
         (self.L.artp_preprocess_params_yaml if kind == "yaml" else self.L.artp_preprocess_params_defaults)(C.byref(p))
         for k, v in overrides.items():
             setattr(p, k, v)
         e = _f32F(elevation)
         t = _f32F(traversability) if traversability is not None else None
+        o = _f32F(observed) if observed is not None else None
+        vs = np.ascontiguousarray(vertices, np.float64).reshape(-1, 7) if vertices is not None else None
+        inp = _capi.PreprocessInputs(e.ctypes.data, t.ctypes.data if t is not None else None,
+                                     o.ctypes.data if o is not None else None,
+                                     vs.ctypes.data if vs is not None else None, 0 if vs is None else vs.shape[0],
+                                     e.shape[0], e.shape[1], len_x, len_y, pos_x, pos_y)
         h = C.c_void_p()
-        self._chk(self.L.artp_preprocess_map(self.h, e.ctypes.data, t.ctypes.data if t is not None else None,
-                                             e.shape[0], e.shape[1], len_x, len_y, pos_x, pos_y, C.byref(p),
-                                             C.byref(h)), "artp_preprocess_map")
-        return PreprocessedMap(self, h, e.shape)
+        self._chk(self.L.artp_preprocess_map_ex(self.h, C.byref(inp), C.byref(p), C.byref(h)), "artp_preprocess_map_ex")
+        pm = PreprocessedMap(self, h, e.shape)
+        pm.geom = (len_x, len_y, pos_x, pos_y)
+        return pm
 
     # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
     def cost_load_weights(self, blob: bytes):
@@ -270,6 +277,16 @@ class PreprocessedMap:
         self.ctx._chk(self.ctx.L.artp_preprocessed_get_layer(self.ctx.h, self.h, name.encode(), out.ctypes.data),
                       "artp_preprocessed_get_layer")
         return out if name == "cum_prob_rowwise" else out.reshape(self.shape[1], self.shape[0]).T
+
+    def change_from(self, old, height_change_for_update=0.05):
+        """computeChange against an older PreprocessedMap: (updated layer, (row0, col0, nrows, ncols), count)."""
+        upd = np.empty(self.shape[0] * self.shape[1], np.float32)
+        rect = (C.c_int * 4)()
+        cnt = C.c_uint64(0)
+        self.ctx._chk(self.ctx.L.artp_preprocessed_change(self.ctx.h, self.h, old.h, height_change_for_update,
+                                                          upd.ctypes.data, C.byref(rect), C.byref(cnt)),
+                      "artp_preprocessed_change")
+        return upd.reshape(self.shape[1], self.shape[0]).T, tuple(rect), cnt.value
 
     def install(self):
         self.ctx._chk(self.ctx.L.artp_preprocessed_install(self.ctx.h, self.h), "artp_preprocessed_install")

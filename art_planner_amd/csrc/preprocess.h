@@ -193,6 +193,124 @@ pre_fill_kernel(float* __restrict__ out, int n, float v) {
   if (t < n) out[t] = v;
 }
 
+// unknown_space_untraversable: traversability = observed > 0.5 ? traversability : 0   (basic.cpp:49-54)
+__global__ void __launch_bounds__(256)
+pre_unknown_untraversable_kernel(const float* __restrict__ observed, int n, float* __restrict__ trav) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n && !(observed[t] > 0.5f)) trav[t] = 0.0f;
+}
+
+// computeInverseSampleDensity (sample_density.cpp:12-43): roadmap vertices per cell ...
+__global__ void __launch_bounds__(256)
+vertex_histogram_kernel(const double* __restrict__ se3, size_t nv, PreGeom g, float* __restrict__ counts) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nv) return;
+  const double px = se3[7 * t + 0], py = se3[7 * t + 1];
+  // grid_map getIndex: inside test, then index = (int)(-((p - L/2 - c) / res))
+  const double tx = -((px - g.pos_x) - 0.5 * g.len_x), ty = -((py - g.pos_y) - 0.5 * g.len_y);
+  if (!(tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y)) return;
+  int i = (int)(tx / (double)g.res), j = (int)(ty / (double)g.res);
+  i = min(i, g.rows - 1);
+  j = min(j, g.cols - 1);
+  atomicAdd(&counts[i + (size_t)j * g.rows], 1.0f);
+}
+// ... blurred with cv::GaussianBlur's separable kernel (k taps, BORDER_REFLECT_101), one pass per axis
+template <bool ALONG_ROWS>
+__global__ void __launch_bounds__(256)
+gauss_pass_kernel(const float* __restrict__ in, int rows, int cols, const float* __restrict__ taps, int k,
+                  float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cols) return;
+  const int i = t % rows, j = t / rows;
+  const int r = k / 2, len = ALONG_ROWS ? rows : cols, at = ALONG_ROWS ? i : j;
+  float acc = 0.f;
+  for (int d = -r; d <= r; ++d) {
+    int p = at + d;
+    if (len == 1) p = 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;  // gfedcb|abcdefgh|gfedcba
+    acc += taps[d + r] * (ALONG_ROWS ? in[p + (size_t)j * rows] : in[i + (size_t)p * rows]);
+  }
+  out[t] = acc;
+}
+// max over a non-negative layer (float bits are monotone there)
+__global__ void __launch_bounds__(256)
+nonneg_max_kernel(const float* __restrict__ in, int n, unsigned* __restrict__ out_bits) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned v = (t < n) ? __float_as_uint(fmaxf(in[t], 0.0f)) : 0u;
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out_bits, v);
+}
+// sample_probability = max - blurred (if the blurred layer is not all zero), then * sample filter
+// (applyBaseSampleDistribution, probability_distribution.cpp:9-16)
+__global__ void __launch_bounds__(256)
+base_distribution_kernel(const float* __restrict__ blurred, const unsigned* __restrict__ max_bits,
+                         const float* __restrict__ filter, int n, float* __restrict__ prob) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float p = 1.0f;
+  if (blurred && *max_bits) p = __uint_as_float(*max_bits) - blurred[t];
+  prob[t] = p * filter[t];
+}
+// applyMaxUnknownProbability (probability_distribution.cpp:50-90): probability mass of the observed and of
+// the unobserved cells ...
+__global__ void __launch_bounds__(256)
+known_unknown_mass_kernel(const float* __restrict__ prob, const float* __restrict__ observed, int n,
+                          double* __restrict__ mass) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double known = 0.0, unknown = 0.0;
+  if (t < n) {
+    if (observed[t] > 0.0f) known = (double)prob[t];
+    else unknown = (double)prob[t];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    known += __shfl_xor(known, off, 64);
+    unknown += __shfl_xor(unknown, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (known != 0.0) atomicAdd(&mass[0], known);
+    if (unknown != 0.0) atomicAdd(&mass[1], unknown);
+  }
+}
+// ... and the rescaling that caps the unobserved share at max_prob
+__global__ void __launch_bounds__(256)
+cap_unknown_kernel(const float* __restrict__ observed, const double* __restrict__ mass, double max_prob, int n,
+                   float* __restrict__ prob) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double known = mass[0], unknown = mass[1];
+  const double base_unknown = unknown / (known + unknown);
+  if (known > 0 && unknown > 0 && base_unknown > max_prob) {
+    const float mult = (float)(observed[t] > 0.0f ? (1 - max_prob) / known : max_prob / unknown);
+    prob[t] = prob[t] * mult;
+  }
+}
+// computeChange (change.cpp:9-51) for two maps of equal size whose origins differ by (si, sj) cells:
+// updated = 1 unless the cell exists in both, its height moved by <= thres and it did not turn untraversable
+__global__ void __launch_bounds__(256)
+change_kernel(const float* __restrict__ elev_new, const float* __restrict__ trav_new,
+              const float* __restrict__ elev_old, const float* __restrict__ trav_old, int rows, int cols, int si,
+              int sj, float thres, float* __restrict__ updated, int* __restrict__ rect, unsigned long long* __restrict__ count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cols) return;
+  const int i = t % rows, j = t / rows;
+  const int io = i - si, jo = j - sj;
+  float u = 1.0f;
+  if (io >= 0 && jo >= 0 && io < rows && jo < cols) {
+    const size_t o = (size_t)io + (size_t)jo * rows;
+    const bool height_changed = fabsf(elev_new[t] - elev_old[o]) > thres;
+    const bool trav_changed = trav_old[o] - trav_new[t] > 0.5f;
+    if (!height_changed && !trav_changed) u = 0.0f;
+  }
+  updated[t] = u;
+  if (u != 0.0f) {
+    atomicMin(&rect[0], i);
+    atomicMin(&rect[1], j);
+    atomicMax(&rect[2], i);
+    atomicMax(&rect[3], j);
+    atomicAdd(count, 1ull);
+  }
+}
+
 }  // namespace artp
 
 // -------------------------------------------------------------------------------------------------------
@@ -200,13 +318,14 @@ namespace {
 
 enum PreLayer {
   PRE_ELEV = 0, PRE_TRAV, PRE_NX, PRE_NY, PRE_NZ, PRE_STD, PRE_TRAV_FILTER, PRE_SAFETY, PRE_MASKED, PRE_SAMPLE_PROB,
-  PRE_CUM_PROB, PRE_T0, PRE_T1, PRE_T2, PRE_T3, PRE_COUNT
+  PRE_CUM_PROB, PRE_OBSERVED, PRE_NSAMPLES, PRE_SAMPLE_FILTER, PRE_UPDATED, PRE_T0, PRE_T1, PRE_T2, PRE_T3, PRE_COUNT
 };
 
 const char* const kPreLayerNames[] = {"elevation", "traversability", "normal_x", "normal_y", "normal_z",
                                       "plane_fit_std_dev", "traversability_thresholded_no_safety",
                                       "traversability_thresholded", "elevation_masked", "sample_probability",
-                                      "cum_prob"};
+                                      "cum_prob", "observed", "n_samples", "traversability_sample_filter",
+                                      "updated"};
 
 }  // namespace
 
@@ -216,6 +335,8 @@ struct artp_preprocessed {
   float* buf = nullptr;          // PRE_COUNT layers + cum_prob_rowwise (rows) + 1 scalar
   float* layer(int k) const { return buf + (size_t)k * rows * cols; }
   float* rowwise() const { return buf + (size_t)PRE_COUNT * rows * cols; }
+  // scalars behind the row CDF: [0] total probability, [1] max of the blurred density (bits), [2..5] two doubles
+  float* scalars() const { return buf + ((((size_t)PRE_COUNT * rows * cols) + rows + 1) & ~(size_t)1); }
 };
 
 extern "C" {
@@ -225,6 +346,9 @@ void artp_preprocess_params_defaults(artp_preprocess_params* p) {
   std::memset(p, 0, sizeof(*p));
   p->traversability_thres = 0.5f;  // Params::planner.traversability_thres (params.h:24)
   // Params::planner.safety defaults are all zero (params.h:27-34): no morphology
+  p->use_inverse_vertex_density = 0;      // params.h:82-84
+  p->use_max_prob_unknown_samples = 0;
+  p->max_prob_unknown_samples = 0.1;
 }
 
 void artp_preprocess_params_yaml(artp_preprocess_params* p) {  // art_planner_ros/config/params.yaml
@@ -237,6 +361,9 @@ void artp_preprocess_params_yaml(artp_preprocess_params* p) {  // art_planner_ro
   p->foothold_margin_max_drop_search_radius = 0.16;
   p->foothold_margin_min_step = 0.3;
   p->foothold_size = 0.1;
+  p->use_inverse_vertex_density = 1;      // params.yaml:49-51
+  p->use_max_prob_unknown_samples = 1;
+  p->max_prob_unknown_samples = 0.1;
 }
 
 void artp_preprocessed_destroy(artp_preprocessed* pp) {
@@ -248,7 +375,28 @@ void artp_preprocessed_destroy(artp_preprocessed* pp) {
 int artp_preprocess_map(artp_ctx* c, const float* elevation, const float* traversability, int rows, int cols,
                         double len_x, double len_y, double pos_x, double pos_y, const artp_preprocess_params* prm,
                         artp_preprocessed** out) {
-  if (!c || !elevation || !prm || !out || rows < 2 || cols < 2) return ARTP_ERR_INVALID_ARG;
+  artp_preprocess_inputs in;
+  std::memset(&in, 0, sizeof(in));
+  in.elevation = elevation;
+  in.traversability = traversability;
+  in.rows = rows;
+  in.cols = cols;
+  in.len_x = len_x;
+  in.len_y = len_y;
+  in.pos_x = pos_x;
+  in.pos_y = pos_y;
+  return artp_preprocess_map_ex(c, &in, prm, out);
+}
+
+int artp_preprocess_map_ex(artp_ctx* c, const artp_preprocess_inputs* in, const artp_preprocess_params* prm,
+                           artp_preprocessed** out) {
+  if (!c || !in || !in->elevation || !prm || !out || in->rows < 2 || in->cols < 2 ||
+      (in->n_vertices && !in->vertex_se3))
+    return ARTP_ERR_INVALID_ARG;
+  const float* elevation = in->elevation;
+  const float* traversability = in->traversability;
+  const int rows = in->rows, cols = in->cols;
+  const double len_x = in->len_x, len_y = in->len_y, pos_x = in->pos_x, pos_y = in->pos_y;
   *out = nullptr;
   std::unique_lock<std::mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -260,7 +408,7 @@ int artp_preprocess_map(artp_ctx* c, const float* elevation, const float* traver
   pp->len_y = len_y;
   pp->pos_x = pos_x;
   pp->pos_y = pos_y;
-  if (hipMalloc(reinterpret_cast<void**>(&pp->buf), ((size_t)PRE_COUNT * n + rows + 4) * sizeof(float)) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void**>(&pp->buf), ((size_t)PRE_COUNT * n + rows + 2 + 16) * sizeof(float)) != hipSuccess) {
     delete pp;
     c->last_error = "hipMalloc failed in artp_preprocess_map";
     return ARTP_ERR_HIP;
@@ -274,6 +422,15 @@ int artp_preprocess_map(artp_ctx* c, const float* elevation, const float* traver
     ok = ok && hipMemcpyAsync(L(PRE_TRAV), traversability, (size_t)n * 4, hipMemcpyHostToDevice, st) == hipSuccess;
   else
     hipLaunchKernelGGL(artp::pre_fill_kernel, grid, blk, 0, st, L(PRE_TRAV), n, 1.0f);  // checkTraversability
+
+  // addKnownCells (basic.cpp:26-38): "observed" = the cells that were valid before inpainting
+  if (in->observed)
+    ok = ok && hipMemcpyAsync(L(PRE_OBSERVED), in->observed, (size_t)n * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  else
+    hipLaunchKernelGGL(artp::pre_fill_kernel, grid, blk, 0, st, L(PRE_OBSERVED), n, 1.0f);
+  if (c->params.unknown_space_untraversable)
+    hipLaunchKernelGGL(artp::pre_unknown_untraversable_kernel, grid, blk, 0, st, (const float*)L(PRE_OBSERVED), n,
+                       L(PRE_TRAV));
 
   // estimateNormals(map, (torso.length + torso.width) * 0.25)      basic.cpp:47
   {
@@ -320,16 +477,67 @@ int artp_preprocess_map(artp_ctx* c, const float* elevation, const float* traver
                                      (c->params.torso_width - c->params.reach_y) * 0.5);
     dilate(L(PRE_SAFETY), (int)(total_reach / res), L(PRE_T0));
     erode(L(PRE_T0), (int)(total_reach / res), L(PRE_T1));
-    erode(L(PRE_T1), (int)(min_wall / res), L(PRE_SAMPLE_PROB));  // applyBaseSampleDistribution: 1 * filter
+    erode(L(PRE_T1), (int)(min_wall / res), L(PRE_SAMPLE_FILTER));
+  }
+  // the sampling distribution (planner.cpp:43-56): [inverse vertex density] * sample filter [capped unknown share]
+  const artp::PreGeom geom{rows, cols, (float)res, pos_x, pos_y, len_x, len_y};
+  double* d_verts = nullptr;
+  float* d_taps = nullptr;
+  unsigned* max_bits = reinterpret_cast<unsigned*>(pp->scalars() + 1);
+  double* mass = reinterpret_cast<double*>(pp->scalars() + 2);  // 8-byte aligned (even offset, see scalars())
+  ok = ok && hipMemsetAsync(pp->scalars(), 0, 8 * sizeof(float), st) == hipSuccess;
+  const bool density = prm->use_inverse_vertex_density && in->n_vertices > 0;
+  if (density) {
+    const double blur_radius = (c->params.torso_length + c->params.torso_width) * 0.25;  // planner.cpp:48
+    int k = (int)(6 * blur_radius / res);
+    const double sigma = blur_radius / res;
+    if (k % 2 == 0) k += 1;
+    // cv::getGaussianKernel: t_i = exp(-(i - (k-1)/2)^2 / (2 sigma^2)) as float, normalised by their sum
+    std::vector<float> taps(k);
+    double sum = 0.0;
+    for (int i = 0; i < k; ++i) {
+      const double x = i - (k - 1) * 0.5;
+      taps[i] = (float)std::exp(-0.5 / (sigma * sigma) * x * x);
+      sum += taps[i];
+    }
+    for (int i = 0; i < k; ++i) taps[i] = (float)(taps[i] * (1.0 / sum));
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&d_verts), in->n_vertices * 7 * sizeof(double)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&d_taps), k * sizeof(float)) == hipSuccess &&
+         hipMemcpyAsync(d_verts, in->vertex_se3, in->n_vertices * 7 * sizeof(double), hipMemcpyHostToDevice, st) ==
+             hipSuccess &&
+         hipMemcpyAsync(d_taps, taps.data(), k * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipMemsetAsync(L(PRE_T0), 0, (size_t)n * 4, st) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(artp::vertex_histogram_kernel, dim3((unsigned)((in->n_vertices + 255) / 256)), blk, 0, st,
+                         (const double*)d_verts, in->n_vertices, geom, L(PRE_T0));
+      hipLaunchKernelGGL(artp::gauss_pass_kernel<true>, grid, blk, 0, st, (const float*)L(PRE_T0), rows, cols,
+                         (const float*)d_taps, k, L(PRE_T1));
+      hipLaunchKernelGGL(artp::gauss_pass_kernel<false>, grid, blk, 0, st, (const float*)L(PRE_T1), rows, cols,
+                         (const float*)d_taps, k, L(PRE_NSAMPLES));
+      hipLaunchKernelGGL(artp::nonneg_max_kernel, grid, blk, 0, st, (const float*)L(PRE_NSAMPLES), n, max_bits);
+    }
+  } else {
+    ok = ok && hipMemsetAsync(L(PRE_NSAMPLES), 0, (size_t)n * 4, st) == hipSuccess;
+  }
+  hipLaunchKernelGGL(artp::base_distribution_kernel, grid, blk, 0, st,
+                     density ? (const float*)L(PRE_NSAMPLES) : (const float*)nullptr, (const unsigned*)max_bits,
+                     (const float*)L(PRE_SAMPLE_FILTER), n, L(PRE_SAMPLE_PROB));
+  if (prm->use_max_prob_unknown_samples) {
+    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, grid, blk, 0, st, (const float*)L(PRE_SAMPLE_PROB),
+                       (const float*)L(PRE_OBSERVED), n, mass);
+    hipLaunchKernelGGL(artp::cap_unknown_kernel, grid, blk, 0, st, (const float*)L(PRE_OBSERVED), (const double*)mass,
+                       prm->max_prob_unknown_samples, n, L(PRE_SAMPLE_PROB));
   }
   // computeCumulativeProbabilityDistribution                       probability_distribution.cpp:20-46
   float* row_sum = L(PRE_T0);
-  float* total = pp->rowwise() + rows;
+  float* total = pp->scalars();
   hipLaunchKernelGGL(artp::cdf_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st,
                      (const float*)L(PRE_SAMPLE_PROB), rows, cols, L(PRE_CUM_PROB), row_sum);
   hipLaunchKernelGGL(artp::cdf_rowwise_kernel, dim3(1), dim3(1), 0, st, (const float*)row_sum, rows, pp->rowwise(),
                      total);
   ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  if (d_verts) (void)hipFree(d_verts);
+  if (d_taps) (void)hipFree(d_taps);
   if (!ok) {
     c->last_error = "device preprocessing failed";
     lock.unlock();
@@ -357,6 +565,47 @@ int artp_preprocessed_get_layer(artp_ctx* c, const artp_preprocessed* pp, const 
   return ARTP_ERR_INVALID_ARG;
 }
 
+// computeChange (change.cpp:9-51, the "updated" layer of LazyPRMStarMinUpdate's maintenance) between two
+// preprocessed maps of the same size and resolution; rect = {row0, col0, nrows, ncols} of the updated cells
+// in the NEW map (nrows = 0 when nothing changed) -- what artp_update_layer_rect / a roadmap re-check need.
+int artp_preprocessed_change(artp_ctx* c, artp_preprocessed* map_new, const artp_preprocessed* map_old,
+                             float height_change_for_update, float* updated_out, int rect[4], uint64_t* n_updated) {
+  if (!c || !map_new || !map_old || map_new->rows != map_old->rows || map_new->cols != map_old->cols)
+    return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int rows = map_new->rows, cols = map_new->cols, n = rows * cols;
+  const double res = map_new->len_x / rows;
+  // cell (i, j) of the new map lies over cell (i - si, j - sj) of the old one
+  const int si = (int)std::lround((map_new->pos_x - map_old->pos_x) / res);
+  const int sj = (int)std::lround((map_new->pos_y - map_old->pos_y) / res);
+  int* d_rect = reinterpret_cast<int*>(map_new->scalars() + 8);
+  unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(map_new->scalars() + 12);
+  const int init[4] = {0x7fffffff, 0x7fffffff, -1, -1};
+  HIP_TRY(c, hipMemcpyAsync(d_rect, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
+  hipLaunchKernelGGL(artp::change_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     (const float*)map_new->layer(PRE_ELEV), (const float*)map_new->layer(PRE_SAFETY),
+                     (const float*)map_old->layer(PRE_ELEV), (const float*)map_old->layer(PRE_SAFETY), rows, cols, si, sj,
+                     height_change_for_update, map_new->layer(PRE_UPDATED), d_rect, d_cnt);
+  HIP_TRY(c, hipGetLastError());
+  int r[4];
+  unsigned long long cnt = 0;
+  HIP_TRY(c, hipMemcpyAsync(r, d_rect, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+  if (updated_out)
+    HIP_TRY(c, hipMemcpyAsync(updated_out, map_new->layer(PRE_UPDATED), (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (rect) {
+    rect[0] = cnt ? r[0] : 0;
+    rect[1] = cnt ? r[1] : 0;
+    rect[2] = cnt ? r[2] - r[0] + 1 : 0;
+    rect[3] = cnt ? r[3] - r[1] + 1 : 0;
+  }
+  if (n_updated) *n_updated = cnt;
+  return ARTP_OK;
+}
+
 // Planner::setMap (planner.cpp:135-163): make the preprocessed layers the context's current map -- both
 // height fields (with their range / partner tables), the sampler layers and the z bounds.
 int artp_preprocessed_install(artp_ctx* c, const artp_preprocessed* pp) {
@@ -366,7 +615,7 @@ int artp_preprocessed_install(artp_ctx* c, const artp_preprocessed* pp) {
   {
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpy(&total, pp->rowwise() + pp->rows, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&total, pp->scalars(), 4, hipMemcpyDeviceToHost));
   }
   if (!(total > 0.f)) {
     c->last_error = "sample_probability is zero everywhere: nothing can be sampled on this map";

@@ -243,7 +243,19 @@ typedef struct artp_preprocess_params {
   double foothold_margin_max_drop_search_radius;
   double foothold_margin_min_step;
   double foothold_size;
+  int use_inverse_vertex_density;                /* Params::sampler.* (params.h:82-84, planner.cpp:43-55) */
+  int use_max_prob_unknown_samples;
+  double max_prob_unknown_samples;
 } artp_preprocess_params;
+typedef struct artp_preprocess_inputs { /* column-major rows x cols float layers on the host */
+  const float* elevation;       /* required */
+  const float* traversability;  /* NULL = all 1 (Basic::checkTraversability, basic.cpp:13-22) */
+  const float* observed;        /* NULL = all 1; Basic::addKnownCells (basic.cpp:26-38): cells valid before inpainting */
+  const double* vertex_se3;     /* roadmap vertices (n_vertices x 7) for computeInverseSampleDensity; may be NULL */
+  size_t n_vertices;
+  int rows, cols;
+  double len_x, len_y, pos_x, pos_y;
+} artp_preprocess_inputs;
 void artp_preprocess_params_defaults(artp_preprocess_params* p); /* params.h defaults */
 void artp_preprocess_params_yaml(artp_preprocess_params* p);     /* art_planner_ros/config/params.yaml */
 /* elevation: required; traversability: NULL = all 1 (Basic::checkTraversability, basic.cpp:13-22).
@@ -251,9 +263,20 @@ void artp_preprocess_params_yaml(artp_preprocess_params* p);     /* art_planner_
 int artp_preprocess_map(artp_ctx* ctx, const float* elevation, const float* traversability, int rows, int cols,
                         double len_x, double len_y, double pos_x, double pos_y,
                         const artp_preprocess_params* params, artp_preprocessed** out);
+/* The whole new-map chain of Planner::setUpMapProcessors (planner.cpp:39-58): Basic, then -- when the params ask
+ * for it -- computeInverseSampleDensity (sample_density.cpp:12-43: vertices per cell, cv::GaussianBlur of radius
+ * (torso.length + torso.width) / 4, probability = max - blurred), applyBaseSampleDistribution,
+ * applyMaxUnknownProbability (probability_distribution.cpp:50-90) and the CDF. */
+int artp_preprocess_map_ex(artp_ctx* ctx, const artp_preprocess_inputs* in, const artp_preprocess_params* params,
+                           artp_preprocessed** out);
+/* The old-map chain: computeChange (processors/change.cpp:9-51) between two results of the same size (their
+ * origins may differ by whole cells).  updated_out (rows x cols, may be NULL) receives the "updated" layer,
+ * rect = {row0, col0, nrows, ncols} bounds the updated cells of the new map (nrows = 0: none). */
+int artp_preprocessed_change(artp_ctx* ctx, artp_preprocessed* map_new, const artp_preprocessed* map_old,
+                             float height_change_for_update, float* updated_out, int rect[4], uint64_t* n_updated);
 /* name: elevation, traversability, normal_x/_y/_z, plane_fit_std_dev, traversability_thresholded_no_safety,
- * traversability_thresholded, elevation_masked, sample_probability, cum_prob (rows x cols floats each) or
- * cum_prob_rowwise (rows floats). */
+ * traversability_thresholded, elevation_masked, sample_probability, cum_prob, observed, n_samples (the blurred
+ * vertex density), traversability_sample_filter, updated (rows x cols floats each) or cum_prob_rowwise (rows). */
 int artp_preprocessed_get_layer(artp_ctx* ctx, const artp_preprocessed* pp, const char* name, float* out);
 /* Planner::setMap (planner.cpp:135-163): make the result the context's map -- both height fields with
  * their tables, the sampler layers and the z bounds. */

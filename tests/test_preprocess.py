@@ -59,3 +59,131 @@ def test_install_equals_host_upload():
     pp.close()
     a.close()
     b.close()
+
+
+def _gauss_taps(k, sigma):
+    """cv::getGaussianKernel: float taps exp(-x^2 / (2 sigma^2)), normalised by their (double) sum."""
+    x = np.arange(k) - (k - 1) * 0.5
+    t = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)
+    return (t * (1.0 / t.astype(np.float64).sum())).astype(np.float32)
+
+
+def _blur_reflect101(a, taps):
+    r = len(taps) // 2
+    out = a.astype(np.float32)
+    for axis in (0, 1):
+        p = np.pad(out, [(r, r) if ax == axis else (0, 0) for ax in (0, 1)], mode="reflect")  # gfedcb|abc...
+        acc = np.zeros_like(out)
+        for d in range(len(taps)):
+            sl = [slice(None), slice(None)]
+            sl[axis] = slice(d, d + out.shape[axis])
+            acc = acc + taps[d] * p[tuple(sl)]
+        out = acc.astype(np.float32)
+    return out
+
+
+def test_sampling_distribution_processors():
+    """The rest of Planner::setUpMapProcessors' new-map chain (planner.cpp:43-56): inverse vertex density
+    (sample_density.cpp:12-43), base distribution, capped unknown share (probability_distribution.cpp:50-90),
+    CDF -- against a numpy restatement; and unknown_space_untraversable through the "observed" layer."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map, cumulative_distribution
+    gm = make_map(160, 0.05, seed=12)
+    ctx = Context(0, "yaml")
+    rng = np.random.default_rng(4)
+    observed = np.ones((gm.rows, gm.cols), np.float32)
+    observed[:, :40] = 0.0                      # a strip the sensors never saw
+    verts = np.zeros((3000, 7))
+    verts[:, 0] = gm.pos_x + rng.uniform(-0.6, 0.6, 3000) * gm.len_x   # some fall outside the map
+    verts[:, 1] = gm.pos_y + rng.normal(0, 0.12, 3000) * gm.len_y
+    verts[:, 6] = 1.0
+    plain = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
+                               traversability=gm["traversability"], use_inverse_vertex_density=0,
+                               use_max_prob_unknown_samples=0)
+    sf = plain.layer("traversability_sample_filter")
+    assert np.array_equal(sf, plain.layer("sample_probability"))        # 1 * filter
+    # with everything on; unknown space stays traversable here so that it keeps some probability mass
+    prm = ctx.params
+    ctx2 = Context(0, __import__("art_planner_amd.context", fromlist=["make_params"]).make_params(
+        "yaml", unknown_space_untraversable=0))
+    pp = ctx2.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
+                             traversability=gm["traversability"], observed=observed, vertices=verts,
+                             max_prob_unknown_samples=0.05)
+    # --- restatement
+    res = gm.res
+    tx = -((verts[:, 0] - gm.pos_x) - 0.5 * gm.len_x)
+    ty = -((verts[:, 1] - gm.pos_y) - 0.5 * gm.len_y)
+    ins = (tx >= 0) & (ty >= 0) & (tx < gm.len_x) & (ty < gm.len_y)
+    cnt = np.zeros((gm.rows, gm.cols), np.float32)
+    np.add.at(cnt, ((tx[ins] / np.float32(res).astype(np.float64)).astype(int).clip(0, gm.rows - 1),
+                    (ty[ins] / np.float32(res).astype(np.float64)).astype(int).clip(0, gm.cols - 1)), 1.0)
+    radius = (prm.torso_length + prm.torso_width) * 0.25
+    k = int(6 * radius / res)
+    k += 1 if k % 2 == 0 else 0
+    blurred = _blur_reflect101(cnt, _gauss_taps(k, radius / res))
+    got_blur = pp.layer("n_samples")
+    assert np.abs(got_blur - blurred).max() < 1e-5 * max(1.0, blurred.max())
+    prob = (np.float32(got_blur.max()) - got_blur) * sf
+    known, unknown = prob[observed > 0].astype(np.float64).sum(), prob[observed <= 0].astype(np.float64).sum()
+    assert unknown / (known + unknown) > 0.05                            # the cap really acts
+    mult = np.where(observed > 0, (1 - 0.05) / known, 0.05 / unknown).astype(np.float32)
+    expect = prob * mult
+    got = pp.layer("sample_probability")
+    assert np.abs(got - expect).max() <= 2e-6 * expect.max()
+    assert abs(got[observed <= 0].astype(np.float64).sum() / got.astype(np.float64).sum() - 0.05) < 1e-5
+    cp, cr = cumulative_distribution(got)
+    with np.errstate(invalid="ignore"):
+        assert np.nanmax(np.abs(pp.layer("cum_prob") - cp)) < 1e-5
+    assert np.abs(pp.layer("cum_prob_rowwise") - cr).max() < 1e-5
+    # unknown_space_untraversable (the default): unobserved cells lose their traversability
+    pu = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
+                            traversability=gm["traversability"], observed=observed)
+    assert (pu.layer("traversability_thresholded_no_safety")[:, :40] == 0).all()
+    assert np.isneginf(pu.layer("elevation_masked")[:, :35]).all()
+    for m in (plain, pp, pu):
+        m.close()
+    ctx.close()
+    ctx2.close()
+
+
+def test_change_detection_between_maps():
+    """computeChange (change.cpp:9-51): the 'updated' layer between an old and a new map, also when the new
+    map's origin moved by whole cells; the rectangle bounds the updated cells."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(160, 0.05, seed=12)
+    ctx = Context(0, "yaml")
+    old = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y, traversability=gm["traversability"])
+    e2 = gm["elevation"].copy()
+    e2[30:50, 70:95] += np.float32(0.2)           # a changed block
+    t2 = gm["traversability"].copy()
+    t2[100:110, 20:30] = 0.0                       # a patch that turned untraversable
+    new = ctx.preprocess_map(e2, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y, traversability=t2)
+    upd, rect, cnt = new.change_from(old, 0.05)
+    safety_old, safety_new = old.layer("traversability_thresholded"), new.layer("traversability_thresholded")
+    expect = ((np.abs(e2 - gm["elevation"]) > np.float32(0.05)) | ((safety_old - safety_new) > 0.5)).astype(np.float32)
+    assert np.array_equal(upd, expect) and cnt == int(expect.sum())
+    ii, jj = np.nonzero(expect)
+    assert rect == (ii.min(), jj.min(), ii.max() - ii.min() + 1, jj.max() - jj.min() + 1)
+    assert expect[30:50, 70:95].all() and expect[100:110, 20:30].any()
+    same_upd, same_rect, same_cnt = old.change_from(old, 0.05)
+    assert same_cnt == 0 and same_rect[2] == 0 and not same_upd.any()
+    # the map followed the robot: origin shifted by (+3, -2) cells; cells without an old counterpart are "updated"
+    sh = ctx.preprocess_map(e2, gm.len_x, gm.len_y, gm.pos_x + 3 * gm.res, gm.pos_y - 2 * gm.res, traversability=t2)
+    upd2, _, _ = sh.change_from(old, 0.05)
+    exp2 = np.ones_like(expect)
+    ss_old = safety_old
+    ss_new = sh.layer("traversability_thresholded")
+    for i in range(gm.rows):
+        io = i - 3
+        if not 0 <= io < gm.rows:
+            continue
+        for j in range(gm.cols):
+            jo = j + 2
+            if 0 <= jo < gm.cols:
+                ch = abs(e2[i, j] - gm["elevation"][io, jo]) > np.float32(0.05) or (ss_old[io, jo] - ss_new[i, j]) > 0.5
+                exp2[i, j] = 1.0 if ch else 0.0
+    assert np.array_equal(upd2, exp2)
+    for m in (old, new, sh):
+        m.close()
+    ctx.close()
