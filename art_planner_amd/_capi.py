@@ -27,7 +27,7 @@ SYMBOLS = [
     "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
     "artp_preprocess_map_ex", "artp_preprocessed_change",
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
-    "artp_cost_blob_bytes", "artp_cost_load_weights",
+    "artp_cost_blob_bytes", "artp_cost_load_weights", "artp_cost_update_map_layer",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
 
@@ -148,6 +148,7 @@ def load():
     L.artp_cost_blob_bytes.restype = sz
     L.artp_cost_load_weights.argtypes = [vp, vp, sz]
     L.artp_cost_update_map.argtypes = [vp, vp, i32, i32, dbl, dbl, dbl, dbl, dbl]
+    L.artp_cost_update_map_layer.argtypes = [vp, vp, i32, i32, dbl, dbl, dbl, dbl, dbl]
     L.artp_cost_query.argtypes = [vp, vp, sz, vp]
     L.artp_cost_query_dev.argtypes = [vp, vp, sz, vp]
     L.artp_cost_get_features.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32)]

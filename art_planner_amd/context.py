@@ -236,6 +236,12 @@ class Context:
         self._chk(self.L.artp_cost_update_map(self.h, a.ctypes.data, a.shape[0], a.shape[1], res, len_x, len_y,
                                               cx, cy), "artp_cost_update_map")
 
+    def cost_update_map_layer(self, layer, res, len_x, len_y, pos_x=0.0, pos_y=0.0):
+        """From the planner's grid_map layer (the cost server's re-indexing is applied inside)."""
+        a = _f32F(layer)
+        self._chk(self.L.artp_cost_update_map_layer(self.h, a.ctypes.data, a.shape[0], a.shape[1], res, len_x, len_y,
+                                                    pos_x, pos_y), "artp_cost_update_map_layer")
+
     def cost_query(self, edges):
         e = np.ascontiguousarray(edges, np.float32).reshape(-1, 6)
         out = np.empty((e.shape[0], 3), np.float32)

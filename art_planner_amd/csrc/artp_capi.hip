@@ -1324,6 +1324,26 @@ int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, 
   return ARTP_OK;
 }
 
+// cost_query_server.py:46-74 receives the planner's grid_map layer and stores it as
+// np.rot90(layer_as_sent, 2).transpose(); for the Eigen matrix layer(i, j) (column-major) that is the array
+// a[r][c] = layer(rows-1-r, cols-1-c): index r grows along world x, c along world y.
+int artp_cost_update_map_layer(artp_ctx* c, const float* layer, int rows, int cols, double res, double len_x,
+                               double len_y, double pos_x, double pos_y) {
+  if (!c || !layer || rows < 1 || cols < 1) return ARTP_ERR_INVALID_ARG;
+  std::vector<float> a((size_t)rows * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < cols; ++k) {
+      const float v = layer[(size_t)(rows - 1 - r) + (size_t)(cols - 1 - k) * rows];
+      if (!std::isfinite(v)) {
+        // the server inpaints holes with cv.inpaint (cost_query_server.py:90-111); that stays with the caller
+        c->last_error = "elevation layer has holes (NaN / inf): inpaint before artp_cost_update_map_layer";
+        return ARTP_ERR_INVALID_ARG;
+      }
+      a[(size_t)r * cols + k] = v;
+    }
+  return artp_cost_update_map(c, a.data(), rows, cols, res, len_x, len_y, pos_x, pos_y);
+}
+
 int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) {
   if (!c || (b && (!edges || !cost))) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(c->mu);

@@ -299,6 +299,11 @@ int artp_cost_load_weights(artp_ctx* ctx, const void* blob, size_t bytes);
  * along world y (cost_query_server.py:66-74), holes already inpainted; (cx, cy) = map centre. */
 int artp_cost_update_map(artp_ctx* ctx, const float* elev_xy, int rows, int cols, double res, double len_x,
                          double len_y, double cx, double cy);
+/* The same from the planner's grid_map elevation layer (column-major rows x cols, as PlannerRos publishes it
+ * to the cost node): applies the server's rot90(.., 2).transpose() re-indexing (cost_query_server.py:66-74).
+ * Holes (NaN / inf) are an error: the server's cv.inpaint (cost_query_server.py:90-111) stays with the caller. */
+int artp_cost_update_map_layer(artp_ctx* ctx, const float* layer, int rows, int cols, double res, double len_x,
+                               double len_y, double pos_x, double pos_y);
 /* MotionCostFunc: edges [B][6] = target x y yaw, start x y yaw (prm_motion_cost.cpp:41-52);
  * cost [B][3] = energy, time, risk (= 1 - prob; cost_query.py:65-69). */
 int artp_cost_query(artp_ctx* ctx, const float* edges, size_t b, float* cost);

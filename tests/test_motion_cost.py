@@ -88,3 +88,29 @@ def test_gpu_cost_full_map_properties(big_map):
     co = mo.fc_costs(p, np.transpose(f, (2, 0, 1)), e[:4096], big_map.res, big_map.len_x, big_map.len_y)
     assert np.abs(c1[:4096] - co).max() < 1e-3
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_cost_map_from_gridmap_layer_matches_server_layout(big_map):
+    """N3: the cost node receives the planner's grid_map layer and re-indexes it with
+    np.rot90(.., 2).transpose() (cost_query_server.py:66-74); artp_cost_update_map_layer must give the same
+    features as handing over the re-indexed array, and refuse a layer with holes."""
+    from art_planner_amd._capi import ArtpError
+    from art_planner_amd.context import Context
+    a, b = Context(0, "yaml"), Context(0, "yaml")
+    blob = convert_weights.to_blob(mo.random_params(0))
+    a.cost_load_weights(blob)
+    b.cost_load_weights(blob)
+    layer = big_map["elevation"]
+    # what the server computes from the message: data = column-major layer, dims (cols, rows)
+    sent = np.asarray(layer, np.float32).flatten(order="F")
+    server = np.rot90(sent.reshape((layer.shape[1], layer.shape[0])), 2).transpose()
+    a.cost_update_map(np.ascontiguousarray(server), big_map.res, big_map.len_x, big_map.len_y)
+    b.cost_update_map_layer(layer, big_map.res, big_map.len_x, big_map.len_y)
+    assert np.array_equal(a.cost_features(), b.cost_features())
+    holes = layer.copy()
+    holes[5, 7] = np.nan
+    with pytest.raises(ArtpError):
+        b.cost_update_map_layer(holes, big_map.res, big_map.len_x, big_map.len_y)
+    a.close()
+    b.close()
