@@ -426,6 +426,20 @@ def main():
         c4 = {"states_per_s": S / (ms4 * 1e-3), "ms_per_batch": ms4, "valid_frac": float(valid.float().mean().item()),
               "map": "800x800@0.04", "robot": "Params defaults"}
         ctx4.close()
+        # secondary robot of SURVEY.md 8d on the C2 map
+        gm2d = make_map(args.map, args.res, seed=1234, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
+        ctx2d = Context(local_rank, "defaults")
+        ctx2d.upload_map(gm2d)
+        ctx2d.use_torch_stream()
+        ctx2d.sample_and_validate_dev(seed, 0, S, se3, valid)
+        ev0.record()
+        for i4 in range(3):
+            ctx2d.sample_and_validate_dev(seed, (i4 + 1) * S, S, se3, valid)
+        ev1.record()
+        torch.cuda.synchronize()
+        c4["c2_map_defaults_robot"] = {"states_per_s": S / (ev0.elapsed_time(ev1) / 3 * 1e-3),
+                                       "valid_frac": float(valid.float().mean().item())}
+        ctx2d.close()
         ctx.use_torch_stream()
     except Exception as ex:  # pragma: no cover
         c4 = {"error": repr(ex)}
