@@ -338,7 +338,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
   {
     const size_t lds = (size_t)CandCap<16>::value * 36 * 4 * ARTP_STREAM_WAVES;
-    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3((unsigned)c->n_cus * 4), dim3(64 * ARTP_STREAM_WAVES), lds,
+    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3((unsigned)c->n_cus * 5), dim3(64 * ARTP_STREAM_WAVES), lds,
                        c->stream, c->field[1], c->robot, q, valid);
   }
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,

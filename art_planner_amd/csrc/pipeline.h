@@ -569,8 +569,9 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
 // NaN or is thinner than the smallest table block): (f) streamed from the map, then the list-free corner
 // stage.  Decides everything except boxes whose corner candidates may have partners (-> queue 5, list
 // pass).  Records without table verdict go to queue 4 (sequential lane scan with the running-dMAX quirk).
+// 5 wavefronts per SIMD (96 VGPRs, 5 of them spilled) beat 4 at 100 VGPRs by 4 %; 6 (24 spills) lose 20 %
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, GPW = 4;
