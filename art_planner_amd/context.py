@@ -189,7 +189,8 @@ class Context:
         out = (C.c_uint64 * 8)()
         self._chk(self.L.artp_debug_pipeline_counters(self.h, C.byref(out)), "artp_debug_pipeline_counters")
         return {"torso_queued": out[0], "feet_queued": out[4], "exact_grouping": out[1], "feet_plane_stage": out[5],
-                "feet_partner_pass": out[6]}
+                "feet_partner_pass": out[6],
+                "torso_staged_pass": out[2]}
 
     def partner_table(self, slot, shape):
         """(flags[nD, nW] uint8 in ODE sample layout, radius) of a layer's partner table; (None, 0) if

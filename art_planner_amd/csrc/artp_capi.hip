@@ -203,7 +203,7 @@ int set_kernel_lds(artp_ctx* c) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(plane_stage_kernel<1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>),
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 3>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet(c)));
@@ -321,7 +321,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   }
   int rc = ensure_tmp(c, 4, 5 * n * sizeof(PendingBox));
   if (rc) return rc;
-  rc = ensure_tmp(c, 5, (5 + 4 + 4 + 4) * n * sizeof(unsigned) + 64);
+  rc = ensure_tmp(c, 5, (5 + 4 + 4 + 4 + 1) * n * sizeof(unsigned) + 64);
   if (rc) return rc;
   PipelineQueues q;
   q.q1 = static_cast<PendingBox*>(c->tmp[4]);
@@ -330,6 +330,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   q.q3 = q.q2 + 5 * n;
   q.q5 = q.q3 + 4 * n;
   q.q4 = q.q5 + 4 * n;
+  q.q6 = q.q4 + 4 * n;
   q.feet_base = n;
   HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
   const size_t per_block = 64 * ARTP_CLASSIFY_SUB;
@@ -343,7 +344,15 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   }
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);
-  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_scan(c, lds_scan(c))),
+  {
+    // streaming pass: only the corner-candidate scratch; the staged pass behind it takes the rest
+    const ScratchCaps caps_stream{64 * 36, 0, 0, 0};
+    const size_t lds_stream = (size_t)64 * 36 * ARTP_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3((unsigned)c->n_cus * 10),
+                       dim3(64 * ARTP_WAVES_PER_BLOCK), lds_stream, c->stream, c->field[0], c->robot, q, valid,
+                       caps_stream, c->d_error);
+  }
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 3>), dim3(grid_scan(c, lds_scan(c))),
                      dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->robot, q, valid,
                      c->caps_scan, c->d_error);
   hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>), dim3(grid_scan(c, lds_feet(c))),

@@ -236,7 +236,8 @@ struct PipelineQueues {
   unsigned* q3;                  // indices into q1 of foot boxes that survive the lane scan stage
   unsigned* q4;                  // foot boxes whose exits the tables could not evaluate (lane-scan path)
   unsigned* q5;                  // foot boxes whose corner candidates may have partners (list pass)
-  unsigned long long* counters;  // [0] torso, [1] q2, [4] feet, [5] q3, [6] q5, [7] q4 counts
+  unsigned* q6;                  // torso boxes the streaming pass cannot finish (staged pass)
+  unsigned long long* counters;  // [0] torso, [1] q2, [2] q6, [4] feet, [5] q3, [6] q5, [7] q4 counts
   unsigned long long feet_base;  // = n
 };
 
@@ -621,8 +622,10 @@ __device__ unsigned long long g_stage_cycles[2][10];
 // ---- stage 2: one lane group per undecided box ---------------------------------------------------------
 // G = 64: torso queue, one wavefront per box.  G = 16: foot queue, four boxes per wavefront.
 // Static striding over the queue (a shared work cursor would serialise on one atomic word).
-// PASS 0: torso queue.  PASS 1: foot queue 3, fast -- no kept-triangle list; boxes whose corner candidates
-// might have a partner (partner table) go to queue 5.  PASS 2: queue 5 with the list and the partner search.
+// PASS 0: torso queue, streaming only; what it cannot finish goes to queue 6.  PASS 3: queue 6, the staged
+// torso path (LDS tile, exits, (f), list, partner search).  PASS 1: foot queue 3 (boxes without a table
+// verdict, after the lane scan), fast -- no kept-triangle list; boxes whose corner candidates might have a
+// partner go to queue 5.  PASS 2: queue 5 with the list and the partner search.
 template <int WAVES, int G, int PASS>
 __global__ void __launch_bounds__(64 * WAVES)
 resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
@@ -634,7 +637,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
   const bool feet = (G != 64);  // feet: only the boxes the lane-per-box stages handed over (queue 3)
-  const unsigned long long count = q.counters[PASS == 0 ? 0 : (PASS == 1 ? 5 : 6)];
+  const unsigned long long count = q.counters[PASS == 0 ? 0 : (PASS == 1 ? 5 : (PASS == 2 ? 6 : 2))];
   const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
 #ifdef ARTP_STAGE_TIMING
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -642,7 +645,8 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
 #endif
   for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
        it += stride) {
-    const unsigned long long item = PASS == 0 ? it : (unsigned long long)(PASS == 1 ? q.q3[it] : q.q5[it]);
+    const unsigned long long item =
+        PASS == 0 ? it : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : q.q6[it]));
 #ifdef ARTP_STAGE_TIMING
     long long t_prev = clock64();
 #endif
@@ -650,30 +654,41 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
     if (valid[rec.state] == 0) continue;        // another box of this state already failed
     BoxHF b;
     box_from_record(rec, rb, b);
-    const int total = (b.maxX - b.minX + 1) * (b.maxZ - b.minZ + 1);
-    if (total > s.cap_verts) {
-      if (gl == 0) atomicExch(error_flag, 1);
-      continue;
-    }
     ARTP_T_MARK(0);
     int result = 0, ec, fast_r = 2;
     bool decided = false;
-    if (PASS == 0 && fld.partner_flags != nullptr && (rec.kind & ARTP_REC_ALL_FINITE)) {
-      // Streaming path: the tables already ruled out exits (b)-(e) and found the window all finite, so
+    if constexpr (PASS == 0) {
+      // Streaming pass: the tables already ruled out exits (b)-(e) and found the window all finite, so
       // (f) runs straight off the map and the corner stage reads its few cells from the map too: no LDS
-      // tile, no list.  Only a box whose candidates may have partners falls through to the staged path.
-      if (grp_vertex_stream<G>(fld, b, lane, true)) {
-        result = 1;
-        decided = true;
-      } else {
-        ARTP_T_MARK(2);
-        const int r = grp_plane_stage_corners<G, true>(fld, b, s, lane, 0, true);
-        if (r != 2) {
-          result = r;
+      // tile, no list.  A box whose candidates may have partners (or whose window is not known to be all
+      // finite) goes to queue 6 for the staged pass (PASS 3) -- keeping that code out of this kernel keeps
+      // its register count down.
+      if (fld.partner_flags != nullptr && (rec.kind & ARTP_REC_ALL_FINITE)) {
+        if (grp_vertex_stream<G>(fld, b, lane, true)) {
+          result = 1;
           decided = true;
+        } else {
+          ARTP_T_MARK(2);
+          const int r = grp_plane_stage_corners<G, true>(fld, b, s, lane, 0, true);
+          if (r != 2) {
+            result = r;
+            decided = true;
+          }
         }
+        ARTP_T_MARK(4);
       }
-      ARTP_T_MARK(4);
+      if (!decided) {
+        if (gl == 0) q.q6[atomicAdd(&q.counters[2], 1ull)] = (unsigned)item;
+      } else if (gl == 0 && result != 0) {
+        valid[rec.state] = 0;  // the torso touches
+      }
+      wave_lds_sync();
+      continue;
+    }
+    const int total = (b.maxX - b.minX + 1) * (b.maxZ - b.minZ + 1);
+    if (total > s.cap_verts) {  // the staged passes hold the window in LDS
+      if (gl == 0) atomicExch(error_flag, 1);
+      continue;
     }
     WindowStats w;
     if (!decided) {
@@ -698,7 +713,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
           const unsigned long long slot = atomicAdd(&q.counters[6], 1ull);
           q.q5[slot] = (unsigned)item;
         }
-      } else if (PASS == 0 && fld.partner_flags != nullptr &&
+      } else if (PASS == 3 && fld.partner_flags != nullptr &&
                  (fast_r = grp_plane_stage_corners<G>(fld, b, s, lane, 0, true)) != 2) {
         ARTP_T_MARK(4);
         result = fast_r;
