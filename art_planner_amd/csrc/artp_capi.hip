@@ -874,7 +874,11 @@ int artp_sample_states_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, siz
   HIP_TRY(c, hipSetDevice(c->device));
   size_t blocks = (n + 255) / 256;
   if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
-  hipLaunchKernelGGL(sample_states_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
+  if (c->sampler.from_distribution)
+    hipLaunchKernelGGL(sample_states_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
+                     c->geom, c->robot, seed, first_index, n, se3_out);
+  else
+    hipLaunchKernelGGL(sample_states_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
                      c->geom, c->robot, seed, first_index, n, se3_out);
   HIP_TRY(c, hipGetLastError());
   return ARTP_OK;
@@ -1123,7 +1127,12 @@ int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, c
   HIP_TRY(c, hipSetDevice(c->device));
   size_t blocks = (cap + 255) / 256;
   if (blocks > (size_t)c->n_cus * 16) blocks = (size_t)c->n_cus * 16;
-  hipLaunchKernelGGL(sample_states_at_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler, c->geom,
+  if (c->sampler.from_distribution)
+    hipLaunchKernelGGL(sample_states_at_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler, c->geom,
+                     c->robot, seed, base_index, idx, reinterpret_cast<const unsigned long long*>(count_dev), cap,
+                     se3_out);
+  else
+    hipLaunchKernelGGL(sample_states_at_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler, c->geom,
                      c->robot, seed, base_index, idx, reinterpret_cast<const unsigned long long*>(count_dev), cap,
                      se3_out);
   HIP_TRY(c, hipGetLastError());

@@ -244,10 +244,11 @@ ARTP_HD double uniform01(uint64_t seed, uint64_t index, unsigned k) {
 // SE3FromSE2Sampler::sampleUniform (art_planner/src/sampler.cpp:82-131) with
 // samplePositionInMapFromDist (:56-78).  The two linear CDF scans become binary searches for the
 // same "first index whose cumulative value exceeds u, else the last index".
+template <bool FROM_DIST>
 __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& g, const RobotDev& rb,
                                            uint64_t seed, uint64_t index, double out[7]) {
   double px, py;
-  if (sm.from_distribution) {  // samplePositionInMapFromDist (sampler.cpp:56-78)
+  if (FROM_DIST) {  // samplePositionInMapFromDist (sampler.cpp:56-78)
     const double samp_col = uniform01(seed, index, 0);
     const double samp_row = uniform01(seed, index, 1);
     int lo = 0, hi = g.rows - 1;  // answer in [0, rows-1]
@@ -332,13 +333,14 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
   }
 }
 
+template <bool FROM_DIST>
 __global__ void __launch_bounds__(256)
 sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t first_index,
                      size_t n, double* __restrict__ se3_out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     double st[7];
-    sample_one(sm, g, rb, seed, first_index + i, st);
+    sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st);
 #pragma unroll
     for (int k = 0; k < 7; ++k) se3_out[7 * i + k] = st[k];
   }
@@ -347,6 +349,7 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
 // States of the global sample stream at explicit indices base + idx[j], j < *count (device counter):
 // how a rank materialises the accepted states of another rank from the 4-byte indices it received
 // (a state is a pure function of (seed, index), so only indices need to cross xGMI).
+template <bool FROM_DIST>
 __global__ void __launch_bounds__(256)
 sample_states_at_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t base_index,
                         const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ count,
@@ -355,7 +358,7 @@ sample_states_at_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, ui
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     double st[7];
-    sample_one(sm, g, rb, seed, base_index + idx[i], st);
+    sample_one<FROM_DIST>(sm, g, rb, seed, base_index + idx[i], st);
 #pragma unroll
     for (int k = 0; k < 7; ++k) se3_out[7 * i + k] = st[k];
   }
