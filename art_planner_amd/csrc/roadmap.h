@@ -194,6 +194,20 @@ gather_edge_states_kernel(const double* __restrict__ verts, const unsigned long 
   }
 }
 
+__global__ void __launch_bounds__(256)
+gather_edge_states_uv_kernel(const double* __restrict__ verts, const uint32_t* __restrict__ eu,
+                             const uint32_t* __restrict__ ev, size_t ne, double* __restrict__ s1,
+                             double* __restrict__ s2) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const uint32_t u = eu[e], v = ev[e];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    s1[e * 7 + c] = verts[(size_t)u * 7 + c];
+    s2[e * 7 + c] = verts[(size_t)v * 7 + c];
+  }
+}
+
 struct PathLengthParams {  // Params::objectives.custom_path_length (params.h:69-73)
   int directional;
   double max_lon_vel, max_lat_vel, max_ang_vel;
@@ -328,8 +342,10 @@ struct artp_roadmap {
   // CSR over the valid, not removed edges
   std::vector<uint32_t> row, adj, adj_edge;
   bool csr_dirty = true;
-  // endpoint states of all edges, resident in HBM for artp_roadmap_revalidate (s1 rows, then s2 rows)
+  // resident in HBM for artp_roadmap_revalidate: the endpoint states of all edges (s1 rows, then s2 rows), and
+  // what they are gathered from after a re-query replaced the first edges (vertex states, edge end points)
   double* d_edge_states = nullptr;
+  size_t d_edge_cap = 0;
   bool d_edge_states_stale = true;
   size_t nv() const { return verts.size() / 7; }
 };
@@ -744,6 +760,7 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
       rm->ev[e] = (uint32_t)(keys[e] & 0xffffffffu);
     }
     rm->d_edge_states = d_s1;  // stays resident (freed by artp_roadmap_destroy)
+    rm->d_edge_cap = ne;
     rm->d_edge_states_stale = false;
     d_s1 = d_s2 = nullptr;
   }
@@ -766,17 +783,32 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
   uint64_t before = 0, after = 0, vbad = 0;
   for (size_t e = 0; e < ne; ++e) before += rm->evalid[e] ? 1 : 0;
   if (ne) {
-    if (rm->d_edge_states_stale) {  // the query vertices changed since the states were staged
-      if (rm->d_edge_states) (void)hipFree(rm->d_edge_states);
-      rm->d_edge_states = nullptr;
-      std::vector<double> sbuf(2 * ne * 7);
-      for (size_t e = 0; e < ne; ++e) {
-        std::memcpy(&sbuf[e * 7], &rm->verts[(size_t)rm->eu[e] * 7], 7 * sizeof(double));
-        std::memcpy(&sbuf[(ne + e) * 7], &rm->verts[(size_t)rm->ev[e] * 7], 7 * sizeof(double));
+    if (rm->d_edge_states_stale) {
+      // the query vertices changed since the states were staged: vertex states and edge end points go up
+      // (2 MB for 10^4 vertices), the 19 MB of endpoint states are gathered on the device
+      double* d_v = nullptr;
+      uint32_t* d_uv = nullptr;
+      bool okk = hipSetDevice(c->device) == hipSuccess;
+      if (okk && rm->d_edge_cap < ne) {
+        if (rm->d_edge_states) (void)hipFree(rm->d_edge_states);
+        rm->d_edge_states = nullptr;
+        okk = hipMalloc(reinterpret_cast<void**>(&rm->d_edge_states), 2 * ne * 7 * sizeof(double)) == hipSuccess;
+        rm->d_edge_cap = okk ? ne : 0;
       }
-      if (hipSetDevice(c->device) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&rm->d_edge_states), sbuf.size() * sizeof(double)) != hipSuccess ||
-          hipMemcpy(rm->d_edge_states, sbuf.data(), sbuf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      okk = okk && hipMalloc(reinterpret_cast<void**>(&d_v), nv * 7 * sizeof(double)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&d_uv), 2 * ne * sizeof(uint32_t)) == hipSuccess &&
+            hipMemcpyAsync(d_v, rm->verts.data(), nv * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+            hipMemcpyAsync(d_uv, rm->eu.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+            hipMemcpyAsync(d_uv + ne, rm->ev.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+      if (okk) {
+        hipLaunchKernelGGL(artp::gather_edge_states_uv_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)d_v, (const uint32_t*)d_uv, (const uint32_t*)(d_uv + ne), ne, rm->d_edge_states,
+                           rm->d_edge_states + ne * 7);
+        okk = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+      }
+      if (d_v) (void)hipFree(d_v);
+      if (d_uv) (void)hipFree(d_uv);
+      if (!okk) {
         c->last_error = "staging the edge states failed";
         return ARTP_ERR_HIP;
       }

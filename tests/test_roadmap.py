@@ -348,3 +348,15 @@ def test_simplify_path_is_valid_and_never_worse(planning_setup):
             best[b] = best[a] + ww
     assert abs(best[-1] - scost) < 1e-9 * max(1.0, scost)
     rm.close()
+
+
+def test_replan_loop_example_runs():
+    """examples/replan_loop.py: raw map -> device preprocessing -> install -> roadmap upkeep -> plan, 5 cycles."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("replan_loop", os.path.join(common.ROOT, "examples", "replan_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stats = mod.main(5, verbose=False)
+    assert len(stats) >= 3 and np.isfinite(stats).all()
+    assert np.median(stats.sum(axis=1)) < 100.0   # the reference's 10 Hz budget, with two orders of margin
