@@ -237,7 +237,9 @@ def main():
                 "kernel": "validate_states_kernel", "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_state": alg_bytes / S,
-                "validate_only_states_per_s": S / (k_ms * 1e-3)}
+                "validate_only_states_per_s": S / (k_ms * 1e-3),
+                "note": "achieved = ALGORITHMIC bytes (what the reference's scan reads, SURVEY.md 8d) / kernel time; "
+                        "frac > 1 means exact range / partner tables avoided reading them -- `traffic` is what moved"}
 
     # sampler alone
     ev0.record()
