@@ -302,3 +302,9 @@ class PreprocessedMap:
         if self.h:
             self.ctx.L.artp_preprocessed_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
