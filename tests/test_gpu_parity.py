@@ -358,3 +358,36 @@ def test_uniform_position_sampler_branch(big_map):
     vg = ctx.validate_states(sg)
     assert np.array_equal(vg, O.OracleMap(big_map).states_valid(rob, sg))
     ctx.close()
+
+
+def test_non_square_map(big_map):
+    """rows != cols (the reference's grid_map need not be square): 300 x 180 crop of the C2 map."""
+    from art_planner_amd.synthetic import GridMap, cumulative_distribution
+    i0, j0, nr, nc = 40, 150, 300, 180
+    gm = GridMap(nr, nc, big_map.res)
+    gm.pos_x = float(big_map.cell_x()[i0:i0 + nr].mean())
+    gm.pos_y = float(big_map.cell_y()[j0:j0 + nc].mean())
+    for k, v in big_map.layers.items():
+        if v.ndim == 2:
+            gm.layers[k] = np.asfortranarray(v[i0:i0 + nr, j0:j0 + nc])
+    cp, cr = cumulative_distribution(gm["sample_probability"])
+    gm.layers["cum_prob"] = np.asfortranarray(cp)
+    gm.layers["cum_prob_rowwise"] = np.ascontiguousarray(cr, np.float32)
+    assert abs(gm.len_x - nr * gm.res) < 1e-12 and abs(gm.len_y - nc * gm.res) < 1e-12
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm)
+    rob = O.robot("yaml")
+    so, _ = O.OracleSampler(gm).sample(rob, 3, 0, 30000)
+    sg = ctx.sample_states(3, 0, 30000)
+    assert np.abs(sg - so).max() < 1e-12
+    om = O.OracleMap(gm)
+    assert np.array_equal(ctx.validate_states(sg), om.states_valid(rob, sg))
+    rng = np.random.default_rng(8)
+    rs = common.random_states(gm, 40000, rng, z_off=(0.0, 0.05), tilt=0.2, spread=0.55)
+    assert np.array_equal(ctx.validate_states(rs), om.states_valid(rob, rs))
+    acc = sg[ctx.validate_states(sg) != 0]
+    vg, ng = ctx.check_edges_interp(acc[:2000], acc[1:2001])
+    vo, no = om.edges_interp_valid(rob, acc[:2000], acc[1:2001])
+    assert np.array_equal(vg, vo) and np.array_equal(ng, no)
+    assert np.array_equal(ctx.check_motions(acc[:300], acc[1:301]), om.check_motions(rob, acc[:300], acc[1:301])[0])
+    ctx.close()
