@@ -37,13 +37,15 @@ def variant(name):
     elif name == "inf":
         m[rng.random(e.shape) < 0.05] = np.inf
         e[rng.random(e.shape) < 0.002] = -np.inf
+    if name == "far":  # a map far from the world origin: float cancellation in every pose -> field transform
+        gm.pos_x, gm.pos_y = 512.3, -77.7
     gm.layers["elevation"] = np.asfortranarray(e)
     gm.layers["elevation_masked"] = np.asfortranarray(m)
     return gm
 
 
 cases = [("plain", "yaml"), ("nan", "yaml"), ("terraced", "yaml"), ("steps", "defaults"), ("inf", "yaml"),
-         ("plain", "tiny"), ("terraced", "defaults")]
+         ("plain", "tiny"), ("terraced", "defaults"), ("far", "yaml")]
 bad_total = 0
 for mapname, robot in cases:
     gm = variant(mapname)
