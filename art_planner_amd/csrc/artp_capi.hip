@@ -1373,8 +1373,7 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
     return ARTP_ERR_INVALID_ARG;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), FcWeights::TOTAL * sizeof(float),
-                     c->stream, edges, b, (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
+  hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, c->stream, edges, b, (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
   HIP_TRY(c, hipGetLastError());
   return ARTP_OK;
 }

@@ -328,9 +328,8 @@ struct CostMapGeom {
 __global__ void __launch_bounds__(256)
 fc_cost_kernel(const float* __restrict__ edges, size_t B, const half_t* __restrict__ feat, CostMapGeom g,
                const float* __restrict__ wts, float* __restrict__ cost) {
-  extern __shared__ float sw[];
-  for (int i = threadIdx.x; i < FcWeights::TOTAL; i += blockDim.x) sw[i] = wts[i];
-  __syncthreads();
+  // the weights are wave-uniform operands: read straight from the (scalar-cached) blob, they arrive in SGPRs
+  const float* __restrict__ sw = wts;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
   const float* ed = edges + 6 * e;
