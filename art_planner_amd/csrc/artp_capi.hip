@@ -1427,7 +1427,14 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_stage_cycles), 20 * sizeof(unsigned long long)) != hipSuccess)
     return -1;
-  if (out20 && reset >= 2 &&
+  if (out20 && reset >= 3 &&
+      hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_feet_cycles), 4 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned long long z4[4] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_feet_cycles), z4, sizeof(z4)) != hipSuccess) return -1;
+  }
+  if (out20 && reset == 2 &&
       hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_classify_cycles), 16 * sizeof(unsigned long long)) != hipSuccess)
     return -1;
   if (reset) {

@@ -571,6 +571,9 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
 // stage.  Decides everything except boxes whose corner candidates may have partners (-> queue 5, list
 // pass).  Records without table verdict go to queue 4 (sequential lane scan with the running-dMAX quirk).
 // 5 wavefronts per SIMD (96 VGPRs, 5 of them spilled) beat 4 at 100 VGPRs by 4 %; 6 (24 spills) lose 20 %
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_feet_cycles[4];  // stream cycles, corner cycles, boxes that reached the corners
+#endif
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
@@ -594,8 +597,22 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
     }
     BoxHF b;
     box_from_record(rec, rb, b);
-    if (grp_vertex_stream<G>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0)) continue;  // it touches
+#ifdef ARTP_STAGE_TIMING
+    const long long tf0 = clock64();
+#endif
+    const bool touches = grp_vertex_stream<G>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);
+#ifdef ARTP_STAGE_TIMING
+    const long long tf1 = clock64();
+    if (gl == 0) atomicAdd(&g_feet_cycles[0], (unsigned long long)(tf1 - tf0));
+#endif
+    if (touches) continue;
     const int r = grp_plane_stage_corners<G, true>(ff, b, s, lane, 0, true);
+#ifdef ARTP_STAGE_TIMING
+    if (gl == 0) {
+      atomicAdd(&g_feet_cycles[1], (unsigned long long)(clock64() - tf1));
+      atomicAdd(&g_feet_cycles[2], 1ull);
+    }
+#endif
     if (gl == 0) {
       if (r == 2)
         q.q5[atomicAdd(&q.counters[6], 1ull)] = (unsigned)item;

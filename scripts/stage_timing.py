@@ -27,6 +27,11 @@ a = np.array(list(out), dtype=np.float64).reshape(2, 10)
 names = ["record", "scan", "vertex(f)", "compact", "corners"]
 cnt = ctx.pipeline_counters()
 print("counters", cnt)
+ff = (C.c_ulonglong * 20)()
+L.artp_debug_stage_cycles(ff, 3)  # reset >= 3: the feet_stream counters
+print("feet_stream: stream ticks", ff[0], "corner ticks", ff[1], "boxes reaching the corner stage", ff[2])
+ctx.sample_and_validate_dev(1234, n, n, se3, va)
+torch.cuda.synchronize()
 cc = (C.c_ulonglong * 20)()
 L.artp_debug_stage_cycles(cc, 2)  # reset >= 2: read the classify phase counters instead (and reset all)
 c = np.array(list(cc)[:16], dtype=np.float64).reshape(2, 8)
