@@ -329,20 +329,29 @@ __device__ __forceinline__ bool grp_vertex_pass(const FieldDev& f, const BoxHF& 
 // colliding vertex belongs to an all-finite triangle; otherwise the six neighbours that share a triangle
 // with the vertex are looked up (only for colliding vertices inside the box: rare).  8 loads in flight per
 // lane; the group polls for a hit after every chunk.
-template <int G>
+template <int G, int U = 8>
 __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF& b, int lane, bool all_finite) {
   const int gl = grp_lane<G>(lane);
   const int numX = b.maxX - b.minX + 1;
   const int numZ = b.maxZ - b.minZ + 1;
-  const int total = numX * numZ;
   if (numX < 2 || numZ < 2) return false;  // no cell, no triangle, no member vertex
   const int cellsX = numX - 1, cellsZ = numZ - 1;
   const float minO2 = b.aabb[2];
-  const int qz = G / numX, rx = G - qz * numX;
-  int xl = gl % numX, zl = gl / numX;
+  // The index window is the AABB widened to the sample grid (+ a sample of rounding slack on every side), and
+  // a vertex inside the box is inside the AABB: the outermost rows / columns are skipped when they lie outside
+  // it (10 um of slack against the roundings of the AABB; samples are centimetres apart).
+  const float slack = 1.0e-5f;
+  const int x0 = ((float)b.minX * f.sample_w < b.aabb[0] - slack) ? 1 : 0;
+  const int x1 = ((float)b.maxX * f.sample_w > b.aabb[1] + slack) ? 1 : 0;
+  const int z0 = ((float)b.minZ * f.sample_d < b.aabb[4] - slack) ? 1 : 0;
+  const int z1 = ((float)b.maxZ * f.sample_d > b.aabb[5] + slack) ? 1 : 0;
+  const int inX = numX - x0 - x1, inZ = numZ - z0 - z1;
+  if (inX < 1 || inZ < 1) return false;
+  const int total = inX * inZ;
+  const int qz = G / inX, rx = G - qz * inX;
+  int xl = gl % inX, zl = gl / inX;  // position in the inner grid; window-local = (x0 + xl, z0 + zl)
   const int nW = f.nW;
-  const float* base = f.data + b.minX + (size_t)b.minZ * nW;
-  constexpr int U = 8;
+  const float* base = f.data + (b.minX + x0) + (size_t)(b.minZ + z0) * nW;
   bool hit = false;
   for (int e0 = gl; e0 < total; e0 += G * U) {
     float hv[U];
@@ -354,8 +363,8 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
       hv[u] = (e0 + G * u < total) ? base[xl + zl * nW] : -INFINITY;
       xl += rx;
       zl += qz;
-      if (xl >= numX) {
-        xl -= numX;
+      if (xl >= inX) {
+        xl -= inX;
         zl += 1;
       }
     }
@@ -363,12 +372,13 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
     for (int u = 0; u < U; ++u) {
       const float h = hv[u];
       if (is_finite(h) && h > minO2 && !hit &&
-          point_in_box(b, (float)(b.minX + xs[u]) * f.sample_w, h, (float)(b.minZ + zs[u]) * f.sample_d)) {
+          point_in_box(b, (float)(b.minX + x0 + xs[u]) * f.sample_w, h, (float)(b.minZ + z0 + zs[u]) * f.sample_d)) {
         if (all_finite) {
           hit = true;
         } else {
           const float* c = base + xs[u] + zs[u] * nW;
-          const bool xm = xs[u] > 0, xp = xs[u] < cellsX, zm = zs[u] > 0, zp = zs[u] < cellsZ;
+          const int wx = x0 + xs[u], wz = z0 + zs[u];  // window-local: the triangles counted are the window's
+          const bool xm = wx > 0, xp = wx < cellsX, zm = wz > 0, zp = wz < cellsZ;
           const bool f_xp = xp && is_finite(c[1]);
           const bool f_xm = xm && is_finite(c[-1]);
           const bool f_zp = zp && is_finite(c[nW]);

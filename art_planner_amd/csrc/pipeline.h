@@ -600,7 +600,7 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
 #ifdef ARTP_STAGE_TIMING
     const long long tf0 = clock64();
 #endif
-    const bool touches = grp_vertex_stream<G>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);
+    const bool touches = grp_vertex_stream<G, 6>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);  // ~80 samples
 #ifdef ARTP_STAGE_TIMING
     const long long tf1 = clock64();
     if (gl == 0) atomicAdd(&g_feet_cycles[0], (unsigned long long)(tf1 - tf0));
