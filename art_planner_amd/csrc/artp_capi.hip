@@ -739,8 +739,10 @@ int artp_validate_states_dev(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (detail) {
-    // per-box exit codes in the reference's evaluation order: wave-per-state kernel
+  if (detail || n <= 16) {
+    // per-box exit codes in the reference's evaluation order: wave-per-state kernel.  Also the path of tiny
+    // batches (the per-state isValid() of the host mirror): ONE launch instead of the pipeline's nine; the
+    // labels are the same by construction (both are pinned to the oracle).
     hipLaunchKernelGGL(validate_states_kernel<1>, dim3(grid_full(c, n)), dim3(64), lds_full(c), c->stream,
                        c->field[0], c->field[1], c->geom, c->robot, se3, n, valid, detail, c->caps_full,
                        c->d_error, (unsigned long long*)nullptr);

@@ -1,0 +1,13 @@
+"""Per-call latency of the host-buffer validity API for small batches (the per-state isValid() of the host mirror)."""
+import time, numpy as np, sys
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from art_planner_amd.context import Context
+from art_planner_amd.synthetic import make_map
+gm = make_map(400, 0.04, seed=1234)
+ctx = Context(0, "yaml"); ctx.upload_map(gm)
+se3 = ctx.sample_states(1, 0, 4096)
+for n in (1, 64, 128, 129, 1024):
+    ctx.validate_states(se3[:n])
+    t0 = time.perf_counter()
+    for _ in range(200): ctx.validate_states(se3[:n])
+    print(n, "states:", (time.perf_counter() - t0) / 200 * 1e6, "us per call")
