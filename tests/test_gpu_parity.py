@@ -391,3 +391,44 @@ def test_non_square_map(big_map):
     assert np.array_equal(vg, vo) and np.array_equal(ng, no)
     assert np.array_equal(ctx.check_motions(acc[:300], acc[1:301]), om.check_motions(rob, acc[:300], acc[1:301])[0])
     ctx.close()
+
+
+@pytest.mark.parametrize("rows,cols", [(2, 2), (3, 5), (7, 4), (17, 33), (31, 64), (65, 129)])
+def test_tiny_and_odd_sized_maps(rows, cols):
+    """Maps smaller than (or straddling) the 4/8/16/32-cell range-table blocks, with NaN / inf holes: the
+    table shortcuts, the partner table and the streaming passes must clamp exactly like the reference's
+    GetHeight / zone clamping (heightfield.cpp:325-384, :973-1040)."""
+    from art_planner_amd.synthetic import GridMap
+    rng = np.random.default_rng(rows * 1000 + cols)
+    gm = GridMap(rows, cols, 0.08)
+    gm.pos_x, gm.pos_y = 0.3, -0.2
+    h = (rng.normal(0, 0.08, (rows, cols)) + 0.05 * np.arange(rows)[:, None]).astype(np.float32)
+    hf = h.copy()
+    if rows * cols > 6:
+        k = max(1, rows * cols // 15)
+        hf.flat[rng.choice(rows * cols, k, replace=False)] = np.nan
+        hf.flat[rng.choice(rows * cols, 1)] = np.inf
+    gm.add("elevation", h)
+    gm.add("elevation_masked", hf)
+    om = O.OracleMap(gm)
+    for kind in ("yaml", "defaults"):
+        ctx = _ctx(kind)
+        ctx.upload_map(gm, sampler=False)
+        rob = O.robot(kind)
+        rs = common.random_states(gm, 6000, rng, z_off=(0.0, 0.08), tilt=0.25, spread=0.9)
+        rs[:, 0] += rng.uniform(-0.6, 0.6, len(rs))       # well off the map too
+        rs[:, 1] += rng.uniform(-0.6, 0.6, len(rs))
+        assert np.array_equal(ctx.validate_states(rs), om.states_valid(rob, rs))
+        assert np.array_equal(ctx.validate_states(rs[:7]), om.states_valid(rob, rs[:7]))   # single-launch path
+        vg, ng = ctx.check_edges_interp(rs[:500], rs[1:501])
+        vo, no = om.edges_interp_valid(rob, rs[:500], rs[1:501])
+        assert np.array_equal(vg, vo) and np.array_equal(ng, no)
+        # whole-robot labels are mostly 0 on maps this small; per-box hit flags + exit codes are not
+        for slot, layer in ((0, "elevation"), (1, "elevation_masked")):
+            of = O.OracleField(gm[layer], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+            for side in (rob.foot, np.asarray(rob.foot) * np.float32(0.4), rob.torso):
+                P = common.random_dposes(gm, 5000, rng, (0.05, 0.1), tilt=0.4)
+                ho, eo, _ = of.check_boxes(side, P, True)
+                hg, eg = ctx.check_boxes(slot, side, P, want_exit_codes=True)
+                assert np.array_equal(hg, ho) and np.array_equal(eg, eo)
+        ctx.close()
