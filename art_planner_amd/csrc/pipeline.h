@@ -290,10 +290,11 @@ __device__ __forceinline__ void state_box_pose(const RobotDev& rb, const float t
 // membership is looked up).  (f) is an existence test, hence any vertex found inside decides it; finding none
 // decides nothing.  Only valid once exits (b)-(e) are ruled out (no NaN in the window).
 template <int N>
-__device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const BoxHF& b, float frac,
+__device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const TablesDev& t, const BoxHF& b, float frac,
                                                       bool window_all_finite) {
   if (b.maxX - b.minX < 1 || b.maxZ - b.minZ < 1) return false;
   float h[N * N];
+  unsigned nf[N * N];
   int ix[N * N], iz[N * N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -309,32 +310,22 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const B
       ix[j * N + i] = x;
       iz[j * N + i] = z;
       h[j * N + i] = f.data[x + (size_t)z * f.nW];
+      // A window with masked cells: the vertex only counts as a corner of an all-finite triangle OF THE WINDOW
+      // (heightfield.cpp:1306-1441).  The 4 x 4 block anchored one sample before the vertex being all finite
+      // and the vertex's neighbours lying in the window is sufficient (its ABC triangle qualifies); the flag
+      // is fetched together with the height so the probe stays one round trip.
+      nf[j * N + i] = 0u;
+      if (!window_all_finite) {
+        const bool inner = x > b.minX && x < b.maxX && z > b.minZ && z < b.maxZ;
+        nf[j * N + i] = inner ? (unsigned)t.fl[0][(x - 1) + (size_t)(z - 1) * f.nW] : 1u;
+      }
     }
   }
   bool hit = false;
 #pragma unroll
-  for (int k = 0; k < N * N; ++k) {
-    if (!hit && is_finite(h[k]) && h[k] > b.aabb[2] &&
-        point_in_box(b, (float)ix[k] * f.sample_w, h[k], (float)iz[k] * f.sample_d)) {
-      if (window_all_finite) {
-        hit = true;
-      } else {
-        // the vertex only counts as a corner of an all-finite triangle OF THE WINDOW (heightfield.cpp:1306-1441;
-        // same six-neighbour rule as grp_vertex_stream)
-        const float* c = f.data + ix[k] + (size_t)iz[k] * f.nW;
-        const int nW = f.nW;
-        const bool xm = ix[k] > b.minX, xp = ix[k] < b.maxX, zm = iz[k] > b.minZ, zp = iz[k] < b.maxZ;
-        const bool f_xp = xp && is_finite(c[1]);
-        const bool f_xm = xm && is_finite(c[-1]);
-        const bool f_zp = zp && is_finite(c[nW]);
-        const bool f_zm = zm && is_finite(c[-nW]);
-        const bool f_xm_zp = xm && zp && is_finite(c[nW - 1]);
-        const bool f_xp_zm = xp && zm && is_finite(c[1 - nW]);
-        hit = (f_xp && f_zp) || (f_xm && f_xm_zp) || (f_xm_zp && f_zp) || (f_zm && f_xp_zm) ||
-              (f_xp_zm && f_xp) || (f_zm && f_xm);
-      }
-    }
-  }
+  for (int k = 0; k < N * N; ++k)
+    hit = hit || (nf[k] == 0u && is_finite(h[k]) && h[k] > b.aabb[2] &&
+                  point_in_box(b, (float)ix[k] * f.sample_w, h[k], (float)iz[k] * f.sample_d));
   return hit;
 }
 
@@ -370,7 +361,7 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     if (!(have_stats && decide_exits(b, w, hit, ec))) {
       // feet only: 3/5 of the undecided foot boxes hold a vertex and the 2 x 2 probe finds most of them;
       // torso hits sit at the rim of the box (a 3 x 3 probe caught 1 in 4) and do not pay for the probe
-      if (have_stats && !body && probe_vertices_inside<2>(f, b, 0.25f, all_finite)) return 0;  // exit (f): the foot touches
+      if (have_stats && !body && probe_vertices_inside<2>(f, tab, b, 0.25f, all_finite)) return 0;  // exit (f): the foot touches
       return have_stats ? 2 : 3;
     }
   }
