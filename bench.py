@@ -235,6 +235,8 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "validate_states_kernel", "kernel_ms": k_ms,
+                "kernel_launches": "artp_validate_states_dev = classify_states_kernel + feet_stream_kernel<4> + "
+                                   "resolve_boxes_kernel<2,64,0> + 5 near-empty fallback launches (profiles/README.md)",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_state": alg_bytes / S,
                 "validate_only_states_per_s": S / (k_ms * 1e-3),
