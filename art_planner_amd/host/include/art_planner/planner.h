@@ -1,0 +1,300 @@
+// art_planner::Planner with the reference's public surface (art_planner/include/art_planner/planner.h:31-71;
+// art_planner/src/planner.cpp:75-330), every step routed to the MI355X through the C ABI:
+//   setMap  -> the processor chain + CDF on the device (artp_preprocess_map_ex), installed as both height
+//              fields + sampler layers + z bounds (artp_preprocessed_install); a kept roadmap is re-validated
+//              against the new map (LazyPRMStarMinUpdate's upkeep, lazy_prm_star_min_update.cpp:18-217)
+//   plan    -> goal clipped to the bounds and dropped onto the map (planner.cpp:204-238), start / goal
+//              region search as ONE validity batch each (start.cpp:9-47, goal.cpp:11-45), then the batched PRM
+//   getSolutionPath(simplify) -> the cheaper of original and simplified path (planner.cpp:266-330)
+// OMPL's SimpleSetup / ScopedState / PathGeometric are not in this image: states are SE3StateSpace::StateType
+// (ompl_min.h, or the real one with -DARTP_HAVE_OMPL) and a path is a vector of flattened SE3 states.
+// grid_map is not in this image either: setMap takes the Map wrapper (map/map.h).  Inpainting stays with the
+// caller (include/artp_c.h, N2): the elevation layer must be hole-free, "observed" marks the cells that were.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <vector>
+
+#include "art_planner/gpu_context.h"
+#include "art_planner/map/map.h"
+#include "art_planner/ompl_min.h"
+#include "art_planner/params.h"
+#include "art_planner/planner_status.h"
+#include "art_planner/planners/batch_prm.h"
+
+namespace ob = ompl::base;
+
+namespace art_planner {
+
+// utils.h:85-88
+inline double getYawFromSO3(const ob::SO3StateSpace::StateType& s) {
+  return std::atan2(2 * (s.w * s.z + s.x * s.y), 1 - 2 * (s.y * s.y + s.z * s.z));
+}
+
+// utils.h:101-115
+inline void setSO3FromRPY(ob::SO3StateSpace::StateType& s, const double* rpy) {
+  const double r2 = rpy[0] * 0.5, p2 = rpy[1] * 0.5, y2 = rpy[2] * 0.5;
+  const double cr = std::cos(r2), cp = std::cos(p2), cy = std::cos(y2);
+  const double sr = std::sin(r2), sp = std::sin(p2), sy = std::sin(y2);
+  s.w = cy * cp * cr + sy * sp * sr;
+  s.x = cy * cp * sr - sy * sp * cr;
+  s.y = sy * cp * sr + cy * sp * cr;
+  s.z = sy * cp * cr - cy * sp * sr;
+}
+
+class Planner {
+ public:
+  using StateSpace = ob::SE3StateSpace;
+  using StateType = typename StateSpace::StateType;
+  using StateArray = BatchPRM::StateArray;
+  using Path = std::vector<StateArray>;
+
+  explicit Planner(const ParamsConstPtr& params = std::make_shared<const Params>(), int device = 0)
+      : params_(params), gpu_(std::make_shared<GpuContext>(params, device)),
+        prm_(std::make_shared<BatchPRM>(params, gpu_)) {}
+  ~Planner() {
+    if (pre_) artp_preprocessed_destroy(pre_);
+  }
+  Planner(const Planner&) = delete;
+  Planner& operator=(const Planner&) = delete;
+
+  // planner.cpp:135-163.  Silently returns when the elevation layer is missing (:137-144).
+  void setMap(std::unique_ptr<Map>&& map) {
+    if (!map || !map->exists(params_->planner.elevation_layer)) {
+      if (params_->verbose)
+        std::cout << "Grid map does not have \"" << params_->planner.elevation_layer << "\" layer." << std::endl;
+      return;
+    }
+    const auto g = map->getGeometry();
+    const auto& elev = map->getLayer(params_->planner.elevation_layer);
+    float lo = std::numeric_limits<float>::infinity(), hi = -lo;  // min/maxCoeffOfFinites
+    for (const float h : elev) {
+      if (std::isfinite(h)) {
+        lo = h < lo ? h : lo;
+        hi = h > hi ? h : hi;
+      }
+    }
+    if (!(lo <= hi)) lo = hi = 0.0f;
+
+    artp_preprocess_params pp;
+    artp_preprocess_params_defaults(&pp);
+    pp.traversability_thres = params_->planner.traversability_thres;
+    pp.foothold_margin = params_->planner.safety.foothold_margin;
+    pp.foothold_margin_max_hole_size = params_->planner.safety.foothold_margin_max_hole_size;
+    pp.foothold_margin_max_drop = params_->planner.safety.foothold_margin_max_drop;
+    pp.foothold_margin_max_drop_search_radius = params_->planner.safety.foothold_margin_max_drop_search_radius;
+    pp.foothold_margin_min_step = params_->planner.safety.foothold_margin_min_step;
+    pp.foothold_size = params_->planner.safety.foothold_size;
+    pp.use_inverse_vertex_density = 0;  // the density term needs the kept roadmap's vertices: not wired here
+    pp.use_max_prob_unknown_samples = params_->sampler.use_max_prob_unknown_samples ? 1 : 0;
+    pp.max_prob_unknown_samples = params_->sampler.max_prob_unknown_samples;
+    artp_preprocess_inputs in{};
+    in.elevation = elev.data();
+    in.traversability =
+        map->exists(params_->planner.traversability_layer) ? map->getLayer(params_->planner.traversability_layer).data() : nullptr;
+    in.observed = map->exists("observed") ? map->getLayer("observed").data() : nullptr;
+    in.rows = g.rows;
+    in.cols = g.cols;
+    in.len_x = g.length_x;
+    in.len_y = g.length_y;
+    in.pos_x = g.position_x;
+    in.pos_y = g.position_y;
+
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    artp_preprocessed* fresh = nullptr;
+    throwOnError(gpu_->get(), artp_preprocess_map_ex(gpu_->get(), &in, &pp, &fresh), "artp_preprocess_map_ex");
+    const int rc = artp_preprocessed_install(gpu_->get(), fresh);
+    if (rc != ARTP_OK) {
+      artp_preprocessed_destroy(fresh);
+      throwOnError(gpu_->get(), rc, "artp_preprocessed_install");
+    }
+    // the normals of get3DPoseFrom2D (map.cpp:77-90) come back from the device once per map
+    const size_t cells = static_cast<size_t>(g.rows) * g.cols;
+    std::vector<float> n[3] = {std::vector<float>(cells), std::vector<float>(cells), std::vector<float>(cells)};
+    const char* names[3] = {"normal_x", "normal_y", "normal_z"};
+    for (int k = 0; k < 3; ++k)
+      throwOnError(gpu_->get(), artp_preprocessed_get_layer(gpu_->get(), fresh, names[k], n[k].data()),
+                   "artp_preprocessed_get_layer");
+    for (int k = 0; k < 3; ++k) map->addLayer(names[k], n[k].data());
+    if (pre_) artp_preprocessed_destroy(pre_);
+    pre_ = fresh;
+    map_ = std::move(map);
+    // ob::RealVectorBounds of planner.cpp:146-156 (x / y: position -+ length, as the reference has it)
+    low_[0] = g.position_x - g.length_x;
+    high_[0] = g.position_x + g.length_x;
+    low_[1] = g.position_y - g.length_y;
+    high_[1] = g.position_y + g.length_y;
+    low_[2] = lo - params_->robot.feet.reach.z / 2;
+    high_[2] = hi + params_->robot.feet.reach.z / 2;
+    if (have_roadmap_) prm_->revalidate();  // the kept roadmap follows the map; plan() re-queries it
+    solved_ = false;
+  }
+
+  bool hasMap() const {
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    return static_cast<bool>(map_);
+  }
+
+  void setSeed(uint64_t seed) {
+    seed_ = seed;
+    prm_->setSeed(seed);
+  }
+
+  // planner.cpp:192-262
+  PlannerStatus plan(const StateType& start, const StateType& goal) {
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    if (!map_) {
+      std::cout << "Planner does not have the elevation map set, yet." << std::endl;
+      return PlannerStatus::NO_MAP;
+    }
+    // enforce the goal inside the bounds (:204-221)
+    StateType goal_clipped = goal;
+    goal_clipped.setXYZ(clamp(goal.getX(), 0), clamp(goal.getY(), 1), clamp(goal.getZ(), 2));
+    // height, roll, pitch from the map (:224-238)
+    if (map_->isInside(goal_clipped.getX(), goal_clipped.getY())) {
+      double xyzrpy[6] = {goal_clipped.getX(), goal_clipped.getY(), 0, 0, 0, getYawFromSO3(goal_clipped.rotation())};
+      get3DPoseFrom2D(xyzrpy);
+      goal_clipped.setZ(xyzrpy[2]);
+      setSO3FromRPY(goal_clipped.rotation(), xyzrpy + 3);
+    }
+    solved_ = false;
+    StateType start_valid = start, goal_valid = goal_clipped;
+    const auto& sg = params_->planner.start_goal_search;
+    if (!searchValid(start, sg.start_radius, sg.n_iter, 0x5741u, &start_valid)) return PlannerStatus::INVALID_START;
+    if (!searchValid(goal_clipped, sg.goal_radius, sg.n_iter, 0x474fu, &goal_valid)) return PlannerStatus::INVALID_GOAL;
+    try {
+      if (have_roadmap_) {
+        prm_->setQuery(start_valid, goal_valid);  // clearQuery + new start / goal on the kept graph (:241-242)
+      } else {
+        prm_->sampleGraph(start_valid, goal_valid);
+        have_roadmap_ = true;
+      }
+      solved_ = prm_->solve(&path_, &cost_);
+    } catch (const std::exception& e) {  // "All graph edges to goal where actually invalid" (:248-253)
+      std::cout << e.what() << std::endl;
+      solved_ = false;
+      return PlannerStatus::NOT_SOLVED;
+    }
+    return solved_ ? PlannerStatus::SOLVED : PlannerStatus::NOT_SOLVED;
+  }
+
+  // planner.cpp:266-330: throws when the last plan() did not solve; with simplify, the simplified path
+  // only when it is valid and not more expensive than the original.
+  Path getSolutionPath(const bool& simplify = false) const {
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    if (!solved_) throw std::runtime_error("Requested failed solution path.");
+    if (!simplify) return path_;
+    Path simple = path_;
+    double cost_simple = cost_;
+    try {
+      prm_->simplify(&simple, &cost_simple);
+    } catch (const std::exception&) {
+      std::cout << "Simplified path is invalid. Returning original." << std::endl;
+      return path_;
+    }
+    if (params_->verbose) {
+      std::cout << "cost_simple " << cost_simple << std::endl;
+      std::cout << "cost_orig " << cost_ << std::endl;
+    }
+    if (cost_ < cost_simple) {
+      if (params_->verbose) std::cout << "Original path cost is lower than simplified. Returning original." << std::endl;
+      return path_;
+    }
+    return simple;
+  }
+
+  double getSolutionCost() const { return cost_; }
+  const GpuContextPtr& gpu() const { return gpu_; }
+  const std::shared_ptr<BatchPRM>& roadmap() const { return prm_; }
+
+ protected:
+  ParamsConstPtr params_;
+  GpuContextPtr gpu_;
+  std::shared_ptr<BatchPRM> prm_;
+  std::shared_ptr<Map> map_;
+  mutable std::mutex map_mutex_;
+  bool solved_{false};
+
+ private:
+  double clamp(double v, int axis) const { return v < low_[axis] ? low_[axis] : (v > high_[axis] ? high_[axis] : v); }
+
+  // Map::get3DPoseFrom2D (map.cpp:77-90): cell of the position (same arithmetic as the sampler's
+  // getIndexOfPosition), its height, and roll / pitch from the cell normal turned into the yaw frame.
+  void get3DPoseFrom2D(double* xyzrpy) const {
+    const auto g = map_->getGeometry();
+    int ri = static_cast<int>(-(((xyzrpy[0] - 0.5 * g.length_x) - g.position_x) / g.resolution));
+    int ci = static_cast<int>(-(((xyzrpy[1] - 0.5 * g.length_y) - g.position_y) / g.resolution));
+    ri = ri < 0 ? 0 : (ri >= g.rows ? g.rows - 1 : ri);
+    ci = ci < 0 ? 0 : (ci >= g.cols ? g.cols - 1 : ci);
+    const size_t ind = static_cast<size_t>(ri) + static_cast<size_t>(ci) * g.rows;
+    xyzrpy[2] = map_->getLayer(params_->planner.elevation_layer)[ind];
+    const double nx = map_->getLayer("normal_x")[ind], ny = map_->getLayer("normal_y")[ind],
+                 nz = map_->getLayer("normal_z")[ind];
+    const double c = std::cos(xyzrpy[5]), s = std::sin(xyzrpy[5]);
+    const double bx = c * nx + s * ny, by = -s * nx + c * ny;  // R_yaw^-1 * n
+    xyzrpy[3] = -std::atan2(by, nz);
+    xyzrpy[4] = std::atan2(bx, nz);
+  }
+
+  // StartState::sampleGoal / GoalStateRegion::sampleGoal: the centre if it is valid, else the first valid of
+  // n_iter candidates offset uniformly in a disc of the given radius (x / y only; z and attitude are kept).
+  // The reference tests them one by one; here they are ONE batch and the first valid index wins -- the same
+  // answer for the same offsets.
+  bool searchValid(const StateType& center, double radius, unsigned n_iter, uint64_t salt, StateType* out) const {
+    std::vector<double> se3(static_cast<size_t>(n_iter + 1) * 7);
+    uint64_t x = seed_ * 0x9e3779b97f4a7c15ull + salt;
+    auto next01 = [&x]() {  // splitmix64
+      uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      z ^= z >> 31;
+      return static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0);
+    };
+    for (unsigned i = 0; i <= n_iter; ++i) {
+      double ox = 0.0, oy = 0.0;
+      if (i > 0) {  // RNG::uniformInBall(r, 2-vector): direction uniform, radius r * u^(1/2)
+        const double r = radius * std::sqrt(next01()), a = 2.0 * M_PI * next01();
+        ox = r * std::cos(a);
+        oy = r * std::sin(a);
+      }
+      double* s = &se3[static_cast<size_t>(i) * 7];
+      s[0] = center.getX() + ox;
+      s[1] = center.getY() + oy;
+      s[2] = center.getZ();
+      s[3] = center.rotation().x;
+      s[4] = center.rotation().y;
+      s[5] = center.rotation().z;
+      s[6] = center.rotation().w;
+    }
+    std::vector<uint8_t> valid(n_iter + 1);
+    throwOnError(gpu_->get(), artp_validate_states(gpu_->get(), se3.data(), valid.size(), valid.data(), nullptr),
+                 "artp_validate_states");
+    for (unsigned i = 0; i <= n_iter; ++i) {
+      if (valid[i]) {
+        *out = center;
+        out->setX(se3[static_cast<size_t>(i) * 7]);
+        out->setY(se3[static_cast<size_t>(i) * 7 + 1]);
+        if (i > 0 && params_->verbose)
+          std::cout << "Found valid state offset by " << out->getX() - center.getX() << " "
+                    << out->getY() - center.getY() << std::endl;
+        return true;
+      }
+    }
+    return false;
+  }
+
+  artp_preprocessed* pre_{nullptr};
+  double low_[3]{0, 0, 0}, high_[3]{0, 0, 0};
+  bool have_roadmap_{false};
+  Path path_;
+  double cost_{0.0};
+  uint64_t seed_{42};
+};
+
+}  // namespace art_planner

@@ -15,6 +15,8 @@
 #include "art_planner/ompl_min.h"
 #include "art_planner/params.h"
 
+namespace ob = ompl::base;
+
 namespace art_planner {
 
 class BatchPRM {
