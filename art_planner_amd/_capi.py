@@ -23,7 +23,7 @@ SYMBOLS = [
     "artp_algorithmic_vertices_dev",
     "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_roadmap_params_defaults",
     "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
-    "artp_roadmap_revalidate", "artp_roadmap_set_query", "artp_roadmap_simplify_path",
+    "artp_roadmap_revalidate", "artp_roadmap_set_query", "artp_roadmap_simplify_path", "artp_roadmap_grow",
     "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
     "artp_preprocess_map_ex", "artp_preprocessed_change",
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
@@ -131,6 +131,7 @@ def load():
     L.artp_roadmap_revalidate.argtypes = [vp, C.POINTER(u64 * 4)]
     L.artp_roadmap_set_query.argtypes = [vp, vp, vp]
     L.artp_roadmap_simplify_path.argtypes = [vp, vp, sz, vp, C.POINTER(sz), C.POINTER(dbl)]
+    L.artp_roadmap_grow.argtypes = [vp, C.c_uint64, vp]
     L.artp_roadmap_destroy.argtypes = [vp]
     L.artp_roadmap_destroy.restype = None
     for name in ("artp_preprocess_params_defaults", "artp_preprocess_params_yaml"):

@@ -548,13 +548,17 @@ void artp_roadmap_destroy(artp_roadmap* rm) {
   delete rm;
 }
 
-int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
-                       artp_roadmap** out) {
-  if (!c || !prm || !start7 || !goal7 || !out || prm->n_milestones < 1 || prm->objective < 0 ||
-      prm->objective > 2 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0))
-    return ARTP_ERR_INVALID_ARG;
+// Build over [start, goal, kept milestones (host, n_keep x 7, already known valid), n_new fresh accepted samples
+// drawn from sample index first_new on].  artp_roadmap_build: no kept milestones; artp_roadmap_grow: the
+// roadmap's own.
+static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, const double* start7, const double* goal7,
+                              const double* keep, size_t n_keep, size_t n_new, uint64_t first_new,
+                              artp_roadmap** out) {
+  artp_roadmap_params prm_local = *prm_in;
+  prm_local.n_milestones = n_keep + n_new;
+  const artp_roadmap_params* prm = &prm_local;
   *out = nullptr;
-  const size_t nm = prm->n_milestones, nv = nm + 2;
+  const size_t nm = n_keep + n_new, nv = nm + 2;
   double* d_verts = nullptr;     // nv x 7
   double* d_batch = nullptr;     // sample batch
   uint8_t* d_valid = nullptr;
@@ -590,11 +594,13 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
     RM_HIP(hipMemcpyAsync(d_verts, sg, sizeof(sg), hipMemcpyHostToDevice, st));
   }
 
-  // 1. milestones: accepted states of the sample stream, in index order
-  size_t have = 0;
-  uint64_t next = prm->first_index;
-  {
-    size_t batch = std::max<size_t>(4 * nm, 1u << 16);
+  // 1. milestones: the kept ones, then accepted states of the sample stream, in index order
+  size_t have = n_keep;
+  uint64_t next = first_new;
+  if (n_keep)
+    RM_HIP(hipMemcpyAsync(d_verts + 2 * 7, keep, n_keep * 7 * sizeof(double), hipMemcpyHostToDevice, st));
+  if (n_new) {
+    size_t batch = std::max<size_t>(4 * n_new, 1u << 16);
     if (batch > (1u << 22)) batch = 1u << 22;
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_batch), batch * 7 * sizeof(double)));
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_compact), batch * 7 * sizeof(double)));
@@ -724,7 +730,7 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   rm->ctx = c;
   rm->params = *prm;
   rm->k = k;
-  rm->samples_drawn = next - prm->first_index;
+  rm->samples_drawn = next - first_new;
   rm->verts.resize(nv * 7);
   rm->knn.resize(nk);
   rm->knn_dist.resize(nk);
@@ -766,6 +772,51 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
   }
   cleanup();
   *out = rm;
+  return ARTP_OK;
+}
+
+int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
+                       artp_roadmap** out) {
+  if (!c || !prm || !start7 || !goal7 || !out || prm->n_milestones < 1 || prm->objective < 0 ||
+      prm->objective > 2 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0))
+    return ARTP_ERR_INVALID_ARG;
+  return roadmap_build_impl(c, prm, start7, goal7, nullptr, 0, prm->n_milestones, prm->first_index, out);
+}
+
+// PRMMotionCostMaintainer::sampleGraph keeps adding milestones to the kept graph between queries
+// (prm_motion_cost.cpp:145-219), LazyPRM* grows its roadmap for as long as it plans.  Batched: the milestones
+// still valid on the CURRENT map stay, n_more new ones are drawn where the sample stream left off, and the
+// connection rule (k grows with the vertex count, KStarStrategy) + every edge verdict are recomputed for the
+// whole set -- 10^4 vertices / 10^5 edges are one small batch, cheaper than bookkeeping which edges survive.
+int artp_roadmap_grow(artp_roadmap* rm, uint64_t n_more, uint64_t out[2]) {
+  if (!rm) return ARTP_ERR_INVALID_ARG;
+  artp_ctx* c = rm->ctx;
+  const size_t nv = rm->nv();
+  std::vector<uint8_t> vok(nv, 0);
+  int rc = artp_validate_states(c, rm->verts.data(), nv, vok.data(), nullptr);
+  if (rc != ARTP_OK) return rc;
+  if (!vok[0] || !vok[1]) {
+    c->last_error = !vok[0] ? "start state is not valid" : "goal state is not valid";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  std::vector<double> keep;
+  keep.reserve((nv - 2) * 7);
+  for (size_t v = 2; v < nv; ++v)
+    if (vok[v]) keep.insert(keep.end(), rm->verts.begin() + v * 7, rm->verts.begin() + (v + 1) * 7);
+  const size_t n_keep = keep.size() / 7;
+  if (n_keep + n_more < 1) return ARTP_ERR_INVALID_ARG;
+  artp_roadmap* fresh = nullptr;
+  const uint64_t drawn_before = rm->samples_drawn;
+  rc = roadmap_build_impl(c, &rm->params, rm->verts.data(), rm->verts.data() + 7, keep.data(), n_keep, (size_t)n_more,
+                          rm->params.first_index + drawn_before, &fresh);
+  if (rc != ARTP_OK) return rc;
+  fresh->samples_drawn += drawn_before;
+  std::swap(*rm, *fresh);
+  artp_roadmap_destroy(fresh);
+  if (out) {
+    out[0] = n_keep;
+    out[1] = (nv - 2) - n_keep;  // milestones the current map invalidated
+  }
   return ARTP_OK;
 }
 

@@ -1,8 +1,9 @@
 // art_planner::Planner with the reference's public surface (art_planner/include/art_planner/planner.h:31-71;
 // art_planner/src/planner.cpp:75-330), every step routed to the MI355X through the C ABI:
 //   setMap  -> the processor chain + CDF on the device (artp_preprocess_map_ex), installed as both height
-//              fields + sampler layers + z bounds (artp_preprocessed_install); a kept roadmap is re-validated
-//              against the new map (LazyPRMStarMinUpdate's upkeep, lazy_prm_star_min_update.cpp:18-217)
+//              fields + sampler layers + z bounds (artp_preprocessed_install); a kept roadmap follows the new map:
+//              invalidated milestones dropped and replenished (artp_roadmap_grow; the upkeep of
+//              PRMMotionCostMaintainer / LazyPRMStarMinUpdate, lazy_prm_star_min_update.cpp:18-217)
 //   plan    -> goal clipped to the bounds and dropped onto the map (planner.cpp:204-238), start / goal
 //              region search as ONE validity batch each (start.cpp:9-47, goal.cpp:11-45), then the batched PRM
 //   getSolutionPath(simplify) -> the cheaper of original and simplified path (planner.cpp:266-330)
@@ -71,6 +72,7 @@ class Planner {
         std::cout << "Grid map does not have \"" << params_->planner.elevation_layer << "\" layer." << std::endl;
       return;
     }
+    std::lock_guard<std::mutex> lock(map_mutex_);
     const auto g = map->getGeometry();
     const auto& elev = map->getLayer(params_->planner.elevation_layer);
     float lo = std::numeric_limits<float>::infinity(), hi = -lo;  // min/maxCoeffOfFinites
@@ -91,7 +93,10 @@ class Planner {
     pp.foothold_margin_max_drop_search_radius = params_->planner.safety.foothold_margin_max_drop_search_radius;
     pp.foothold_margin_min_step = params_->planner.safety.foothold_margin_min_step;
     pp.foothold_size = params_->planner.safety.foothold_size;
-    pp.use_inverse_vertex_density = 0;  // the density term needs the kept roadmap's vertices: not wired here
+    // computeInverseSampleDensity (sample_density.cpp:12-43) counts the kept roadmap's vertices per cell
+    std::vector<double> vertices;
+    if (params_->sampler.use_inverse_vertex_density && have_roadmap_) vertices = prm_->vertices();
+    pp.use_inverse_vertex_density = vertices.empty() ? 0 : 1;
     pp.use_max_prob_unknown_samples = params_->sampler.use_max_prob_unknown_samples ? 1 : 0;
     pp.max_prob_unknown_samples = params_->sampler.max_prob_unknown_samples;
     artp_preprocess_inputs in{};
@@ -99,6 +104,8 @@ class Planner {
     in.traversability =
         map->exists(params_->planner.traversability_layer) ? map->getLayer(params_->planner.traversability_layer).data() : nullptr;
     in.observed = map->exists("observed") ? map->getLayer("observed").data() : nullptr;
+    in.vertex_se3 = vertices.empty() ? nullptr : vertices.data();
+    in.n_vertices = vertices.size() / 7;
     in.rows = g.rows;
     in.cols = g.cols;
     in.len_x = g.length_x;
@@ -106,7 +113,6 @@ class Planner {
     in.pos_x = g.position_x;
     in.pos_y = g.position_y;
 
-    std::lock_guard<std::mutex> lock(map_mutex_);
     artp_preprocessed* fresh = nullptr;
     throwOnError(gpu_->get(), artp_preprocess_map_ex(gpu_->get(), &in, &pp, &fresh), "artp_preprocess_map_ex");
     const int rc = artp_preprocessed_install(gpu_->get(), fresh);
@@ -132,7 +138,17 @@ class Planner {
     high_[1] = g.position_y + g.length_y;
     low_[2] = lo - params_->robot.feet.reach.z / 2;
     high_[2] = hi + params_->robot.feet.reach.z / 2;
-    if (have_roadmap_) prm_->revalidate();  // the kept roadmap follows the map; plan() re-queries it
+    if (have_roadmap_) {
+      // the kept roadmap follows the map (PRMMotionCostMaintainer / LazyPRMStarMinUpdate upkeep): milestones the
+      // new map invalidated are dropped and replaced by as many new samples; plan() then re-queries it
+      try {
+        const size_t dropped = prm_->grow(0);
+        if (dropped) prm_->grow(dropped);
+      } catch (const std::exception&) {  // the old start / goal are gone with the map: rebuild at the next plan
+        prm_->clear();
+        have_roadmap_ = false;
+      }
+    }
     solved_ = false;
   }
 

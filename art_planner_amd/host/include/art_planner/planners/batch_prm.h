@@ -84,6 +84,15 @@ class BatchPRM {
     return (out[3] & 3u) == 3u;
   }
 
+  // PRMMotionCostMaintainer::sampleGraph between queries (prm_motion_cost.cpp:145-219): n_more milestones on top
+  // of the ones the current map still accepts; returns how many of the old ones the map invalidated
+  size_t grow(size_t n_more) {
+    if (!rm_) throw std::runtime_error("BatchPRM::grow before sampleGraph");
+    uint64_t out[2] = {};
+    throwOnError(gpu_->get(), artp_roadmap_grow(rm_, n_more, out), "artp_roadmap_grow");
+    return static_cast<size_t>(out[1]);
+  }
+
   // new start / goal on the kept roadmap (every OMPL query adds them as milestones)
   void setQuery(const ob::SE3StateSpace::StateType& start, const ob::SE3StateSpace::StateType& goal) {
     if (!rm_) throw std::runtime_error("BatchPRM::setQuery before sampleGraph");
@@ -103,6 +112,16 @@ class BatchPRM {
     out.resize(n);
     path->swap(out);
     if (cost) *cost = c;
+  }
+
+  // the roadmap's vertices (start, goal, milestones), n x 7 -- what computeInverseSampleDensity counts per cell
+  std::vector<double> vertices() const {
+    std::vector<double> v(numVertices() * 7);
+    if (rm_ && !v.empty())
+      throwOnError(gpu_->get(),
+                   artp_roadmap_export(rm_, v.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr),
+                   "artp_roadmap_export");
+    return v;
   }
 
   size_t numVertices() const { return stat(0); }

@@ -70,6 +70,12 @@ class Roadmap:
         return {"invalid_vertices": out[0], "valid_edges_before": out[1], "valid_edges_after": out[2],
                 "start_valid": bool(out[3] & 1), "goal_valid": bool(out[3] & 2)}
 
+    def grow(self, n_more: int) -> dict:
+        """Keep the milestones still valid on the current map, add n_more new ones, reconnect everything."""
+        out = (C.c_uint64 * 2)()
+        self.ctx._chk(self.L.artp_roadmap_grow(self.h, int(n_more), C.byref(out)), "artp_roadmap_grow")
+        return {"kept": out[0], "dropped": out[1]}
+
     def set_query(self, start, goal):
         s = np.ascontiguousarray(start, np.float64).reshape(7)
         g = np.ascontiguousarray(goal, np.float64).reshape(7)

@@ -225,6 +225,12 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start_se3, const doub
  * shortcuts is returned -- deterministic, never worse than the input.  out_se3 holds up to n states. */
 int artp_roadmap_simplify_path(artp_roadmap* rm, const double* path_se3, size_t n, double* out_se3,
                                size_t* n_out, double* cost);
+/* Growing the kept roadmap (PRMMotionCostMaintainer::sampleGraph keeps adding milestones between queries,
+ * prm_motion_cost.cpp:145-219; LazyPRM* grows while it plans): the milestones still valid on the CURRENT map
+ * stay, n_more new ones are drawn where the sample stream left off, connections (k follows the vertex count)
+ * and edge verdicts are recomputed for the whole set.  out (may be NULL) = {milestones kept, milestones the
+ * current map invalidated}.  Start and goal must still be valid (else ARTP_ERR_INVALID_ARG: set a new query). */
+int artp_roadmap_grow(artp_roadmap* rm, uint64_t n_more, uint64_t out[2]);
 void artp_roadmap_destroy(artp_roadmap* rm);
 
 /* ---- "next" row N2: the per-map preprocessing chain on the device -----------------------

@@ -316,6 +316,74 @@ def test_revalidate_after_map_update_and_new_query(planning_setup):
     ctx.upload_map(gm)  # restore the module fixture's map
 
 
+def test_grow_keeps_valid_milestones_and_continues_the_sample_stream(planning_setup):
+    """artp_roadmap_grow (sampleGraph between queries): on an unchanged map the grown roadmap equals a roadmap
+    built with the larger milestone count in one go (same sample stream, same connection rule); after a map
+    change the milestones the map invalidated are dropped, the others stay in order, and the plan is valid."""
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    rob = O.robot("yaml")
+    rm = Roadmap(ctx, start, goal, n_milestones=1500, seed=21)
+    st0 = rm.stats()
+    info = rm.grow(1000)
+    assert info == {"kept": 1500, "dropped": 0}
+    d = rm.export()
+    assert rm.stats()["vertices"] == 2502 and rm.stats()["k"] >= st0["k"]
+    ref = Roadmap(ctx, start, goal, n_milestones=2500, seed=21)
+    dr = ref.export()
+    # both draw accepted samples in index order; the grown one skipped the unused tail of its first batch, so
+    # compare the common prefix exactly and the whole graph through its own invariants
+    assert np.array_equal(d["verts"][:1502], dr["verts"][:1502])
+    V, E = d["verts"], d["edges"].astype(np.int64)
+    om = O.OracleMap(gm)
+    assert om.states_valid(rob, V).all()
+    sub = np.random.default_rng(4).choice(len(E), 6000, replace=False)
+    eo, no = om.edges_interp_valid(rob, V[E[sub, 0]], V[E[sub, 1]])
+    assert np.array_equal(d["edge_valid"][sub], eo) and np.array_equal(d["edge_interp"][sub], no)
+    D = _se3_distance(V[:40], V)
+    D[np.arange(40), np.arange(40)] = np.inf
+    k = rm.stats()["k"]
+    for q in range(40):
+        want = set(np.argsort(D[q], kind="stable")[:k].tolist())
+        got = set(int(v) if u == q else int(u) for u, v in E[(E[:, 0] == q) | (E[:, 1] == q)])
+        assert want <= got
+    p1, c1, _ = rm.solve()
+    assert p1 is not None and om.check_motions(rob, p1[:-1], p1[1:])[0].all()
+    ref.close()
+    # map change: a block in the middle of the plan becomes an obstacle
+    mid = p1[len(p1) // 2]
+    ix = int((gm.pos_x + 0.5 * gm.len_x - mid[0]) / gm.res)
+    iy = int((gm.pos_y + 0.5 * gm.len_y - mid[1]) / gm.res)
+    r0, c0 = max(ix - 6, 0), max(iy - 6, 0)
+    import copy
+    gm2 = copy.deepcopy(gm)
+    for slot, name in ((0, "elevation"), (1, "elevation_masked")):
+        lay = gm[name].copy()
+        patch = lay[r0:r0 + 12, c0:c0 + 12]
+        patch = (np.where(np.isfinite(patch), patch, np.float32(0)) + np.float32(0.6)) if slot == 0 \
+            else np.full_like(patch, -np.inf)
+        lay[r0:r0 + 12, c0:c0 + 12] = patch
+        gm2.layers[name] = np.asfortranarray(lay)
+        ctx.update_layer_rect(slot, np.asfortranarray(patch), r0, c0)
+    om2 = O.OracleMap(gm2)
+    vok = om2.states_valid(rob, V) != 0
+    info2 = rm.grow(500)
+    assert info2["dropped"] == int((~vok[2:]).sum()) > 0 and info2["kept"] == int(vok[2:].sum())
+    d2 = rm.export()
+    V2, E2 = d2["verts"], d2["edges"].astype(np.int64)
+    assert len(V2) == 2 + info2["kept"] + 500
+    assert np.array_equal(V2[2:2 + info2["kept"]], V[2:][vok[2:]])        # kept milestones, order preserved
+    assert om2.states_valid(rob, V2).all()
+    sub = np.random.default_rng(5).choice(len(E2), 6000, replace=False)
+    eo, _ = om2.edges_interp_valid(rob, V2[E2[sub, 0]], V2[E2[sub, 1]])
+    assert np.array_equal(d2["edge_valid"][sub], eo)
+    p2, c2, _ = rm.solve()
+    if p2 is not None:
+        assert om2.states_valid(rob, p2).all() and om2.check_motions(rob, p2[:-1], p2[1:])[0].all()
+    rm.close()
+    ctx.upload_map(gm)  # restore the module fixture's map
+
+
 def test_simplify_path_is_valid_and_never_worse(planning_setup):
     """The batched shortcutting: the result is a subsequence of the plan from start to goal, every edge of
     it passes the oracle's interpolation rule and discrete motion validator, and its cost is <= the plan's
