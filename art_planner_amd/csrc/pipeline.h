@@ -361,7 +361,7 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     if (!(have_stats && decide_exits(b, w, hit, ec))) {
       // feet only: 3/5 of the undecided foot boxes hold a vertex and the 2 x 2 probe finds most of them;
       // torso hits sit at the rim of the box (a 3 x 3 probe caught 1 in 4) and do not pay for the probe
-      if (have_stats && !body && probe_vertices_inside<2>(f, tab, b, 0.25f, all_finite)) return 0;  // exit (f): the foot touches
+      if (have_stats && !body && probe_vertices_inside<2>(f, tab, b, 0.33f, all_finite)) return 0;  // exit (f): the foot touches
       return have_stats ? 2 : 3;
     }
   }
