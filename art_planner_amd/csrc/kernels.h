@@ -241,6 +241,34 @@ ARTP_HD double uniform01(uint64_t seed, uint64_t index, unsigned k) {
   return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// sin and cos of a half Euler angle, |x| <= ~3 (the sampler's yaw/2, roll/2, pitch/2): one Cody-Waite step to
+// the nearest multiple of pi/2 (two-part constant, exact for the handful of quadrants that can occur), then the
+// classic minimax kernels on [-pi/4, pi/4] -- within one ulp of libm, without the large-argument reduction of the
+// general sincos (which alone costs this kernel 40 registers).
+__device__ __forceinline__ void sincos_half_angle(double x, double* sn, double* cs) {
+  const double kf = rint(x * 6.36619772367581382433e-01);  // x * 2/pi
+  const int k = (int)kf;
+  double r = fma(-kf, 1.57079632673412561417e+00, x);
+  r = fma(-kf, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                 2.75573137070700676789e-06),
+                                          -1.98412698298579493134e-04),
+                                   8.33333333332248946124e-03),
+                        -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                 -2.75573143513906633035e-07),
+                                          2.48015872894767294178e-05),
+                                   -1.38888888888741095749e-03),
+                        4.16666666666666019037e-02);
+  const double s0 = fma(r * z, ps, r);
+  const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const bool swap = (k & 1) != 0;
+  const double sa = swap ? c0 : s0, ca = swap ? s0 : c0;
+  *sn = (k & 2) ? -sa : sa;
+  *cs = ((k + 1) & 2) ? -ca : ca;
+}
+
 // SE3FromSE2Sampler::sampleUniform (art_planner/src/sampler.cpp:82-131) with
 // samplePositionInMapFromDist (:56-78).  The two linear CDF scans become binary searches for the
 // same "first index whose cumulative value exceeds u, else the last index".
@@ -248,6 +276,7 @@ template <bool FROM_DIST>
 __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& g, const RobotDev& rb,
                                            uint64_t seed, uint64_t index, double out[7]) {
   double px, py;
+  int cell_row = 0, cell_col = 0;
   if (FROM_DIST) {  // samplePositionInMapFromDist (sampler.cpp:56-78)
     const double samp_col = uniform01(seed, index, 0);
     const double samp_row = uniform01(seed, index, 1);
@@ -264,6 +293,8 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
       if ((double)sm.cum_prob[(size_t)row + (size_t)mid * g.rows] > samp_col) hi = mid; else lo = mid + 1;
     }
     const int col = lo;
+    cell_row = row;
+    cell_col = col;
     // grid_map getPosition: (c + (L/2 - res/2)) + res * (-i)
     px = (g.pos_x + (0.5 * g.len_x - 0.5 * g.res)) + g.res * (double)(-row);
     py = (g.pos_y + (0.5 * g.len_y - 0.5 * g.res)) + g.res * (double)(-col);
@@ -278,9 +309,16 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
       if (map_is_inside(g, px, py) || a >= 255) break;
     }
   }
-  // getIndexOfPosition (sampler.cpp:95) -- reproduces (row, col)
-  const int ri = (int)(-(((px - 0.5 * g.len_x) - g.pos_x) / g.res));
-  const int ci = (int)(-(((py - 0.5 * g.len_y) - g.pos_y) / g.res));
+  // getIndexOfPosition (sampler.cpp:95).  From the distribution the position is the centre of cell (row, col):
+  // the quotient is row + 0.5 up to rounding in the 13th digit, its truncation is row -- no division needed.
+  int ri, ci;
+  if (FROM_DIST) {
+    ri = cell_row;
+    ci = cell_col;
+  } else {
+    ri = (int)(-(((px - 0.5 * g.len_x) - g.pos_x) / g.res));
+    ci = (int)(-(((py - 0.5 * g.len_y) - g.pos_y) / g.res));
+  }
   const size_t ind = (size_t)ri + (size_t)ci * g.rows;
   double v0 = px, v1 = py, v2 = (double)sm.elevation[ind];
   const double nwx = (double)sm.normal_x[ind];
@@ -302,7 +340,7 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
   const double rpy2 = pi * (-2.0 * uniform01(seed, index, 5) + 1.0);
   // sin and cos of yaw/2 are needed twice (the yaw quaternion here, setSO3FromRPY below): one sincos
   double sy2s, sy2c, qw, qz;
-  sincos(0.5 * rpy2, &sy2s, &sy2c);
+  sincos_half_angle(0.5 * rpy2, &sy2s, &sy2c);
   {
     // normal_b = Quaterniond(AngleAxisd(yaw, Z)).inverse() * normal_w (sampler.cpp:120-123)
     qw = sy2c;
@@ -323,8 +361,8 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
   }
   {  // setSO3FromRPY (utils.h:101-115)
     double cr, cp, sr, sp;
-    sincos(rpy0 * 0.5, &sr, &cr);
-    sincos(rpy1 * 0.5, &sp, &cp);
+    sincos_half_angle(rpy0 * 0.5, &sr, &cr);
+    sincos_half_angle(rpy1 * 0.5, &sp, &cp);
     const double cy = sy2c, sy = sy2s;
     out[6] = cy * cp * cr + sy * sp * sr;
     out[3] = cy * cp * sr - sy * sp * cr;
@@ -337,12 +375,28 @@ template <bool FROM_DIST>
 __global__ void __launch_bounds__(256)
 sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t first_index,
                      size_t n, double* __restrict__ se3_out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
-    double st[7];
-    sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st);
+  // A lane's 7 doubles are 56 bytes apart from its neighbour's: written directly, every store instruction
+  // touches 28 cache lines with 8 useful bytes in each 56.  The wavefront's 64 states go through LDS instead and
+  // leave as seven fully coalesced 512-byte rows.
+  __shared__ double stage[4][64 * 7];
+  const int lane = threadIdx.x & 63;
+  double* sw = stage[threadIdx.x >> 6];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); i0 < n; i0 += stride) {  // wave-uniform
+    const size_t i = i0 + lane;
+    if (i < n) {
+      double st[7];
+      sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) se3_out[7 * i + k] = st[k];
+      for (int k = 0; k < 7; ++k) sw[lane * 7 + k] = st[k];
+    }
+    wave_lds_sync();
+    const size_t cnt = (n - i0 < 64 ? n - i0 : 64) * 7;
+    double* out = se3_out + 7 * i0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if ((size_t)(k * 64 + lane) < cnt) out[k * 64 + lane] = sw[k * 64 + lane];
+    wave_lds_sync();
   }
 }
 
