@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
+    ap.add_argument("--materialise", type=int, default=1 << 16,
+                    help="N>1: accepted states of EVERY rank re-materialised on every rank per step, per rank block "
+                         "(-1 = all of them, 0 = none; the gathered index lists are always complete)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-gather path even with one rank (self-test)")
     args = ap.parse_args()
@@ -137,7 +140,11 @@ def main():
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
         gatherers = [ValidIndexGatherer(N, cap, dev), ValidIndexGatherer(N, cap, dev)]  # double-buffered
         gatherer = gatherers[0]
-        all_states = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)  # every rank's accepted states
+        # every rank's accepted states, re-materialised from the gathered indices: the first mat_cap per rank and
+        # step (default 2^16 = 6.5x the reference's whole roadmap, max_n_vertices = 10^4); anything beyond is
+        # one artp_sample_states_at_dev call away because the index lists are complete
+        mat_cap = cap if args.materialise < 0 else min(cap, args.materialise)
+        all_states = torch.empty((N, max(mat_cap, 1), 7), dtype=torch.float64, device=dev)
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         for e in done_ev:
             e.record()
@@ -165,14 +172,14 @@ def main():
             # whole step to complete): a state is a pure function of (seed, index).  On the main stream:
             # the validity kernels are persistent grids with static striding, and a kernel that shares their
             # CUs from a side stream costs them more than it hides (measured: +0.36 ms for 0.15 ms of work).
-            if i > 0:
+            if i > 0 and mat_cap > 0:
                 materialise(i - 1)
 
     def materialise(j):
         gb = gatherers[j & 1]
         torch.cuda.current_stream().wait_event(done_ev[j & 1])
         for r in range(N):
-            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), gb.gathered[r], gb.counts[r:r + 1], cap,
+            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), gb.gathered[r], gb.counts[r:r + 1], mat_cap,
                                      all_states[r])
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides -----------------------
@@ -182,7 +189,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
-    if do_gather:
+    if do_gather and mat_cap > 0:
         materialise(K - 1)
     torch.cuda.synchronize()
     if dist is not None:
@@ -487,7 +494,9 @@ def main():
                                "(seed 1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
                    "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}",
                    "sharding": f"sample-index ranges over {N} GPU(s)" +
-                               (", accepted-state indices all-gathered over RCCL + states re-materialised on every rank" if do_gather else "")},
+                               (", accepted-state indices all-gathered over RCCL (complete lists) + the first "
+                                f"{'all' if args.materialise < 0 else args.materialise} accepted states of every rank per step "
+                                "re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
         "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess, "c4_800_defaults": c4,
