@@ -372,7 +372,7 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
 }
 
 template <bool FROM_DIST>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t first_index,
                      size_t n, double* __restrict__ se3_out) {
   // A lane's 7 doubles are 56 bytes apart from its neighbour's: written directly, every store instruction
