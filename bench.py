@@ -70,8 +70,8 @@ def cpu_baseline(gm, states, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1 << 22, help="candidate states per GPU per step")
     ap.add_argument("--edges", type=int, default=1 << 18)
     ap.add_argument("--map", type=int, default=400)
