@@ -18,6 +18,7 @@ SYMBOLS = [
     "artp_upload_layer", "artp_update_layer_rect", "artp_check_boxes", "artp_check_boxes_dev",
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
+    "artp_sample_and_validate", "artp_check_motions_last_valid", "artp_check_motions_last_valid_dev",
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_algorithmic_vertices_dev",
@@ -111,7 +112,10 @@ def load():
     for name in ("artp_sample_states", "artp_sample_states_dev"):
         getattr(L, name).argtypes = [vp, u64, u64, sz, vp]
     L.artp_sample_and_validate_dev.argtypes = [vp, u64, u64, sz, vp, vp, C.POINTER(sz)]
+    L.artp_sample_and_validate.argtypes = [vp, u64, u64, sz, vp, vp]
     L.artp_set_z_bounds.argtypes = [vp, dbl, dbl]
+    for name in ("artp_check_motions_last_valid", "artp_check_motions_last_valid_dev"):
+        getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, vp]
     for name in ("artp_check_motions", "artp_check_motions_dev"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, vp]
     for name in ("artp_check_edges_interp", "artp_check_edges_interp_dev"):

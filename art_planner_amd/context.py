@@ -120,6 +120,25 @@ class Context:
                                             valid.ctypes.data), "artp_check_motions")
         return valid
 
+    def check_motions_last_valid(self, s1, s2):
+        """(valid, lastValid.second, *lastValid.first) of checkMotion's second overload; t = 1 / s2 where valid."""
+        s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
+        s2 = np.ascontiguousarray(s2, np.float64).reshape(-1, 7)
+        n = s1.shape[0]
+        valid = np.empty(n, np.uint8)
+        t = np.empty(n, np.float64)
+        st = np.empty((n, 7), np.float64)
+        self._chk(self.L.artp_check_motions_last_valid(self.h, s1.ctypes.data, s2.ctypes.data, n, valid.ctypes.data,
+                                                       t.ctypes.data, st.ctypes.data), "artp_check_motions_last_valid")
+        return valid, t, st
+
+    def sample_and_validate(self, seed, first_index, n):
+        se3 = np.empty((n, 7), np.float64)
+        valid = np.empty(n, np.uint8)
+        self._chk(self.L.artp_sample_and_validate(self.h, seed, first_index, n, se3.ctypes.data, valid.ctypes.data),
+                  "artp_sample_and_validate")
+        return se3, valid
+
     def check_edges_interp(self, s1, s2):
         s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
         s2 = np.ascontiguousarray(s2, np.float64).reshape(-1, 7)

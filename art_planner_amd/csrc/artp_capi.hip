@@ -7,6 +7,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -16,6 +18,8 @@
 #include "cost_kernels.h"
 
 using namespace artp;
+
+#define ARTP_FEW_STATES 16
 
 struct artp_ctx {
   int device = 0;
@@ -49,7 +53,14 @@ struct artp_ctx {
   ScratchCaps caps_full{0, 0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
   ScratchCaps caps_scan{0, 0, 0, 0};  // torso resolve stage: window tile + short triangle list, per wave
   ScratchCaps caps_feet{0, 0, 0, 0};  // foot resolve stage: per 16-lane group
+  ScratchCaps caps_foot_full{0, 0, 0, 0};  // validate_few_kernel: a foot wavefront's full zone-test scratch
   int n_cus = 256;
+  // latency path (<= ARTP_FEW_STATES states per call): mapped pinned host memory, read / written by the kernel
+  double* pin_states = nullptr;           // host view, ARTP_FEW_STATES x 7
+  volatile uint8_t* pin_labels = nullptr; // host view
+  double* pin_states_dev = nullptr;       // device view of the same memory
+  uint8_t* pin_labels_dev = nullptr;
+  bool poll_labels = true;                // spin on the mapped labels instead of hipStreamSynchronize
   // device scratch
   int* d_error = nullptr;
   unsigned long long* d_count = nullptr;
@@ -74,7 +85,7 @@ struct artp_ctx {
   bool have_features = false;
   std::string last_error;
   std::string arch;
-  std::mutex mu;
+  std::recursive_mutex mu;  // recursive: host entry points hold it across the _dev calls they are built from
 };
 
 namespace {
@@ -182,9 +193,16 @@ int size_scratch(artp_ctx* c) {
     long ft = (2L * (fdim - 1) * (fdim - 1) + 7) & ~7L;
     if (ft > 1024) ft = 1024;
     c->caps_feet = ScratchCaps{32 * 36, (int)fv, (int)ft, 0};
+    // a whole wavefront per foot box (validate_few_kernel): full list + hash table like caps_full
+    long ftf = (2L * (fdim - 1) * (fdim - 1) + 7) & ~7L;
+    if (ftf > 4096) ftf = 4096;
+    long ftab = 64;
+    while (ftab < 2 * ftf && ftab < 4096) ftab <<= 1;
+    c->caps_foot_full = ScratchCaps{64 * 36, (int)fv, (int)ftf, (int)ftab};
   }
   if (scratch_bytes_per_wave(c->caps_full) > 160 * 1024 ||
-      scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK > 160 * 1024) {
+      scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK > 160 * 1024 ||
+      scratch_bytes_per_wave(c->caps_full) + 4 * scratch_bytes_per_wave(c->caps_foot_full) > 160 * 1024) {
     c->last_error = "box too large for the LDS window tile";
     return ARTP_ERR_CAPACITY;
   }
@@ -194,6 +212,9 @@ int size_scratch(artp_ctx* c) {
 size_t lds_full(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_full); }
 size_t lds_scan(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK; }
 size_t lds_feet(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_feet) * 4 * ARTP_WAVES_PER_BLOCK; }
+size_t lds_few(const artp_ctx* c) {
+  return scratch_bytes_per_wave(c->caps_full) + 4 * scratch_bytes_per_wave(c->caps_foot_full);
+}
 
 int set_kernel_lds(artp_ctx* c) {
   // > 64 KiB of dynamic LDS needs the opt-in attribute
@@ -203,6 +224,8 @@ int set_kernel_lds(artp_ctx* c) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(plane_stage_kernel<1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(validate_few_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 3>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>),
@@ -449,6 +472,23 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
     return ARTP_ERR_HIP;
   }
   c->stream = c->own_stream;
+  {
+    void *ps = nullptr, *pl = nullptr, *psd = nullptr, *pld = nullptr;
+    if (hipHostMalloc(&ps, ARTP_FEW_STATES * 7 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(&pl, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&psd, ps, 0) != hipSuccess || hipHostGetDevicePointer(&pld, pl, 0) != hipSuccess) {
+      if (ps) (void)hipHostFree(ps);
+      if (pl) (void)hipHostFree(pl);
+      artp_destroy(c);
+      return ARTP_ERR_HIP;
+    }
+    c->pin_states = static_cast<double*>(ps);
+    c->pin_labels = static_cast<volatile uint8_t*>(pl);
+    c->pin_states_dev = static_cast<double*>(psd);
+    c->pin_labels_dev = static_cast<uint8_t*>(pld);
+    const char* e = std::getenv("ARTP_NO_POLL");
+    c->poll_labels = !(e && e[0] == '1');
+  }
   fill_robot(c);
   *out = c;
   return ARTP_OK;
@@ -480,6 +520,8 @@ void artp_destroy(artp_ctx* c) {
     if (c->d_act[l]) (void)hipFree(c->d_act[l]);
   if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->d_map_f32) (void)hipFree(c->d_map_f32);
+  if (c->pin_states) (void)hipHostFree(c->pin_states);
+  if (c->pin_labels) (void)hipHostFree(const_cast<uint8_t*>(c->pin_labels));
   if (c->d_error) (void)hipFree(c->d_error);
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -488,21 +530,21 @@ void artp_destroy(artp_ctx* c) {
 
 int artp_set_stream(artp_ctx* c, void* hip_stream) {
   if (!c) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   c->stream = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream
   return ARTP_OK;
 }
 
 int artp_use_own_stream(artp_ctx* c) {
   if (!c) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   c->stream = c->own_stream;
   return ARTP_OK;
 }
 
 int artp_synchronize(artp_ctx* c) {
   if (!c) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
@@ -615,7 +657,7 @@ int ensure_field_storage(artp_ctx* c, int slot, size_t elems) {
 int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int cols, double len_x,
                       double len_y, double pos_x, double pos_y) {
   if (!c || !layer || slot < 0 || slot > 1 || rows < 2 || cols < 2) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t elems = (size_t)rows * cols;
   // field_.mat = layer.rowwise().reverse() (height_map_box_checker.cpp:44): ODE sample (x, z) =
@@ -642,7 +684,7 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
 // on the device; only the 640 kB host mirror that rectangle updates patch comes back.
 static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer, int rows, int cols, double len_x,
                              double len_y, double pos_x, double pos_y) {
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t elems = (size_t)rows * cols;
   int rc = ensure_field_storage(c, slot, elems);
@@ -664,7 +706,7 @@ static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer,
 int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, int col0, int nrows,
                            int ncols) {
   if (!c || !patch || slot < 0 || slot > 1) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
   const int rows = c->field[slot].nW, cols = c->field[slot].nD;
   if (row0 < 0 || col0 < 0 || nrows <= 0 || ncols <= 0 || row0 + nrows > rows || col0 + ncols > cols)
@@ -698,7 +740,7 @@ int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, 
 int artp_check_boxes_dev(artp_ctx* c, int slot, const float box[3], const float* dposes, size_t n,
                          uint8_t* hit, uint8_t* exit_codes) {
   if (!c || !box || slot < 0 || slot > 1 || (n && (!dposes || !hit))) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -713,21 +755,19 @@ int artp_check_boxes(artp_ctx* c, int slot, const float box[3], const float* dpo
                      uint8_t* hit, uint8_t* exit_codes) {
   if (!c || (n && (!dposes || !hit))) return ARTP_ERR_INVALID_ARG;
   if (n == 0) return ARTP_OK;
-  {
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_tmp(c, 0, n * 16 * sizeof(float));
-    if (rc) return rc;
-    rc = ensure_tmp(c, 1, n * 2);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], dposes, n * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  }
+  // one lock for the whole call: the staging buffers c->tmp[0..1] are shared by every host entry point
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_tmp(c, 0, n * 16 * sizeof(float));
+  if (rc) return rc;
+  rc = ensure_tmp(c, 1, n * 2);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->tmp[0], dposes, n * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   uint8_t* d_hit = static_cast<uint8_t*>(c->tmp[1]);
   uint8_t* d_ec = d_hit + n;
-  int rc = artp_check_boxes_dev(c, slot, box, static_cast<const float*>(c->tmp[0]), n, d_hit,
-                                exit_codes ? d_ec : nullptr);
+  rc = artp_check_boxes_dev(c, slot, box, static_cast<const float*>(c->tmp[0]), n, d_hit,
+                            exit_codes ? d_ec : nullptr);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(c, hipMemcpyAsync(hit, d_hit, n, hipMemcpyDeviceToHost, c->stream));
   if (exit_codes) HIP_TRY(c, hipMemcpyAsync(exit_codes, d_ec, n, hipMemcpyDeviceToHost, c->stream));
   return check_error_flag(c);
@@ -735,14 +775,20 @@ int artp_check_boxes(artp_ctx* c, int slot, const float box[3], const float* dpo
 
 int artp_validate_states_dev(artp_ctx* c, const double* se3, size_t n, uint8_t* valid, int8_t* detail) {
   if (!c || (n && (!se3 || !valid))) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (detail || n <= 16) {
-    // per-box exit codes in the reference's evaluation order: wave-per-state kernel.  Also the path of tiny
-    // batches (the per-state isValid() of the host mirror): ONE launch instead of the pipeline's nine; the
-    // labels are the same by construction (both are pinned to the oracle).
+  if (!detail && n <= ARTP_FEW_STATES) {
+    // tiny batches (the per-state isValid() of the host mirror): ONE launch, one workgroup per state with the
+    // five boxes side by side; the labels are the same by construction (both are pinned to the oracle)
+    hipLaunchKernelGGL(validate_few_kernel, dim3((unsigned)n), dim3(320), lds_few(c), c->stream, c->field[0],
+                       c->field[1], c->geom, c->robot, se3, n, valid, c->caps_full, c->caps_foot_full, c->d_error, 0u);
+    HIP_TRY(c, hipGetLastError());
+    return ARTP_OK;
+  }
+  if (detail) {
+    // per-box exit codes in the reference's evaluation order: wave-per-state kernel
     hipLaunchKernelGGL(validate_states_kernel<1>, dim3(grid_full(c, n)), dim3(64), lds_full(c), c->stream,
                        c->field[0], c->field[1], c->geom, c->robot, se3, n, valid, detail, c->caps_full,
                        c->d_error, (unsigned long long*)nullptr);
@@ -755,21 +801,53 @@ int artp_validate_states_dev(artp_ctx* c, const double* se3, size_t n, uint8_t* 
 int artp_validate_states(artp_ctx* c, const double* se3, size_t n, uint8_t* valid, int8_t* detail) {
   if (!c || (n && (!se3 || !valid))) return ARTP_ERR_INVALID_ARG;
   if (n == 0) return ARTP_OK;
-  {
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
-    if (rc) return rc;
-    rc = ensure_tmp(c, 1, n * 7);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], se3, n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!detail && n <= ARTP_FEW_STATES) {
+    // latency path: the kernel reads the states from / writes the labels to mapped pinned host memory -- one
+    // launch, no copies.  The labels carry a "done" bit the host polls for (a stream synchronise costs more
+    // than the kernel); ARTP_NO_POLL=1 or a poll that outlasts 2 ms falls back to hipStreamSynchronize.
+    if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
+    std::memcpy(c->pin_states, se3, n * 7 * sizeof(double));
+    for (size_t i = 0; i < n; ++i) c->pin_labels[i] = 0;
+    const unsigned tag = 0x80u;
+    hipLaunchKernelGGL(validate_few_kernel, dim3((unsigned)n), dim3(320), lds_few(c), c->stream, c->field[0],
+                       c->field[1], c->geom, c->robot, (const double*)c->pin_states_dev, n,
+                       (volatile uint8_t*)c->pin_labels_dev, c->caps_full, c->caps_foot_full, c->d_error, tag);
+    HIP_TRY(c, hipGetLastError());
+    bool done = false;
+    if (c->poll_labels) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spin = 0; !done; ++spin) {
+        done = true;
+        for (size_t i = 0; i < n; ++i) done = done && (c->pin_labels[i] & 0x80u);
+        if (!done && (spin & 1023u) == 1023u &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+          break;
+      }
+    }
+    if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool overflow = false;
+    for (size_t i = 0; i < n; ++i) {
+      valid[i] = c->pin_labels[i] & 1u;
+      overflow = overflow || (c->pin_labels[i] & 2u);
+    }
+    if (overflow) {
+      c->last_error = "a box window exceeded the LDS tile capacity";
+      return ARTP_ERR_CAPACITY;
+    }
+    return ARTP_OK;
   }
+  int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
+  if (rc) return rc;
+  rc = ensure_tmp(c, 1, n * 7);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->tmp[0], se3, n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   uint8_t* d_valid = static_cast<uint8_t*>(c->tmp[1]);
   int8_t* d_detail = reinterpret_cast<int8_t*>(d_valid + n);
-  int rc = artp_validate_states_dev(c, static_cast<const double*>(c->tmp[0]), n, d_valid,
-                                    detail ? d_detail : nullptr);
+  rc = artp_validate_states_dev(c, static_cast<const double*>(c->tmp[0]), n, d_valid,
+                                detail ? d_detail : nullptr);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, c->stream));
   if (detail) HIP_TRY(c, hipMemcpyAsync(detail, d_detail, n * 6, hipMemcpyDeviceToHost, c->stream));
   return check_error_flag(c);
@@ -782,7 +860,7 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
   if (!c || !cum_prob || !cum_prob_rowwise || !elevation || !normal_x || !normal_y || !normal_z ||
       !plane_fit_std_dev || rows < 1 || cols < 1)
     return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t e = (size_t)rows * cols;
   if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
@@ -815,7 +893,7 @@ static int upload_sampler_layers_from_device(artp_ctx* c, const float* cum_prob,
                                       const float* elevation, const float* normal_x, const float* normal_y,
                                       const float* normal_z, const float* plane_fit_std_dev, int rows, int cols,
                                       double len_x, double len_y, double pos_x, double pos_y) {
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t e = (size_t)rows * cols;
   if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
@@ -845,7 +923,7 @@ static int upload_sampler_layers_from_device(artp_ctx* c, const float* cum_prob,
 
 // min / max of the finite samples of a device layer (host result); false if there is none
 static int finite_min_max_dev(artp_ctx* c, const float* d_layer, size_t n, float* lo, float* hi, bool* any) {
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   int init[2] = {0x7fffffff, (int)0x80000000};
   int* d_keys = reinterpret_cast<int*>(c->d_count);
@@ -870,7 +948,7 @@ static int finite_min_max_dev(artp_ctx* c, const float* d_layer, size_t n, float
 
 int artp_sample_states_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out) {
   if (!c || (n && !se3_out)) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_sampler) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -889,15 +967,12 @@ int artp_sample_states_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, siz
 int artp_sample_states(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out) {
   if (!c || (n && !se3_out)) return ARTP_ERR_INVALID_ARG;
   if (n == 0) return ARTP_OK;
-  {
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
-    if (rc) return rc;
-  }
-  int rc = artp_sample_states_dev(c, seed, first_index, n, static_cast<double*>(c->tmp[0]));
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(c->mu);
+  rc = artp_sample_states_dev(c, seed, first_index, n, static_cast<double*>(c->tmp[0]));
+  if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(se3_out, c->tmp[0], n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
@@ -906,9 +981,9 @@ int artp_sample_states(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t 
 int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n,
                                  double* se3_out, uint8_t* valid_out, size_t* n_valid) {
   if (!c || (n && (!se3_out || !valid_out))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   int rc = artp_sample_states_dev(c, seed, first_index, n, se3_out);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(c->mu);
   if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   if (n == 0) {
     if (n_valid) *n_valid = 0;
@@ -934,37 +1009,68 @@ int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_inde
   return ARTP_OK;
 }
 
+// Host-buffer form of the fused rejection-sampling step: states AND labels come back, so a caller that hands the
+// states out one at a time (SE3FromSE2Sampler::sampleUniform of the host mirror) already knows their labels.
+int artp_sample_and_validate(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out,
+                             uint8_t* valid_out) {
+  if (!c || (n && (!se3_out || !valid_out))) return ARTP_ERR_INVALID_ARG;
+  if (n == 0) return ARTP_OK;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
+  if (rc) return rc;
+  rc = ensure_tmp(c, 1, n);
+  if (rc) return rc;
+  rc = artp_sample_and_validate_dev(c, seed, first_index, n, static_cast<double*>(c->tmp[0]),
+                                    static_cast<uint8_t*>(c->tmp[1]), nullptr);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(se3_out, c->tmp[0], n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(valid_out, c->tmp[1], n, hipMemcpyDeviceToHost, c->stream));
+  return check_error_flag(c);
+}
+
 int artp_set_z_bounds(artp_ctx* c, double z_low, double z_high) {
   if (!c) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   c->z_low = z_low;
   c->z_high = z_high;
   c->have_z = true;
   return ARTP_OK;
 }
 
+// mode 0: checkMotion, mode 1: the 0.5 m interpolation rule.  last_t / last_state (mode 0 only, device, may be
+// NULL): the lastValid pair of checkMotion's second overload.
 static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
-                         uint8_t* valid, uint32_t* aux_out) {
+                         uint8_t* valid, uint32_t* aux_out, double* last_t = nullptr, double* last_state = nullptr) {
   if (!c || (n && (!s1 || !s2 || !valid))) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   if (mode == 0 && !c->have_z) {
     c->last_error = "artp_set_z_bounds must be called before artp_check_motions";
     return ARTP_ERR_NO_MAP;
   }
   if (n == 0) return ARTP_OK;
+  if (n + 1 > (size_t)0x7fffffff) {
+    c->last_error = "edge batch too large (the scan is 32 bit)";
+    return ARTP_ERR_CAPACITY;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
-  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n)
-  int rc = ensure_tmp(c, 2, (3 * n + 2) * sizeof(uint32_t));
+  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n) | first_bad (n) | total64, overflow flag
+  int rc = ensure_tmp(c, 2, (4 * n + 2) * sizeof(uint32_t) + 32);
   if (rc) return rc;
   uint32_t* counts = static_cast<uint32_t*>(c->tmp[2]);
   uint32_t* offsets = counts + (n + 1);
   uint32_t* aux = aux_out ? aux_out : offsets + (n + 1);
+  uint32_t* first_bad = offsets + (n + 1) + n;
+  unsigned long long* d_total = reinterpret_cast<unsigned long long*>(
+      (reinterpret_cast<uintptr_t>(first_bad + n) + 7) & ~(uintptr_t)7);
+  int* d_overflow = reinterpret_cast<int*>(d_total + 1);
   HIP_TRY(c, hipMemsetAsync(counts + n, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_total, 0, 16, c->stream));
   size_t blocks = (n + 255) / 256;
   if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
   hipLaunchKernelGGL(motion_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->geom,
-                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid);
+                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total);
   HIP_TRY(c, hipGetLastError());
   size_t need = 0;
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(n + 1), c->stream));
@@ -978,51 +1084,77 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, cap, counts, offsets, (int)(n + 1), c->stream));
   // expand every interior state into one state batch, validate it with the standard pipeline, then
   // fold the labels back onto the edges
-  uint32_t total = 0;
-  HIP_TRY(c, hipMemcpyAsync(&total, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  struct { unsigned long long total; int overflow; int pad; } plan{0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(&plan, d_total, 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (total == 0) return ARTP_OK;
-  rc = ensure_tmp(c, 3, (size_t)total * (7 * sizeof(double) + sizeof(uint32_t) + 1) + 64);
-  if (rc) return rc;
-  double* ex_states = static_cast<double*>(c->tmp[3]);
-  uint32_t* edge_of = reinterpret_cast<uint32_t*>(ex_states + (size_t)7 * total);
-  uint8_t* ex_valid = reinterpret_cast<uint8_t*>(edge_of + total);
+  if (plan.overflow) {
+    c->last_error = "an edge has non-finite states or needs more than 2^22 interpolation states";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  if (plan.total >= (1ull << 32)) {
+    c->last_error = "edge batch expands to 2^32 or more states: split it";
+    return ARTP_ERR_CAPACITY;
+  }
+  const uint32_t total = (uint32_t)plan.total;
+  const bool want_last = (mode == 0) && last_t;
+  if (want_last) HIP_TRY(c, hipMemsetAsync(first_bad, 0xff, n * sizeof(uint32_t), c->stream));
   size_t eb = ((size_t)total + 255) / 256;
   if (eb > (size_t)c->n_cus * 32) eb = (size_t)c->n_cus * 32;
-  hipLaunchKernelGGL(expand_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream, mode, s1, s2, n,
-                     (const uint32_t*)offsets, (const uint32_t*)aux, ex_states, edge_of);
-  HIP_TRY(c, hipGetLastError());
-  rc = launch_validate_pipeline(c, ex_states, total, ex_valid);
-  if (rc) return rc;
-  hipLaunchKernelGGL(reduce_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream,
-                     (const uint8_t*)ex_valid, (const uint32_t*)edge_of, (const uint32_t*)offsets, n, valid);
-  HIP_TRY(c, hipGetLastError());
+  if (total != 0) {
+    rc = ensure_tmp(c, 3, (size_t)total * (7 * sizeof(double) + sizeof(uint32_t) + 1) + 64);
+    if (rc) return rc;
+    double* ex_states = static_cast<double*>(c->tmp[3]);
+    uint32_t* edge_of = reinterpret_cast<uint32_t*>(ex_states + (size_t)7 * total);
+    uint8_t* ex_valid = reinterpret_cast<uint8_t*>(edge_of + total);
+    hipLaunchKernelGGL(expand_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream, mode, s1, s2, n,
+                       (const uint32_t*)offsets, (const uint32_t*)aux, ex_states, edge_of);
+    HIP_TRY(c, hipGetLastError());
+    rc = launch_validate_pipeline(c, ex_states, total, ex_valid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream,
+                       (const uint8_t*)ex_valid, (const uint32_t*)edge_of, (const uint32_t*)offsets, n, valid);
+    if (want_last)
+      hipLaunchKernelGGL(reduce_edges_first_bad_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream,
+                         (const uint8_t*)ex_valid, (const uint32_t*)edge_of, (const uint32_t*)offsets,
+                         (const uint32_t*)aux, n, first_bad);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (want_last) {
+    hipLaunchKernelGGL(last_valid_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, s1, s2, n,
+                       (const uint32_t*)aux, (const uint32_t*)first_bad, last_t, last_state);
+    HIP_TRY(c, hipGetLastError());
+  }
   return ARTP_OK;
 }
 
 static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
-                          uint8_t* valid, uint32_t* aux_out) {
+                          uint8_t* valid, uint32_t* aux_out, double* last_t = nullptr, double* last_state = nullptr) {
   if (!c || (n && (!s1 || !s2 || !valid))) return ARTP_ERR_INVALID_ARG;
   if (n == 0) return ARTP_OK;
-  {
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_tmp(c, 0, 2 * n * 7 * sizeof(double));
-    if (rc) return rc;
-    rc = ensure_tmp(c, 1, n + 4 * n + 16);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], s1, n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(static_cast<double*>(c->tmp[0]) + 7 * n, s2, n * 7 * sizeof(double),
-                              hipMemcpyHostToDevice, c->stream));
-  }
-  uint32_t* d_aux = static_cast<uint32_t*>(c->tmp[1]);
-  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_aux + n);
-  int rc = run_edges_dev(c, mode, static_cast<const double*>(c->tmp[0]),
-                         static_cast<const double*>(c->tmp[0]) + 7 * n, n, d_valid, d_aux);
+  // one lock for the whole call: the staging buffers c->tmp[0..1] are shared by every host entry point
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_tmp(c, 0, 2 * n * 7 * sizeof(double));
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(c->mu);
+  // tmp[1]: last_t (n doubles) | last_state (7n doubles) | aux (n u32) | valid (n)
+  rc = ensure_tmp(c, 1, n * 8 * sizeof(double) + n * 4 + n + 16);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->tmp[0], s1, n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(static_cast<double*>(c->tmp[0]) + 7 * n, s2, n * 7 * sizeof(double),
+                            hipMemcpyHostToDevice, c->stream));
+  double* d_last_t = static_cast<double*>(c->tmp[1]);
+  double* d_last_state = d_last_t + n;
+  uint32_t* d_aux = reinterpret_cast<uint32_t*>(d_last_state + 7 * n);
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_aux + n);
+  rc = run_edges_dev(c, mode, static_cast<const double*>(c->tmp[0]),
+                     static_cast<const double*>(c->tmp[0]) + 7 * n, n, d_valid, d_aux,
+                     last_t ? d_last_t : nullptr, last_state ? d_last_state : nullptr);
+  if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, c->stream));
   if (aux_out) HIP_TRY(c, hipMemcpyAsync(aux_out, d_aux, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (last_t) HIP_TRY(c, hipMemcpyAsync(last_t, d_last_t, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (last_t && last_state)
+    HIP_TRY(c, hipMemcpyAsync(last_state, d_last_state, n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return check_error_flag(c);
 }
 
@@ -1031,6 +1163,16 @@ int artp_check_motions_dev(artp_ctx* c, const double* s1, const double* s2, size
 }
 int artp_check_motions(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid) {
   return run_edges_host(c, 0, s1, s2, n, valid, nullptr);
+}
+int artp_check_motions_last_valid_dev(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                                      double* last_valid_t, double* last_valid_se3) {
+  if (n && !last_valid_t) return ARTP_ERR_INVALID_ARG;
+  return run_edges_dev(c, 0, s1, s2, n, valid, nullptr, last_valid_t, last_valid_se3);
+}
+int artp_check_motions_last_valid(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                                  double* last_valid_t, double* last_valid_se3) {
+  if (n && !last_valid_t) return ARTP_ERR_INVALID_ARG;
+  return run_edges_host(c, 0, s1, s2, n, valid, nullptr, last_valid_t, last_valid_se3);
 }
 int artp_check_edges_interp_dev(artp_ctx* c, const double* s1, const double* s2, size_t n,
                                 uint8_t* valid, uint32_t* n_interp_out) {
@@ -1048,7 +1190,7 @@ struct Se3Row { double v[7]; };
 
 int artp_debug_pipeline_counters(artp_ctx* c, uint64_t out[8]) {
   if (!c || !out) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->tmp[5]) return ARTP_ERR_NO_MAP;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(out, c->tmp[5], 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -1058,7 +1200,7 @@ int artp_debug_pipeline_counters(artp_ctx* c, uint64_t out[8]) {
 
 int artp_debug_partner_table(artp_ctx* c, int slot, uint8_t* out, size_t out_bytes, int* radius) {
   if (!c || slot < 0 || slot > 1 || !radius) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_field[slot]) return ARTP_ERR_NO_MAP;
   const FieldDev& f = c->field[slot];
   *radius = f.partner_flags ? f.partner_R : 0;
@@ -1074,7 +1216,7 @@ int artp_debug_partner_table(artp_ctx* c, int slot, uint8_t* out, size_t out_byt
 int artp_compact_valid_dev(artp_ctx* c, const double* se3, const uint8_t* valid, size_t n,
                            double* out_se3, uint64_t* n_out_dev) {
   if (!c || (n && (!se3 || !valid || !out_se3)) || !n_out_dev) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n == 0) {
     HIP_TRY(c, hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), c->stream));
@@ -1099,7 +1241,7 @@ int artp_compact_valid_dev(artp_ctx* c, const double* se3, const uint8_t* valid,
 int artp_compact_valid_indices_dev(artp_ctx* c, const uint8_t* valid, size_t n, uint32_t* out_idx,
                                    uint64_t* n_out_dev) {
   if (!c || (n && (!valid || !out_idx)) || !n_out_dev || n >= (1ull << 32)) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n == 0) {
     HIP_TRY(c, hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), c->stream));
@@ -1123,7 +1265,7 @@ int artp_compact_valid_indices_dev(artp_ctx* c, const uint8_t* valid, size_t n, 
 int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, const uint32_t* idx,
                               const uint64_t* count_dev, size_t cap, double* se3_out) {
   if (!c || !idx || !count_dev || (cap && !se3_out)) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_sampler) return ARTP_ERR_NO_MAP;
   if (cap == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1143,7 +1285,7 @@ int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, c
 
 int artp_algorithmic_vertices_dev(artp_ctx* c, const double* se3, size_t n, uint64_t* total) {
   if (!c || (n && !se3) || !total) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
@@ -1191,7 +1333,7 @@ size_t artp_cost_blob_bytes(void) { return 8 + cost_blob_floats() * sizeof(float
 
 int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
   if (!c || !blob) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   const unsigned char* p = static_cast<const unsigned char*>(blob);
   if (bytes != artp_cost_blob_bytes() || std::memcmp(p, "ARMC", 4) != 0 || p[4] != 1) {
     c->last_error = "motion-cost blob: bad magic, version or size";
@@ -1318,7 +1460,7 @@ static int cost_run_cnn(artp_ctx* c, int H, int W) {
 int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, double res, double len_x,
                          double len_y, double cx, double cy) {
   if (!c || !elev_xy || rows < 1 || cols < 1 || !(res > 0)) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t n = (size_t)rows * cols;
@@ -1366,7 +1508,7 @@ int artp_cost_update_map_layer(artp_ctx* c, const float* layer, int rows, int co
 
 int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) {
   if (!c || (b && (!edges || !cost))) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
   if (!c->have_features) return ARTP_ERR_NO_MAP;
   if (b == 0) return ARTP_OK;
@@ -1383,18 +1525,15 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
 int artp_cost_query(artp_ctx* c, const float* edges, size_t b, float* cost) {
   if (!c || (b && (!edges || !cost))) return ARTP_ERR_INVALID_ARG;
   if (b == 0) return ARTP_OK;
-  {
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_tmp(c, 0, b * 6 * sizeof(float));
-    if (rc) return rc;
-    rc = ensure_tmp(c, 1, b * 3 * sizeof(float));
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->tmp[0], edges, b * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  }
-  int rc = artp_cost_query_dev(c, static_cast<const float*>(c->tmp[0]), b, static_cast<float*>(c->tmp[1]));
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_tmp(c, 0, b * 6 * sizeof(float));
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(c->mu);
+  rc = ensure_tmp(c, 1, b * 3 * sizeof(float));
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->tmp[0], edges, b * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  rc = artp_cost_query_dev(c, static_cast<const float*>(c->tmp[0]), b, static_cast<float*>(c->tmp[1]));
+  if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(cost, c->tmp[1], b * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
@@ -1403,7 +1542,7 @@ int artp_cost_query(artp_ctx* c, const float* edges, size_t b, float* cost) {
 // Copy the feature map out (tests / diagnostics): NHWC fp16 -> float [F][F][48]
 int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
   if (!c || !fh || !fw) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_features) return ARTP_ERR_NO_MAP;
   *fh = c->feat_h;
   *fw = c->feat_w;

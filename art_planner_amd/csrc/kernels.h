@@ -222,6 +222,80 @@ validate_states_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb,
   if (n_valid && lane == 0 && local_valid) atomicAdd(n_valid, local_valid);
 }
 
+// Latency path of a handful of states (the per-state isValid() of the host mirror: one OMPL call = one state).
+// One workgroup per state, five wavefronts = the five boxes side by side (torso against the body layer, four
+// feet against the masked layer), each with its own LDS scratch, so the call costs the slowest box instead of
+// their sum.  The label is the AND over the boxes (the reference's short-circuit only skips work).  States and
+// labels may live in mapped host memory: one launch, no copies.
+__global__ void __launch_bounds__(320)
+validate_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const double* __restrict__ se3, size_t n,
+                    volatile uint8_t* valid, ScratchCaps caps_torso, ScratchCaps caps_foot,
+                    int* __restrict__ error_flag, unsigned done_tag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int box_ok[5];
+  const int lane = threadIdx.x & 63;
+  const int k = threadIdx.x >> 6;  // box index, wave-uniform
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const bool body = (k == 0);
+  WaveScratch s;
+  if (body) {
+    s = carve_scratch(smem, 0, caps_torso);
+  } else {
+    s = carve_scratch(smem + scratch_bytes_per_wave(caps_torso), k - 1, caps_foot);
+  }
+  double st[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
+  float t[3], R[9];
+  pose3_from_se3(st, t, R);
+  const float ox = body ? rb.torso_off[0] : ((k <= 2) ? rb.feet_off_x : -rb.feet_off_x);
+  const float oy = body ? rb.torso_off[1] : ((k & 1) ? rb.feet_off_y : -rb.feet_off_y);
+  const float oz = body ? rb.torso_off[2] : 0.0f;
+  float pose[16];  // pose * Pose3FromXYZ(o), Eigen's x0 + (x1 + x2) dot (see wave_state_valid)
+  pose[0] = (R[0] * ox + (R[1] * oy + R[2] * oz)) + t[0];
+  pose[1] = (R[3] * ox + (R[4] * oy + R[5] * oz)) + t[1];
+  pose[2] = (R[6] * ox + (R[7] * oy + R[8] * oz)) + t[2];
+  pose[3] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    pose[4 + 4 * r + 0] = R[3 * r + 0];
+    pose[4 + 4 * r + 1] = R[3 * r + 1];
+    pose[4 + 4 * r + 2] = R[3 * r + 2];
+    pose[4 + 4 * r + 3] = 0.0f;
+  }
+  int ok;
+  if (!map_is_inside(g, (double)pose[0], (double)pose[1])) {
+    ok = body ? 1 : !rb.unknown_space_untraversable;  // validity_checker_body.cpp:29-32, _feet.cpp:34-37
+  } else {
+    BoxHF b;
+    int ec, r;
+    if (body) {
+      setup_box(fb, pose, rb.torso[0], rb.torso[1], rb.torso[2], b);
+      r = wave_check_box(fb, b, s, lane, &ec);
+    } else {
+      setup_box(ff, pose, rb.foot[0], rb.foot[1], rb.foot[2], b);
+      r = wave_check_box(ff, b, s, lane, &ec);
+    }
+    ok = (r < 0) ? -1 : (body ? !r : r);
+    if (r < 0 && lane == 0 && !done_tag) atomicExch(error_flag, 1);
+  }
+  if (lane == 0) box_ok[k] = ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool err = false, v = true;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      err = err || box_ok[q] < 0;
+      v = v && box_ok[q] > 0;
+    }
+    // done_tag != 0 (host call through mapped memory): the host polls for the tag bit instead of synchronising
+    // the stream; bit 1 = a window exceeded the LDS scratch (ARTP_ERR_CAPACITY)
+    valid[i] = (uint8_t)((v && !err ? 1u : 0u) | (done_tag && err ? 2u : 0u) | done_tag);
+    if (done_tag) __threadfence_system();
+  }
+}
+
 // ---- R6 ------------------------------------------------------------------------------------------
 // Counter-based uniform01 (replaces ompl::RNG::uniform01): splitmix64 finaliser over
 // (seed, index, k) -- integer-exact, identical on host and device.
@@ -456,10 +530,25 @@ __device__ __forceinline__ void se3_interpolate(const double* a, const double* b
 // mode 0: DiscreteMotionValidator::checkMotion -> tasks = 1 (s2) + max(nd-1, 0), nd = validSegmentCount
 // mode 1: PRMMotionCost::addValidMilestone     -> tasks = n_interp = floor(lateral / 0.5)
 // counts[e] = number of wave-tasks of edge e, aux[e] = nd (mode 0) or n_interp (mode 1).
+// Per-edge task counts are capped at ARTP_MAX_EDGE_TASKS (an edge needing more -- non-finite states, a
+// degenerate state-space extent -- is reported through *overflow and the call fails with ARTP_ERR_INVALID_ARG
+// instead of wrapping the 32-bit scan); *total64 receives the sum of all counts.
+#define ARTP_MAX_EDGE_TASKS (1u << 22)
+__device__ __forceinline__ unsigned clamp_task_count(double x, int* overflow) {
+  if (!(x >= 0.0) || !(x <= (double)ARTP_MAX_EDGE_TASKS)) {  // NaN, negative, huge
+    *overflow = 1;
+    return 0u;
+  }
+  return (unsigned)x;
+}
+
 __global__ void __launch_bounds__(256)
 motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restrict__ s1,
                    const double* __restrict__ s2, size_t n, uint32_t* __restrict__ counts,
-                   uint32_t* __restrict__ aux, uint8_t* __restrict__ valid) {
+                   uint32_t* __restrict__ aux, uint8_t* __restrict__ valid, int* __restrict__ overflow,
+                   unsigned long long* __restrict__ total64) {
+  unsigned long long my_total = 0;
+  int my_overflow = 0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (size_t)gridDim.x * blockDim.x) {
     const double* a = s1 + 7 * e;
@@ -481,9 +570,9 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
         const double diff = a[i] - b[i];
         d2 += diff * diff;
       }
-      const unsigned n_r3 = (unsigned)ceil(sqrt(d2) / seg_r3);
+      const unsigned n_r3 = clamp_task_count(ceil(sqrt(d2) / seg_r3), &my_overflow);
       const double seg_so3 = (0.5 * 3.14159265358979323846) * 0.01;
-      const unsigned n_so3 = (unsigned)ceil(so3_arc_length(a + 3, b + 3) / seg_so3);
+      const unsigned n_so3 = clamp_task_count(ceil(so3_arc_length(a + 3, b + 3) / seg_so3), &my_overflow);
       const unsigned nd = n_r3 > n_so3 ? n_r3 : n_so3;
       ax = nd;
       cnt = 1u + (nd >= 2 ? nd - 1 : 0u);
@@ -491,14 +580,19 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
       const double dx = b[0] - a[0];
       const double dy = b[1] - a[1];
       const double dist = sqrt(dx * dx + dy * dy);
-      const unsigned n_interp = (unsigned)(dist / 0.5);
+      const unsigned n_interp = clamp_task_count(floor(dist / 0.5), &my_overflow);
       ax = n_interp;
       cnt = n_interp;
     }
     counts[e] = cnt;
     aux[e] = ax;
     valid[e] = 1;
+    my_total += cnt;
   }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) my_total += __shfl_xor(my_total, m, 64);
+  if ((threadIdx.x & 63) == 0 && my_total) atomicAdd(total64, my_total);
+  if (my_overflow) atomicExch(overflow, 1);
 }
 
 // offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  One lane per wave-task:
@@ -547,6 +641,53 @@ reduce_edges_kernel(const uint8_t* __restrict__ state_valid, const uint32_t* __r
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
        w += (size_t)gridDim.x * blockDim.x)
     if (!state_valid[w]) edge_valid[edge_of[w]] = 0;
+}
+
+// checkMotion(s1, s2, lastValid) (OMPL 1.4.2 DiscreteMotionValidator, second overload): the interior states
+// j = 1 .. nd-1 are tested in order, then s2; lastValid.second = (j - 1) / nd at the first failing j, and
+// (nd - 1) / nd when only s2 fails.  With "order" = j - 1 for interior task j and nd - 1 for s2 both read
+// order / nd, so the first failure is a minimum over the failing tasks of an edge (mode-0 task k = 0 is s2,
+// k >= 1 is interior state j = k).
+__global__ void __launch_bounds__(256)
+reduce_edges_first_bad_kernel(const uint8_t* __restrict__ state_valid, const uint32_t* __restrict__ edge_of,
+                              const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux, size_t n,
+                              uint32_t* __restrict__ first_bad) {
+  const size_t total = offsets[n];
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+       w += (size_t)gridDim.x * blockDim.x) {
+    if (state_valid[w]) continue;
+    const uint32_t e = edge_of[w];
+    const uint32_t k = (uint32_t)(w - offsets[e]);
+    const uint32_t nd = aux[e];
+    atomicMin(&first_bad[e], k == 0 ? (nd >= 1 ? nd - 1 : 0u) : k - 1);
+  }
+}
+
+// t_out[e] = lastValid.second, state_out[e] = interpolate(s1, s2, lastValid.second) for failing edges; passing
+// edges report t = 1 and s2 (OMPL leaves lastValid untouched for them).
+__global__ void __launch_bounds__(256)
+last_valid_kernel(const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
+                  const uint32_t* __restrict__ aux, const uint32_t* __restrict__ first_bad,
+                  double* __restrict__ t_out, double* __restrict__ state_out) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t fb = first_bad[e];
+    const int nd = (int)aux[e];
+    double st[7];
+    double t = 1.0;
+    if (fb == 0xffffffffu) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) st[i] = s2[7 * e + i];
+    } else {
+      // nd == 0 (identical states, invalid s2): OMPL evaluates (double)(nd - 1) / (double)nd = -inf
+      t = nd > 0 ? (double)fb / (double)nd : (double)(nd - 1) / (double)nd;
+      se3_interpolate(s1 + 7 * e, s2 + 7 * e, t, st);
+    }
+    t_out[e] = t;
+    if (state_out) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) state_out[7 * e + i] = st[i];
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256)

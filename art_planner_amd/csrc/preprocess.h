@@ -398,7 +398,7 @@ int artp_preprocess_map_ex(artp_ctx* c, const artp_preprocess_inputs* in, const 
   const int rows = in->rows, cols = in->cols;
   const double len_x = in->len_x, len_y = in->len_y, pos_x = in->pos_x, pos_y = in->pos_y;
   *out = nullptr;
-  std::unique_lock<std::mutex> lock(c->mu);
+  std::unique_lock<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const int n = rows * cols;
   auto pp = new artp_preprocessed();
@@ -550,7 +550,7 @@ int artp_preprocess_map_ex(artp_ctx* c, const artp_preprocess_inputs* in, const 
 
 int artp_preprocessed_get_layer(artp_ctx* c, const artp_preprocessed* pp, const char* name, float* out) {
   if (!c || !pp || !name || !out) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   if (std::strcmp(name, "cum_prob_rowwise") == 0) {
     HIP_TRY(c, hipMemcpy(out, pp->rowwise(), (size_t)pp->rows * 4, hipMemcpyDeviceToHost));
@@ -572,7 +572,7 @@ int artp_preprocessed_change(artp_ctx* c, artp_preprocessed* map_new, const artp
                              float height_change_for_update, float* updated_out, int rect[4], uint64_t* n_updated) {
   if (!c || !map_new || !map_old || map_new->rows != map_old->rows || map_new->cols != map_old->cols)
     return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const int rows = map_new->rows, cols = map_new->cols, n = rows * cols;
   const double res = map_new->len_x / rows;
@@ -613,7 +613,7 @@ int artp_preprocessed_install(artp_ctx* c, const artp_preprocessed* pp) {
   const size_t n = (size_t)pp->rows * pp->cols;
   float total = 0.f;
   {
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpy(&total, pp->scalars(), 4, hipMemcpyDeviceToHost));
   }

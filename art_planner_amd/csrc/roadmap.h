@@ -636,7 +636,7 @@ static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, co
     // grid over the map: about three vertices per cell
     artp::KnnGrid g;
     {
-      std::lock_guard<std::mutex> lock(c->mu);
+      std::lock_guard<std::recursive_mutex> lock(c->mu);
       g.x0 = c->geom.pos_x - 0.5 * c->geom.len_x;
       g.y0 = c->geom.pos_y - 0.5 * c->geom.len_y;
       const double area = c->geom.len_x * c->geom.len_y;

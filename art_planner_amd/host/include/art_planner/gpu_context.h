@@ -2,14 +2,81 @@
 // Planner -- the role art_planner::Planner's members play in the reference (planner.h:40-52).
 #pragma once
 
+#include <atomic>
+#include <cstdint>
+#include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "art_planner/params.h"
 #include "artp_c.h"
 
 namespace art_planner {
+
+// Labels of states the sampler mirror issued, computed by the SAME validity kernels on the SAME map in the same
+// launch that sampled them (artp_sample_and_validate).  The planners' rejection loops call
+// `do sampler_->sampleUniform(s); while (!si_->isValid(s))` (prm_motion_cost.cpp:174-186,
+// lazy_prm_star_min_update.cpp:552-554): with the block pre-validated, that isValid() is a lookup instead of a
+// kernel launch.  A block dies with the map it was validated on (mapChanged()).
+class ValidatedStateBlock {
+ public:
+  ValidatedStateBlock(std::vector<double>&& se3, std::vector<uint8_t>&& labels, uint64_t epoch, bool validated)
+      : se3_(std::move(se3)), labels_(std::move(labels)), epoch_(epoch), validated_(validated) {
+    if (!validated_) return;  // plain states: no lookups
+    size_t cap = 16;
+    while (cap < 4 * labels_.size()) cap <<= 1;
+    table_.assign(cap, 0xffffffffu);
+    for (uint32_t i = 0; i < labels_.size(); ++i) {
+      size_t slot = hash(state(i)) & (cap - 1);
+      while (table_[slot] != 0xffffffffu) slot = (slot + 1) & (cap - 1);
+      table_[slot] = i;
+    }
+  }
+  size_t size() const { return labels_.size(); }
+  uint64_t epoch() const { return epoch_; }
+  bool validated() const { return validated_; }
+  const double* state(size_t i) const { return se3_.data() + 7 * i; }
+  uint8_t label(size_t i) const { return labels_[i]; }
+  // the state last handed out is the one the next isValid() most likely asks about
+  void setHint(size_t i) { hint_.store(i, std::memory_order_relaxed); }
+  bool lookup(const double s[7], uint8_t* label) const {
+    if (!validated_) return false;
+    const size_t hint = hint_.load(std::memory_order_relaxed);
+    if (hint < labels_.size() && same(state(hint), s)) {
+      *label = labels_[hint];
+      return true;
+    }
+    const size_t mask = table_.size() - 1;
+    for (size_t slot = hash(s) & mask; table_[slot] != 0xffffffffu; slot = (slot + 1) & mask)
+      if (same(state(table_[slot]), s)) {
+        *label = labels_[table_[slot]];
+        return true;
+      }
+    return false;
+  }
+
+ private:
+  static bool same(const double* a, const double* b) { return std::memcmp(a, b, 7 * sizeof(double)) == 0; }
+  static size_t hash(const double* s) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (int k = 0; k < 7; ++k) {
+      uint64_t u;
+      std::memcpy(&u, s + k, 8);
+      h = (h ^ u) * 0xbf58476d1ce4e5b9ull;
+      h ^= h >> 29;
+    }
+    return static_cast<size_t>(h);
+  }
+  std::vector<double> se3_;
+  std::vector<uint8_t> labels_;
+  std::vector<uint32_t> table_;
+  uint64_t epoch_;
+  bool validated_;
+  std::atomic<size_t> hint_{0};
+};
 
 class GpuContext {
  public:
@@ -39,8 +106,54 @@ class GpuContext {
   GpuContext& operator=(const GpuContext&) = delete;
   artp_ctx* get() const { return ctx_; }
 
+  // ---- validated-state blocks (see ValidatedStateBlock) ----
+  // every map upload (checker, sampler, box checker) ends the validity of the blocks
+  void mapChanged() {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    ++map_epoch_;
+    for (auto& b : blocks_) b.reset();
+  }
+  uint64_t mapEpoch() const {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    return map_epoch_;
+  }
+  // a sampler publishes its current block in its own slot (slot = -1: take a free one); returns the slot
+  int publishBlock(int slot, const std::shared_ptr<ValidatedStateBlock>& block) {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    if (slot < 0) slot = next_slot_++ % kBlockSlots;
+    blocks_[slot] = (block->validated() && block->epoch() == map_epoch_) ? block : nullptr;
+    return slot;
+  }
+  bool lookupLabel(const double s[7], uint8_t* label) const {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    for (const auto& b : blocks_)
+      if (b && b->epoch() == map_epoch_ && b->lookup(s, label)) return true;
+    return false;
+  }
+  // isValid() / checkMotion() never throw (ob::StateValidityChecker contract): a failing call is remembered here
+  void noteError(const char* what, int rc) const {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    last_error_ = std::string(what) + ": " + artp_status_string(rc) + " " + artp_last_error(ctx_);
+    ++n_errors_;
+  }
+  std::string lastError() const {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    return last_error_;
+  }
+  size_t errorCount() const {
+    std::lock_guard<std::mutex> lock(blocks_mutex_);
+    return n_errors_;
+  }
+
  private:
+  static constexpr int kBlockSlots = 4;
   artp_ctx* ctx_{nullptr};
+  mutable std::mutex blocks_mutex_;
+  std::shared_ptr<ValidatedStateBlock> blocks_[kBlockSlots];
+  uint64_t map_epoch_{1};
+  int next_slot_{0};
+  mutable std::string last_error_;
+  mutable size_t n_errors_{0};
 };
 
 using GpuContextPtr = std::shared_ptr<GpuContext>;

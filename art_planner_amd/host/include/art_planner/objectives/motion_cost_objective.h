@@ -7,12 +7,15 @@
 #include <memory>
 #include <vector>
 
+#ifdef ARTP_HAVE_EIGEN
+#include <Eigen/Dense>
+#endif
+
 #include "art_planner/gpu_context.h"
 
 namespace art_planner {
 
 #ifdef ARTP_HAVE_EIGEN
-#include <Eigen/Dense>
 using EdgeMatrix = Eigen::Matrix<float, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
 #else
 // Row-major float matrix with the three Eigen members the reference's call sites use.

@@ -1,6 +1,16 @@
-// Minimal OMPL-shaped interfaces (just the virtuals the hot path overrides) for builds where OMPL
-// 1.4.2 is not installed (it is not in this image; art_planner/README.md:53 pins it).  With
-// -DARTP_HAVE_OMPL the real headers are used instead and this file is empty.
+// OMPL-1.4.2-shaped interfaces for builds where OMPL is not installed (it is not in this image;
+// art_planner/README.md:53 pins 1.4.2).  With -DARTP_HAVE_OMPL the real headers are used instead and this file
+// declares nothing.
+//
+// The stand-ins are STRICT: every pure virtual of the real ompl::base::StateSampler (sampleUniform,
+// sampleUniformNear, sampleGaussian), ompl::base::MotionValidator (both checkMotion overloads) and
+// ompl::base::StateValidityChecker (isValid) is pure here too, with the real signatures, so a mirror class that
+// would be abstract against the real library is abstract against this header as well and the stand-in build fails
+// the same way.  Non-pure virtuals the mirror may override (clearance, the isValid overloads with distance) and
+// the members the reference's code touches (si_, space_, rng_, valid_ / invalid_ counters, SE3 bounds) are there
+// with OMPL's names.  Written from the published OMPL 1.4.2 headers (ompl/base/StateSampler.h,
+// MotionValidator.h, StateValidityChecker.h, spaces/SE3StateSpace.h, spaces/RealVectorBounds.h, util/
+// RandomNumbers.h); nothing of OMPL is executed here.
 #pragma once
 
 #ifdef ARTP_HAVE_OMPL
@@ -9,15 +19,45 @@
 #include <ompl/base/StateSampler.h>
 #include <ompl/base/StateValidityChecker.h>
 #include <ompl/base/spaces/SE3StateSpace.h>
+#include <ompl/util/RandomNumbers.h>
 #else
 
+#include <cmath>
 #include <memory>
+#include <random>
+#include <utility>
+#include <vector>
 
 namespace ompl {
+
+// ompl/util/RandomNumbers.h (the members the path's call sites use: sampler.cpp:58-59,105,116)
+class RNG {
+ public:
+  RNG() : generator_(std::random_device{}()) {}
+  explicit RNG(std::uint_fast32_t seed) : generator_(seed) {}
+  double uniform01() { return uniDist_(generator_); }
+  double uniformReal(double lower_bound, double upper_bound) { return (upper_bound - lower_bound) * uniDist_(generator_) + lower_bound; }
+  double gaussian01() { return normalDist_(generator_); }
+  double gaussian(double mean, double stddev) { return normalDist_(generator_) * stddev + mean; }
+  void eulerRPY(double value[3]) {
+    value[0] = M_PI * (-2.0 * uniDist_(generator_) + 1.0);
+    value[1] = std::acos(1.0 - 2.0 * uniDist_(generator_)) - M_PI / 2.0;
+    value[2] = M_PI * (-2.0 * uniDist_(generator_) + 1.0);
+  }
+
+ private:
+  std::mt19937 generator_;
+  std::uniform_real_distribution<> uniDist_{0.0, 1.0};
+  std::normal_distribution<> normalDist_{0.0, 1.0};
+};
+
 namespace base {
 
 class State {
  public:
+  State() = default;
+  State(const State&) = default;
+  State& operator=(const State&) = default;
   virtual ~State() = default;
   template <class T>
   const T* as() const { return static_cast<const T*>(this); }
@@ -25,24 +65,43 @@ class State {
   T* as() { return static_cast<T*>(this); }
 };
 
-class SO3StateSpace {
+// ompl/base/spaces/RealVectorBounds.h
+class RealVectorBounds {
  public:
-  struct StateType : public State {
-    double x{0}, y{0}, z{0}, w{1};
-    void setIdentity() { x = y = z = 0; w = 1; }
-  };
+  explicit RealVectorBounds(unsigned int dim) { resize(dim); }
+  void setLow(double value) { low.assign(low.size(), value); }
+  void setHigh(double value) { high.assign(high.size(), value); }
+  void setLow(unsigned int index, double value) { low[index] = value; }
+  void setHigh(unsigned int index, double value) { high[index] = value; }
+  void resize(std::size_t size) {
+    low.resize(size, 0.0);
+    high.resize(size, 0.0);
+  }
+  std::vector<double> low;
+  std::vector<double> high;
 };
 
 class StateSpace {
  public:
   virtual ~StateSpace() = default;
+  template <class T>
+  const T* as() const { return static_cast<const T*>(this); }
+  template <class T>
+  T* as() { return static_cast<T*>(this); }
+};
+
+class SO3StateSpace : public StateSpace {
+ public:
+  class StateType : public State {
+   public:
+    void setIdentity() { x = y = z = 0; w = 1; }
+    double x{0}, y{0}, z{0}, w{1};
+  };
 };
 
 class SE3StateSpace : public StateSpace {
  public:
   class StateType : public State {
-    double xyz_[3]{0, 0, 0};
-    SO3StateSpace::StateType rot_;
    public:
     double getX() const { return xyz_[0]; }
     double getY() const { return xyz_[1]; }
@@ -53,37 +112,78 @@ class SE3StateSpace : public StateSpace {
     void setXYZ(double x, double y, double z) { xyz_[0] = x; xyz_[1] = y; xyz_[2] = z; }
     const SO3StateSpace::StateType& rotation() const { return rot_; }
     SO3StateSpace::StateType& rotation() { return rot_; }
+
+   private:
+    double xyz_[3]{0, 0, 0};
+    SO3StateSpace::StateType rot_;
   };
+  void setBounds(const RealVectorBounds& bounds) { bounds_ = bounds; }
+  const RealVectorBounds& getBounds() const { return bounds_; }
+
+ private:
+  RealVectorBounds bounds_{3};
 };
 
-class SpaceInformation {};
+class SpaceInformation {
+ public:
+  virtual ~SpaceInformation() = default;
+};
 using SpaceInformationPtr = std::shared_ptr<SpaceInformation>;
 
+// ompl/base/StateValidityChecker.h
 class StateValidityChecker {
  public:
-  explicit StateValidityChecker(const SpaceInformationPtr& si) : si_(si) {}
+  explicit StateValidityChecker(SpaceInformation* si) : si_(si) {}
+  explicit StateValidityChecker(const SpaceInformationPtr& si) : si_(si.get()) {}
   virtual ~StateValidityChecker() = default;
   virtual bool isValid(const State* state) const = 0;
+  virtual bool isValid(const State* state, double& dist) const {
+    dist = clearance(state);
+    return isValid(state);
+  }
+  virtual bool isValid(const State* state, double& dist, State* /*validState*/, bool& validStateAvailable) const {
+    dist = clearance(state);
+    validStateAvailable = false;
+    return isValid(state);
+  }
+  virtual double clearance(const State* /*state*/) const { return 0.0; }
+
  protected:
-  SpaceInformationPtr si_;
+  SpaceInformation* si_;
 };
 
+// ompl/base/MotionValidator.h
 class MotionValidator {
  public:
-  explicit MotionValidator(const SpaceInformationPtr& si) : si_(si) {}
+  explicit MotionValidator(SpaceInformation* si) : si_(si) {}
+  explicit MotionValidator(const SpaceInformationPtr& si) : si_(si.get()) {}
   virtual ~MotionValidator() = default;
   virtual bool checkMotion(const State* s1, const State* s2) const = 0;
+  virtual bool checkMotion(const State* s1, const State* s2, std::pair<State*, double>& lastValid) const = 0;
+  unsigned int getValidMotionCount() const { return valid_; }
+  unsigned int getInvalidMotionCount() const { return invalid_; }
+  unsigned int getCheckedMotionCount() const { return valid_ + invalid_; }
+  double getValidMotionFraction() const { return valid_ == 0 ? 0.0 : (double)valid_ / (double)(invalid_ + valid_); }
+  void resetMotionCounter() { valid_ = invalid_ = 0; }
+
  protected:
-  SpaceInformationPtr si_;
+  SpaceInformation* si_;
+  mutable unsigned int valid_{0};
+  mutable unsigned int invalid_{0};
 };
 
+// ompl/base/StateSampler.h
 class StateSampler {
  public:
   explicit StateSampler(const StateSpace* space) : space_(space) {}
   virtual ~StateSampler() = default;
   virtual void sampleUniform(State* state) = 0;
+  virtual void sampleUniformNear(State* state, const State* near, double distance) = 0;
+  virtual void sampleGaussian(State* state, const State* mean, double stdDev) = 0;
+
  protected:
   const StateSpace* space_;
+  RNG rng_;
 };
 
 }  // namespace base

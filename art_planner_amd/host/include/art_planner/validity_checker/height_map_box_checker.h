@@ -30,6 +30,7 @@ class HeightMapBoxChecker {
     const auto& layer = map->getLayer(layer_name);
     throwOnError(gpu_->get(), artp_upload_layer(gpu_->get(), slot_, layer.data(), g.rows, g.cols, g.length_x,
                                                 g.length_y, g.position_x, g.position_y), "artp_upload_layer");
+    gpu_->mapChanged();
   }
 
   // height_map_box_checker.cpp:58-72: number of poses in contact

@@ -1,10 +1,15 @@
 // art_planner::StateValidityChecker with the reference's interface
 // (art_planner/include/art_planner/validity_checker/validity_checker.h:22-47), plus the batch entry the
-// new batched planner loops use.  isValid() on a single state is a batch of one on the GPU -- there is
-// no CPU path in this library.
+// new batched planner loops use.  There is no CPU path in this library: isValid() is either a lookup of the label
+// the GPU computed when the sampler mirror issued the state (GpuContext::lookupLabel) or a batch of one through
+// the latency path of artp_validate_states (one launch, mapped host memory).  Like the reference's, isValid() and
+// checkMotion() never throw: a failing call returns false and is recorded in GpuContext::lastError().
+//
+// Differences from the reference's class, on purpose: the constructors take the GpuContext.
 #pragma once
 
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "art_planner/gpu_context.h"
@@ -26,6 +31,15 @@ inline void flattenSE3(const ob::State* state, double out[7]) {
   out[6] = s->rotation().w;
 }
 
+inline void unflattenSE3(const double s[7], ob::State* state) {
+  auto* o = state->as<ob::SE3StateSpace::StateType>();
+  o->setXYZ(s[0], s[1], s[2]);
+  o->rotation().x = s[3];
+  o->rotation().y = s[4];
+  o->rotation().z = s[5];
+  o->rotation().w = s[6];
+}
+
 class StateValidityChecker : public ob::StateValidityChecker {
  public:
   StateValidityChecker(const ob::SpaceInformationPtr& si, const ParamsConstPtr& params, const GpuContextPtr& gpu)
@@ -44,6 +58,7 @@ class StateValidityChecker : public ob::StateValidityChecker {
                                                 g.length_y, g.position_x, g.position_y), "artp_upload_layer");
     throwOnError(gpu_->get(), artp_upload_layer(gpu_->get(), ARTP_SLOT_FEET, feet.data(), g.rows, g.cols, g.length_x,
                                                 g.length_y, g.position_x, g.position_y), "artp_upload_layer");
+    gpu_->mapChanged();  // labels of states issued on the previous map are void
     has_field_ = true;
   }
 
@@ -54,7 +69,12 @@ class StateValidityChecker : public ob::StateValidityChecker {
     double s[7];
     flattenSE3(state, s);
     uint8_t v = 0;
-    throwOnError(gpu_->get(), artp_validate_states(gpu_->get(), s, 1, &v, nullptr), "artp_validate_states");
+    if (gpu_->lookupLabel(s, &v)) return v != 0;  // a state the sampler mirror issued on this map
+    const int rc = artp_validate_states(gpu_->get(), s, 1, &v, nullptr);
+    if (rc != ARTP_OK) {
+      gpu_->noteError("artp_validate_states", rc);
+      return false;
+    }
     return v != 0;
   }
 
@@ -90,7 +110,35 @@ class BatchMotionValidator : public ob::MotionValidator {
     flattenSE3(s1, a);
     flattenSE3(s2, b);
     uint8_t v = 0;
-    throwOnError(gpu_->get(), artp_check_motions(gpu_->get(), a, b, 1, &v), "artp_check_motions");
+    const int rc = artp_check_motions(gpu_->get(), a, b, 1, &v);
+    if (rc != ARTP_OK) {
+      gpu_->noteError("artp_check_motions", rc);
+      v = 0;
+    }
+    if (v) ++valid_; else ++invalid_;  // DiscreteMotionValidator keeps these counters
+    return v != 0;
+  }
+
+  // the second pure virtual of ob::MotionValidator: on failure lastValid.second = the parameter of the last
+  // valid state on the discretised segment and *lastValid.first (when not null) = that state
+  bool checkMotion(const ob::State* s1, const ob::State* s2, std::pair<ob::State*, double>& lastValid) const override {
+    double a[7], b[7], t = 0.0, st[7];
+    flattenSE3(s1, a);
+    flattenSE3(s2, b);
+    uint8_t v = 0;
+    const int rc = artp_check_motions_last_valid(gpu_->get(), a, b, 1, &v, &t, st);
+    if (rc != ARTP_OK) {
+      gpu_->noteError("artp_check_motions_last_valid", rc);
+      ++invalid_;
+      lastValid.second = 0.0;  // nothing beyond s1 is known to be valid
+      if (lastValid.first) unflattenSE3(a, lastValid.first);
+      return false;
+    }
+    if (!v) {
+      lastValid.second = t;
+      if (lastValid.first) unflattenSE3(st, lastValid.first);
+    }
+    if (v) ++valid_; else ++invalid_;
     return v != 0;
   }
 

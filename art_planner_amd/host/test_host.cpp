@@ -1,21 +1,44 @@
-// Exercises the C++ host mirror (reference class names / signatures) over libartp.so.
-//   test_host <fixture.bin>
+// Exercises the C++ host mirror (reference class names / signatures) over libartp.so, compiled against the
+// STRICT OMPL-shaped stand-ins of ompl_min.h (every pure virtual of the real base classes is pure there).
+//   test_host <fixture.bin> [latency_out.json]
 // fixture: int32 rows, cols; float64 len_x len_y pos_x pos_y; float32 elevation[rows*cols] (col-major),
-//          float32 elevation_masked[rows*cols]; int32 n; float64 se3[n*7]; uint8 expected[n]
-// Exit code 0 = every label (single-state isValid AND batch) equals the expected (oracle) label.
-// Without a GPU the context constructor must throw (no CPU fallback): exit code 3.
+//          float32 elevation_masked, cum_prob, cum_prob_rowwise_hack, normal_x, normal_y, normal_z,
+//          plane_fit_std_dev (rows*cols each); float64 z_low, z_high; int32 n; float64 se3[n*7]; uint8 expected[n]
+//          (oracle labels); int32 m; float64 s1[m*7], s2[m*7]; uint8 motion_ok[m]; float64 last_t[m],
+//          last_state[m*7] (oracle, DiscreteMotionValidator::checkMotion(s1, s2, lastValid))
+// Exit code 0 = every label (single-state isValid AND batch), every checkMotion verdict and every lastValid pair
+// equals the oracle's.  Without a GPU the context constructor must throw (no CPU fallback): exit code 3.
+#include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <type_traits>
 #include <vector>
 
 #include "art_planner/objectives/motion_cost_objective.h"
-#include "art_planner/sampler.h"
 #include "art_planner/planners/batch_prm.h"
+#include "art_planner/sampler.h"
 #include "art_planner/validity_checker/height_map_box_checker.h"
 #include "art_planner/validity_checker/validity_checker.h"
 
 using namespace art_planner;
+
+// the mirror classes must be concrete against OMPL-1.4.2-shaped bases (std::make_shared in INTEGRATION.md)
+static_assert(!std::is_abstract<SE3FromSE2Sampler>::value, "SE3FromSE2Sampler misses a StateSampler pure virtual");
+static_assert(!std::is_abstract<BatchMotionValidator>::value, "BatchMotionValidator misses a MotionValidator pure virtual");
+static_assert(!std::is_abstract<StateValidityChecker>::value, "StateValidityChecker misses isValid");
+static_assert(std::is_abstract<ob::StateSampler>::value && std::is_abstract<ob::MotionValidator>::value, "stand-ins must be strict");
+
+static void toState(const double* s, ob::SE3StateSpace::StateType* o) {
+  o->setXYZ(s[0], s[1], s[2]);
+  o->rotation().x = s[3]; o->rotation().y = s[4]; o->rotation().z = s[5]; o->rotation().w = s[6];
+}
+
+static double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int main(int argc, char** argv) {
   auto params = std::make_shared<Params>();
@@ -33,63 +56,191 @@ int main(int argc, char** argv) {
   }
   if (argc < 2) return 2;
   std::ifstream f(argv[1], std::ios::binary);
-  int32_t rows, cols, n;
-  double geo[4];
+  int32_t rows, cols, n, m;
+  double geo[4], zb[2];
   f.read(reinterpret_cast<char*>(&rows), 4);
   f.read(reinterpret_cast<char*>(&cols), 4);
   f.read(reinterpret_cast<char*>(geo), 32);
-  std::vector<float> elev(static_cast<size_t>(rows) * cols), masked(elev.size());
-  f.read(reinterpret_cast<char*>(elev.data()), elev.size() * 4);
-  f.read(reinterpret_cast<char*>(masked.data()), masked.size() * 4);
+  const size_t cells = static_cast<size_t>(rows) * cols;
+  const char* names[9] = {"elevation", "elevation_masked", "cum_prob", "cum_prob_rowwise_hack", "normal_x",
+                          "normal_y", "normal_z", "plane_fit_std_dev", nullptr};
+  auto map = std::make_shared<Map>();
+  map->setGeometry({rows, cols, geo[0] / rows, geo[0], geo[1], geo[2], geo[3]});
+  std::vector<float> layer(cells);
+  for (int k = 0; names[k]; ++k) {
+    f.read(reinterpret_cast<char*>(layer.data()), cells * 4);
+    map->addLayer(names[k], layer.data());
+  }
+  f.read(reinterpret_cast<char*>(zb), 16);
   f.read(reinterpret_cast<char*>(&n), 4);
   std::vector<double> se3(static_cast<size_t>(n) * 7);
   std::vector<uint8_t> expected(n);
   f.read(reinterpret_cast<char*>(se3.data()), se3.size() * 8);
   f.read(reinterpret_cast<char*>(expected.data()), n);
+  f.read(reinterpret_cast<char*>(&m), 4);
+  std::vector<double> s1(static_cast<size_t>(m) * 7), s2(s1.size()), last_t(m), last_state(s1.size());
+  std::vector<uint8_t> motion_ok(m);
+  f.read(reinterpret_cast<char*>(s1.data()), s1.size() * 8);
+  f.read(reinterpret_cast<char*>(s2.data()), s2.size() * 8);
+  f.read(reinterpret_cast<char*>(motion_ok.data()), m);
+  f.read(reinterpret_cast<char*>(last_t.data()), m * 8);
+  f.read(reinterpret_cast<char*>(last_state.data()), last_state.size() * 8);
   if (!f) return 2;
 
-  auto map = std::make_shared<Map>();
-  map->setGeometry({rows, cols, geo[0] / rows, geo[0], geo[1], geo[2], geo[3]});
-  map->addLayer("elevation", elev.data());
-  map->addLayer("elevation_masked", masked.data());
-
-  StateValidityChecker checker(std::make_shared<ob::SpaceInformation>(), params, gpu);
+  auto si = std::make_shared<ob::SpaceInformation>();
+  StateValidityChecker checker(si, params, gpu);
   checker.setMap(map);
   checker.updateHeightField();
   if (!checker.hasMap()) return 4;
 
   int bad = 0;
+  // ---- isValid: batch + single states (arbitrary states: the latency path) ----
   const auto batch = checker.isValidBatch(se3);
   for (int i = 0; i < n; ++i) bad += batch[i] != expected[i];
-  const int n_single = n < 200 ? n : 200;
+  const int n_single = n < 2000 ? n : 2000;
+  ob::SE3StateSpace::StateType st;
+  double t0 = now_us();
   for (int i = 0; i < n_single; ++i) {
-    ob::SE3StateSpace::StateType s;
-    s.setXYZ(se3[7 * i], se3[7 * i + 1], se3[7 * i + 2]);
-    s.rotation().x = se3[7 * i + 3]; s.rotation().y = se3[7 * i + 4];
-    s.rotation().z = se3[7 * i + 5]; s.rotation().w = se3[7 * i + 6];
-    bad += checker.isValid(&s) != (expected[i] != 0);
+    toState(&se3[7 * i], &st);
+    bad += checker.isValid(&st) != (expected[i] != 0);
   }
+  const double us_single = (now_us() - t0) / n_single;
+  // a checker without a map must answer false, not throw (ob::StateValidityChecker::isValid never throws)
+  {
+    auto gpu2 = std::make_shared<GpuContext>(params, 0);
+    StateValidityChecker unmapped(si, params, gpu2);
+    toState(&se3[0], &st);
+    bool threw = false, v = true;
+    try { v = unmapped.isValid(&st); } catch (...) { threw = true; }
+    bad += (threw || v || gpu2->errorCount() != 1) ? 1 : 0;
+  }
+
+  // ---- MotionValidator: both overloads against the oracle ----
+  BatchMotionValidator mv(si, gpu);
+  mv.setZBounds(zb[0], zb[1]);
+  const auto mb = mv.checkMotionBatch(s1, s2);
+  for (int i = 0; i < m; ++i) bad += mb[i] != motion_ok[i];
+  const int m_single = m < 300 ? m : 300;
+  ob::SE3StateSpace::StateType a, b, lv;
+  int bad_last = 0;
+  for (int i = 0; i < m_single; ++i) {
+    toState(&s1[7 * i], &a);
+    toState(&s2[7 * i], &b);
+    bad += mv.checkMotion(&a, &b) != (motion_ok[i] != 0);
+    std::pair<ob::State*, double> last(&lv, -7.0);
+    lv.setXYZ(1e9, 1e9, 1e9);
+    const bool ok = mv.checkMotion(&a, &b, last);
+    bad += ok != (motion_ok[i] != 0);
+    if (ok) {
+      bad_last += (last.second != -7.0 || lv.getX() != 1e9) ? 1 : 0;  // untouched on success, like OMPL
+    } else {
+      double got[7];
+      flattenSE3(&lv, got);
+      bool same = last.second == last_t[i];
+      for (int k = 0; k < 7; ++k) same = same && std::fabs(got[k] - last_state[7 * i + k]) <= 1e-12;
+      bad_last += same ? 0 : 1;
+    }
+  }
+  bad += bad_last;
+  bad += (mv.getCheckedMotionCount() != 2u * m_single) ? 1 : 0;
+
+  // ---- StateSampler: the planners' rejection loop; sampler-issued states are pre-validated ----
+  ob::SE3StateSpace space;
+  ob::RealVectorBounds bounds(3);
+  bounds.setLow(0, geo[2] - geo[0]); bounds.setHigh(0, geo[2] + geo[0]);   // planner.cpp:146-156
+  bounds.setLow(1, geo[3] - geo[1]); bounds.setHigh(1, geo[3] + geo[1]);
+  bounds.setLow(2, zb[0]); bounds.setHigh(2, zb[1]);
+  space.setBounds(bounds);
+  SE3FromSE2SamplerAllocator alloc(params, gpu);
+  alloc.setMap(map);
+  checker.updateHeightField();
+  auto sampler = alloc.getSampler(&space);
+  const int n_loop = 200000;
+  int accepted = 0, attempts = 0;
+  std::vector<double> acc_states;
+  t0 = now_us();
+  std::vector<double> rej_states;
+  while (attempts < n_loop) {
+    ob::SE3StateSpace::StateType s;
+    bool ok = false;
+    do {  // prm_motion_cost.cpp:174-186 / lazy_prm_star_min_update.cpp:552-554
+      sampler->sampleUniform(&s);
+      ++attempts;
+      ok = checker.isValid(&s);
+      if (!ok && rej_states.size() < 64 * 7) {
+        double fl[7];
+        flattenSE3(&s, fl);
+        rej_states.insert(rej_states.end(), fl, fl + 7);
+      }
+    } while (!ok && attempts < n_loop);
+    if (!ok) break;
+    if (accepted < 64) {
+      double fl[7];
+      flattenSE3(&s, fl);
+      acc_states.insert(acc_states.end(), fl, fl + 7);
+    }
+    ++accepted;
+  }
+  const double us_loop = (now_us() - t0) / attempts;
+  // the looked-up labels are the labels of the batch kernel
+  for (uint8_t v : checker.isValidBatch(acc_states)) bad += v ? 0 : 1;
+  for (uint8_t v : checker.isValidBatch(rej_states)) bad += v ? 1 : 0;
+  bad += (acc_states.size() < 64 * 7 || rej_states.empty()) ? 1 : 0;
+  // a map update voids the published labels: after updateHeightField() lookups must miss (-> latency path)
+  checker.updateHeightField();
+  {
+    toState(&acc_states[0], &st);
+    uint8_t lab = 0;
+    double fl[7];
+    flattenSE3(&st, fl);
+    bad += gpu->lookupLabel(fl, &lab) ? 1 : 0;
+    bad += checker.isValid(&st) ? 0 : 1;  // same map data: still valid, now through a launch
+  }
+  // sampleUniformNear / sampleGaussian (sampler.cpp:135-187): inside the bounds, yaw-only rotation
+  {
+    ob::SE3StateSpace::StateType near, out;
+    toState(&acc_states[0], &near);
+    for (int i = 0; i < 200; ++i) {
+      out.rotation().setIdentity();
+      if (i & 1) sampler->sampleUniformNear(&out, &near, 0.5); else sampler->sampleGaussian(&out, &near, 0.3);
+      const bool in_bounds = out.getX() >= bounds.low[0] && out.getX() <= bounds.high[0] && out.getY() >= bounds.low[1] &&
+                             out.getY() <= bounds.high[1] && out.getZ() >= bounds.low[2] && out.getZ() <= bounds.high[2];
+      const bool near_enough = !(i & 1) || (std::fabs(out.getX() - near.getX()) <= 0.5 && std::fabs(out.getY() - near.getY()) <= 0.5);
+      const bool yaw_only = out.rotation().x == 0 && out.rotation().y == 0 &&
+                            std::fabs(out.rotation().w * out.rotation().w + out.rotation().z * out.rotation().z - 1.0) < 1e-12;
+      bad += (in_bounds && near_enough && yaw_only) ? 0 : 1;
+    }
+  }
+
   // HeightMapBoxChecker at the dPose boundary: an identity-rotation torso far above the map never hits
   HeightMapBoxChecker box(gpu, ARTP_SLOT_BODY, 1.31f, 0.65f, 0.3f);
   box.setHeightField(map, "elevation");
   HeightMapBoxChecker::dPose high;
   high.origin = {0.f, 0.f, 50.f, 0.f};
   bad += box.checkCollision({high}) != 0;
-  // BatchPRM compiles against the same Params; it needs the sampler layers, which this fixture does not
-  // carry: building a roadmap must fail loudly, not fall back to anything
+  // BatchPRM compiles against the same Params and builds a small roadmap between two accepted states
   {
-    BatchPRM prm(params, gpu);
-    ob::SE3StateSpace::StateType a;
-    a.setXYZ(se3[0], se3[1], se3[2]);
-    a.rotation().x = se3[3]; a.rotation().y = se3[4]; a.rotation().z = se3[5]; a.rotation().w = se3[6];
+    auto p2 = std::make_shared<Params>(*params);
+    p2->planner.prm_motion_cost.max_n_vertices = 300;
+    BatchPRM prm(p2, gpu);
+    toState(&acc_states[0], &a);
+    toState(&acc_states[7 * 40], &b);
     bool threw = false;
     try {
-      prm.sampleGraph(a, a);
-    } catch (const std::exception&) {
+      prm.sampleGraph(a, b);
+    } catch (const std::exception& e) {
+      std::printf("BatchPRM: %s\n", e.what());
       threw = true;
     }
-    bad += threw ? 0 : 1;
+    bad += (threw || prm.numVertices() != 302) ? 1 : 0;
   }
-  std::printf("host mirror: %d states batch + %d single, %d mismatches\n", n, n_single, bad);
+  std::printf("host mirror: %d states batch + %d single (%.1f us per isValid on arbitrary states), %d motions (%d lastValid "
+              "mismatches), rejection loop %d attempts / %d accepted at %.3f us per sampleUniform+isValid, %d mismatches\n",
+              n, n_single, us_single, m, bad_last, attempts, accepted, us_loop, bad);
+  if (argc > 2) {
+    std::ofstream o(argv[2]);
+    o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"sampler_loop_us_per_state\": " << us_loop
+      << ", \"loop_attempts\": " << attempts << ", \"loop_accepted\": " << accepted << "}\n";
+  }
   return bad == 0 ? 0 : 1;
 }

@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - opaque context per device; all entry points return 0 (ARTP_OK) or a negative artp_status and
- *     never throw; calls on one context are serialised internally, contexts are independent.
+ *     never throw; calls on one context are serialised internally (one recursive lock held for the whole
+ *     call, staging buffers included), contexts are independent.
  *   - plain pointers and sizes only.  Pointers are HOST memory unless the function name ends in
  *     `_dev`, in which case every buffer argument is DEVICE memory on the context's GPU and the call
  *     is asynchronous on the context's stream (artp_set_stream / artp_synchronize).
@@ -101,6 +102,8 @@ int artp_check_boxes_dev(artp_ctx* ctx, int slot, const float box_lengths[3], co
  *      (art_planner/src/validity_checker/validity_checker.cpp:39-45) ----------------------------
  * valid[i] = body_ok && feet_ok for state i.  detail (optional): n x 6 int8 =
  * {body exit code | -1 outside map, 4 x foot exit code | -1 outside | -2 not evaluated, 0}. */
+/* Up to 16 states without `detail` take the latency path: one launch, one workgroup per state with the five
+ * boxes side by side, states / labels through mapped pinned host memory (no copies). */
 int artp_validate_states(artp_ctx* ctx, const double* se3, size_t n, uint8_t* valid, int8_t* detail);
 int artp_validate_states_dev(artp_ctx* ctx, const double* se3, size_t n, uint8_t* valid,
                              int8_t* detail);
@@ -124,6 +127,10 @@ int artp_sample_states_dev(artp_ctx* ctx, uint64_t seed, uint64_t first_index, s
  * (forces a stream sync when non-NULL). */
 int artp_sample_and_validate_dev(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n,
                                  double* se3_out, uint8_t* valid_out, size_t* n_valid);
+/* Host-buffer form: states and labels come back together, so a sampler that hands the states out one at a
+ * time (ob::StateSampler::sampleUniform) already holds the label the following isValid() will ask for. */
+int artp_sample_and_validate(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n, double* se3_out,
+                             uint8_t* valid_out);
 
 /* ---- ob::MotionValidator::checkMotion (OMPL DiscreteMotionValidator; call sites
  *      prm_motion_cost.cpp:652, lazy_prm_star_min_update.cpp:725), batched -----------------------
@@ -134,6 +141,15 @@ int artp_set_z_bounds(artp_ctx* ctx, double z_low, double z_high);
 int artp_check_motions(artp_ctx* ctx, const double* s1, const double* s2, size_t n, uint8_t* valid);
 int artp_check_motions_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
                            uint8_t* valid);
+/* ob::MotionValidator::checkMotion(s1, s2, std::pair<State*, double>& lastValid) (pure virtual in OMPL 1.4.2;
+ * DiscreteMotionValidator tests the interior states j = 1 .. nd-1 in order, then s2): for a failing edge
+ * last_valid_t[i] = lastValid.second = (j - 1) / nd of the first failing j ((nd - 1) / nd when only s2 fails) and
+ * last_valid_se3[i] (n x 7, may be NULL) = interpolate(s1, s2, last_valid_t[i]) = *lastValid.first; a passing
+ * edge reports t = 1 and s2 (OMPL leaves lastValid untouched). */
+int artp_check_motions_last_valid(artp_ctx* ctx, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                                  double* last_valid_t, double* last_valid_se3);
+int artp_check_motions_last_valid_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                                      double* last_valid_t, double* last_valid_se3);
 /* PRM-build edge validation of PRMMotionCost::addValidMilestone (prm_motion_cost.cpp:340-377):
  * n_interp = floor(lateral distance / 0.5) interior states at t = step * (1/(n_interp+1)), each
  * must be valid.  n_interp_out optional (uint32 per edge). */

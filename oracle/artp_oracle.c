@@ -1208,6 +1208,38 @@ int artp_oracle_check_motion(const artp_oracle_map* m, const artp_oracle_robot* 
   return result;
 }
 
+/* DiscreteMotionValidator::checkMotion(s1, s2, lastValid) of OMPL 1.4.2 (src/ompl/base/src/
+ * DiscreteMotionValidator.cpp, second overload; pure virtual in ob::MotionValidator -- OMPL is not vendored,
+ * restated from the published source): the interior states j = 1 .. nd-1 are tested IN ORDER, then s2;
+ * lastValid.second = (j - 1) / nd at the first failing j, (nd - 1) / nd when only s2 fails, and
+ * *lastValid.first = interpolate(s1, s2, lastValid.second). */
+int artp_oracle_check_motion_last_valid(const artp_oracle_map* m, const artp_oracle_robot* r, double z_extent,
+                                        const double s1[7], const double s2[7], double* last_valid_t,
+                                        double last_valid_state[7]) {
+  int result = 1;
+  const int nd = (int)artp_oracle_valid_segment_count(m, z_extent, s1, s2);
+  if (nd > 1) {
+    for (int j = 1; j < nd; ++j) {
+      double test[7];
+      artp_oracle_interpolate(s1, s2, (double)j / (double)nd, test);
+      if (!artp_oracle_state_valid(m, r, test, NULL)) {
+        *last_valid_t = (double)(j - 1) / (double)nd;
+        if (last_valid_state) artp_oracle_interpolate(s1, s2, *last_valid_t, last_valid_state);
+        result = 0;
+        break;
+      }
+    }
+  }
+  if (result) {
+    if (!artp_oracle_state_valid(m, r, s2, NULL)) {
+      *last_valid_t = (double)(nd - 1) / (double)nd;
+      if (last_valid_state) artp_oracle_interpolate(s1, s2, *last_valid_t, last_valid_state);
+      result = 0;
+    }
+  }
+  return result;
+}
+
 int artp_oracle_edge_interp_valid(const artp_oracle_map* m, const artp_oracle_robot* r,
                                   const double s1[7], const double s2[7], unsigned* n_interp_out,
                                   double* interior, unsigned max_interior) {

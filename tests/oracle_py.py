@@ -90,6 +90,9 @@ def lib():
         L.artp_oracle_check_motion.argtypes = [C.POINTER(Map), C.POINTER(Robot), C.c_double, C.c_void_p,
                                                C.c_void_p, C.c_void_p]
         L.artp_oracle_check_motion.restype = C.c_int
+        L.artp_oracle_check_motion_last_valid.argtypes = [C.POINTER(Map), C.POINTER(Robot), C.c_double, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.artp_oracle_check_motion_last_valid.restype = C.c_int
         L.artp_oracle_edge_interp_valid.argtypes = [C.POINTER(Map), C.POINTER(Robot), C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
         L.artp_oracle_edge_interp_valid.restype = C.c_int
@@ -184,6 +187,24 @@ class OracleMap:
                                                     s2[i].ctypes.data, C.byref(c))
             nchk[i] = c.value
         return out, nchk
+
+    def check_motions_last_valid(self, rob, s1, s2):
+        """DiscreteMotionValidator::checkMotion(s1, s2, lastValid): (valid, t, state); t = 1 / state = s2 where
+        the motion is valid (the convention of artp_check_motions_last_valid)."""
+        s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
+        s2 = np.ascontiguousarray(s2, np.float64).reshape(-1, 7)
+        n = s1.shape[0]
+        out = np.empty(n, np.uint8)
+        t = np.ones(n, np.float64)
+        st = s2.copy()
+        ze = self.z_extent(rob)
+        tt = C.c_double(0)
+        for i in range(n):
+            out[i] = lib().artp_oracle_check_motion_last_valid(C.byref(self.m), C.byref(rob), ze, s1[i].ctypes.data,
+                                                               s2[i].ctypes.data, C.byref(tt), st[i].ctypes.data)
+            if not out[i]:
+                t[i] = tt.value
+        return out, t, st
 
     def segment_counts(self, rob, s1, s2):
         s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)

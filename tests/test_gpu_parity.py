@@ -432,3 +432,97 @@ def test_tiny_and_odd_sized_maps(rows, cols):
                 hg, eg = ctx.check_boxes(slot, side, P, want_exit_codes=True)
                 assert np.array_equal(hg, ho) and np.array_equal(eg, eo)
         ctx.close()
+
+
+@pytest.mark.parametrize("name", golden_io.MAPS)
+@pytest.mark.parametrize("rname", ["yaml", "defaults"])
+def test_latency_path_few_states_golden(name, rname):
+    """artp_validate_states with <= 16 states and no `detail` takes validate_few_kernel (one workgroup per state,
+    five boxes side by side, mapped host memory): labels of the golden states (real-ODE labels at the dPose
+    boundary), in chunks of 1..16, with and without host polling."""
+    gm, _ = golden_io.load_boxes(name)
+    s = golden_io.load_states(name)[rname]
+    se3, ref = s["se3"][:1200], s["valid"][:1200]
+    ctx = _ctx(rname)
+    ctx.upload_map(gm, sampler=False)
+    got = np.empty(len(se3), np.uint8)
+    i, k = 0, 1
+    while i < len(se3):
+        got[i:i + k] = ctx.validate_states(se3[i:i + k])
+        i += k
+        k = k % 16 + 1
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} label mismatches on the latency path"
+    # device-pointer form of the same kernel (n <= 16)
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(se3[:16])).cuda()
+    v = torch.empty(16, dtype=torch.uint8, device="cuda")
+    ctx.validate_states_dev(t, v)
+    ctx.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ref[:16])
+    ctx.close()
+
+
+def test_latency_path_without_polling(big_map, monkeypatch):
+    """ARTP_NO_POLL=1: the same labels through hipStreamSynchronize instead of the mapped-memory poll."""
+    monkeypatch.setenv("ARTP_NO_POLL", "1")
+    rob = O.robot("yaml")
+    ctx = _ctx("yaml")
+    ctx.upload_map(big_map)
+    se3 = ctx.sample_states(3, 0, 400)
+    ref = O.OracleMap(big_map).states_valid(rob, se3)
+    got = np.concatenate([ctx.validate_states(se3[i:i + 7]) for i in range(0, 400, 7)])
+    assert np.array_equal(got, ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", golden_io.MAPS)
+def test_check_motion_last_valid_golden(name):
+    """checkMotion(s1, s2, lastValid) -- the second pure virtual of ob::MotionValidator -- on the golden edges:
+    verdicts = the golden check_motion bits, lastValid.second / *lastValid.first = the oracle's restatement of
+    DiscreteMotionValidator (exact t, states to 1e-12)."""
+    gm, _ = golden_io.load_boxes(name)
+    om = O.OracleMap(gm)
+    for rname, e in golden_io.load_edges(name).items():
+        ctx = _ctx(rname)
+        ctx.upload_map(gm, sampler=False)
+        rob = O.robot(rname)
+        s1, s2 = e["s1"][:600], e["s2"][:600]
+        ok, t, st = ctx.check_motions_last_valid(s1, s2)
+        assert np.array_equal(ok, e["check_motion"][:600])
+        rok, rt, rst = om.check_motions_last_valid(rob, s1, s2)
+        assert np.array_equal(ok, rok)
+        assert np.array_equal(t, rt), f"lastValid.second differs on {int((t != rt).sum())} edges"
+        assert np.abs(st - rst).max() <= 1e-12
+        # degenerate edge s1 == s2 ending on an invalid state: nd = 0, OMPL's (nd - 1) / nd = -inf
+        inv = e["s2"][np.flatnonzero(e["check_motion"] == 0)]
+        inv = inv[om.states_valid(rob, inv) == 0][:3]
+        if len(inv):
+            ok0, t0, _ = ctx.check_motions_last_valid(inv, inv)
+            rok0, rt0, _ = om.check_motions_last_valid(rob, inv, inv)
+            assert not ok0.any() and np.array_equal(ok0, rok0) and np.array_equal(t0, rt0)
+        ctx.close()
+
+
+def test_sample_and_validate_host_form(big_map, ctx_yaml):
+    """artp_sample_and_validate (host buffers): the states of artp_sample_states and the labels of
+    artp_validate_states for the same (seed, index) range."""
+    ctx_yaml.upload_map(big_map)
+    se3, valid = ctx_yaml.sample_and_validate(9, 12345, 5000)
+    assert np.array_equal(se3, ctx_yaml.sample_states(9, 12345, 5000))
+    assert np.array_equal(valid, ctx_yaml.validate_states(se3))
+    assert np.array_equal(valid, O.OracleMap(big_map).states_valid(O.robot("yaml"), se3))
+
+
+def test_edge_batches_with_non_finite_states_are_rejected(big_map, ctx_yaml):
+    """NaN / inf states must not wrap the 32-bit task scan -- the call fails with INVALID_ARG."""
+    from art_planner_amd._capi import ArtpError
+    ctx_yaml.upload_map(big_map)
+    se3 = ctx_yaml.sample_states(5, 0, 8)
+    bad = se3.copy()
+    bad[3, 0] = np.nan
+    with pytest.raises(ArtpError):
+        ctx_yaml.check_motions(se3, bad)
+    bad[3, 0] = np.inf
+    with pytest.raises(ArtpError):
+        ctx_yaml.check_edges_interp(se3, bad)
+    assert ctx_yaml.check_motions(se3, se3).shape == (8,)   # the context stays usable

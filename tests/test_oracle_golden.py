@@ -69,6 +69,33 @@ def test_interpolate_endpoints_and_unit_norm():
         assert abs(np.linalg.norm(m[3:]) - 1.0) < 1e-9
 
 
+def test_check_motion_last_valid_overload_matches_first_overload():
+    """The second checkMotion overload (lastValid) of the restated DiscreteMotionValidator: same verdicts as the
+    first overload on the golden edges (which carry the first overload's verdicts); on a failing edge the state at
+    lastValid.second is the returned state, and when lastValid.second > 0 it is a valid state whose successor on
+    the discretised segment (or s2) is invalid."""
+    for name in ("perlin64", "slab120"):
+        gm, _ = golden_io.load_boxes(name)
+        om = O.OracleMap(gm)
+        for kind in ("yaml", "defaults"):
+            e = golden_io.load_edges(name)[kind]
+            rob = O.robot(kind)
+            s1, s2 = e["s1"][:400], e["s2"][:400]
+            ok, t, st = om.check_motions_last_valid(rob, s1, s2)
+            assert np.array_equal(ok, e["check_motion"][:400])
+            nd = e["nd"][:400].astype(np.int64)
+            bad = np.flatnonzero(ok == 0)
+            assert len(bad) > 10
+            for i in bad[:60]:
+                j = int(round(t[i] * nd[i]))            # lastValid.second = j / nd
+                assert 0 <= j <= nd[i] - 1 and abs(t[i] - j / nd[i]) < 1e-15
+                assert np.allclose(st[i], O.interpolate(s1[i], s2[i], t[i]), atol=0, rtol=0)
+                nxt = s2[i] if j + 1 == nd[i] else O.interpolate(s1[i], s2[i], (j + 1) / nd[i])
+                assert om.states_valid(rob, nxt[None])[0] == 0
+                if j >= 1:
+                    assert om.states_valid(rob, st[i][None])[0] == 1
+
+
 def test_sampler_oracle_properties(big_map):
     """R6: samples are cell centres of cells with non-zero sample probability, z near the terrain,
     unit quaternions; pure function of (seed, index)."""
