@@ -4,7 +4,8 @@
 Build container only (imports /root/reference/art_planner_motion_cost/.../network_light.py; the file is
 imported where it lies, nothing is copied).  Stores data only: a 112x112 elevation crop, the reference
 feature map (CNNpart, float32 on CPU) and FCpart outputs for 4096 seeded edges, for the seeded parameters
-of oracle/motion_cost_oracle.random_params(0).
+of oracle/motion_cost_oracle.random_params(0); and a second, 120x120 crop (-> 36x36 features: partial tiles in
+the HIP kernels) with its reference feature map (motion_cost_120.npz).
 """
 import math
 import os
@@ -75,6 +76,19 @@ def main():
     assert np.abs(c_o - costs).max() < 1e-3
     np.savez_compressed(os.path.join(HERE, "motion_cost.npz"), crop=crop.astype(np.float16), res=res,
                         features=feats.astype(np.float32), edges=edges, costs=costs)
+
+    # a size whose feature map has PARTIAL tiles in the HIP kernels (8-row x 16-pixel output tiles of the 15x15
+    # layer, 32-pixel wavefront tiles of the 3x3 layers): 120 x 120 -> 36 x 36 features
+    n2 = 120
+    crop2 = elv[30:30 + n2, 250:250 + n2].astype(np.float16).astype(np.float32)
+    with torch.no_grad():
+        feats2 = net.CNNpart(torch.from_numpy(crop2).view(1, 1, n2, n2)).numpy()[0]  # [48,36,36]
+    assert feats2.shape == (48, 36, 36)
+    f2_o = mo.cnn_features(params, crop2)
+    print("120x120: max |oracle-ref|", np.abs(f2_o - feats2).max())
+    assert np.abs(f2_o - feats2).max() < 2e-3 * max(1.0, np.abs(feats2).max())
+    np.savez_compressed(os.path.join(HERE, "motion_cost_120.npz"), crop=crop2.astype(np.float16), res=res,
+                        features=feats2.astype(np.float32))
 
 
 if __name__ == "__main__":

@@ -39,6 +39,109 @@ def test_blob_layout():
     assert _capi.load().artp_cost_blob_bytes() == len(blob)
 
 
+def test_oracle_matches_reference_network_partial_tile_size():
+    """The second reference fixture: 120 x 120 -> 36 x 36 features (partial tiles in the HIP kernels)."""
+    g = np.load(os.path.join(common.GOLDEN_DIR, "motion_cost_120.npz"))
+    f = mo.cnn_features(mo.random_params(0), g["crop"].astype(np.float32))
+    assert f.shape == (48, 36, 36)
+    assert np.abs(f - g["features"]).max() < 1e-3
+
+
+def _check_blob_from_checkpoint(path, tmp_path, monkeypatch):
+    out = tmp_path / "model.armc"
+    monkeypatch.setattr(sys, "argv", ["convert_weights.py", str(path), str(out)])
+    convert_weights.main()
+    assert open(out, "rb").read() == convert_weights.to_blob(mo.random_params(0))
+
+
+def test_convert_weights_main_on_a_torch_saved_state_dict(tmp_path, monkeypatch):
+    """N3: tools/convert_weights.py main() on a torch.save()d state_dict with the reference's key set (incl. the
+    BatchNorm num_batches_tracked entries a real checkpoint carries) gives the blob of the same parameters."""
+    import torch
+    p = mo.random_params(0)
+    sd = {}
+    for name in convert_weights.SHAPES:           # the order network_light.py registers its modules in
+        sd[name + ".weight"] = torch.from_numpy(p[name + ".weight"].copy())
+        if name in convert_weights.WITH_BIAS:
+            sd[name + ".bias"] = torch.from_numpy(p[name + ".bias"].copy())
+        else:
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                sd[f"{name}_bn.{k}"] = torch.from_numpy(p[f"{name}_bn.{k}"].copy())
+            sd[f"{name}_bn.num_batches_tracked"] = torch.tensor(0)
+    ck = tmp_path / "model.pt"
+    torch.save(sd, ck)
+    _check_blob_from_checkpoint(ck, tmp_path, monkeypatch)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/art_planner_motion_cost"),
+                    reason="the reference network class only exists in the build container")
+def test_convert_weights_main_on_the_reference_networks_checkpoint(tmp_path, monkeypatch):
+    """The same through the REFERENCE class: network_light.network().state_dict() torch.save()d by
+    tests/golden/make_reference_state_dict.py (the format predictor.py:20 loads)."""
+    import subprocess
+    ck = tmp_path / "ref_model.pt"
+    subprocess.check_call([sys.executable, os.path.join(common.GOLDEN_DIR, "make_reference_state_dict.py"), str(ck)])
+    _check_blob_from_checkpoint(ck, tmp_path, monkeypatch)
+
+
+def _gpu_features(ctx, elv, res):
+    ctx.cost_update_map(np.ascontiguousarray(elv, np.float32), res, elv.shape[0] * res, elv.shape[1] * res)
+    return ctx.cost_features()
+
+
+def _assert_features_close(f, ref_chw, what):
+    """fp16 activations / fp32 accumulate vs the float32 reference: 2e-2 absolute per element + 2e-3 mean
+    (values reach +-5; six fp16-rounded layers, K up to 10800)."""
+    ref = np.transpose(ref_chw, (1, 2, 0))
+    assert f.shape == ref.shape, (what, f.shape, ref.shape)
+    err = np.abs(f - ref)
+    assert err.max() < 2e-2 + 4e-3 * np.abs(ref).max(), (what, float(err.max()), float(err.mean()))
+    assert err.mean() < 2e-3, (what, float(err.mean()))
+
+
+@pytest.mark.gpu
+def test_gpu_features_partial_tiles_match_reference_golden():
+    """120 x 120 -> 36 x 36: partial tiles in every MFMA kernel (36 = 2 * 16 + 4 pixels, 4 * 8 + 4 rows) against
+    the REFERENCE network's features."""
+    from art_planner_amd.context import Context
+    g = np.load(os.path.join(common.GOLDEN_DIR, "motion_cost_120.npz"))
+    ctx = Context(0, "yaml")
+    ctx.cost_load_weights(convert_weights.to_blob(mo.random_params(0)))
+    f = _gpu_features(ctx, g["crop"].astype(np.float32), float(g["res"]))
+    _assert_features_close(f, g["features"], "120x120")
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,F", [(400, 176), (800, 376), (141, 46), (97, 24)])
+def test_gpu_features_match_oracle_at_c3_c4_and_odd_sizes(n, F):
+    """C3 (400^2 -> 176^2), C4 (800^2 -> 376^2: 23.5 16-pixel tiles per row) and two odd sizes against the numpy
+    oracle (pinned on the reference network at 112^2 and 120^2), then the per-edge costs of 20 000 edges against
+    the oracle fed with the ORACLE's features (whole-path parity, not the GPU's own features)."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(n, 0.04, seed=1234 if n == 400 else 77)
+    elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float16).astype(np.float32)
+    p = mo.random_params(0)
+    ref = mo.cnn_features(p, elv)
+    assert ref.shape == (48, F, F)
+    ctx = Context(0, "yaml")
+    ctx.cost_load_weights(convert_weights.to_blob(p))
+    f = _gpu_features(ctx, elv, gm.res)
+    _assert_features_close(f, ref, f"{n}x{n}")
+    rng = np.random.default_rng(n)
+    B = 20000
+    s = rng.uniform(-0.55 * gm.len_x, 0.55 * gm.len_x, (B, 2))
+    d = rng.uniform(-0.6, 0.6, (B, 2))
+    e = np.stack([s[:, 0] + d[:, 0], s[:, 1] + d[:, 1], rng.uniform(-np.pi, np.pi, B), s[:, 0], s[:, 1],
+                  rng.uniform(-np.pi, np.pi, B)], 1).astype(np.float32)
+    c = ctx.cost_query(e)
+    co = mo.fc_costs(p, ref, e, gm.res, gm.len_x, gm.len_y)
+    cerr = np.abs(c - co)
+    assert (cerr <= 2e-3 * np.abs(co) + 5e-3).all(), float(cerr.max())
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_gpu_features_and_costs_match_reference_golden():
     """fp16 activations / fp32 accumulate on the matrix cores vs the reference network in float32:
