@@ -256,6 +256,11 @@ class Context:
         self._chk(self.L.artp_cost_update_map(self.h, a.ctypes.data, a.shape[0], a.shape[1], res, len_x, len_y,
                                               cx, cy), "artp_cost_update_map")
 
+    def cost_update_map_dev(self, elev_xy_t, res, len_x, len_y, cx=0.0, cy=0.0):
+        """elev_xy_t: float32 device tensor [rows, cols] (row-major); asynchronous."""
+        self._chk(self.L.artp_cost_update_map_dev(self.h, elev_xy_t.data_ptr(), elev_xy_t.shape[0], elev_xy_t.shape[1],
+                                                  res, len_x, len_y, cx, cy), "artp_cost_update_map_dev")
+
     def cost_update_map_layer(self, layer, res, len_x, len_y, pos_x=0.0, pos_y=0.0):
         """From the planner's grid_map layer (the cost server's re-indexing is applied inside)."""
         a = _f32F(layer)
@@ -285,6 +290,12 @@ class Context:
         self._chk(self.L.artp_compact_valid_indices_dev(self.h, valid_t.data_ptr(), valid_t.shape[0],
                                                         idx_t.data_ptr(), count_t.data_ptr()),
                   "artp_compact_valid_indices_dev")
+
+    def pack_edge_results_dev(self, valid_t, ei_t, ej_t, cost_t, records_t, count_t):
+        """records_t: int32/uint32 device tensor [>= n, 5]; count_t: 1-element int64 device tensor."""
+        self._chk(self.L.artp_pack_edge_results_dev(self.h, valid_t.data_ptr(), ei_t.data_ptr(), ej_t.data_ptr(),
+                                                    cost_t.data_ptr(), valid_t.shape[0], records_t.data_ptr(),
+                                                    count_t.data_ptr()), "artp_pack_edge_results_dev")
 
     def sample_states_at_dev(self, seed, base_index, idx_t, count_t, cap, out_t):
         self._chk(self.L.artp_sample_states_at_dev(self.h, seed, base_index, idx_t.data_ptr(), count_t.data_ptr(),

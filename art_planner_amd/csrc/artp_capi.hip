@@ -1262,6 +1262,47 @@ int artp_compact_valid_indices_dev(artp_ctx* c, const uint8_t* valid, size_t n, 
   return ARTP_OK;
 }
 
+namespace {
+// record e of the exchange = {u32 i, u32 j, f32 cost[3]} of the sel[e]-th edge
+__global__ void __launch_bounds__(256)
+gather_edge_records_kernel(const uint32_t* __restrict__ sel, const unsigned long long* __restrict__ count,
+                           const uint32_t* __restrict__ edge_i, const uint32_t* __restrict__ edge_j,
+                           const float* __restrict__ cost, uint32_t* __restrict__ out) {
+  const size_t n = (size_t)(*count);
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t k = sel[e];
+    out[5 * e + 0] = edge_i[k];
+    out[5 * e + 1] = edge_j[k];
+    out[5 * e + 2] = __float_as_uint(cost[3 * k + 0]);
+    out[5 * e + 3] = __float_as_uint(cost[3 * k + 1]);
+    out[5 * e + 4] = __float_as_uint(cost[3 * k + 2]);
+  }
+}
+}  // namespace
+
+int artp_pack_edge_results_dev(artp_ctx* c, const uint8_t* valid, const uint32_t* edge_i, const uint32_t* edge_j,
+                               const float* cost, size_t n, uint32_t* records_out, uint64_t* n_out_dev) {
+  if (!c || !n_out_dev || (n && (!valid || !edge_i || !edge_j || !cost || !records_out)) || n >= (1ull << 31))
+    return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n == 0) {
+    HIP_TRY(c, hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), c->stream));
+    return ARTP_OK;
+  }
+  int rc = ensure_tmp(c, 6, n * sizeof(uint32_t));
+  if (rc) return rc;
+  uint32_t* sel = static_cast<uint32_t*>(c->tmp[6]);
+  rc = artp_compact_valid_indices_dev(c, valid, n, sel, n_out_dev);  // input order is kept
+  if (rc) return rc;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > (size_t)c->n_cus * 16) blocks = (size_t)c->n_cus * 16;
+  hipLaunchKernelGGL(gather_edge_records_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const uint32_t*)sel,
+                     reinterpret_cast<const unsigned long long*>(n_out_dev), edge_i, edge_j, cost, records_out);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
 int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, const uint32_t* idx,
                               const uint64_t* count_dev, size_t cap, double* se3_out) {
   if (!c || !idx || !count_dev || (cap && !se3_out)) return ARTP_ERR_INVALID_ARG;
@@ -1457,8 +1498,8 @@ static int cost_run_cnn(artp_ctx* c, int H, int W) {
   return ARTP_OK;
 }
 
-int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, double res, double len_x,
-                         double len_y, double cx, double cy) {
+static int cost_update_map_impl(artp_ctx* c, const float* elev_xy, bool on_device, int rows, int cols, double res,
+                                double len_x, double len_y, double cx, double cy) {
   if (!c || !elev_xy || rows < 1 || cols < 1 || !(res > 0)) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
@@ -1470,7 +1511,8 @@ int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, 
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_map_f32), n * sizeof(float)));
     c->map_cap = n;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_map_f32, elev_xy, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_map_f32, elev_xy, n * sizeof(float),
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   const int rc = cost_run_cnn(c, rows, cols);
   if (rc) return rc;
   // CostQuery.setMapParams (cost_query.py:26-35): featureResFactor = 2, mapClip = 24
@@ -1481,9 +1523,20 @@ int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, 
   g.col_bias = (int)((len_y / res - 2 * 24) / 2 * 0.5);
   g.cx = cx;
   g.cy = cy;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's host buffer is free again
   c->have_features = true;
   return ARTP_OK;
+}
+
+int artp_cost_update_map(artp_ctx* c, const float* elev_xy, int rows, int cols, double res, double len_x,
+                         double len_y, double cx, double cy) {
+  return cost_update_map_impl(c, elev_xy, false, rows, cols, res, len_x, len_y, cx, cy);
+}
+
+// the same with the map array already in HBM; asynchronous on the context's stream
+int artp_cost_update_map_dev(artp_ctx* c, const float* elev_xy_dev, int rows, int cols, double res, double len_x,
+                             double len_y, double cx, double cy) {
+  return cost_update_map_impl(c, elev_xy_dev, true, rows, cols, res, len_x, len_y, cx, cy);
 }
 
 // cost_query_server.py:46-74 receives the planner's grid_map layer and stores it as

@@ -75,3 +75,36 @@ class ValidIndexGatherer:
         parts = [self.gathered[r, :min(c, self.cap)].to(torch.int64) + shard_first_index(step, r, self.world, batch)
                  for r, c in enumerate(counts)]
         return torch.cat(parts, 0), ok
+
+
+class EdgeResultGatherer:
+    """The second exchange of SURVEY.md 8e: all-gather of the edge results of every rank as fixed-capacity blocks
+    of 20-byte records {u32 i, u32 j, f32 cost[3]} (artp_pack_edge_results_dev packs the valid edges of a rank;
+    int32 storage, the cost floats bit-cast).  i / j are vertex ids in the owner's numbering (in-batch sample
+    indices); global_records() turns them into global sample indices."""
+
+    def __init__(self, world: int, cap: int, device, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.cap, self.group = world, cap, group
+        self.gathered = torch.empty((world, cap, 5), dtype=torch.int32, device=device)
+        self.counts = torch.empty(world, dtype=torch.int64, device=device)
+
+    def gather(self, records: torch.Tensor, count: torch.Tensor):
+        """records: int32 [>= cap, 5] with the valid records first; count: int64[1].  Asynchronous on the current
+        stream for NCCL."""
+        self.dist.all_gather_into_tensor(self.counts, count, group=self.group)
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), records[:self.cap].reshape(-1), group=self.group)
+
+    def global_records(self, step: int, batch: int) -> Tuple[torch.Tensor, torch.Tensor, bool]:
+        """(ij [E, 2] int64 global sample indices, cost [E, 3] float32) of every rank's edges in rank order (host
+        sync).  Third value: no block overflowed."""
+        counts = self.counts.tolist()
+        ok = all(c <= self.cap for c in counts)
+        ij, cost = [], []
+        for r, c in enumerate(counts):
+            blk = self.gathered[r, :min(c, self.cap)]
+            # in-batch indices are unsigned 32 bit in int32 storage
+            ij.append((blk[:, :2].to(torch.int64) & 0xffffffff) + shard_first_index(step, r, self.world, batch))
+            cost.append(blk[:, 2:].contiguous().view(torch.float32))
+        return torch.cat(ij, 0), torch.cat(cost, 0), ok

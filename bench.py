@@ -10,13 +10,22 @@ owns a disjoint sample-index range (weak scaling) and the accepted states are co
 all-gathered over RCCL on a side stream (the planners need every accepted state on every rank).
 
 Prints ONE JSON line on rank 0 (see the repo prompt's bench contract) incl. `roofline` and
-`cpu_baseline`.
+`cpu_baseline`.  `roofline.pmc` is measured IN THIS RUN: bench.py re-launches itself (`--pmc-child`, a few
+sample+validate batches and nothing else) under `rocprofv3 --kernel-trace --pmc ...`, one pass per counter
+group (PMC is never combined with other trace domains), and derives HBM traffic, VALU / LDS busy and L2 hit rate
+per pipeline kernel.  If rocprofv3 is not usable it falls back to the committed profiles/pmc_r02.json -- only
+when that file was measured on the very kernel sources of this checkout (hash of art_planner_amd/csrc).
 """
 import argparse
+import glob
 import hashlib
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -28,9 +37,159 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 peak, same guide
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+PIPELINE = ["classify_states_kernel", "feet_stream_kernel", "feet_lane_kernel", "resolve_boxes_kernel<2, 64, 0>",
+            "resolve_boxes_kernel<2, 64, 3>", "resolve_boxes_kernel<2, 16, 1>", "resolve_boxes_kernel<2, 16, 2>",
+            "plane_stage_kernel", "sample_states_kernel", "sample_classify_kernel"]
+PMC_PASSES = [
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+    ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+     "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+]
 
 
+def csrc_hash():
+    """Identity of the kernel sources a PMC profile belongs to."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "art_planner_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PMC: child workload + parent-side collection
+# ---------------------------------------------------------------------------------------------------------
+def pmc_child(args):
+    """Only the launches to be measured: warm-up + 3 sample+validate batches of S states."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+    dev = torch.device("cuda", 0)
+    gm = make_map(args.map, args.res, seed=1234)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    ctx.use_torch_stream()
+    se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
+    valid = torch.empty(args.batch, dtype=torch.uint8, device=dev)
+    for i in range(4):
+        ctx.sample_and_validate_dev(42, i * args.batch, args.batch, se3, valid)
+    torch.cuda.synchronize()
+    ctx.close()
+
+
+def _read_pass(db_path):
+    """{kernel: {"n": dispatches, "avg_us": .., counters..}} of one rocprofv3 rocpd database, the LARGEST
+    dispatches of each kernel only (the S-state launches; map upload launches smaller grids of other kernels)."""
+    db = sqlite3.connect(db_path)
+    out = {}
+    for name, n, avg, mx in db.execute("select name, count(*), avg(end-start), max(end-start) from kernels group by name"):
+        out[name] = {"n": n, "avg_us": avg / 1e3, "max_us": mx / 1e3}
+    try:
+        rows = db.execute("select kernel_name, counter_name, avg(value), max(value) from counters_collection "
+                          "group by kernel_name, counter_name").fetchall()
+    except sqlite3.OperationalError:
+        rows = []
+    for kn, cn, avg, mx in rows:
+        out.setdefault(kn, {})[cn] = mx  # the S-state launch is the largest dispatch of its kernel
+    return out
+
+
+def collect_pmc_live(args, timeout_s=150):
+    """Run the PMC passes; returns (summary dict | None, note)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="artp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    merged = {}
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            out_dir = os.path.join(work, f"p{i}")
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", out_dir, "-o", f"p{i}", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(args.batch),
+                   "--map", str(args.map), "--res", str(args.res)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(out_dir, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 pass {i} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            for kn, vals in _read_pass(dbs[0]).items():
+                m = merged.setdefault(kn, {})
+                for key, v in vals.items():
+                    if key == "max_us":
+                        m.setdefault("max_us_by_pass", []).append(v)
+                    elif key not in ("n", "avg_us"):
+                        m[key] = v
+    except Exception as ex:  # pragma: no cover
+        return None, f"pmc collection failed: {ex!r}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return summarise_pmc(merged), "live"
+
+
+def summarise_pmc(per_kernel):
+    """Derived figures per pipeline kernel of one S-state batch.  Corrections per MI355X_MICROARCH.md (HBM):
+    FETCH_SIZE (KiB) x 2 -- gfx950 tallies 128-B requests as 64 B; WRITE_SIZE (KiB) as reported (calibrated 1.000x on
+    sample_states_kernel's 7*8*S bytes in round 1).  busy = SQ_ACTIVE_INST_x * 4 / (1024 SIMDs * kernel cycles),
+    kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs."""
+    kernels = {}
+    tot_fetch = tot_write = tot_us = 0.0
+    w_valu = w_lds = 0.0
+    for kn, v in per_kernel.items():
+        pk = next((p for p in PIPELINE if p in kn), None)
+        if pk is None or "GRBM_GUI_ACTIVE" not in v:
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        us = float(np.median(v.get("max_us_by_pass", [0.0])))
+        fetch = 2.0 * 1024.0 * v.get("FETCH_SIZE", 0.0)
+        write = 1024.0 * v.get("WRITE_SIZE", 0.0)
+        hit, miss = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
+        k = {"us": us, "hbm_fetch_bytes": fetch, "hbm_write_bytes": write,
+             "valu_busy": v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (N_SIMD * cyc) if cyc else None,
+             "lds_busy": v.get("SQ_ACTIVE_INST_LDS", 0.0) * 4.0 / (N_SIMD * cyc) if cyc else None,
+             "lds_insts": v.get("SQ_INSTS_LDS"), "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT"),
+             # every LDS wave-instruction moves at least 64 lanes x 4 B: a lower bound of the LDS traffic
+             "lds_gbs_min": (v.get("SQ_INSTS_LDS", 0.0) * 256.0 / (us * 1e-6) / 1e9) if us else None,
+             "wait_frac": (v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]) if v.get("SQ_WAVE_CYCLES") else None,
+             "l2_hit": hit / (hit + miss) if hit + miss else None}
+        kernels[pk] = k
+        if pk not in ("sample_states_kernel",):
+            tot_fetch += fetch
+            tot_write += write
+            if us > 5.0:  # the near-empty fallback launches do not carry the average
+                tot_us += us
+                w_valu += (k["valu_busy"] or 0.0) * us
+                w_lds += (k["lds_busy"] or 0.0) * us
+    if not kernels:
+        return None
+    return {"kernels": kernels, "validity_hbm_bytes_per_launch": tot_fetch + tot_write,
+            "validity_kernel_us_sum": tot_us, "valu_busy_time_weighted": w_valu / tot_us if tot_us else None,
+            "lds_busy_time_weighted": w_lds / tot_us if tot_us else None, "csrc_hash": csrc_hash()}
+
+
+def load_committed_pmc():
+    """profiles/pmc_r02.json, only if it was measured on THIS checkout's kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_r02.json")
+    if not os.path.exists(path):
+        return None, "no committed PMC profile"
+    try:
+        d = json.load(open(path))
+    except Exception as ex:  # pragma: no cover
+        return None, f"unreadable committed PMC profile: {ex!r}"
+    if d.get("csrc_hash") != csrc_hash():
+        return None, f"committed PMC profile is STALE (measured on csrc {d.get('csrc_hash')}, checkout is {csrc_hash()})"
+    return d, "committed profiles/pmc_r02.json (same kernel sources)"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline legs (the ONLY users of the oracle in this file)
+# ---------------------------------------------------------------------------------------------------------
 def cpu_baseline(gm, states, target_s=12.0):
     """The CPU oracle ("port": bit-identical restatement of the reference OMPL+ODE validity path,
     faithful algorithmic structure) timed on this box's host cores on a bounded sample of the SAME
@@ -67,6 +226,81 @@ def cpu_baseline(gm, states, target_s=12.0):
             "single_core_value": r1}, out, v1
 
 
+def c1_leg(local_rank):
+    """BASELINE config C1: lazy_prm_star_min_update on a flat 100x100 @ 0.1 m map, CPU only --
+    the restated LazyPRM* loop over the C oracle (sampler, validity, discrete motion validator; OMPL itself cannot
+    be built here) -- next to the batched GPU front end on the same query (-4, -4, yaw 0) -> (4, 4)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lazy_prm_cpu as LP
+    import oracle_py as O
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(100, 0.1, flat=True)
+    rob, om, smp = O.robot("yaml"), O.OracleMap(gm), O.OracleSampler(gm)
+    probe, _ = smp.sample(rob, 1, 0, 64)
+    z0 = float(probe[om.states_valid(rob, probe) != 0][0, 2])
+    s = np.array([-4.0, -4.0, z0, 0, 0, 0, 1.0])
+    g = np.array([4.0, 4.0, z0, 0, 0, 0, 1.0])
+    cpu = LP.lazy_prm_star(om, smp, rob, s, g, 2000, seed=42)
+    path = cpu.pop("path")
+    simp, c_simp = LP.shortcut(om, rob, path) if path is not None else (None, None)
+    cpu["simplified_path_cost"] = c_simp
+    optimum = 8.0 * np.sqrt(2.0) / 0.5
+    # the same query on the GPU front end; labels of the CPU leg's sample stream must hash the same
+    ctx = Context(local_rank, "yaml")
+    ctx.upload_map(gm)
+    n_drawn = cpu["states_drawn"]
+    gl = ctx.validate_states(ctx.sample_states(42, 0, n_drawn))
+    gpu = {"label_hash": hashlib.sha1(gl.tobytes()).hexdigest()[:16]}
+    rm = Roadmap(ctx, s, g, n_milestones=2000, seed=42)
+    p, c, _ = rm.solve()
+    q, d = rm.simplify(p)
+    gpu.update({"path_cost": c, "simplified_path_cost": d})
+    rm.close()
+    ctx.close()
+    return {"config": "C1: flat 100x100@0.1m, start (-4,-4,yaw 0) -> goal (4,4), PathLengthObjective, 2000 milestones",
+            "cpu_lazy_prm_star": cpu, "gpu_batch_prm": gpu, "analytic_optimum_s": optimum,
+            "labels_match": gpu["label_hash"] == cpu["label_hash"],
+            "path_cost_within_1e-4": bool(c_simp is not None and abs(c_simp - optimum) < 1e-4 and abs(d - optimum) < 1e-4)}
+
+
+def cnn_flops(n):
+    h, tot = n, 0.0
+    for (k, cin, cout, pool) in ((3, 1, 24, 0), (3, 24, 24, 2), (3, 24, 48, 0), (3, 48, 48, 3), (3, 48, 48, 0),
+                                 (15, 48, 48, 0)):
+        h = h - k + 1
+        tot += 2.0 * k * k * cin * cout * h * h
+        if pool == 2:
+            h //= 2
+        elif pool == 3:
+            h -= 2
+    return tot
+
+
+def yaw_of(q):
+    return np.arctan2(2 * (q[:, 6] * q[:, 5] + q[:, 3] * q[:, 4]), 1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2))
+
+
+def edge_rows(a, b):
+    """MotionCostFunc rows: target x y yaw, start x y yaw (prm_motion_cost.cpp:41-52)."""
+    return np.concatenate([b[:, [0, 1]], yaw_of(b)[:, None], a[:, [0, 1]], yaw_of(a)[:, None]], 1).astype(np.float32)
+
+
+def pair_edges(acc, want, max_gap=3):
+    """SURVEY.md 8d edges: accepted state i paired with accepted states i+1 .. i+max_gap when their lateral
+    distance is below 2 m.  Returns (index_i, index_j) into acc."""
+    ii, jj = [], []
+    for d in range(1, max_gap + 1):
+        a, b = acc[:-d], acc[d:]
+        near = np.flatnonzero(np.hypot(a[:, 0] - b[:, 0], a[:, 1] - b[:, 1]) < 2.0)
+        ii.append(near)
+        jj.append(near + d)
+        if sum(len(x) for x in ii) >= want:
+            break
+    return np.concatenate(ii)[:want], np.concatenate(jj)[:want]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +312,8 @@ def main():
     ap.add_argument("--res", type=float, default=0.04)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
     ap.add_argument("--materialise", type=int, default=1 << 16,
                     help="N>1: accepted states of EVERY rank re-materialised on every rank per step, per rank block "
@@ -85,6 +321,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-gather path even with one rank (self-test)")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,6 +340,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from art_planner_amd.context import Context
+    from art_planner_amd.distributed import shard_first_index
     from art_planner_amd.synthetic import make_map
 
     gm = make_map(args.map, args.res, seed=1234)
@@ -118,33 +357,28 @@ def main():
     do_gather = (N > 1 or args.force_dist) and not args.no_gather
     comm = torch.cuda.Stream(device=dev) if do_gather else None
 
-    from art_planner_amd.distributed import shard_first_index
-
     def first_index(step):
         return shard_first_index(step, rank, N, S)
 
     # ---- warmup (also sizes the fixed-capacity all-gather blocks) -----------------------------
     cap = 0
-    compact = [None, None]
     counts = [None, None]
-    gatherer = None
     gather_error = None
     for i in range(max(W, 1)):
         c = ctx.sample_and_validate_dev(seed, first_index(1000000 + i), S, se3, valid, count=True)
         cap = max(cap, c)
     torch.cuda.synchronize()
+    mat_cap = 0
     if do_gather:
-        from art_planner_amd.distributed import ValidIndexGatherer, agree_capacity
+        from art_planner_amd.distributed import EdgeResultGatherer, ValidIndexGatherer, agree_capacity
         cap = agree_capacity(cap, S, dev)
         idx_buf = [torch.zeros(S, dtype=torch.int32, device=dev) for _ in range(2)]
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
         gatherers = [ValidIndexGatherer(N, cap, dev), ValidIndexGatherer(N, cap, dev)]  # double-buffered
-        gatherer = gatherers[0]
         # every rank's accepted states, re-materialised from the gathered indices: the first mat_cap per rank and
         # step (default 2^16 = 6.5x the reference's whole roadmap, max_n_vertices = 10^4); anything beyond is
         # one artp_sample_states_at_dev call away because the index lists are complete
-        mat_cap = cap if args.materialise < 0 else min(cap, args.materialise)
-        all_states = torch.empty((N, max(mat_cap, 1), 7), dtype=torch.float64, device=dev)
+        all_states = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         for e in done_ev:
             e.record()
@@ -155,6 +389,13 @@ def main():
         except Exception as ex:  # pragma: no cover
             gather_error = repr(ex)
             do_gather = False
+
+    def materialise(j):
+        gb = gatherers[j & 1]
+        torch.cuda.current_stream().wait_event(done_ev[j & 1])
+        for r in range(N):
+            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), gb.gathered[r], gb.counts[r:r + 1], mat_cap,
+                                     all_states[r])
 
     def step(i):
         ctx.sample_and_validate_dev(seed, first_index(i), S, se3, valid)
@@ -175,33 +416,97 @@ def main():
             if i > 0 and mat_cap > 0:
                 materialise(i - 1)
 
-    def materialise(j):
-        gb = gatherers[j & 1]
-        torch.cuda.current_stream().wait_event(done_ev[j & 1])
-        for r in range(N):
-            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), gb.gathered[r], gb.counts[r:r + 1], mat_cap,
-                                     all_states[r])
+    def timed_region(n_steps):
+        """Exactly n_steps steps, barrier + synchronize on both sides, MAX over ranks."""
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i)
+        if do_gather and mat_cap > 0:
+            materialise(n_steps - 1)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides -----------------------
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(i)
-    if do_gather and mat_cap > 0:
-        materialise(K - 1)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        assert (not do_gather) or max(int(g_.counts.max().item()) for g_ in gatherers) <= cap, "all-gather block capacity exceeded"
-    total_states = N * S * K
-    value = total_states / dt
+    # ---- the headline region -----------------------------------------------------------------------
+    mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise)) if do_gather else 0
+    dt = timed_region(K)
+    if do_gather:
+        assert max(int(g_.counts.max().item()) for g_ in gatherers) <= cap, "all-gather block capacity exceeded"
+    value = N * S * K / dt
+
+    # ---- N > 1 (or --force-dist): the other materialisation setting and the edge exchange, all ranks -------
+    dist_extras = None
+    if do_gather:
+        dist_extras = {"materialise_default": args.materialise, "states_per_s_default": value}
+        k2 = max(3, min(K, 20))
+        for name, mc in (("states_per_s_materialise_all", cap), ("states_per_s_materialise_none", 0)):
+            mat_cap = mc
+            dist_extras[name] = N * S * k2 / timed_region(k2)
+        mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise))
+        # edges follow the GPU that owns the source state (SURVEY.md 8e): every rank validates E edges between its
+        # own accepted states (0.5 m interpolation rule), scores them with the learned cost when weights are
+        # there (else the length triple), packs the valid ones as {u32 i, u32 j, f32 cost[3]} and all-gathers them
+        try:
+            ctx.sample_and_validate_dev(seed, first_index(2000000), S, se3, valid)
+            torch.cuda.synchronize()
+            st_h = se3.cpu().numpy()
+            pos = np.flatnonzero(valid.cpu().numpy())
+            ii, jj = pair_edges(st_h[pos], args.edges)
+            E = len(ii)
+            s1 = torch.from_numpy(np.ascontiguousarray(st_h[pos[ii]])).to(dev)
+            s2 = torch.from_numpy(np.ascontiguousarray(st_h[pos[jj]])).to(dev)
+            ei = torch.from_numpy(pos[ii].astype(np.int32)).to(dev)
+            ej = torch.from_numpy(pos[jj].astype(np.int32)).to(dev)
+            rows = torch.from_numpy(edge_rows(st_h[pos[ii]], st_h[pos[jj]])).to(dev)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import convert_weights
+            ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
+            elv_t = torch.from_numpy(np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)).to(dev)
+            ctx.cost_update_map_dev(elv_t, gm.res, gm.len_x, gm.len_y)
+            ev = torch.empty(E, dtype=torch.uint8, device=dev)
+            cost3 = torch.empty((E, 3), dtype=torch.float32, device=dev)
+            rec = torch.zeros((E, 5), dtype=torch.int32, device=dev)
+            ecount = torch.zeros(1, dtype=torch.int64, device=dev)
+            eg = EdgeResultGatherer(N, E, dev)
+
+            def edge_step():
+                ctx.check_edges_interp_dev(s1, s2, ev)
+                ctx.cost_query_dev(rows, cost3)
+                ctx.pack_edge_results_dev(ev, ei, ej, cost3, rec, ecount)
+                ready = torch.cuda.Event()
+                ready.record()
+                comm.wait_event(ready)
+                with torch.cuda.stream(comm):
+                    eg.gather(rec, ecount)
+                torch.cuda.current_stream().wait_stream(comm)
+
+            edge_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                edge_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ij, cst, ok = eg.global_records(0, S)
+            dist_extras["edges"] = {"edges_per_gpu_per_step": E, "steps": k2,
+                                    "edges_per_s": N * E * k2 / float(t.item()),
+                                    "valid_edges_gathered": int(ij.shape[0]), "blocks_ok": bool(ok),
+                                    "what": "0.5 m interpolation rule + learned cost (seeded weights) + "
+                                            "{u32 i, u32 j, f32 cost[3]} all-gather (RCCL, side stream)"}
+        except Exception as ex:  # pragma: no cover
+            dist_extras["edges"] = {"error": repr(ex)}
 
     if rank != 0:
         if dist is not None:
@@ -217,7 +522,7 @@ def main():
     label_hash = hashlib.sha1(labels.tobytes()).hexdigest()[:16]
     valid_frac = float(labels.mean())
 
-    # dominant kernel: validate_states_kernel; HIP events on the stream it is launched on
+    # dominant kernel: the validity pipeline; HIP events on the stream it is launched on
     alg_vertices = ctx.algorithmic_vertices_dev(se3)
     alg_bytes = 4 * alg_vertices + 29 * S  # 28 B pose in (7 f32) + 1 B label out per state
     reps = max(5, min(K, 20))
@@ -231,24 +536,54 @@ def main():
     torch.cuda.synchronize()
     k_ms = ev0.elapsed_time(ev1) / reps
     pipeline_counts = ctx.pipeline_counters()
+    # the fused step the timed region runs (sampling inside the first validity kernel where the build has it)
+    ev0.record()
+    for i in range(reps):
+        ctx.sample_and_validate_dev(seed, i * S, S, se3, valid)
+    ev1.record()
+    torch.cuda.synchronize()
+    step_ms = ev0.elapsed_time(ev1) / reps
+    ctx.sample_and_validate_dev(seed, 0, S, se3, valid)
+    torch.cuda.synchronize()
+
+    pmc, pmc_note = (None, "skipped")
+    if N == 1 and not args.no_pmc:
+        pmc, pmc_note = collect_pmc_live(args)
+        if pmc is None:
+            live_note = pmc_note
+            pmc, pmc_note = load_committed_pmc()
+            pmc_note = f"{pmc_note}; live collection: {live_note}"
+        else:
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                json.dump(pmc, open(os.path.join(ROOT, "gpurun_out", "pmc_live.json"), "w"), indent=1)
+            except Exception:
+                pass
+    elif N > 1:
+        pmc_note = "N > 1: PMC passes only run at N = 1"
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get("validate_states_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "validate_states_kernel", "kernel_ms": k_ms,
-                "kernel_launches": "artp_validate_states_dev = classify_states_kernel + feet_stream_kernel<4> + "
-                                   "resolve_boxes_kernel<2,64,0> + 5 near-empty fallback launches (profiles/README.md)",
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_per_state": alg_bytes / S,
-                "validate_only_states_per_s": S / (k_ms * 1e-3),
-                "note": "achieved = ALGORITHMIC bytes (what the reference's scan reads, SURVEY.md 8d) / kernel time; "
-                        "frac > 1 means exact range / partner tables avoided reading them -- `traffic` is what moved"}
+    traffic = pmc["validity_hbm_bytes_per_launch"] if pmc else None
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "kernel": "validity pipeline (artp_validate_states_dev)", "kernel_ms": k_ms,
+        "fused_sample_validate_ms": step_ms,
+        "kernel_launches": "classify_states_kernel + feet_stream_kernel<4> + resolve_boxes_kernel<2,64,0> + 5 "
+                           "near-empty fallback launches (profiles/README.md)",
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "algorithmic_bytes_per_state": alg_bytes / S,
+        "validate_only_states_per_s": S / (k_ms * 1e-3),
+        "note": "SECONDARY yardstick by the bench contract: achieved = ALGORITHMIC bytes (what the reference's window "
+                "scans read, SURVEY.md 8d) / kernel time; frac > 1 because exact range / partner tables avoid reading "
+                "them.  What binds is VALU issue: see `binding`.",
+        # the bound that binds: instruction issue, from this run's PMC passes
+        "binding": None if not pmc else {
+            "bound": "valu_issue", "valu_busy_time_weighted": pmc["valu_busy_time_weighted"],
+            "lds_busy_time_weighted": pmc["lds_busy_time_weighted"],
+            "hbm_traffic_frac_of_peak": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "per_kernel": pmc["kernels"],
+            "pmc_kernel_us_sum_vs_hip_events_ms": [pmc["validity_kernel_us_sum"], k_ms]},
+        "pmc_source": pmc_note, "csrc_hash": csrc_hash()}
 
     # sampler alone
     ev0.record()
@@ -260,20 +595,20 @@ def main():
     ctx.sample_and_validate_dev(seed, 0, S, se3, valid)
     torch.cuda.synchronize()
 
-    # edges: accepted state i paired with accepted state i+1 when their lateral distance < 2 m
+    # edges: E >= 2^18 pairs of accepted states closer than 2 m
     states = se3.cpu().numpy()
     acc = states[labels != 0]
-    a, b = acc[:-1], acc[1:]
-    near = np.hypot(a[:, 0] - b[:, 0], a[:, 1] - b[:, 1]) < 2.0
-    a, b = a[near][:args.edges], b[near][:args.edges]
+    ii, jj = pair_edges(acc, args.edges)
+    a, b = acc[ii], acc[jj]
     E = 0 if args.skip_extras else len(a)
     edges = {}
     if E > 0:
         s1 = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         s2 = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
-        ev = torch.empty(E, dtype=torch.uint8, device=dev)
-        for name, fn in (("check_motion", lambda: ctx.check_motions_dev(s1, s2, ev)),
-                         ("interp_0p5m", lambda: ctx.check_edges_interp_dev(s1, s2, ev))):
+        evd = torch.empty(E, dtype=torch.uint8, device=dev)
+        lt = torch.empty(E, dtype=torch.float64, device=dev)
+        for name, fn in (("check_motion", lambda: ctx.check_motions_dev(s1, s2, evd)),
+                         ("interp_0p5m", lambda: ctx.check_edges_interp_dev(s1, s2, evd))):
             fn()
             torch.cuda.synchronize()
             ev0.record()
@@ -283,9 +618,10 @@ def main():
             torch.cuda.synchronize()
             ms = ev0.elapsed_time(ev1) / 3
             edges[name] = {"edges": E, "edges_per_s": E / (ms * 1e-3), "ms": ms,
-                           "valid_frac": float(ev.float().mean().item())}
+                           "valid_frac": float(evd.float().mean().item())}
+        del lt
 
-    # ---- C3 extras: learned motion cost (seeded random weights: the trained ones are git-LFS stubs) ----
+    # ---- C3 / C4 extras: learned motion cost (seeded random weights: the trained ones are git-LFS stubs) ----
     motion_cost = None
     try:
         if args.skip_extras:
@@ -293,70 +629,91 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import convert_weights
         ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
-        elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)  # cost_query_server.py:66-74
-        ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y)   # H2D of the map + CNN, synchronous
-        cnn_ms = (time.perf_counter() - t0) / 5 * 1e3
-        shp = []
-        h = gm.rows
-        for (k, cin, cout, pool) in ((3, 1, 24, 0), (3, 24, 24, 2), (3, 24, 48, 0), (3, 48, 48, 3), (3, 48, 48, 0),
-                                     (15, 48, 48, 0)):
-            h = h - k + 1
-            shp.append(2.0 * k * k * cin * cout * h * h)
-            if pool == 2:
-                h //= 2
-            elif pool == 3:
-                h -= 2
-        cnn_gflop = sum(shp) / 1e9
-        Bq = 1 << 20
-        if E > 0:
-            reps_e = (Bq + E - 1) // E
-            em = np.concatenate([np.concatenate([b[:, [0, 1]], np.arctan2(2 * (b[:, 6] * b[:, 5] + b[:, 3] * b[:, 4]),
-                                 1 - 2 * (b[:, 4] ** 2 + b[:, 5] ** 2))[:, None],
-                                 a[:, [0, 1]], np.arctan2(2 * (a[:, 6] * a[:, 5] + a[:, 3] * a[:, 4]),
-                                 1 - 2 * (a[:, 4] ** 2 + a[:, 5] ** 2))[:, None]], 1)] * reps_e)[:Bq]
-            edges_t = torch.from_numpy(np.ascontiguousarray(em, dtype=np.float32)).to(dev)
-            cost_t = torch.empty((Bq, 3), dtype=torch.float32, device=dev)
-            ctx.cost_query_dev(edges_t, cost_t)
+        motion_cost = {"weights": "seeded random (tools/convert_weights.random_params(0))"}
+        for tag, n_map, g_ in (("c3_400", gm.rows, gm), ("c4_800", 800, None)):
+            if g_ is None:
+                g_ = make_map(800, 0.04, seed=77)
+            elv = np.ascontiguousarray(g_["elevation"][::-1, ::-1]).astype(np.float32)  # cost_query_server.py:66-74
+            ctx.cost_update_map(elv, g_.res, g_.len_x, g_.len_y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.cost_update_map(elv, g_.res, g_.len_x, g_.len_y)   # H2D of the map + CNN, synchronous
+            wall_ms = (time.perf_counter() - t0) / 5 * 1e3
+            elv_t = torch.from_numpy(elv).to(dev)
+            ctx.cost_update_map_dev(elv_t, g_.res, g_.len_x, g_.len_y)
             torch.cuda.synchronize()
             ev0.record()
-            for _ in range(5):
-                ctx.cost_query_dev(edges_t, cost_t)
+            for _ in range(10):
+                ctx.cost_update_map_dev(elv_t, g_.res, g_.len_x, g_.len_y)  # the nine launches only (HIP events)
             ev1.record()
             torch.cuda.synchronize()
-            q_ms = ev0.elapsed_time(ev1) / 5
-            motion_cost = {"cnn_ms_incl_h2d": cnn_ms, "cnn_gflop": cnn_gflop,
-                           "cnn_tflops": cnn_gflop / cnn_ms, "cnn_frac_of_mfma_f16_peak": cnn_gflop / cnn_ms / 2500.0,
-                           "cost_queries": Bq, "cost_queries_per_s": Bq / (q_ms * 1e-3), "cost_query_ms": q_ms,
-                           "weights": "seeded random (tools/convert_weights.random_params(0))"}
+            kern_ms = ev0.elapsed_time(ev1) / 10
+            gf = cnn_flops(n_map) / 1e9
+            motion_cost[tag] = {"cnn_gflop": gf, "cnn_ms_incl_h2d": wall_ms, "cnn_kernels_ms": kern_ms,
+                                "cnn_kernels_tflops": gf / kern_ms,
+                                "cnn_kernels_frac_of_mfma_f16_peak": gf / kern_ms / MFMA_F16_PEAK_TFLOPS,
+                                "feature_map": list(ctx.cost_features().shape[:2])}
+        # back to the C3 map for the queries
+        elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)
+        ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y)
+        if E > 0:
+            em = edge_rows(a, b)
+            for Bq in (50000, 1 << 20):
+                rows = np.concatenate([em] * ((Bq + E - 1) // E))[:Bq]
+                edges_t = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+                cost_t = torch.empty((Bq, 3), dtype=torch.float32, device=dev)
+                ctx.cost_query_dev(edges_t, cost_t)
+                torch.cuda.synchronize()
+                ev0.record()
+                for _ in range(5):
+                    ctx.cost_query_dev(edges_t, cost_t)
+                ev1.record()
+                torch.cuda.synchronize()
+                q_ms = ev0.elapsed_time(ev1) / 5
+                motion_cost[f"cost_queries_{Bq}"] = {"ms": q_ms, "queries_per_s": Bq / (q_ms * 1e-3)}
     except Exception as ex:  # pragma: no cover
         motion_cost = {"error": repr(ex)}
 
-    # ---- C5 extras: persistent HBM map with incremental updates, one replanning cycle -----------------
+    # ---- C5: persistent HBM map, 100 map versions, each changing ~5 % of the cells in 3 rectangles; per cycle =
+    # dirty-rectangle upload + table refresh + feature-map refresh + 2^18 states + 50 000 cost edges
     c5 = None
     try:
-        if args.skip_extras:
+        if args.skip_extras or E == 0:
             raise RuntimeError("skipped (--skip-extras)")
         rng5 = np.random.default_rng(55)
-        elev0 = gm["elevation"].copy()
-        n5, cyc = 1 << 18, []
+        elev5 = gm["elevation"].copy()
+        n5, cyc, stg = 1 << 18, [], {"rects": [], "cnn": [], "states": [], "cost": []}
         se5 = torch.empty((n5, 7), dtype=torch.float64, device=dev)
         va5 = torch.empty(n5, dtype=torch.uint8, device=dev)
-        for c_i in range(10):
+        rows5 = torch.from_numpy(np.ascontiguousarray(edge_rows(a, b)[:50000])).to(dev)
+        cost5 = torch.empty((rows5.shape[0], 3), dtype=torch.float32, device=dev)
+        side = int(round(np.sqrt(0.05 * gm.rows * gm.cols / 3)))  # 3 squares = 5 % of the cells
+        for c_i in range(100):
             t0 = time.perf_counter()
-            for _ in range(3):  # 3 rectangles ~ 5 % of the cells
-                r0, c0 = int(rng5.integers(0, gm.rows - 52)), int(rng5.integers(0, gm.cols - 52))
-                patch = (elev0[r0:r0 + 52, c0:c0 + 52] + np.float32(rng5.normal(0, 0.02))).astype(np.float32)
-                ctx.update_layer_rect(0, patch, r0, c0)   # dirty tiles -> HBM + range-table refresh
+            for _ in range(3):
+                r0, c0 = int(rng5.integers(0, gm.rows - side)), int(rng5.integers(0, gm.cols - side))
+                elev5[r0:r0 + side, c0:c0 + side] += np.float32(rng5.normal(0, 0.01))
+                ctx.update_layer_rect(0, elev5[r0:r0 + side, c0:c0 + side], r0, c0)  # dirty cells -> HBM + tables
+            t1 = time.perf_counter()
+            ctx.cost_update_map(np.ascontiguousarray(elev5[::-1, ::-1]), gm.res, gm.len_x, gm.len_y)  # features
+            t2 = time.perf_counter()
             ctx.sample_and_validate_dev(seed, 7_000_000 + c_i * n5, n5, se5, va5)
             torch.cuda.synchronize()
-            cyc.append((time.perf_counter() - t0) * 1e3)
+            t3 = time.perf_counter()
+            ctx.cost_query_dev(rows5, cost5)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            cyc.append((t4 - t0) * 1e3)
+            for k_, v_ in zip(("rects", "cnn", "states", "cost"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                stg[k_].append(v_ * 1e3)
         ctx.upload_map(gm)  # restore
-        c5 = {"cycle_ms_median": float(np.median(cyc)), "cycle_ms_max": float(np.max(cyc)),
-              "states_per_cycle": n5, "dirty_rects_per_cycle": 3, "budget_ms_at_10hz": 100.0}
+        ctx.cost_update_map(np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32), gm.res, gm.len_x, gm.len_y)
+        c5 = {"versions": 100, "cycle_ms_median": float(np.median(cyc)), "cycle_ms_max": float(np.max(cyc)),
+              "stage_ms_median": {k_: float(np.median(v_)) for k_, v_ in stg.items()},
+              "states_per_cycle": n5, "cost_edges_per_cycle": int(rows5.shape[0]), "dirty_rects_per_cycle": 3,
+              "cells_changed_per_cycle": 3 * side * side, "budget_ms_at_10hz": 100.0,
+              "sustained_states_per_s": n5 / (float(np.median(cyc)) * 1e-3)}
     except Exception as ex:  # pragma: no cover
         c5 = {"error": repr(ex)}
 
@@ -435,7 +792,8 @@ def main():
         torch.cuda.synchronize()
         ms4 = ev0.elapsed_time(ev1) / 3
         c4 = {"states_per_s": S / (ms4 * 1e-3), "ms_per_batch": ms4, "valid_frac": float(valid.float().mean().item()),
-              "map": "800x800@0.04", "robot": "Params defaults"}
+              "map": "800x800@0.04", "robot": "Params defaults",
+              "motion_cost_cnn": None if not motion_cost else motion_cost.get("c4_800")}
         ctx4.close()
         # secondary robot of SURVEY.md 8d on the C2 map
         gm2d = make_map(args.map, args.res, seed=1234, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
@@ -473,17 +831,37 @@ def main():
                 t0 = time.perf_counter()
                 hb = rb.check(poses[:, 0])
                 ok = (hb == 0) | (inside[:, 0] == 0)
-                nbox = m
                 for k in range(4):  # same short-circuit as the reference
                     idx = np.flatnonzero(ok)
                     hk = rf.check(poses[idx, 1 + k])
-                    nbox += len(idx)
                     ok[idx] = np.where(inside[idx, 1 + k] != 0, hk != 0, False)
                 dtr = time.perf_counter() - t0
                 cpu["reference_ode_single_core_states_per_s"] = m / dtr
                 cpu["reference_ode_labels_match_gpu"] = bool(np.array_equal(ok.astype(np.uint8), labels[:m]))
         except Exception as e:  # pragma: no cover
             cpu["reference_ode_error"] = repr(e)
+        # edges/s of the CPU path on a bounded sample of the same edges (single thread)
+        try:
+            import oracle_py as O
+            if E > 0:
+                rob, om = O.robot("yaml"), O.OracleMap(gm)
+                m_e = min(E, 1500)
+                t0 = time.perf_counter()
+                okm, _ = om.check_motions(rob, a[:m_e], b[:m_e])
+                t1 = time.perf_counter()
+                oki, _ = om.edges_interp_valid(rob, a[:m_e], b[:m_e])
+                t2 = time.perf_counter()
+                g_cm = ctx.check_motions(a[:m_e], b[:m_e])
+                g_ci, _ = ctx.check_edges_interp(a[:m_e], b[:m_e])
+                cpu["edges"] = {"sample": f"first {m_e} bench edges, single thread",
+                                "check_motion_edges_per_s": m_e / (t1 - t0), "interp_0p5m_edges_per_s": m_e / (t2 - t1),
+                                "verdicts_match_gpu": bool(np.array_equal(okm, g_cm) and np.array_equal(oki, g_ci))}
+        except Exception as e:  # pragma: no cover
+            cpu["edges"] = {"error": repr(e)}
+        try:
+            cpu["c1"] = c1_leg(local_rank)
+        except Exception as e:  # pragma: no cover
+            cpu["c1"] = {"error": repr(e)}
 
     out = {
         "metric": "validated states/sec on 400x400@0.04m map (sample + validity check)",
@@ -499,7 +877,9 @@ def main():
                                 "re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
-        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts, "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess, "c4_800_defaults": c4,
+        "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts,
+        "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess,
+        "c4_800_defaults": c4, "distributed": dist_extras,
         "device": ctx.arch, "gather_error": gather_error,
     }
     print(json.dumps(out))

@@ -172,6 +172,12 @@ int artp_compact_valid_indices_dev(artp_ctx* ctx, const uint8_t* valid, size_t n
                                    uint64_t* n_out_dev);
 int artp_sample_states_at_dev(artp_ctx* ctx, uint64_t seed, uint64_t base_index, const uint32_t* idx,
                               const uint64_t* count_dev, size_t cap, double* se3_out);
+/* The second exchange of SURVEY.md 8e: the edge results of a rank as fixed-size records {u32 i, u32 j,
+ * f32 cost[3]} (20 bytes; i / j = the caller's vertex ids of the edge's endpoints, cost = the MotionCostFunc row
+ * of artp_cost_query_dev or any 3 floats).  records_out (n x 5 u32) receives the records of the edges with
+ * valid[e] != 0 in input order, *n_out_dev their number; the block is then all-gathered (RCCL). */
+int artp_pack_edge_results_dev(artp_ctx* ctx, const uint8_t* valid, const uint32_t* edge_i, const uint32_t* edge_j,
+                               const float* cost, size_t n, uint32_t* records_out, uint64_t* n_out_dev);
 /* Measurement helper: the ALGORITHMIC window size of a batch = sum over states of
  * the heightfield vertices (nMaxX-nMinX+1)*(nMaxZ-nMinZ+1) of all five boxes, no credit for
  * early-outs or short-circuiting, 0 for a box whose centre is outside the map or whose AABB is off
@@ -321,6 +327,9 @@ int artp_cost_load_weights(artp_ctx* ctx, const void* blob, size_t bytes);
  * along world y (cost_query_server.py:66-74), holes already inpainted; (cx, cy) = map centre. */
 int artp_cost_update_map(artp_ctx* ctx, const float* elev_xy, int rows, int cols, double res, double len_x,
                          double len_y, double cx, double cy);
+/* The same with the map array already in HBM (asynchronous on the context's stream). */
+int artp_cost_update_map_dev(artp_ctx* ctx, const float* elev_xy_dev, int rows, int cols, double res, double len_x,
+                             double len_y, double cx, double cy);
 /* The same from the planner's grid_map elevation layer (column-major rows x cols, as PlannerRos publishes it
  * to the cost node): applies the server's rot90(.., 2).transpose() re-indexing (cost_query_server.py:66-74).
  * Holes (NaN / inf) are an error: the server's cv.inpaint (cost_query_server.py:90-111) stays with the caller. */

@@ -1,0 +1,60 @@
+"""CPU suite: the host-side logic of bench.py that does not need a GPU -- the PMC summary arithmetic, the
+staleness rule for the committed PMC fallback, the edge pairing and the CNN flop count of SURVEY.md 8a-R8."""
+import json
+import os
+
+import numpy as np
+
+import common  # noqa: F401  (sys.path)
+import bench
+
+
+def test_cnn_flops_match_the_survey_figures():
+    assert abs(bench.cnn_flops(400) / 1e9 - 37.66) < 0.02      # 37.66 GFLOP at C2
+    assert 165 < bench.cnn_flops(800) / 1e9 < 175              # "~170 GFLOP" at C4
+
+
+def test_pair_edges_follow_the_8d_rule():
+    rng = np.random.default_rng(0)
+    acc = np.zeros((5000, 7))
+    acc[:, :2] = rng.uniform(-8, 8, (5000, 2))
+    ii, jj = bench.pair_edges(acc, 400)
+    assert len(ii) == 400 and (jj > ii).all() and (jj - ii <= 3).all()
+    assert (np.hypot(*(acc[ii, :2] - acc[jj, :2]).T) < 2.0).all()
+
+
+def test_pmc_summary_arithmetic_and_corrections():
+    cyc = 2.0e6  # per-XCD kernel cycles
+    per_kernel = {
+        "void artp::classify_states_kernel(...)": {
+            "GRBM_GUI_ACTIVE": 8 * cyc, "SQ_ACTIVE_INST_VALU": 0.55 * bench.N_SIMD * cyc / 4,
+            "SQ_ACTIVE_INST_LDS": 0.10 * bench.N_SIMD * cyc / 4, "SQ_INSTS_LDS": 1.0e6, "SQ_WAVE_CYCLES": 100.0,
+            "SQ_WAIT_ANY": 70.0, "FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0, "TCC_HIT_sum": 80.0, "TCC_MISS_sum": 20.0,
+            "max_us_by_pass": [900.0, 905.0, 910.0]},
+        "void artp::some_other_kernel()": {"GRBM_GUI_ACTIVE": 1.0, "max_us_by_pass": [1.0]},
+    }
+    s = bench.summarise_pmc(per_kernel)
+    k = s["kernels"]["classify_states_kernel"]
+    assert abs(k["valu_busy"] - 0.55) < 1e-12 and abs(k["lds_busy"] - 0.10) < 1e-12
+    assert k["hbm_fetch_bytes"] == 2 * 1024 * 1000.0          # gfx950: FETCH_SIZE doubled
+    assert k["hbm_write_bytes"] == 1024 * 500.0
+    assert abs(k["l2_hit"] - 0.8) < 1e-12 and abs(k["wait_frac"] - 0.7) < 1e-12 and k["us"] == 905.0
+    assert s["validity_hbm_bytes_per_launch"] == 2 * 1024 * 1000.0 + 1024 * 500.0
+    assert abs(s["valu_busy_time_weighted"] - 0.55) < 1e-12
+    assert s["csrc_hash"] == bench.csrc_hash()
+
+
+def test_committed_pmc_profile_is_only_used_for_the_same_kernel_sources(tmp_path, monkeypatch):
+    """`roofline.traffic` must not silently go stale: the committed fallback is refused unless it
+    was measured on exactly this checkout's art_planner_amd/csrc."""
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "art_planner_amd" / "csrc")
+    (tmp_path / "art_planner_amd" / "csrc" / "k.h").write_text("// v1\n")
+    h = bench.csrc_hash()
+    json.dump({"csrc_hash": h, "validity_hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / "pmc_r02.json", "w"))
+    d, note = bench.load_committed_pmc()
+    assert d is not None and "same kernel sources" in note
+    (tmp_path / "art_planner_amd" / "csrc" / "k.h").write_text("// v2\n")
+    d, note = bench.load_committed_pmc()
+    assert d is None and "STALE" in note

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 import common
 import oracle_py as O
-from art_planner_amd.distributed import (ValidIndexGatherer, ValidStateGatherer, agree_capacity,
+from art_planner_amd.distributed import (EdgeResultGatherer, ValidIndexGatherer, ValidStateGatherer, agree_capacity,
                                          shard_first_index)
 from art_planner_amd.synthetic import make_map
 
@@ -33,6 +33,25 @@ def _shard_valid(gm, rob, step, rank, world):
     return se3, valid
 
 
+def _shard_edges(gm, rob, se3, valid):
+    """Edges of a shard as SURVEY.md 8d pairs them: accepted state i with accepted states i+1 .. i+3 when their
+    lateral distance is below 2 m; verdict = the 0.5 m interpolation rule (oracle), cost = a deterministic
+    stand-in triple (length, |dz|, |dyaw| proxy) -- the exchange does not care what the three floats are."""
+    pos = np.flatnonzero(valid)
+    acc = se3[pos]
+    ei, ej = [], []
+    for d in (1, 2, 3):
+        a, b = acc[:-d], acc[d:]
+        near = np.hypot(a[:, 0] - b[:, 0], a[:, 1] - b[:, 1]) < 2.0
+        ei.append(pos[:-d][near])
+        ej.append(pos[d:][near])
+    ei, ej = np.concatenate(ei), np.concatenate(ej)
+    ok, _ = O.OracleMap(gm).edges_interp_valid(rob, se3[ei], se3[ej])
+    d3 = se3[ej, :3] - se3[ei, :3]
+    cost = np.stack([np.linalg.norm(d3, axis=1), np.abs(d3[:, 2]), np.abs(se3[ej, 6] - se3[ei, 6])], 1).astype(np.float32)
+    return ei.astype(np.uint32), ej.astype(np.uint32), ok, cost
+
+
 def _worker(rank, port, out_dir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -48,8 +67,23 @@ def _worker(rank, port, out_dir):
     gi = ValidIndexGatherer(WORLD, cap, dev)
     smp = O.OracleSampler(gm)
     merged = []
+    ge = EdgeResultGatherer(WORLD, 3 * BATCH, dev)
+    all_ij, all_cost = [], []
     for step in range(STEPS):
         se3, valid = _shard_valid(gm, rob, step, rank, WORLD)
+        # the second exchange: edge results {u32 i, u32 j, f32 cost[3]} of the valid edges, fixed-capacity blocks
+        ei, ej, ok_e, cost = _shard_edges(gm, rob, se3, valid)
+        keep = ok_e != 0
+        rec = np.zeros((3 * BATCH, 5), np.int32)
+        n_e = int(keep.sum())
+        rec[:n_e, 0] = ei[keep].view(np.int32)
+        rec[:n_e, 1] = ej[keep].view(np.int32)
+        rec[:n_e, 2:] = cost[keep].view(np.int32)
+        ge.gather(torch.from_numpy(rec), torch.tensor([n_e], dtype=torch.int64))
+        ij, c, ok3 = ge.global_records(step, BATCH)
+        assert ok3
+        all_ij.append(ij.numpy().copy())
+        all_cost.append(c.numpy().copy())
         comp = torch.zeros((BATCH, 7), dtype=torch.float64)
         sel = torch.from_numpy(se3[valid != 0])
         comp[:len(sel)] = sel
@@ -67,6 +101,8 @@ def _worker(rank, port, out_dir):
         assert np.array_equal(regen, m.numpy())
         merged.append(m.numpy().copy())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate(merged, 0))
+    np.save(os.path.join(out_dir, f"edges_ij_rank{rank}.npy"), np.concatenate(all_ij, 0))
+    np.save(os.path.join(out_dir, f"edges_cost_rank{rank}.npy"), np.concatenate(all_cost, 0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,3 +132,23 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     ref = np.concatenate(ref, 0)
     assert np.array_equal(r0, ref)
     assert len(ref) > 0
+    # edge results: every rank holds the same records, equal to a single process's over the union range, with
+    # GLOBAL sample indices (the endpoints can be re-materialised anywhere from (seed, index))
+    ij0, ij1 = np.load(tmp_path / "edges_ij_rank0.npy"), np.load(tmp_path / "edges_ij_rank1.npy")
+    c0, c1 = np.load(tmp_path / "edges_cost_rank0.npy"), np.load(tmp_path / "edges_cost_rank1.npy")
+    assert np.array_equal(ij0, ij1) and np.array_equal(c0, c1)
+    ref_ij, ref_c = [], []
+    for step in range(STEPS):
+        for rank in range(WORLD):
+            se3, valid = _shard_valid(gm, rob, step, rank, WORLD)
+            ei, ej, ok_e, cost = _shard_edges(gm, rob, se3, valid)
+            base = shard_first_index(step, rank, WORLD, BATCH)
+            ref_ij.append(np.stack([ei[ok_e != 0].astype(np.int64) + base, ej[ok_e != 0].astype(np.int64) + base], 1))
+            ref_c.append(cost[ok_e != 0])
+    ref_ij, ref_c = np.concatenate(ref_ij), np.concatenate(ref_c)
+    assert len(ref_ij) > 8
+    assert np.array_equal(ij0, ref_ij) and np.array_equal(c0, ref_c)
+    smp = O.OracleSampler(gm)
+    k = int(ref_ij[7, 1])
+    st = smp.sample(rob, 42, k, 1)[0][0]
+    assert O.OracleMap(gm).states_valid(rob, st[None])[0] == 1     # an endpoint id is a valid state of the stream
