@@ -251,6 +251,12 @@ int grid_scan(const artp_ctx* c, size_t lds) {
   return (int)((size_t)c->n_cus * per_cu);
 }
 
+// persistent grid of the sub-queue consumers: per_cu workgroups per CU, rounded up to a multiple of ARTP_NSUB
+unsigned grid_sub(const artp_ctx* c, int per_cu) {
+  const unsigned g = (unsigned)c->n_cus * (unsigned)per_cu;
+  return (g + ARTP_NSUB - 1) / ARTP_NSUB * ARTP_NSUB;
+}
+
 // Range tables of one layer (pipeline.h).  Levels 0..5 (block 1..32); the kernels use levels 2..5.
 // Partner table of the foot layer (FieldDev::partner_flags).  Radius = the largest index window a foot box
 // can have: box diagonal / sample spacing, + the window's rounding and dCollideHeightfield's +1 border.
@@ -324,10 +330,9 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
                        fl[l]);
   HIP_TRY(c, hipGetLastError());
   TablesDev& t = c->tables[slot];
-  for (int l = 0; l < ARTP_TABLE_LEVELS; ++l) {
-    t.mm[l] = mm[l + 2];
-    t.fl[l] = fl[l + 2];
-  }
+  t.mm = mm[2];  // the kernels use levels 2..5 (blocks of 4..32 samples), stored back to back
+  t.fl = fl[2];
+  t.stride = (unsigned)elems;
   t.has_nan = f.has_nan;
   t.has_nonfinite = c->layer_has_nonfinite[slot];
   const int rc_partner = build_partner_table(c, slot, dirty);
@@ -336,33 +341,52 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
   return ARTP_OK;
 }
 
-// classify -> resolve -> plane stage on the context's stream (all asynchronous).
-int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* valid) {
+// Room for the PoseRecs of a batch (tmp[7]).
+int ensure_recs(artp_ctx* c, size_t n) { return ensure_tmp(c, 7, n * sizeof(PoseRec)); }
+
+// classify -> resolve -> plane stage on the context's stream (all asynchronous).  recs_ready: the PoseRecs of
+// the batch are already in tmp[7] (the fused sampler wrote them); otherwise pose_rec_kernel makes them from se3.
+int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* valid, bool recs_ready = false) {
   if (n >= (1ull << 32)) {
     c->last_error = "batch too large (state index is 32 bit)";
     return ARTP_ERR_INVALID_ARG;
   }
-  int rc = ensure_tmp(c, 4, 5 * n * sizeof(PendingBox));
+  int rc = ensure_recs(c, n);
   if (rc) return rc;
-  rc = ensure_tmp(c, 5, (5 + 4 + 4 + 4 + 1) * n * sizeof(unsigned) + 64);
+  PoseRec* recs = static_cast<PoseRec*>(c->tmp[7]);
+  if (!recs_ready)
+    hipLaunchKernelGGL(pose_rec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->field[0], se3, n,
+                       recs);
+  const size_t per_block_states = 64 * ARTP_CLASSIFY_SUB;
+  const size_t n_blocks = (n + per_block_states - 1) / per_block_states;
+  // sub-queue capacity: every workgroup of a sub-queue may queue all of its boxes
+  const size_t seg_t = ((n_blocks + ARTP_NSUB - 1) / ARTP_NSUB) * per_block_states;
+  rc = ensure_tmp(c, 4, 5 * ARTP_NSUB * seg_t * sizeof(PendingBox));
+  if (rc) return rc;
+  // tmp[5]: 8 counters | pad to 128 B | 2 * ARTP_NSUB sub-queue counters, one per 128-byte line | index queues
+  const size_t ctr_bytes = 128 + (size_t)2 * ARTP_NSUB * 128;
+  rc = ensure_tmp(c, 5, ctr_bytes + (5 + 4 + 4 + 4 + 1) * n * sizeof(unsigned) + 64);
   if (rc) return rc;
   PipelineQueues q;
   q.q1 = static_cast<PendingBox*>(c->tmp[4]);
   q.counters = static_cast<unsigned long long*>(c->tmp[5]);
-  q.q2 = reinterpret_cast<unsigned*>(q.counters + 8);
+  q.sub = q.counters + 16;
+  q.seg_t = seg_t;
+  q.q2 = reinterpret_cast<unsigned*>(static_cast<char*>(c->tmp[5]) + ctr_bytes);
   q.q3 = q.q2 + 5 * n;
   q.q5 = q.q3 + 4 * n;
   q.q4 = q.q5 + 4 * n;
   q.q6 = q.q4 + 4 * n;
-  q.feet_base = n;
-  HIP_TRY(c, hipMemsetAsync(q.counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  q.feet_base = (unsigned long long)ARTP_NSUB * seg_t;
+  HIP_TRY(c, hipMemsetAsync(q.counters, 0, ctr_bytes, c->stream));
   const size_t per_block = 64 * ARTP_CLASSIFY_SUB;
   hipLaunchKernelGGL(classify_states_kernel, dim3((unsigned)((n + per_block - 1) / per_block)),
                      dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
-                     c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, se3, n, valid, q);
+                     c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, (const PoseRec*)recs, n,
+                     valid, q);
   {
     const size_t lds = (size_t)CandCap<16>::value * 36 * 4 * ARTP_STREAM_WAVES;
-    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3((unsigned)c->n_cus * 5), dim3(64 * ARTP_STREAM_WAVES), lds,
+    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, 5)), dim3(64 * ARTP_STREAM_WAVES), lds,
                        c->stream, c->field[1], c->robot, q, valid);
   }
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
@@ -371,7 +395,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
     // streaming pass: only the corner-candidate scratch; the staged pass behind it takes the rest
     const ScratchCaps caps_stream{64 * 36, 0, 0, 0};
     const size_t lds_stream = (size_t)64 * 36 * ARTP_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3((unsigned)c->n_cus * 10),
+    hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_sub(c, 10)),
                        dim3(64 * ARTP_WAVES_PER_BLOCK), lds_stream, c->stream, c->field[0], c->robot, q, valid,
                        caps_stream, c->d_error);
   }
@@ -946,22 +970,27 @@ static int finite_min_max_dev(artp_ctx* c, const float* d_layer, size_t n, float
   return ARTP_OK;
 }
 
+// recs != nullptr: also emit the PoseRecs of the validity pipeline (fused sample + validate)
+static int launch_sampler(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out, PoseRec* recs) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+  if (c->sampler.from_distribution)
+    hipLaunchKernelGGL(sample_states_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
+                       c->geom, c->robot, seed, first_index, n, se3_out, c->field[0], recs);
+  else
+    hipLaunchKernelGGL(sample_states_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
+                       c->geom, c->robot, seed, first_index, n, se3_out, c->field[0], recs);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
 int artp_sample_states_dev(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out) {
   if (!c || (n && !se3_out)) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->have_sampler) return ARTP_ERR_NO_MAP;
   if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  size_t blocks = (n + 255) / 256;
-  if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
-  if (c->sampler.from_distribution)
-    hipLaunchKernelGGL(sample_states_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
-                     c->geom, c->robot, seed, first_index, n, se3_out);
-  else
-    hipLaunchKernelGGL(sample_states_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
-                     c->geom, c->robot, seed, first_index, n, se3_out);
-  HIP_TRY(c, hipGetLastError());
-  return ARTP_OK;
+  return launch_sampler(c, seed, first_index, n, se3_out, nullptr);
 }
 
 int artp_sample_states(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out) {
@@ -982,16 +1011,33 @@ int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_inde
                                  double* se3_out, uint8_t* valid_out, size_t* n_valid) {
   if (!c || (n && (!se3_out || !valid_out))) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  int rc = artp_sample_states_dev(c, seed, first_index, n, se3_out);
-  if (rc) return rc;
-  if (!c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
+  if (!c->have_sampler || !c->have_field[0] || !c->have_field[1]) return ARTP_ERR_NO_MAP;
   if (n == 0) {
     if (n_valid) *n_valid = 0;
     return ARTP_OK;
   }
+  if (n >= (1ull << 32)) {
+    c->last_error = "batch too large (state index is 32 bit)";
+    return ARTP_ERR_INVALID_ARG;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
-  int rcv = launch_validate_pipeline(c, se3_out, n, valid_out);
-  if (rcv) return rcv;
+  // fused: the sampler hands the per-state part of the validity check (float pose, orthogonalised rotation in the
+  // field frame) to the pipeline while the state is still in its registers
+  int rc = ensure_recs(c, n);
+  if (rc) return rc;
+  if (n <= ARTP_FEW_STATES) {  // the few-state kernel reads the states themselves
+    rc = launch_sampler(c, seed, first_index, n, se3_out, nullptr);
+    if (rc) return rc;
+    rc = artp_validate_states_dev(c, se3_out, n, valid_out, nullptr);
+    if (rc) return rc;
+  } else {
+    rc = launch_sampler(c, seed, first_index, n, se3_out, static_cast<PoseRec*>(c->tmp[7]));
+    if (rc) return rc;
+  }
+  if (n > ARTP_FEW_STATES) {
+    const int rcv = launch_validate_pipeline(c, se3_out, n, valid_out, true);
+    if (rcv) return rcv;
+  }
   if (n_valid) {
     HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
     size_t blocks = (n + 255) / 256;
@@ -1193,8 +1239,15 @@ int artp_debug_pipeline_counters(artp_ctx* c, uint64_t out[8]) {
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   if (!c->tmp[5]) return ARTP_ERR_NO_MAP;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpyAsync(out, c->tmp[5], 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  uint64_t raw[16 + 2 * ARTP_NSUB * 16];
+  HIP_TRY(c, hipMemcpyAsync(raw, c->tmp[5], sizeof(raw), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 8; ++k) out[k] = raw[k];
+  out[0] = out[4] = 0;  // the torso / foot queues are the sums over their sub-queues
+  for (int s = 0; s < ARTP_NSUB; ++s) {
+    out[0] += raw[16 + (size_t)s * 16];
+    out[4] += raw[16 + (size_t)(ARTP_NSUB + s) * 16];
+  }
   return ARTP_OK;
 }
 

@@ -142,27 +142,36 @@ ARTP_HD void orthogonalize_R(float* m) {
   if (m[0] != 0.0f || m[1] != 0.0f || m[2] != 0.0f) m[3] = m[7] = m[11] = 0.0f;
 }
 
-// HeightMapBoxChecker::checkCollision pose -> box in heightfield frame + index window.
-// pose = dPose{origin[4], rotation[12]}.
-ARTP_HD void setup_box(const FieldDev& f, const float* pose, float sx, float sy, float sz,
-                       BoxHF& b) {
-  float w0 = pose[4], w1 = pose[5], w2 = pose[6], w4 = pose[8], w5 = pose[9], w6 = pose[10], w8 = pose[12],
-        w9 = pose[13], w10 = pose[14];
+// The rotation part of HeightMapBoxChecker::checkCollision's pose handling, which depends on the STATE only (the
+// five boxes of a state share its rotation, validity_checker.cpp:40-43 / validity_checker_feet.cpp:64-68):
+// dBodySetRotation's dxOrthogonalizeR, then dCollideHeightfield's frame change R1 = Rt^T R (dMultiply1_333,
+// heightfield.cpp:1846).  rot = row-major 3x3 (the dPose's rotation without its padding column).
+ARTP_HD void box_rotation_in_field(const FieldDev& f, const float rot[9], float bR[9]) {
+  float w0 = rot[0], w1 = rot[1], w2 = rot[2], w4 = rot[3], w5 = rot[4], w6 = rot[5], w8 = rot[6], w9 = rot[7],
+        w10 = rot[8];
   orthogonalize_R9(w0, w1, w2, w4, w5, w6, w8, w9, w10);
   const float Rw[12] = {w0, w1, w2, 0.0f, w4, w5, w6, 0.0f, w8, w9, w10, 0.0f};
-  const float p0 = pose[0] - f.pos[0];
-  const float p1 = pose[1] - f.pos[1];
-  const float p2 = pose[2] - f.pos[2];
-  // dMultiply1_331(pos1, Rt, pos0): pos1[i] = Rt[i]*p0 + Rt[4+i]*p1 + Rt[8+i]*p2
-  b.pos[0] = dot3(f.R[0], f.R[4], f.R[8], p0, p1, p2);
-  b.pos[1] = dot3(f.R[1], f.R[5], f.R[9], p0, p1, p2);
-  b.pos[2] = dot3(f.R[2], f.R[6], f.R[10], p0, p1, p2);
   // dMultiply1_333(R1, Rt, R): R1[i][j] = R[0][j]*Rt[0][i] + R[1][j]*Rt[1][i] + R[2][j]*Rt[2][i]
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      b.R[3 * i + j] = dot3(Rw[j], Rw[4 + j], Rw[8 + j], f.R[i], f.R[4 + i], f.R[8 + i]);
+      bR[3 * i + j] = dot3(Rw[j], Rw[4 + j], Rw[8 + j], f.R[i], f.R[4 + i], f.R[8 + i]);
+}
+
+// The rest of the pose handling for one box: position in the field frame, AABB, on-field test, index window
+// (heightfield.cpp:1838-1893, box.cpp:60-77).  origin = the dPose's origin, bR = box_rotation_in_field().
+ARTP_HD void setup_box_rotated(const FieldDev& f, const float origin[3], const float bR[9], float sx, float sy,
+                               float sz, BoxHF& b) {
+  const float p0 = origin[0] - f.pos[0];
+  const float p1 = origin[1] - f.pos[1];
+  const float p2 = origin[2] - f.pos[2];
+  // dMultiply1_331(pos1, Rt, pos0): pos1[i] = Rt[i]*p0 + Rt[4+i]*p1 + Rt[8+i]*p2
+  b.pos[0] = dot3(f.R[0], f.R[4], f.R[8], p0, p1, p2);
+  b.pos[1] = dot3(f.R[1], f.R[5], f.R[9], p0, p1, p2);
+  b.pos[2] = dot3(f.R[2], f.R[6], f.R[10], p0, p1, p2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) b.R[i] = bR[i];
   b.pos[0] += f.half_w;
   b.pos[2] += f.half_d;
   b.side[0] = sx;
@@ -189,6 +198,16 @@ ARTP_HD void setup_box(const FieldDev& f, const float* pose, float sx, float sy,
     b.minZ = nMinZ > 0 ? nMinZ : 0;
     b.maxZ = nMaxZ > f.nD - 1 ? f.nD - 1 : nMaxZ;
   }
+}
+
+// HeightMapBoxChecker::checkCollision pose -> box in heightfield frame + index window.
+// pose = dPose{origin[4], rotation[12]}.
+ARTP_HD void setup_box(const FieldDev& f, const float* pose, float sx, float sy, float sz,
+                       BoxHF& b) {
+  const float rot[9] = {pose[4], pose[5], pose[6], pose[8], pose[9], pose[10], pose[12], pose[13], pose[14]};
+  float bR[9];
+  box_rotation_in_field(f, rot, bR);
+  setup_box_rotated(f, pose, bR, sx, sy, sz, b);
 }
 
 // dGeomBoxPointDepth(...) > dEpsilon  (ode/ode/src/box.cpp:109-173).

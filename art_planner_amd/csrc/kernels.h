@@ -108,11 +108,8 @@ check_boxes_kernel(FieldDev f, float sx, float sy, float sz, const float* __rest
 // ---- R1 + R2 ---------------------------------------------------------------------------------------
 // Pose3FromSE3 (art_planner/include/art_planner/utils.h:25-38): Eigen::Quaternionf(w,x,y,z)
 // .toRotationMatrix(); R row-major 3x3.
-__device__ __forceinline__ void pose3_from_se3(const double* se3, float t[3], float R[9]) {
-  t[0] = (float)se3[0];
-  t[1] = (float)se3[1];
-  t[2] = (float)se3[2];
-  const float x = (float)se3[3], y = (float)se3[4], z = (float)se3[5], w = (float)se3[6];
+// Eigen::Quaternionf(w, x, y, z).toRotationMatrix(), row-major
+__device__ __forceinline__ void rot_from_quat(float x, float y, float z, float w, float R[9]) {
   const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
   const float twx = tx * w, twy = ty * w, twz = tz * w;
   const float txx = tx * x, txy = ty * x, txz = tz * x;
@@ -126,6 +123,48 @@ __device__ __forceinline__ void pose3_from_se3(const double* se3, float t[3], fl
   R[6] = txz - twy;
   R[7] = tyz + twx;
   R[8] = 1.0f - (txx + tyy);
+}
+
+__device__ __forceinline__ void pose3_from_se3(const double* se3, float t[3], float R[9]) {
+  t[0] = (float)se3[0];
+  t[1] = (float)se3[1];
+  t[2] = (float)se3[2];
+  rot_from_quat((float)se3[3], (float)se3[4], (float)se3[5], (float)se3[6], R);
+}
+
+// What the five boxes of a state share, computed ONCE per state (by the sampler, or by pose_rec_kernel for
+// caller-provided states) instead of once per (state, box) lane of the classify stage: the float pose of
+// Pose3FromSE3 (translation + quaternion; the rotation matrix is 27 flops away) and the box rotation in the
+// field frame -- dxOrthogonalizeR (5 IEEE divisions, 2 square roots) + Rt^T R, the same for every box of the
+// state and for both layers (the field rotation is a constant of HeightMapBoxChecker, height_map_box_checker.cpp:22).
+struct __attribute__((aligned(16))) PoseRec {  // 64 bytes = one cache line per state
+  float t[3];
+  float q[4];   // x y z w
+  float bR[9];  // box_rotation_in_field
+};
+
+__device__ __forceinline__ void make_pose_rec(const FieldDev& f, const double* se3, float4 out[4]) {
+  float t[3], R[9], bR[9];
+  pose3_from_se3(se3, t, R);
+  box_rotation_in_field(f, R, bR);
+  out[0] = make_float4(t[0], t[1], t[2], (float)se3[3]);
+  out[1] = make_float4((float)se3[4], (float)se3[5], (float)se3[6], bR[0]);
+  out[2] = make_float4(bR[1], bR[2], bR[3], bR[4]);
+  out[3] = make_float4(bR[5], bR[6], bR[7], bR[8]);
+}
+
+__global__ void __launch_bounds__(256)
+pose_rec_kernel(FieldDev f, const double* __restrict__ se3, size_t n, PoseRec* __restrict__ recs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double st[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
+  float4 r[4];
+  make_pose_rec(f, st, r);
+  float4* dst = reinterpret_cast<float4*>(recs + i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dst[j] = r[j];
 }
 
 // One full StateValidityChecker::isValid for the state held (wave-uniformly) in se3[7].
@@ -448,10 +487,11 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
 template <bool FROM_DIST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t first_index,
-                     size_t n, double* __restrict__ se3_out) {
+                     size_t n, double* __restrict__ se3_out, FieldDev f, PoseRec* __restrict__ recs) {
   // A lane's 7 doubles are 56 bytes apart from its neighbour's: written directly, every store instruction
   // touches 28 cache lines with 8 useful bytes in each 56.  The wavefront's 64 states go through LDS instead and
-  // leave as seven fully coalesced 512-byte rows.
+  // leave as seven fully coalesced 512-byte rows.  recs (may be null): the per-state PoseRec of the validity
+  // pipeline, produced here while the state is in registers (fused sample + validate).
   __shared__ double stage[4][64 * 7];
   const int lane = threadIdx.x & 63;
   double* sw = stage[threadIdx.x >> 6];
@@ -463,6 +503,13 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
       sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st);
 #pragma unroll
       for (int k = 0; k < 7; ++k) sw[lane * 7 + k] = st[k];
+      if (recs) {
+        float4 r[4];
+        make_pose_rec(f, st, r);
+        float4* dst = reinterpret_cast<float4*>(recs + i);  // one whole 64-byte line per lane
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = r[k];
+      }
     }
     wave_lds_sync();
     const size_t cnt = (n - i0 < 64 ? n - i0 : 64) * 7;

@@ -32,12 +32,16 @@ namespace artp {
 
 struct TablesDev {
   // {max, min-of-finite} interleaved so one 8-byte gather answers both (the lookups are random
-  // accesses into tables larger than one XCD's L2: cache lines touched, not bytes, are the cost)
-  const float2* mm[ARTP_TABLE_LEVELS];  // .x = max over [x, x+B) x [z, z+B), NaN samples count as -inf
-                                        // .y = min over the FINITE samples of the block, +inf if none
-  const unsigned char* fl[ARTP_TABLE_LEVELS];  // bit 0: the block holds a non-finite sample, bit 1: a NaN
-  int has_nan;                          // the layer holds a NaN somewhere
-  int has_nonfinite;                    // the layer holds a NaN or an infinity somewhere (else fl is all zero)
+  // accesses into tables larger than one XCD's L2: cache lines touched, not bytes, are the cost).
+  // The levels lie back to back, `stride` entries apart: level l (block 4 << l) of entry i is mm[l * stride + i].
+  // One base pointer + arithmetic instead of an array of pointers: a per-lane level index into a pointer array in
+  // the kernel arguments costs a dependent memory round trip (pointer, then gather) in front of every lookup.
+  const float2* mm;         // .x = max over [x, x+B) x [z, z+B), NaN samples count as -inf
+                            // .y = min over the FINITE samples of the block, +inf if none
+  const unsigned char* fl;  // bit 0: the block holds a non-finite sample, bit 1: a NaN
+  unsigned stride;          // entries per level (= nW * nD)
+  int has_nan;              // the layer holds a NaN somewhere
+  int has_nonfinite;        // the layer holds a NaN or an infinity somewhere (else fl is all zero)
   int valid;
 };
 
@@ -175,9 +179,9 @@ __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const Tables
   const int wmax = wX > wZ ? wX : wZ;
   if (wmax > (4 << (ARTP_TABLE_LEVELS - 1))) return -1;
   const int lc = wmax <= 4 ? 0 : (wmax <= 8 ? 1 : (wmax <= 16 ? 2 : 3));
-  const int at = b.minX + b.minZ * f.nW;
-  const float2 v = t.mm[lc][at];
-  const unsigned fc = t.has_nonfinite ? t.fl[lc][at] : 0u;
+  const unsigned at = (unsigned)lc * t.stride + (unsigned)(b.minX + b.minZ * f.nW);
+  const float2 v = t.mm[at];
+  const unsigned fc = t.has_nonfinite ? t.fl[at] : 0u;
   if (fc & 2u) return -1;  // a NaN nearby: ODE's running dMAX needs the precise path
   const float minO2 = b.aabb[2], maxO2 = b.aabb[3];
   if (minO2 - v.x > -ARTP_EPS) return 0;
@@ -195,22 +199,39 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
   if (m < 4) return false;
   const int lvl = m >= 32 ? 3 : (m >= 16 ? 2 : (m >= 8 ? 1 : 0));
   const int B = 4 << lvl;
-  const float2* __restrict__ mm = t.mm[lvl];
-  const unsigned char* __restrict__ fl = t.fl[lvl];
+  const float2* __restrict__ mm = t.mm + (size_t)lvl * t.stride;
+  const unsigned char* __restrict__ fl = t.fl + (size_t)lvl * t.stride;
   float vmax = -INFINITY, vmin = INFINITY;
   unsigned flags = 0;
   const int lastX = b.maxX - B + 1, lastZ = b.maxZ - B + 1;
-  for (int zz = b.minZ;; zz += B) {
-    const int zc = zz < lastZ ? zz : lastZ;
-    for (int xx = b.minX;; xx += B) {
-      const int xc = xx < lastX ? xx : lastX;
-      const float2 v = mm[xc + zc * f.nW];
-      if (t.has_nonfinite) flags |= fl[xc + zc * f.nW];  // uniform: a fully finite layer skips the lookup
-      vmax = (v.x > vmax) ? v.x : vmax;
-      vmin = (v.y < vmin) ? v.y : vmin;
-      if (xx >= lastX) break;
+  // blocks anchored at min + i * B, the last one clamped to last: ceil(w / B) per axis.  The short axis needs at
+  // most 2 (B <= m < 2 B below the top level), the long one 2 - 3 for the boxes of a legged robot.  A 3 x 2
+  // batch of gathers is issued at once (lanes that need fewer are masked off: no transaction), so the statistics
+  // cost ONE memory round trip instead of up to nine dependent ones; larger windows loop.
+  const int nx = (wX + B - 1) >> (lvl + 2), nz = (wZ + B - 1) >> (lvl + 2);
+  for (int j0 = 0; j0 < nz; j0 += 2) {
+    for (int i0 = 0; i0 < nx; i0 += 3) {
+      float2 v[6];
+      unsigned fb[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + (u % 3), j = j0 + (u / 3);
+        v[u] = make_float2(-INFINITY, INFINITY);
+        fb[u] = 0u;
+        if (i < nx && j < nz) {
+          const int xx = b.minX + i * B, zz = b.minZ + j * B;
+          const int at = (xx < lastX ? xx : lastX) + (zz < lastZ ? zz : lastZ) * f.nW;
+          v[u] = mm[at];
+          if (t.has_nonfinite) fb[u] = fl[at];  // uniform: a fully finite layer skips the lookup
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        vmax = (v[u].x > vmax) ? v[u].x : vmax;
+        vmin = (v[u].y < vmin) ? v[u].y : vmin;
+        flags |= fb[u];
+      }
     }
-    if (zz >= lastZ) break;
   }
   if (flags & 2u) return false;  // a NaN in the window: the running-dMAX quirk needs the ordered scan
   w.allFinite = !(flags & 1u);
@@ -230,16 +251,33 @@ struct __attribute__((aligned(16))) PendingBox {  // 96 bytes
   unsigned pad[2];
 };
 
+// The two big queues (torso, feet) are split into ARTP_NSUB sub-queues, each with its own slot counter on its own
+// 128-byte line: a workgroup of the classify stage takes its slots from sub-queue blockIdx % ARTP_NSUB.  One
+// counter word for all 32 768 workgroups of a 2^22-state batch serialised them on one L2 atomic unit (0.14 ms of
+// the stage); the consumers walk sub-queue blockIdx % ARTP_NSUB, so their launch grids are multiples of ARTP_NSUB.
+#define ARTP_NSUB 16
+
 struct PipelineQueues {
-  PendingBox* q1;                // undecided boxes: torso records at [0, n), foot records at [n, 5n)
+  PendingBox* q1;                // undecided boxes: torso sub-queue s at [s * seg_t, ...), foot sub-queue s at
+                                 // [feet_base + s * 4 * seg_t, ...)
+  unsigned long long* sub;       // slot counters: sub[(kind * ARTP_NSUB + s) * 16], kind 0 = torso, 1 = feet
+  unsigned long long seg_t;      // capacity of one torso sub-queue; a foot sub-queue holds 4 * seg_t
   unsigned* q2;                  // indices into q1 of boxes that need the exact-grouping stage
   unsigned* q3;                  // indices into q1 of foot boxes that survive the lane scan stage
   unsigned* q4;                  // foot boxes whose exits the tables could not evaluate (lane-scan path)
   unsigned* q5;                  // foot boxes whose corner candidates may have partners (list pass)
   unsigned* q6;                  // torso boxes the streaming pass cannot finish (staged pass)
-  unsigned long long* counters;  // [0] torso, [1] q2, [2] q6, [4] feet, [5] q3, [6] q5, [7] q4 counts
-  unsigned long long feet_base;  // = n
+  unsigned long long* counters;  // [1] q2, [2] q6, [5] q3, [6] q5, [7] q4 counts
+  unsigned long long feet_base;  // = ARTP_NSUB * seg_t
 };
+
+__device__ __forceinline__ unsigned long long* sub_counter(const PipelineQueues& q, int kind, int s) {
+  return q.sub + (size_t)(kind * ARTP_NSUB + s) * 16;
+}
+// first record of sub-queue s of the torso (kind 0) / foot (kind 1) queue
+__device__ __forceinline__ unsigned long long sub_base(const PipelineQueues& q, int kind, int s) {
+  return kind ? q.feet_base + (unsigned long long)s * 4ull * q.seg_t : (unsigned long long)s * q.seg_t;
+}
 
 __device__ __forceinline__ void box_from_record(const PendingBox& r, const RobotDev& rb, BoxHF& b) {
 #pragma unroll
@@ -317,7 +355,7 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const T
       nf[j * N + i] = 0u;
       if (!window_all_finite) {
         const bool inner = x > b.minX && x < b.maxX && z > b.minZ && z < b.maxZ;
-        nf[j * N + i] = inner ? (unsigned)t.fl[0][(x - 1) + (size_t)(z - 1) * f.nW] : 1u;
+        nf[j * N + i] = inner ? (unsigned)t.fl[(x - 1) + (size_t)(z - 1) * f.nW] : 1u;
       }
     }
   }
@@ -335,8 +373,8 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const T
 // selecting the FieldDev / TablesDev kernel arguments by a per-lane index would force both structs into
 // per-lane scratch memory (240 B/lane of HBM traffic).
 __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
-                                            const RobotDev& rb, const float t[3], const float R[9], int k,
-                                            BoxHF& b, bool& all_finite) {
+                                            const RobotDev& rb, const float t[3], const float R[9],
+                                            const float bR[9], int k, BoxHF& b, bool& all_finite) {
   all_finite = false;
   const bool body = (k == 0);
   float pose[16];
@@ -346,8 +384,8 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     // !unknown_space_untraversable (validity_checker_feet.cpp:34-37)
     return (!body && rb.unknown_space_untraversable) ? 1 : 0;
   }
-  setup_box(f, pose, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
-            body ? rb.torso[2] : rb.foot[2], b);
+  setup_box_rotated(f, pose, bR, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
+                    body ? rb.torso[2] : rb.foot[2], b);
   int hit = 0;
   if (b.on_field) {
     WindowStats w;
@@ -404,9 +442,14 @@ __device__ unsigned long long g_classify_cycles[2][8];  // [torso waves | foot w
 
 __global__ void __launch_bounds__(ARTP_CLASSIFY_THREADS)
 classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, MapGeom g, RobotDev rb,
-                       const double* __restrict__ se3, size_t n, uint8_t* __restrict__ valid,
+                       const PoseRec* __restrict__ recs, size_t n, uint8_t* __restrict__ valid,
                        PipelineQueues q) {
   constexpr int SUB = ARTP_CLASSIFY_SUB;
+  // The PoseRecs of the workgroup's SUB * 64 states come in ONCE, cooperatively (one 16-byte chunk per lane, fully
+  // coalesced), and are handed to the five box wavefronts of each state through LDS: five wavefronts pulling
+  // the same 64-byte line per lane through the L1 were half of the kernel's L1 accesses, and the L1's miss queue
+  // is what bounds this kernel (TCP_PENDING_STALL ~70 % of its cycles).  80-byte stride: conflict-free b128 reads.
+  __shared__ float4 prec[SUB * 64 * 5];
   __shared__ float4 stage[5 * SUB][32 * 6];
   __shared__ uint8_t codes[SUB][5][64];
   __shared__ unsigned cnts[5 * SUB];
@@ -421,19 +464,28 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   unsigned long long c_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long c_prev = clock64();
 #endif
-  double st[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
-  float t[3], R[9];
-  pose3_from_se3(st, t, R);
+  // the state's PoseRec: float pose + the box rotation in the field frame (shared by its five boxes)
+  if (threadIdx.x < SUB * 64 * 4) {
+    const int sl = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const size_t gi_raw = (size_t)blockIdx.x * SUB * 64 + sl;
+    const size_t gi = gi_raw < n ? gi_raw : n - 1;
+    prec[sl * 5 + part] = reinterpret_cast<const float4*>(recs + gi)[part];
+  }
+  __syncthreads();
+  const float4* rp = &prec[(sub * 64 + lane) * 5];
+  const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+  const float t[3] = {r0.x, r0.y, r0.z};
+  const float bR[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+  float R[9];
+  rot_from_quat(r0.w, r1.x, r1.y, r1.z, R);
   ARTP_C_MARK(0);
   BoxHF b;
   int code;
   bool all_finite;
   if (body)
-    code = classify_box(fb, tb, g, rb, t, R, 0, b, all_finite);
+    code = classify_box(fb, tb, g, rb, t, R, bR, 0, b, all_finite);
   else
-    code = classify_box(ff, tf, g, rb, t, R, k, b, all_finite);
+    code = classify_box(ff, tf, g, rb, t, R, bR, k, b, all_finite);
   ARTP_C_MARK(1);
   codes[sub][k][lane] = (uint8_t)code;
   __syncthreads();
@@ -454,8 +506,9 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       if (w < SUB) tot_t += cnts[w];
       else tot_f += cnts[w];
     }
-    bases[0] = tot_t ? atomicAdd(&q.counters[0], (unsigned long long)tot_t) : 0ull;
-    bases[1] = tot_f ? atomicAdd(&q.counters[4], (unsigned long long)tot_f) : 0ull;
+    const int sq = blockIdx.x % ARTP_NSUB;
+    bases[0] = sub_base(q, 0, sq) + (tot_t ? atomicAdd(sub_counter(q, 0, sq), (unsigned long long)tot_t) : 0ull);
+    bases[1] = sub_base(q, 1, sq) + (tot_f ? atomicAdd(sub_counter(q, 1, sq), (unsigned long long)tot_f) : 0ull);
   }
   __syncthreads();
   ARTP_C_MARK(3);
@@ -469,7 +522,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   }
 #endif
   if (cnt == 0) return;  // wave-uniform; no barrier below
-  unsigned long long base = body ? bases[0] : bases[1] + q.feet_base;
+  unsigned long long base = body ? bases[0] : bases[1];
   for (int w = body ? 0 : SUB; w < wave; ++w) base += cnts[w];
   float4* stg = stage[wave];
   float4* out = reinterpret_cast<float4*>(q.q1 + base);
@@ -513,7 +566,7 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
     const unsigned long long it = rnd * stride + (unsigned long long)blockIdx.x * blockDim.x + tid;
     const bool live = it < count;
-    const unsigned long long item = live ? (unsigned long long)q.q4[it] : q.feet_base;
+    const unsigned long long item = live ? (unsigned long long)q.q4[it] : q.feet_base;  // dead lanes: a valid address
     bool undecided = false;
     if (live) {
       const PendingBox rec = q.q1[item];
@@ -596,11 +649,13 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const ScratchCaps caps{CandCap<G>::value * 36, 0, 0, 0};
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
-  const unsigned long long count = q.counters[4];
-  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
-  for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
+  const int sq = blockIdx.x % ARTP_NSUB;  // this workgroup's foot sub-queue
+  const unsigned long long count = *sub_counter(q, 1, sq);
+  const unsigned long long first = sub_base(q, 1, sq);
+  const unsigned long long stride = (unsigned long long)(gridDim.x / ARTP_NSUB) * WAVES * GPW;
+  for (unsigned long long it = (unsigned long long)(blockIdx.x / ARTP_NSUB) * WAVES * GPW + unit_in_block; it < count;
        it += stride) {
-    const unsigned long long item = q.feet_base + it;
+    const unsigned long long item = first + it;
     const PendingBox rec = q.q1[item];
     if (valid[rec.state] == 0) continue;  // another box of this state already failed
     if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) {
@@ -666,16 +721,21 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
   const bool feet = (G != 64);  // feet: only the boxes the lane-per-box stages handed over (queue 3)
-  const unsigned long long count = q.counters[PASS == 0 ? 0 : (PASS == 1 ? 5 : (PASS == 2 ? 6 : 2))];
-  const unsigned long long stride = (unsigned long long)gridDim.x * WAVES * GPW;
+  // PASS 0 walks torso sub-queue blockIdx % ARTP_NSUB; the other passes walk their (short) index queues
+  const int sq = blockIdx.x % ARTP_NSUB;
+  const unsigned long long count =
+      PASS == 0 ? *sub_counter(q, 0, sq) : q.counters[PASS == 1 ? 5 : (PASS == 2 ? 6 : 2)];
+  const unsigned long long first = PASS == 0 ? sub_base(q, 0, sq) : 0ull;
+  const unsigned long long nblk = PASS == 0 ? gridDim.x / ARTP_NSUB : gridDim.x;
+  const unsigned long long blk = PASS == 0 ? blockIdx.x / ARTP_NSUB : blockIdx.x;
+  const unsigned long long stride = nblk * WAVES * GPW;
 #ifdef ARTP_STAGE_TIMING
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = clock64();
 #endif
-  for (unsigned long long it = (unsigned long long)blockIdx.x * WAVES * GPW + unit_in_block; it < count;
-       it += stride) {
+  for (unsigned long long it = blk * WAVES * GPW + unit_in_block; it < count; it += stride) {
     const unsigned long long item =
-        PASS == 0 ? it : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : q.q6[it]));
+        PASS == 0 ? first + it : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : q.q6[it]));
 #ifdef ARTP_STAGE_TIMING
     long long t_prev = clock64();
 #endif

@@ -1,0 +1,38 @@
+#!/bin/bash
+# One GPU-box visit: the -m gpu suite, the default bench (incl. its live PMC passes), a kernel-trace profile.
+#   gpurun --timeout 1500 -- 'bash scripts/gpu_round.sh <tag>'
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu_$TAG.log 2>&1
+echo "pytest rc $?" >> $OUT/pytest_gpu_$TAG.log
+tail -15 $OUT/pytest_gpu_$TAG.log
+timeout 600 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
+echo "bench rc $?"
+python - <<PY
+import json
+try:
+    d = json.loads(open("$OUT/bench_$TAG.json").read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("value", d["value"], "ms/step", d["ms_per_step"], "kernel_ms", r["kernel_ms"], "fused_ms", r.get("fused_sample_validate_ms"))
+    print("pmc", r["pmc_source"])
+    b = r.get("binding")
+    if b:
+        print("valu_busy_tw", b["valu_busy_time_weighted"], "traffic", r["traffic"])
+        for k, v in b["per_kernel"].items():
+            print("  ", k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items()})
+    for k in ("edges", "motion_cost_c3", "replan_cycle_c5", "c4_800_defaults", "preprocess_n2"):
+        print(k, json.dumps(d.get(k))[:900])
+    print("cpu", json.dumps(d.get("cpu_baseline"))[:1500])
+    print("roadmap", json.dumps(d.get("roadmap_n1"))[:800])
+except Exception as e:
+    print("bench parse failed", e)
+    print(open("$OUT/bench_$TAG.err").read()[-2000:])
+PY
+mkdir -p $OUT/prof_$TAG
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $OUT/prof_$TAG/trace.log 2>&1
+python $GRAFT_REPO_ROOT/scripts/prof_summary.py $OUT/prof_$TAG > $OUT/prof_$TAG/summary.txt 2>&1
+rm -f $OUT/prof_$TAG/*/*.db $OUT/prof_$TAG/*/*/*.db
+head -30 $OUT/prof_$TAG/summary.txt
