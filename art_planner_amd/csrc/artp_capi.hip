@@ -36,6 +36,7 @@ struct artp_ctx {
   std::vector<float> field_host[2];  // ODE-layout host mirror (for rect updates / has_nan)
   SamplerDev sampler{};
   float* sampler_buf = nullptr;
+  float* sampler_pack = nullptr;  // derived tables: packed cells, row-major CDF, pivots
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
@@ -525,6 +526,7 @@ void artp_destroy(artp_ctx* c) {
   for (int s = 0; s < 2; ++s)
     if (c->field_data[s]) (void)hipFree(c->field_data[s]);
   if (c->sampler_buf) (void)hipFree(c->sampler_buf);
+  if (c->sampler_pack) (void)hipFree(c->sampler_pack);
   for (int s = 0; s < 8; ++s)
     if (c->tmp[s]) (void)hipFree(c->tmp[s]);
   for (int s = 0; s < 2; ++s) {
@@ -877,6 +879,8 @@ int artp_validate_states(artp_ctx* c, const double* se3, size_t n, uint8_t* vali
   return check_error_flag(c);
 }
 
+static int pack_sampler_tables(artp_ctx* c, int rows, int cols);
+
 int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* cum_prob_rowwise,
                                const float* elevation, const float* normal_x, const float* normal_y,
                                const float* normal_z, const float* plane_fit_std_dev, int rows,
@@ -902,6 +906,10 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
   HIP_TRY(c, hipMemcpyAsync(p, cum_prob_rowwise, rows * sizeof(float), hipMemcpyHostToDevice, c->stream));
   c->sampler.cum_prob_rowwise = p;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  {
+    const int rcp = pack_sampler_tables(c, rows, cols);
+    if (rcp != ARTP_OK) return rcp;
+  }
   if (!c->have_geom) {
     c->geom.len_x = len_x; c->geom.len_y = len_y; c->geom.pos_x = pos_x; c->geom.pos_y = pos_y;
     c->geom.rows = rows; c->geom.cols = cols; c->geom.res = len_x / rows;
@@ -909,6 +917,30 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
   }
   c->sampler.from_distribution = c->params.sample_from_distribution;
   c->have_sampler = true;
+  return ARTP_OK;
+}
+
+// The derived sampler tables (SamplerDev::cum_prob_t / pivots / cells) from the six layers in c->sampler_buf.
+static int pack_sampler_tables(artp_ctx* c, int rows, int cols) {
+  const size_t e = (size_t)rows * cols;
+  const int npiv = (cols + 15) / 16, pitch = npiv * 16;
+  const size_t floats = (size_t)rows * pitch + (size_t)rows * npiv + 8 * e + 64;
+  if (c->sampler_pack) HIP_TRY(c, hipFree(c->sampler_pack));
+  c->sampler_pack = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_pack), floats * sizeof(float)));
+  HIP_TRY(c, hipMemsetAsync(c->sampler_pack, 0, floats * sizeof(float), c->stream));
+  float* cells = c->sampler_pack;                       // 8 floats per cell, 32-byte aligned
+  float* cdf_t = cells + 8 * e;
+  float* piv = cdf_t + (size_t)rows * pitch;
+  c->sampler.npiv = npiv;
+  c->sampler.pitch = pitch;
+  hipLaunchKernelGGL(sampler_pack_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, c->stream, c->sampler, rows,
+                     cols, cdf_t, piv, reinterpret_cast<float4*>(cells));
+  HIP_TRY(c, hipGetLastError());
+  c->sampler.cells = reinterpret_cast<const float4*>(cells);
+  c->sampler.cum_prob_t = cdf_t;
+  c->sampler.pivots = piv;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
 }
 
@@ -935,6 +967,10 @@ static int upload_sampler_layers_from_device(artp_ctx* c, const float* cum_prob,
   HIP_TRY(c, hipMemcpyAsync(p, cum_prob_rowwise, rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   c->sampler.cum_prob_rowwise = p;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  {
+    const int rcp = pack_sampler_tables(c, rows, cols);
+    if (rcp != ARTP_OK) return rcp;
+  }
   if (!c->have_geom) {
     c->geom.len_x = len_x; c->geom.len_y = len_y; c->geom.pos_x = pos_x; c->geom.pos_y = pos_y;
     c->geom.rows = rows; c->geom.cols = cols; c->geom.res = len_x / rows;

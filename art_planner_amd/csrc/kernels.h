@@ -30,14 +30,37 @@ struct MapGeom {  // grid_map geometry (doubles, as grid_map stores them)
 
 struct SamplerDev {
   int from_distribution;          // Params::sampler.sample_from_distribution
-  const float* cum_prob;          // col-major rows x cols
+  const float* cum_prob;          // col-major rows x cols (grid_map storage, as uploaded)
   const float* cum_prob_rowwise;  // rows
   const float* elevation;
   const float* normal_x;
   const float* normal_y;
   const float* normal_z;
   const float* plane_fit_std_dev;
+  // Derived at upload (sampler_pack_kernel) for the batch sampler, which is bound by the number of L2 requests
+  // per sample, not by arithmetic: the per-row CDF contiguous (row-major), one pivot per 16 columns, and the five
+  // per-cell numbers of a sample in one 32-byte record -- 4 requests per sample instead of 14.
+  const float* cum_prob_t;        // row-major, rows x pitch floats (pitch = cols rounded up to 16: aligned groups)
+  const float* pivots;            // rows x npiv: cum_prob(row, min(16 j + 15, cols - 1))
+  const float4* cells;            // 2 float4 per cell (index row + col * rows): {elev, nx, ny, nz}, {std, -, -, -}
+  int npiv;
+  int pitch;
 };
+
+// one lane per cell: transposed CDF, pivots, packed cell records
+__global__ void __launch_bounds__(256)
+sampler_pack_kernel(SamplerDev sm, int rows, int cols, float* __restrict__ cum_prob_t, float* __restrict__ pivots,
+                    float4* __restrict__ cells) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int row = i % rows, col = i / rows;
+  const float v = sm.cum_prob[i];
+  cum_prob_t[(size_t)row * sm.pitch + col] = v;
+  const int npiv = (cols + 15) / 16;
+  if ((col & 15) == 15 || col == cols - 1) pivots[(size_t)row * npiv + (col >> 4)] = v;
+  cells[2 * (size_t)i] = make_float4(sm.elevation[i], sm.normal_x[i], sm.normal_y[i], sm.normal_z[i]);
+  cells[2 * (size_t)i + 1] = make_float4(sm.plane_fit_std_dev[i], 0.0f, 0.0f, 0.0f);
+}
 
 #define ARTP_WAVES_PER_BLOCK 2
 
@@ -385,9 +408,10 @@ __device__ __forceinline__ void sincos_half_angle(double x, double* sn, double* 
 // SE3FromSE2Sampler::sampleUniform (art_planner/src/sampler.cpp:82-131) with
 // samplePositionInMapFromDist (:56-78).  The two linear CDF scans become binary searches for the
 // same "first index whose cumulative value exceeds u, else the last index".
+// row_cdf: the row CDF (cum_prob_rowwise) in LDS or global memory.
 template <bool FROM_DIST>
 __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& g, const RobotDev& rb,
-                                           uint64_t seed, uint64_t index, double out[7]) {
+                                           uint64_t seed, uint64_t index, double out[7], const float* row_cdf) {
   double px, py;
   int cell_row = 0, cell_col = 0;
   if (FROM_DIST) {  // samplePositionInMapFromDist (sampler.cpp:56-78)
@@ -396,16 +420,32 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
     int lo = 0, hi = g.rows - 1;  // answer in [0, rows-1]
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if ((double)sm.cum_prob_rowwise[mid] > samp_row) hi = mid; else lo = mid + 1;
+      if ((double)row_cdf[mid] > samp_row) hi = mid; else lo = mid + 1;
     }
     const int row = lo;
+    // "first column of [0, cols-2] whose cumulative value exceeds u, else cols-1" in two levels (the CDF of a row
+    // is non-decreasing, so the first group of 16 columns whose LAST value exceeds u holds the answer):
+    // the pivots of the row (<= 2 cache lines), then the group's 16 values (one line, one request).
+    const float* prow = sm.pivots + (size_t)row * sm.npiv;
     lo = 0;
-    hi = g.cols - 1;
+    hi = sm.npiv - 1;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if ((double)sm.cum_prob[(size_t)row + (size_t)mid * g.rows] > samp_col) hi = mid; else lo = mid + 1;
+      if ((double)prow[mid] > samp_col) hi = mid; else lo = mid + 1;
     }
-    const int col = lo;
+    const int c0 = lo << 4;
+    const int c1 = (c0 + 15 < g.cols - 1) ? c0 + 15 : g.cols - 1;
+    const float4* grp = reinterpret_cast<const float4*>(sm.cum_prob_t + (size_t)row * sm.pitch + c0);
+    int below = 0;  // values of the group that do not exceed u (they come first)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 v = grp[q4];
+      below += (c0 + 4 * q4 + 0 <= c1 && !((double)v.x > samp_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 1 <= c1 && !((double)v.y > samp_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 2 <= c1 && !((double)v.z > samp_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 3 <= c1 && !((double)v.w > samp_col)) ? 1 : 0;
+    }
+    const int col = (c0 + below < c1) ? c0 + below : c1;
     cell_row = row;
     cell_col = col;
     // grid_map getPosition: (c + (L/2 - res/2)) + res * (-i)
@@ -433,11 +473,12 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
     ci = (int)(-(((py - 0.5 * g.len_y) - g.pos_y) / g.res));
   }
   const size_t ind = (size_t)ri + (size_t)ci * g.rows;
-  double v0 = px, v1 = py, v2 = (double)sm.elevation[ind];
-  const double nwx = (double)sm.normal_x[ind];
-  const double nwy = (double)sm.normal_y[ind];
-  const double nwz = (double)sm.normal_z[ind];
-  const float sd = sm.plane_fit_std_dev[ind];
+  const float4 ca = sm.cells[2 * ind], cb = sm.cells[2 * ind + 1];  // one 32-byte record: one request
+  double v0 = px, v1 = py, v2 = (double)ca.x;
+  const double nwx = (double)ca.y;
+  const double nwy = (double)ca.z;
+  const double nwz = (double)ca.w;
+  const float sd = cb.x;
   const float sd_min = (0.5f < sd) ? 0.5f : sd;  // std::min(std, 0.5f)
   const double u_pert = uniform01(seed, index, 2);
   const double pert = ((1.0 - (-1.0)) * u_pert + (-1.0)) * (double)sd_min * rb.reach_z;
@@ -484,8 +525,20 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
   }
 }
 
+// The row CDF of the map in LDS (rows <= ARTP_ROW_CDF_LDS; larger maps search it in global memory).
+#define ARTP_ROW_CDF_LDS 2048
+__device__ __forceinline__ const float* stage_row_cdf(const SamplerDev& sm, const MapGeom& g, float* lds) {
+  if (!sm.from_distribution || g.rows > ARTP_ROW_CDF_LDS) return sm.cum_prob_rowwise;
+  for (int i = threadIdx.x; i < g.rows; i += blockDim.x) lds[i] = sm.cum_prob_rowwise[i];
+  __syncthreads();
+  return lds;
+}
+
+#ifndef ARTP_SAMPLER_WAVES
+#define ARTP_SAMPLER_WAVES 5
+#endif
 template <bool FROM_DIST>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ARTP_SAMPLER_WAVES, ARTP_SAMPLER_WAVES)))
 sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t first_index,
                      size_t n, double* __restrict__ se3_out, FieldDev f, PoseRec* __restrict__ recs) {
   // A lane's 7 doubles are 56 bytes apart from its neighbour's: written directly, every store instruction
@@ -493,6 +546,8 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
   // leave as seven fully coalesced 512-byte rows.  recs (may be null): the per-state PoseRec of the validity
   // pipeline, produced here while the state is in registers (fused sample + validate).
   __shared__ double stage[4][64 * 7];
+  __shared__ float row_cdf_lds[ARTP_ROW_CDF_LDS];
+  const float* row_cdf = stage_row_cdf(sm, g, row_cdf_lds);
   const int lane = threadIdx.x & 63;
   double* sw = stage[threadIdx.x >> 6];
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -500,7 +555,7 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
     const size_t i = i0 + lane;
     if (i < n) {
       double st[7];
-      sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st);
+      sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st, row_cdf);
 #pragma unroll
       for (int k = 0; k < 7; ++k) sw[lane * 7 + k] = st[k];
       if (recs) {
@@ -529,11 +584,13 @@ __global__ void __launch_bounds__(256)
 sample_states_at_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint64_t base_index,
                         const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ count,
                         size_t cap, double* __restrict__ se3_out) {
+  __shared__ float row_cdf_lds[ARTP_ROW_CDF_LDS];
+  const float* row_cdf = stage_row_cdf(sm, g, row_cdf_lds);
   const size_t n = (size_t)(*count) < cap ? (size_t)(*count) : cap;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     double st[7];
-    sample_one<FROM_DIST>(sm, g, rb, seed, base_index + idx[i], st);
+    sample_one<FROM_DIST>(sm, g, rb, seed, base_index + idx[i], st, row_cdf);
 #pragma unroll
     for (int k = 0; k < 7; ++k) se3_out[7 * i + k] = st[k];
   }
