@@ -26,6 +26,7 @@ SYMBOLS = [
     "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_roadmap_params_defaults",
     "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
     "artp_roadmap_revalidate", "artp_roadmap_set_query", "artp_roadmap_simplify_path", "artp_roadmap_grow",
+    "artp_roadmap_solve_until", "artp_roadmap_set_density_map", "artp_preprocessed_reweight_dev",
     "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
     "artp_preprocess_map_ex", "artp_preprocessed_change",
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
@@ -69,7 +70,9 @@ class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
                 ("k_neighbors", C.c_uint32), ("objective", C.c_int32), ("max_replans", C.c_uint32),
                 ("max_lon_vel", C.c_double), ("max_lat_vel", C.c_double), ("max_ang_vel", C.c_double),
                 ("w_energy", C.c_float), ("w_time", C.c_float), ("w_risk", C.c_float),
-                ("risk_threshold", C.c_float)]
+                ("risk_threshold", C.c_float),
+                ("max_n_edges", C.c_uint32), ("recompute_density_after_n_samples", C.c_uint32),
+                ("max_sample_time", C.c_double), ("density_map", C.c_void_p), ("density_params", C.c_void_p)]
 
 
 def load():
@@ -138,6 +141,9 @@ def load():
     L.artp_roadmap_set_query.argtypes = [vp, vp, vp]
     L.artp_roadmap_simplify_path.argtypes = [vp, vp, sz, vp, C.POINTER(sz), C.POINTER(dbl)]
     L.artp_roadmap_grow.argtypes = [vp, C.c_uint64, vp]
+    L.artp_roadmap_solve_until.argtypes = [vp, dbl, C.c_uint32, vp, sz, C.POINTER(sz), C.POINTER(dbl), vp]
+    L.artp_roadmap_set_density_map.argtypes = [vp, vp, C.POINTER(PreprocessParams)]
+    L.artp_preprocessed_reweight_dev.argtypes = [vp, vp, C.POINTER(PreprocessParams), vp, sz, i32]
     L.artp_roadmap_destroy.argtypes = [vp]
     L.artp_roadmap_destroy.restype = None
     for name in ("artp_preprocess_params_defaults", "artp_preprocess_params_yaml"):

@@ -244,6 +244,7 @@ class Context:
         self._chk(self.L.artp_preprocess_map_ex(self.h, C.byref(inp), C.byref(p), C.byref(h)), "artp_preprocess_map_ex")
         pm = PreprocessedMap(self, h, e.shape)
         pm.geom = (len_x, len_y, pos_x, pos_y)
+        pm.params = p
         return pm
 
     # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
@@ -327,6 +328,15 @@ class PreprocessedMap:
 
     def install(self):
         self.ctx._chk(self.ctx.L.artp_preprocessed_install(self.ctx.h, self.h), "artp_preprocessed_install")
+
+    def reweight_dev(self, vertices_t=None, install_sampler=True):
+        """Map::reApplyPreprocessing for the sampling distribution: inverse density of the given roadmap vertices
+        (torch float64 device tensor [n, 7], or None for no density term), new CDF, optionally installed."""
+        n = 0 if vertices_t is None else vertices_t.shape[0]
+        self.ctx._chk(self.ctx.L.artp_preprocessed_reweight_dev(self.ctx.h, self.h, C.byref(self.params),
+                                                                vertices_t.data_ptr() if n else None, n,
+                                                                1 if install_sampler else 0),
+                      "artp_preprocessed_reweight_dev")
 
     def close(self):
         if self.h:

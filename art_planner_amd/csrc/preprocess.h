@@ -339,6 +339,79 @@ struct artp_preprocessed {
   float* scalars() const { return buf + ((((size_t)PRE_COUNT * rows * cols) + rows + 1) & ~(size_t)1); }
 };
 
+
+namespace {
+// The sampling distribution of a preprocessed map (planner.cpp:43-56): [inverse vertex density] * sample filter
+// [capped unknown share], then the CDF -- the part of the processor chain that depends on the roadmap's vertices
+// and that Map::reApplyPreprocessing() (map.cpp:94-96) re-runs while PRMMotionCostMaintainer::sampleGraph grows
+// the roadmap (prm_motion_cost.cpp:190-193).  d_verts: n_vertices x 7 doubles in HBM (may be null).  Asynchronous.
+bool pre_sampling_distribution(artp_ctx* c, artp_preprocessed* pp, const artp_preprocess_params* prm,
+                               const double* d_verts, size_t n_vertices) {
+  const int rows = pp->rows, cols = pp->cols, n = rows * cols;
+  const double res = pp->len_x / rows;
+  hipStream_t st = c->stream;
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  auto L = [&](int k) { return pp->layer(k); };
+  const artp::PreGeom geom{rows, cols, (float)res, pp->pos_x, pp->pos_y, pp->len_x, pp->len_y};
+  float* d_taps = nullptr;
+  unsigned* max_bits = reinterpret_cast<unsigned*>(pp->scalars() + 1);
+  double* mass = reinterpret_cast<double*>(pp->scalars() + 2);  // 8-byte aligned (even offset, see scalars())
+  bool ok = hipMemsetAsync(pp->scalars(), 0, 8 * sizeof(float), st) == hipSuccess;
+  const bool density = prm->use_inverse_vertex_density && n_vertices > 0 && d_verts;
+  if (density) {
+    const double blur_radius = (c->params.torso_length + c->params.torso_width) * 0.25;  // planner.cpp:48
+    int k = (int)(6 * blur_radius / res);
+    const double sigma = blur_radius / res;
+    if (k % 2 == 0) k += 1;
+    // cv::getGaussianKernel: t_i = exp(-(i - (k-1)/2)^2 / (2 sigma^2)) as float, normalised by their sum
+    std::vector<float> taps(k);
+    double sum = 0.0;
+    for (int i = 0; i < k; ++i) {
+      const double x = i - (k - 1) * 0.5;
+      taps[i] = (float)std::exp(-0.5 / (sigma * sigma) * x * x);
+      sum += taps[i];
+    }
+    for (int i = 0; i < k; ++i) taps[i] = (float)(taps[i] * (1.0 / sum));
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&d_taps), k * sizeof(float)) == hipSuccess &&
+         hipMemcpyAsync(d_taps, taps.data(), k * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipMemsetAsync(L(PRE_T0), 0, (size_t)n * 4, st) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(artp::vertex_histogram_kernel, dim3((unsigned)((n_vertices + 255) / 256)), blk, 0, st,
+                         d_verts, n_vertices, geom, L(PRE_T0));
+      hipLaunchKernelGGL(artp::gauss_pass_kernel<true>, grid, blk, 0, st, (const float*)L(PRE_T0), rows, cols,
+                         (const float*)d_taps, k, L(PRE_T1));
+      hipLaunchKernelGGL(artp::gauss_pass_kernel<false>, grid, blk, 0, st, (const float*)L(PRE_T1), rows, cols,
+                         (const float*)d_taps, k, L(PRE_NSAMPLES));
+      hipLaunchKernelGGL(artp::nonneg_max_kernel, grid, blk, 0, st, (const float*)L(PRE_NSAMPLES), n, max_bits);
+    }
+  } else {
+    ok = ok && hipMemsetAsync(L(PRE_NSAMPLES), 0, (size_t)n * 4, st) == hipSuccess;
+  }
+  hipLaunchKernelGGL(artp::base_distribution_kernel, grid, blk, 0, st,
+                     density ? (const float*)L(PRE_NSAMPLES) : (const float*)nullptr, (const unsigned*)max_bits,
+                     (const float*)L(PRE_SAMPLE_FILTER), n, L(PRE_SAMPLE_PROB));
+  if (prm->use_max_prob_unknown_samples) {
+    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, grid, blk, 0, st, (const float*)L(PRE_SAMPLE_PROB),
+                       (const float*)L(PRE_OBSERVED), n, mass);
+    hipLaunchKernelGGL(artp::cap_unknown_kernel, grid, blk, 0, st, (const float*)L(PRE_OBSERVED), (const double*)mass,
+                       prm->max_prob_unknown_samples, n, L(PRE_SAMPLE_PROB));
+  }
+  // computeCumulativeProbabilityDistribution                       probability_distribution.cpp:20-46
+  float* row_sum = L(PRE_T0);
+  float* total = pp->scalars();
+  hipLaunchKernelGGL(artp::cdf_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st,
+                     (const float*)L(PRE_SAMPLE_PROB), rows, cols, L(PRE_CUM_PROB), row_sum);
+  hipLaunchKernelGGL(artp::cdf_rowwise_kernel, dim3(1), dim3(1), 0, st, (const float*)row_sum, rows, pp->rowwise(),
+                     total);
+  ok = ok && hipGetLastError() == hipSuccess;
+  if (d_taps) {
+    ok = hipStreamSynchronize(st) == hipSuccess && ok;  // the taps are read by the kernels above
+    (void)hipFree(d_taps);
+  }
+  return ok;
+}
+}  // namespace
+
 extern "C" {
 
 void artp_preprocess_params_defaults(artp_preprocess_params* p) {
@@ -480,64 +553,14 @@ int artp_preprocess_map_ex(artp_ctx* c, const artp_preprocess_inputs* in, const 
     erode(L(PRE_T1), (int)(min_wall / res), L(PRE_SAMPLE_FILTER));
   }
   // the sampling distribution (planner.cpp:43-56): [inverse vertex density] * sample filter [capped unknown share]
-  const artp::PreGeom geom{rows, cols, (float)res, pos_x, pos_y, len_x, len_y};
   double* d_verts = nullptr;
-  float* d_taps = nullptr;
-  unsigned* max_bits = reinterpret_cast<unsigned*>(pp->scalars() + 1);
-  double* mass = reinterpret_cast<double*>(pp->scalars() + 2);  // 8-byte aligned (even offset, see scalars())
-  ok = ok && hipMemsetAsync(pp->scalars(), 0, 8 * sizeof(float), st) == hipSuccess;
-  const bool density = prm->use_inverse_vertex_density && in->n_vertices > 0;
-  if (density) {
-    const double blur_radius = (c->params.torso_length + c->params.torso_width) * 0.25;  // planner.cpp:48
-    int k = (int)(6 * blur_radius / res);
-    const double sigma = blur_radius / res;
-    if (k % 2 == 0) k += 1;
-    // cv::getGaussianKernel: t_i = exp(-(i - (k-1)/2)^2 / (2 sigma^2)) as float, normalised by their sum
-    std::vector<float> taps(k);
-    double sum = 0.0;
-    for (int i = 0; i < k; ++i) {
-      const double x = i - (k - 1) * 0.5;
-      taps[i] = (float)std::exp(-0.5 / (sigma * sigma) * x * x);
-      sum += taps[i];
-    }
-    for (int i = 0; i < k; ++i) taps[i] = (float)(taps[i] * (1.0 / sum));
+  if (prm->use_inverse_vertex_density && in->n_vertices > 0)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&d_verts), in->n_vertices * 7 * sizeof(double)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&d_taps), k * sizeof(float)) == hipSuccess &&
          hipMemcpyAsync(d_verts, in->vertex_se3, in->n_vertices * 7 * sizeof(double), hipMemcpyHostToDevice, st) ==
-             hipSuccess &&
-         hipMemcpyAsync(d_taps, taps.data(), k * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess &&
-         hipMemsetAsync(L(PRE_T0), 0, (size_t)n * 4, st) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(artp::vertex_histogram_kernel, dim3((unsigned)((in->n_vertices + 255) / 256)), blk, 0, st,
-                         (const double*)d_verts, in->n_vertices, geom, L(PRE_T0));
-      hipLaunchKernelGGL(artp::gauss_pass_kernel<true>, grid, blk, 0, st, (const float*)L(PRE_T0), rows, cols,
-                         (const float*)d_taps, k, L(PRE_T1));
-      hipLaunchKernelGGL(artp::gauss_pass_kernel<false>, grid, blk, 0, st, (const float*)L(PRE_T1), rows, cols,
-                         (const float*)d_taps, k, L(PRE_NSAMPLES));
-      hipLaunchKernelGGL(artp::nonneg_max_kernel, grid, blk, 0, st, (const float*)L(PRE_NSAMPLES), n, max_bits);
-    }
-  } else {
-    ok = ok && hipMemsetAsync(L(PRE_NSAMPLES), 0, (size_t)n * 4, st) == hipSuccess;
-  }
-  hipLaunchKernelGGL(artp::base_distribution_kernel, grid, blk, 0, st,
-                     density ? (const float*)L(PRE_NSAMPLES) : (const float*)nullptr, (const unsigned*)max_bits,
-                     (const float*)L(PRE_SAMPLE_FILTER), n, L(PRE_SAMPLE_PROB));
-  if (prm->use_max_prob_unknown_samples) {
-    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, grid, blk, 0, st, (const float*)L(PRE_SAMPLE_PROB),
-                       (const float*)L(PRE_OBSERVED), n, mass);
-    hipLaunchKernelGGL(artp::cap_unknown_kernel, grid, blk, 0, st, (const float*)L(PRE_OBSERVED), (const double*)mass,
-                       prm->max_prob_unknown_samples, n, L(PRE_SAMPLE_PROB));
-  }
-  // computeCumulativeProbabilityDistribution                       probability_distribution.cpp:20-46
-  float* row_sum = L(PRE_T0);
-  float* total = pp->scalars();
-  hipLaunchKernelGGL(artp::cdf_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st,
-                     (const float*)L(PRE_SAMPLE_PROB), rows, cols, L(PRE_CUM_PROB), row_sum);
-  hipLaunchKernelGGL(artp::cdf_rowwise_kernel, dim3(1), dim3(1), 0, st, (const float*)row_sum, rows, pp->rowwise(),
-                     total);
+             hipSuccess;
+  ok = ok && pre_sampling_distribution(c, pp, prm, d_verts, d_verts ? in->n_vertices : 0);
   ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
   if (d_verts) (void)hipFree(d_verts);
-  if (d_taps) (void)hipFree(d_taps);
   if (!ok) {
     c->last_error = "device preprocessing failed";
     lock.unlock();
@@ -639,6 +662,33 @@ int artp_preprocessed_install(artp_ctx* c, const artp_preprocessed* pp) {
   if (rc) return rc;
   if (!any) lo = hi = 0.f;
   return artp_set_z_bounds(c, (double)lo - c->params.reach_z / 2, (double)hi + c->params.reach_z / 2);
+}
+
+
+// Map::reApplyPreprocessing (map.cpp:94-96) for the part of the chain that can change on an unchanged map: the
+// sampling distribution, re-weighted by the inverse density of the given roadmap vertices (device pointer, n x 7
+// doubles; null / 0 = no density term), then the CDF.  With install_sampler the context's sampler switches to the
+// new CDF at once (the height fields are untouched).
+int artp_preprocessed_reweight_dev(artp_ctx* c, artp_preprocessed* pp, const artp_preprocess_params* prm,
+                                   const double* vertex_se3_dev, size_t n_vertices, int install_sampler) {
+  if (!c || !pp || !prm || (n_vertices && !vertex_se3_dev)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!pre_sampling_distribution(c, pp, prm, vertex_se3_dev, n_vertices)) {
+    c->last_error = "re-weighting the sampling distribution failed";
+    return ARTP_ERR_HIP;
+  }
+  if (!install_sampler) return ARTP_OK;
+  float total = 0.f;
+  HIP_TRY(c, hipMemcpyAsync(&total, pp->scalars(), 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!(total > 0.f)) {
+    c->last_error = "sample_probability is zero everywhere: nothing can be sampled on this map";
+    return ARTP_ERR_NO_MAP;
+  }
+  return upload_sampler_layers_from_device(c, pp->layer(PRE_CUM_PROB), pp->rowwise(), pp->layer(PRE_ELEV), pp->layer(PRE_NX),
+                                           pp->layer(PRE_NY), pp->layer(PRE_NZ), pp->layer(PRE_STD), pp->rows, pp->cols,
+                                           pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
 }
 
 }  // extern "C"

@@ -326,11 +326,63 @@ chain_motion_cost_kernel(const float* __restrict__ cost3, const uint32_t* __rest
 }  // namespace artp
 
 // -------------------------------------------------------------------------------------------------------
+namespace artp {
+// Label-correcting single-source shortest paths over the undirected edge list (one lane per edge, both
+// directions): the search of constructSolution (boost::astar_search, prm_motion_cost.cpp:536-620) for roadmaps
+// whose host A* would take tens of milliseconds.  Distances are non-negative doubles, so their bit patterns order
+// like unsigned integers and atomicMin applies.  `rounds` sweeps per launch; *changed counts successful
+// relaxations.  At the fixed point dist[] is exact (every sum is ONE double addition dist[u] + w, the same value the
+// sequential search forms), and every reached vertex has an edge with dist[u] + w == dist[v] bit for bit.
+__global__ void __launch_bounds__(256)
+sssp_relax_kernel(const uint32_t* __restrict__ eu, const uint32_t* __restrict__ ev, const double* __restrict__ w,
+                  size_t ne, unsigned long long* __restrict__ dist, unsigned* __restrict__ changed) {
+  unsigned local = 0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (size_t)gridDim.x * blockDim.x) {
+    const double we = w[e];
+    if (!(we < INFINITY)) continue;
+    const uint32_t u = eu[e], v = ev[e];
+    const double du = __longlong_as_double((long long)dist[u]), dv = __longlong_as_double((long long)dist[v]);
+    if (du + we < dv) {
+      atomicMin(&dist[v], (unsigned long long)__double_as_longlong(du + we));
+      local = 1;
+    } else if (dv + we < du) {
+      atomicMin(&dist[u], (unsigned long long)__double_as_longlong(dv + we));
+      local = 1;
+    }
+  }
+  if (__any(local) && (threadIdx.x & 63) == 0) atomicAdd(changed, 1u);
+}
+
+// pred[v] = a neighbour u with dist[u] + w == dist[v] (the smallest such u: deterministic)
+__global__ void __launch_bounds__(256)
+sssp_pred_kernel(const uint32_t* __restrict__ eu, const uint32_t* __restrict__ ev, const double* __restrict__ w,
+                 size_t ne, const unsigned long long* __restrict__ dist, uint32_t* __restrict__ pred) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (size_t)gridDim.x * blockDim.x) {
+    const double we = w[e];
+    if (!(we < INFINITY)) continue;
+    const uint32_t u = eu[e], v = ev[e];
+    const double du = __longlong_as_double((long long)dist[u]), dv = __longlong_as_double((long long)dist[v]);
+    if (du < INFINITY && du + we == dv) atomicMin(&pred[v], u);
+    if (dv < INFINITY && dv + we == du) atomicMin(&pred[u], v);
+  }
+}
+}  // namespace artp
+
 struct artp_roadmap {
   artp_ctx* ctx = nullptr;
   artp_roadmap_params params{};
   int k = 0;
   uint64_t samples_drawn = 0;
+  artp_preprocess_params density_params_copy{};  // params.density_params points here (see roadmap_fix_params)
+  uint64_t n_reweights = 0;        // density re-weightings during the build
+  uint64_t budget_flags = 0;       // bit 0: max_sample_time ended the sampling, bit 1: max_n_edges cut the graph
+  // device copies for the label-correcting search of large roadmaps (roadmap_sssp_dev)
+  uint32_t* d_euv = nullptr;       // eu | ev
+  double* d_w = nullptr;           // edge weight, +inf = not usable
+  unsigned long long* d_dist = nullptr;
+  uint32_t* d_pred = nullptr;
+  size_t d_graph_ne = 0, d_graph_nv = 0;
+  bool d_graph_dirty = true;
   std::vector<double> verts;       // nv x 7; vertex 0 = start, 1 = goal
   std::vector<uint32_t> knn;       // nv x k (0xffffffff = none)
   std::vector<double> knn_dist;    // nv x k
@@ -351,6 +403,13 @@ struct artp_roadmap {
 };
 
 namespace {
+
+// The roadmap owns a copy of the caller's preprocess parameters; call after every struct assignment / swap.
+void roadmap_fix_params(artp_roadmap* rm) {
+  if (rm->params.density_params && rm->params.density_params != &rm->density_params_copy)
+    rm->density_params_copy = *rm->params.density_params;
+  if (rm->params.density_params) rm->params.density_params = &rm->density_params_copy;
+}
 
 void roadmap_build_csr(artp_roadmap* rm) {
   const size_t nv = rm->nv(), ne = rm->eu.size();
@@ -420,6 +479,85 @@ bool roadmap_astar(artp_roadmap* rm, std::vector<uint32_t>* path, double* cost) 
   for (uint32_t v = 1; v != 0xffffffffu; v = prev[v]) path->push_back(v);
   std::reverse(path->begin(), path->end());
   *cost = g[1];
+  return true;
+}
+
+// The same search on the device for large roadmaps (see sssp_relax_kernel).  Same result as roadmap_astar up to the
+// choice among equal-cost paths.
+bool roadmap_sssp_dev(artp_roadmap* rm, std::vector<uint32_t>* path, double* cost, bool* ok) {
+  artp_ctx* c = rm->ctx;
+  const size_t nv = rm->nv(), ne = rm->eu.size();
+  *ok = false;
+  if (hipSetDevice(c->device) != hipSuccess) return false;
+  hipStream_t st = c->stream;
+  if (rm->d_graph_ne != ne || rm->d_graph_nv != nv || !rm->d_euv) {
+    for (void* p : {(void*)rm->d_euv, (void*)rm->d_w, (void*)rm->d_dist, (void*)rm->d_pred})
+      if (p) (void)hipFree(p);
+    rm->d_euv = nullptr; rm->d_w = nullptr; rm->d_dist = nullptr; rm->d_pred = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&rm->d_euv), 2 * ne * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&rm->d_w), ne * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&rm->d_dist), nv * sizeof(unsigned long long) + 16) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&rm->d_pred), nv * sizeof(uint32_t)) != hipSuccess)
+      return false;
+    rm->d_graph_ne = ne;
+    rm->d_graph_nv = nv;
+    rm->d_graph_dirty = true;
+    if (hipMemcpyAsync(rm->d_euv, rm->eu.data(), ne * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(rm->d_euv + ne, rm->ev.data(), ne * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+      return false;
+  }
+  if (rm->d_graph_dirty || rm->csr_dirty) {
+    std::vector<double> w(ne);
+    for (size_t e = 0; e < ne; ++e)
+      w[e] = (rm->evalid[e] && !rm->eremoved[e] && std::isfinite(rm->ecost[e])) ? rm->ecost[e] : INFINITY;
+    if (hipMemcpyAsync(rm->d_w, w.data(), ne * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return false;
+    rm->d_graph_dirty = false;
+  }
+  unsigned* d_changed = reinterpret_cast<unsigned*>(rm->d_dist + nv);
+  // dist = +inf (0x7ff0...), dist[0] = 0
+  std::vector<unsigned long long> init(nv, 0x7ff0000000000000ull);
+  init[0] = 0ull;
+  if (hipMemcpyAsync(rm->d_dist, init.data(), nv * 8, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+  size_t blocks = (ne + 255) / 256;
+  if (blocks > (size_t)c->n_cus * 8) blocks = (size_t)c->n_cus * 8;
+  for (int sweep = 0; sweep < 100000; sweep += 16) {
+    if (hipMemsetAsync(d_changed, 0, 4, st) != hipSuccess) return false;
+    for (int r = 0; r < 16; ++r)
+      hipLaunchKernelGGL(artp::sssp_relax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)rm->d_euv,
+                         (const uint32_t*)(rm->d_euv + ne), (const double*)rm->d_w, ne, rm->d_dist, d_changed);
+    unsigned changed = 0;
+    if (hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return false;
+    if (!changed) break;
+  }
+  // one more sweep group proved the fixed point (changed == 0 over 16 sweeps); predecessors
+  if (hipMemsetAsync(rm->d_pred, 0xff, nv * 4, st) != hipSuccess) return false;
+  hipLaunchKernelGGL(artp::sssp_pred_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)rm->d_euv,
+                     (const uint32_t*)(rm->d_euv + ne), (const double*)rm->d_w, ne,
+                     (const unsigned long long*)rm->d_dist, rm->d_pred);
+  std::vector<uint32_t> pred(nv);
+  unsigned long long dgoal = 0;
+  if (hipMemcpyAsync(pred.data(), rm->d_pred, nv * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(&dgoal, rm->d_dist + 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return false;
+  *ok = true;
+  double dg;
+  std::memcpy(&dg, &dgoal, 8);
+  if (!(dg < INFINITY)) return false;
+  path->clear();
+  uint32_t v = 1;
+  for (size_t guard = 0; guard <= nv; ++guard) {
+    path->push_back(v);
+    if (v == 0) break;
+    v = pred[v];
+    if (v == 0xffffffffu) return false;  // cannot happen at the fixed point
+  }
+  std::reverse(path->begin(), path->end());
+  *cost = dg;
   return true;
 }
 
@@ -540,29 +678,26 @@ void artp_roadmap_params_defaults(artp_roadmap_params* p) {
   p->w_time = 1.0f;
   p->w_risk = 5.0f;
   p->risk_threshold = 0.1f;        // params.h:55
+  p->max_n_edges = 0;              // budgets and re-weighting are opt-in here (params.h:50-53 carry the
+  p->recompute_density_after_n_samples = 0;  // reference's defaults: 50 000 / 1000 / 2.0 s)
+  p->max_sample_time = 0.0;
+  p->density_map = nullptr;
+  p->density_params = nullptr;
 }
 
 void artp_roadmap_destroy(artp_roadmap* rm) {
   if (!rm) return;
   if (rm->d_edge_states) (void)hipFree(rm->d_edge_states);
+  for (void* p : {(void*)rm->d_euv, (void*)rm->d_w, (void*)rm->d_dist, (void*)rm->d_pred})
+    if (p) (void)hipFree(p);
   delete rm;
 }
 
-// Build over [start, goal, kept milestones (host, n_keep x 7, already known valid), n_new fresh accepted samples
-// drawn from sample index first_new on].  artp_roadmap_build: no kept milestones; artp_roadmap_grow: the
-// roadmap's own.
-static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, const double* start7, const double* goal7,
-                              const double* keep, size_t n_keep, size_t n_new, uint64_t first_new,
-                              artp_roadmap** out) {
-  artp_roadmap_params prm_local = *prm_in;
-  prm_local.n_milestones = n_keep + n_new;
-  const artp_roadmap_params* prm = &prm_local;
+// Connection + evaluation of a vertex set that is already in HBM (d_verts: nv x 7; vertex 0 = start, 1 = goal):
+// k nearest neighbours, symmetrised unique candidate edges, the 0.5 m interpolation rule, chain costs.
+static int roadmap_connect(artp_ctx* c, const artp_roadmap_params* prm, const double* d_verts, size_t nv,
+                           artp_roadmap** out) {
   *out = nullptr;
-  const size_t nm = n_keep + n_new, nv = nm + 2;
-  double* d_verts = nullptr;     // nv x 7
-  double* d_batch = nullptr;     // sample batch
-  uint8_t* d_valid = nullptr;
-  double* d_compact = nullptr;
   uint64_t* d_cnt = nullptr;
   uint32_t* d_knn = nullptr;
   double* d_knn_dist = nullptr;
@@ -570,60 +705,12 @@ static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, co
   double *d_s1 = nullptr, *d_s2 = nullptr;
   void* d_cub = nullptr;
   auto cleanup = [&]() {
-    for (void* p : {(void*)d_verts, (void*)d_batch, (void*)d_valid, (void*)d_compact, (void*)d_cnt, (void*)d_knn,
-                    (void*)d_knn_dist, (void*)d_keys, (void*)d_keys_sorted, (void*)d_keys_unique, (void*)d_s1, d_cub})
+    for (void* p : {(void*)d_cnt, (void*)d_knn, (void*)d_knn_dist, (void*)d_keys, (void*)d_keys_sorted,
+                    (void*)d_keys_unique, (void*)d_s1, d_cub})
       if (p) (void)hipFree(p);
   };
-  RM_HIP(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_verts), nv * 7 * sizeof(double)));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(uint64_t)));
-
-  // start and goal must be valid states (baseSolve: INVALID_START / INVALID_GOAL, prm_motion_cost.cpp:452-476)
-  {
-    double sg[14];
-    std::memcpy(sg, start7, 7 * sizeof(double));
-    std::memcpy(sg + 7, goal7, 7 * sizeof(double));
-    uint8_t ok[2] = {0, 0};
-    RM_TRY(artp_validate_states(c, sg, 2, ok, nullptr));
-    if (!ok[0] || !ok[1]) {
-      c->last_error = !ok[0] ? "start state is not valid" : "goal state is not valid";
-      cleanup();
-      return ARTP_ERR_INVALID_ARG;
-    }
-    RM_HIP(hipMemcpyAsync(d_verts, sg, sizeof(sg), hipMemcpyHostToDevice, st));
-  }
-
-  // 1. milestones: the kept ones, then accepted states of the sample stream, in index order
-  size_t have = n_keep;
-  uint64_t next = first_new;
-  if (n_keep)
-    RM_HIP(hipMemcpyAsync(d_verts + 2 * 7, keep, n_keep * 7 * sizeof(double), hipMemcpyHostToDevice, st));
-  if (n_new) {
-    size_t batch = std::max<size_t>(4 * n_new, 1u << 16);
-    if (batch > (1u << 22)) batch = 1u << 22;
-    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_batch), batch * 7 * sizeof(double)));
-    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_compact), batch * 7 * sizeof(double)));
-    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_valid), batch));
-    int rounds = 0;
-    while (have < nm) {
-      RM_TRY(artp_sample_and_validate_dev(c, prm->seed, next, batch, d_batch, d_valid, nullptr));
-      RM_TRY(artp_compact_valid_dev(c, d_batch, d_valid, batch, d_compact, d_cnt));
-      uint64_t got = 0;
-      RM_HIP(hipMemcpyAsync(&got, d_cnt, sizeof(got), hipMemcpyDeviceToHost, st));
-      RM_HIP(hipStreamSynchronize(st));
-      const size_t take = std::min<size_t>((size_t)got, nm - have);
-      RM_HIP(hipMemcpyAsync(d_verts + (2 + have) * 7, d_compact, take * 7 * sizeof(double), hipMemcpyDeviceToDevice, st));
-      have += take;
-      next += batch;
-      if (++rounds > 256 || (got == 0 && rounds > 8)) {
-        c->last_error = "sampler produced too few valid states for the requested roadmap";
-        cleanup();
-        return ARTP_ERR_CAPACITY;
-      }
-    }
-  }
-
   // 2. k nearest neighbours
   int k = (int)prm->k_neighbors;
   if (k <= 0) k = (int)std::ceil(2.718281828459045 * (1.0 + 1.0 / 6.0) * std::log((double)nv));  // KStarStrategy
@@ -729,8 +816,8 @@ static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, co
   auto rm = new artp_roadmap();
   rm->ctx = c;
   rm->params = *prm;
+  roadmap_fix_params(rm);
   rm->k = k;
-  rm->samples_drawn = next - first_new;
   rm->verts.resize(nv * 7);
   rm->knn.resize(nk);
   rm->knn_dist.resize(nk);
@@ -775,6 +862,156 @@ static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, co
   return ARTP_OK;
 }
 
+
+// Build over [start, goal, kept milestones (host, n_keep x 7, already known valid), n_new fresh accepted samples
+// drawn from sample index first_new on].  artp_roadmap_build: no kept milestones; artp_roadmap_grow: the
+// roadmap's own.
+static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, const double* start7, const double* goal7,
+                              const double* keep, size_t n_keep, size_t n_new, uint64_t first_new,
+                              artp_roadmap** out) {
+  artp_roadmap_params prm_local = *prm_in;
+  prm_local.n_milestones = n_keep + n_new;
+  const artp_roadmap_params* prm = &prm_local;
+  *out = nullptr;
+  const size_t nm = n_keep + n_new, nv = nm + 2;
+  double* d_verts = nullptr;     // nv x 7
+  double* d_batch = nullptr;     // sample batch
+  uint8_t* d_valid = nullptr;
+  double* d_compact = nullptr;
+  uint64_t* d_cnt = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_verts, (void*)d_batch, (void*)d_valid, (void*)d_compact, (void*)d_cnt})
+      if (p) (void)hipFree(p);
+  };
+  RM_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_verts), nv * 7 * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(uint64_t)));
+
+  // start and goal must be valid states (baseSolve: INVALID_START / INVALID_GOAL, prm_motion_cost.cpp:452-476)
+  {
+    double sg[14];
+    std::memcpy(sg, start7, 7 * sizeof(double));
+    std::memcpy(sg + 7, goal7, 7 * sizeof(double));
+    uint8_t ok[2] = {0, 0};
+    RM_TRY(artp_validate_states(c, sg, 2, ok, nullptr));
+    if (!ok[0] || !ok[1]) {
+      c->last_error = !ok[0] ? "start state is not valid" : "goal state is not valid";
+      cleanup();
+      return ARTP_ERR_INVALID_ARG;
+    }
+    RM_HIP(hipMemcpyAsync(d_verts, sg, sizeof(sg), hipMemcpyHostToDevice, st));
+  }
+
+  // 1. milestones: the kept ones, then accepted states of the sample stream, in index order
+  size_t have = n_keep;
+  uint64_t next = first_new;
+  if (n_keep)
+    RM_HIP(hipMemcpyAsync(d_verts + 2 * 7, keep, n_keep * 7 * sizeof(double), hipMemcpyHostToDevice, st));
+  uint64_t n_reweights = 0, budget_flags = 0;
+  size_t nm_final = nm;  // fewer when the sampling-time budget ends the loop
+  if (n_new) {
+    // In-build re-weighting (prm_motion_cost.cpp:190-193): every R accepted vertices the sampling distribution is
+    // recomputed from the inverse density of ALL vertices so far.  A round therefore ends at the next multiple of R;
+    // the sample stream continues right behind the last sample the round consumed (nothing is drawn twice or
+    // skipped, whatever the batch size).
+    const size_t R = (prm->density_map && prm->density_params && prm->recompute_density_after_n_samples)
+                         ? prm->recompute_density_after_n_samples : 0;
+    size_t batch = std::max<size_t>(4 * (R ? std::min<size_t>(R, n_new) : n_new), 1u << 14);
+    if (batch > (1u << 22)) batch = 1u << 22;
+    // with a sampling-time budget the clock is read after every batch (the reference reads it every 100 samples)
+    if (prm->max_sample_time > 0.0 && batch > (1u << 16)) batch = 1u << 16;
+    uint32_t* d_idx = nullptr;
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_batch), batch * 7 * sizeof(double)));
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_compact), batch * 7 * sizeof(double) + batch * sizeof(uint32_t)));
+    d_idx = reinterpret_cast<uint32_t*>(d_compact + batch * 7);
+    RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_valid), batch));
+    const auto t_start = std::chrono::steady_clock::now();
+    size_t n_proc = have / (R ? R : 1);  // the reference counts the graph's milestones (start / goal join later)
+    int rounds = 0;
+    while (have < nm) {
+      RM_TRY(artp_sample_and_validate_dev(c, prm->seed, next, batch, d_batch, d_valid, nullptr));
+      RM_TRY(artp_compact_valid_dev(c, d_batch, d_valid, batch, d_compact, d_cnt));
+      uint64_t got = 0;
+      RM_HIP(hipMemcpyAsync(&got, d_cnt, sizeof(got), hipMemcpyDeviceToHost, st));
+      RM_HIP(hipStreamSynchronize(st));
+      size_t want = nm - have;
+      if (R) want = std::min(want, (n_proc + 1) * R - have);  // up to the next re-weighting point
+      const size_t take = std::min<size_t>((size_t)got, want);
+      RM_HIP(hipMemcpyAsync(d_verts + (2 + have) * 7, d_compact, take * 7 * sizeof(double), hipMemcpyDeviceToDevice, st));
+      have += take;
+      if (take < got) {
+        // the round ended inside the batch: continue behind the sample that gave the last vertex taken
+        uint32_t last = 0;
+        RM_TRY(artp_compact_valid_indices_dev(c, d_valid, batch, d_idx, d_cnt));
+        RM_HIP(hipMemcpyAsync(&last, d_idx + (take - 1), sizeof(last), hipMemcpyDeviceToHost, st));
+        RM_HIP(hipStreamSynchronize(st));
+        next += (uint64_t)last + 1;
+      } else {
+        next += batch;
+      }
+      if (R && have / R > n_proc) {
+        // Map::reApplyPreprocessing(): the CDF follows the inverse vertex density from here on (also after the
+        // last vertex, like the reference: the next growth samples from it)
+        RM_TRY(artp_preprocessed_reweight_dev(c, prm->density_map, prm->density_params, d_verts + 14, have, 1));
+        n_proc = have / R;
+        ++n_reweights;
+      }
+      if (prm->max_sample_time > 0.0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > prm->max_sample_time) {
+        if (have < nm) budget_flags |= 1u;  // "Reached sample timer limit." (prm_motion_cost.cpp:177-185)
+        break;
+      }
+      if (++rounds > 100000 || (got == 0 && rounds > 8 && !R)) {
+        c->last_error = "sampler produced too few valid states for the requested roadmap";
+        cleanup();
+        return ARTP_ERR_CAPACITY;
+      }
+    }
+    nm_final = have;
+    if (nm_final < 1) {
+      c->last_error = "the sampling-time budget ended before the first milestone";
+      cleanup();
+      return ARTP_ERR_CAPACITY;
+    }
+  }
+
+  // 2.-4. connect; PRMMotionCostMaintainer::sampleGraph also stops at max_n_edges (prm_motion_cost.cpp:171-172): the
+  // vertex set is cut back to the longest prefix whose candidate edges stay within the budget and reconnected
+  // (edge (u, v), u < v, exists among the first m vertices iff v < m; the counts per larger endpoint are a histogram)
+  size_t nv_use = nm_final + 2;
+  artp_roadmap* rm = nullptr;
+  for (int attempt = 0;; ++attempt) {
+    artp_roadmap_params p_use = *prm;
+    p_use.n_milestones = (uint32_t)(nv_use - 2);
+    const int rc = roadmap_connect(c, &p_use, d_verts, nv_use, &rm);
+    if (rc != ARTP_OK) {
+      cleanup();
+      return rc;
+    }
+    if (!prm->max_n_edges || rm->eu.size() <= prm->max_n_edges || nv_use <= 3 || attempt >= 12) break;
+    std::vector<uint32_t> per_v(nv_use, 0);
+    for (uint32_t v : rm->ev) ++per_v[v];
+    size_t m = 2, acc = 0;  // edges of THIS graph among its first m vertices
+    while (m < nv_use && acc + per_v[m] <= prm->max_n_edges) acc += per_v[m++];
+    // reconnecting the prefix gives its vertices nearer neighbours inside the prefix, i.e. more edges than `acc`:
+    // from the second attempt on also shrink in proportion to the overshoot
+    if (attempt > 0) m = std::min(m, (size_t)((double)(nv_use - 2) * prm->max_n_edges / (double)rm->eu.size() * 0.98) + 2);
+    if (m >= nv_use) m = nv_use - 1;
+    if (m < 3) m = 3;
+    artp_roadmap_destroy(rm);
+    rm = nullptr;
+    nv_use = m;
+    budget_flags |= 2u;
+  }
+  rm->samples_drawn = next - first_new;
+  rm->n_reweights = n_reweights;
+  rm->budget_flags = budget_flags;
+  cleanup();
+  *out = rm;
+  return ARTP_OK;
+}
+
 int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
                        artp_roadmap** out) {
   if (!c || !prm || !start7 || !goal7 || !out || prm->n_milestones < 1 || prm->objective < 0 ||
@@ -811,7 +1048,10 @@ int artp_roadmap_grow(artp_roadmap* rm, uint64_t n_more, uint64_t out[2]) {
                           rm->params.first_index + drawn_before, &fresh);
   if (rc != ARTP_OK) return rc;
   fresh->samples_drawn += drawn_before;
+  fresh->n_reweights += rm->n_reweights;
   std::swap(*rm, *fresh);
+  roadmap_fix_params(rm);
+  roadmap_fix_params(fresh);
   artp_roadmap_destroy(fresh);
   if (out) {
     out[0] = n_keep;
@@ -876,6 +1116,7 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
   }
   std::fill(rm->eremoved.begin(), rm->eremoved.end(), 0);
   rm->csr_dirty = true;
+  rm->d_graph_dirty = true;
   if (out) {
     out[0] = vbad;
     out[1] = before;
@@ -890,6 +1131,7 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
 int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double* goal7) {
   if (!rm || !start7 || !goal7) return ARTP_ERR_INVALID_ARG;
   artp_ctx* c = rm->ctx;
+  double old_sg[14];
   {
     double sg[14];
     std::memcpy(sg, start7, 7 * sizeof(double));
@@ -901,10 +1143,15 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
       c->last_error = !ok[0] ? "start state is not valid" : "goal state is not valid";
       return ARTP_ERR_INVALID_ARG;
     }
+    std::memcpy(old_sg, &rm->verts[0], sizeof(old_sg));
     std::memcpy(&rm->verts[0], sg, sizeof(sg));
   }
   const size_t nv = rm->nv();
   const int k = rm->k;
+  // everything below either commits completely or leaves the roadmap as it was (a failing edge evaluation must
+  // not leave new query states with the old edge prefix)
+  const std::vector<uint32_t> old_knn(rm->knn.begin(), rm->knn.begin() + 2 * (size_t)k);
+  const std::vector<double> old_knn_dist(rm->knn_dist.begin(), rm->knn_dist.begin() + 2 * (size_t)k);
   // edges are sorted by (u, v) with u < v: everything that touches vertex 0 or 1 is a prefix
   size_t first_keep = 0;
   while (first_keep < rm->eu.size() && rm->eu[first_keep] < 2) ++first_keep;
@@ -952,7 +1199,12 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
   }
   const int rc = roadmap_eval_edges_host(c, &rm->params, rm->verts, pu.data(), pv.data(), np, pvalid.data(),
                                          pinterp.data(), pcost.data());
-  if (rc != ARTP_OK) return rc;
+  if (rc != ARTP_OK) {
+    std::memcpy(&rm->verts[0], old_sg, sizeof(old_sg));
+    std::copy(old_knn.begin(), old_knn.end(), rm->knn.begin());
+    std::copy(old_knn_dist.begin(), old_knn_dist.end(), rm->knn_dist.begin());
+    return rc;
+  }
   auto splice = [&](auto& vec, const auto& head) {
     vec.erase(vec.begin(), vec.begin() + first_keep);
     vec.insert(vec.begin(), head.begin(), head.end());
@@ -966,6 +1218,7 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
   splice(rm->eremoved, zeros);
   rm->csr_dirty = true;
   rm->d_edge_states_stale = true;
+  rm->d_graph_ne = 0;  // the edge list changed: the device copy is rebuilt at the next search
   return ARTP_OK;
 }
 
@@ -1046,7 +1299,8 @@ int artp_roadmap_stats(const artp_roadmap* rm, uint64_t out[8]) {
   out[3] = nrem;
   out[4] = (uint64_t)rm->k;
   out[5] = rm->samples_drawn;
-  out[6] = out[7] = 0;
+  out[6] = rm->n_reweights;
+  out[7] = rm->budget_flags;
   return ARTP_OK;
 }
 
@@ -1069,6 +1323,9 @@ int artp_roadmap_export(const artp_roadmap* rm, double* verts, uint32_t* knn, do
   return ARTP_OK;
 }
 
+// from this vertex count on the search runs on the device (host A*: 1.3 ms at 10^4 vertices, 41 ms at 10^5)
+#define ARTP_SSSP_MIN_VERTICES 30000
+
 int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
                        int* n_replans) {
   if (!rm || !n_path || !cost) return ARTP_ERR_INVALID_ARG;
@@ -1081,7 +1338,16 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
   std::vector<uint8_t> ok;
   for (;;) {
     double cst = INFINITY;
-    if (!roadmap_astar(rm, &path, &cst)) {
+    bool found;
+    if (rm->nv() >= ARTP_SSSP_MIN_VERTICES) {
+      if (rm->csr_dirty) roadmap_build_csr(rm);  // the lazy removal below looks edges up in the CSR
+      bool dev_ok = false;
+      found = roadmap_sssp_dev(rm, &path, &cst, &dev_ok);
+      if (!dev_ok) found = roadmap_astar(rm, &path, &cst);
+    } else {
+      found = roadmap_astar(rm, &path, &cst);
+    }
+    if (!found) {
       if (n_replans) *n_replans = replans;
       return ARTP_OK;  // *n_path == 0: start and goal are not connected (PlannerStatus::TIMEOUT)
     }
@@ -1125,12 +1391,71 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
     const uint32_t a = std::min(path[bad], path[bad + 1]), b = std::max(path[bad], path[bad + 1]);
     for (uint32_t t = rm->row[a]; t < rm->row[a + 1]; ++t)
       if (rm->adj[t] == b) rm->eremoved[rm->adj_edge[t]] = 1;  // the search skips removed edges
+    rm->d_graph_dirty = true;
     if (++replans > (int)rm->params.max_replans) {
       c->last_error = "too many lazy edge removals";
       if (n_replans) *n_replans = replans;
       return ARTP_ERR_CAPACITY;
     }
   }
+}
+
+
+int artp_roadmap_set_density_map(artp_roadmap* rm, artp_preprocessed* pp, const artp_preprocess_params* prm) {
+  if (!rm || (pp && !prm)) return ARTP_ERR_INVALID_ARG;
+  rm->params.density_map = pp;
+  rm->params.density_params = pp ? prm : nullptr;
+  roadmap_fix_params(rm);
+  return ARTP_OK;
+}
+
+int artp_roadmap_solve_until(artp_roadmap* rm, double plan_time, uint32_t grow_step, double* path_se3,
+                             size_t cap_states, size_t* n_path, double* cost, uint64_t stats[3]) {
+  if (!rm || !n_path || !cost || !(plan_time >= 0.0)) return ARTP_ERR_INVALID_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  std::vector<double> best, cur(cap_states ? cap_states * 7 : 7);
+  double best_cost = INFINITY;
+  uint64_t rounds = 0, improved = 0;
+  *n_path = 0;
+  *cost = INFINITY;
+  for (;;) {
+    size_t n = 0;
+    double cst = INFINITY;
+    int replans = 0;
+    int rc = artp_roadmap_solve(rm, nullptr, 0, &n, &cst, &replans);  // length first
+    if (rc != ARTP_OK) return rc;
+    if (n > 0 && cst < best_cost) {  // opt_->isCostBetterThan(c, bestCost_)
+      cur.resize(n * 7);
+      rc = artp_roadmap_solve(rm, cur.data(), n, &n, &cst, &replans);
+      if (rc != ARTP_OK) return rc;
+      best.assign(cur.begin(), cur.begin() + n * 7);
+      best_cost = cst;
+      ++improved;
+    }
+    if (elapsed() >= plan_time || grow_step == 0) break;  // ptc
+    uint64_t g[2];
+    rc = artp_roadmap_grow(rm, grow_step, g);  // `do sampleUniform while !isValid; addValidMilestone` in batches
+    if (rc != ARTP_OK) return rc;
+    ++rounds;
+  }
+  if (stats) {
+    stats[0] = rounds;
+    stats[1] = rm->nv();
+    stats[2] = improved;
+  }
+  const size_t np = best.size() / 7;
+  if (np == 0) return ARTP_OK;
+  *n_path = np;
+  *cost = best_cost;
+  if (path_se3) {
+    if (cap_states < np) {
+      rm->ctx->last_error = "path buffer too small";
+      return ARTP_ERR_CAPACITY;
+    }
+    std::memcpy(path_se3, best.data(), np * 7 * sizeof(double));
+  }
+  return ARTP_OK;
 }
 
 }  // extern "C"

@@ -113,13 +113,12 @@ class Planner {
     in.pos_x = g.position_x;
     in.pos_y = g.position_y;
 
-    artp_preprocessed* fresh = nullptr;
-    throwOnError(gpu_->get(), artp_preprocess_map_ex(gpu_->get(), &in, &pp, &fresh), "artp_preprocess_map_ex");
-    const int rc = artp_preprocessed_install(gpu_->get(), fresh);
-    if (rc != ARTP_OK) {
-      artp_preprocessed_destroy(fresh);
-      throwOnError(gpu_->get(), rc, "artp_preprocessed_install");
-    }
+    artp_preprocessed* fresh_raw = nullptr;
+    throwOnError(gpu_->get(), artp_preprocess_map_ex(gpu_->get(), &in, &pp, &fresh_raw), "artp_preprocess_map_ex");
+    // owned until it becomes pre_: nothing below may leak it by throwing
+    std::unique_ptr<artp_preprocessed, void (*)(artp_preprocessed*)> fresh_guard(fresh_raw, artp_preprocessed_destroy);
+    artp_preprocessed* fresh = fresh_raw;
+    throwOnError(gpu_->get(), artp_preprocessed_install(gpu_->get(), fresh), "artp_preprocessed_install");
     // the normals of get3DPoseFrom2D (map.cpp:77-90) come back from the device once per map
     const size_t cells = static_cast<size_t>(g.rows) * g.cols;
     std::vector<float> n[3] = {std::vector<float>(cells), std::vector<float>(cells), std::vector<float>(cells)};
@@ -128,8 +127,11 @@ class Planner {
       throwOnError(gpu_->get(), artp_preprocessed_get_layer(gpu_->get(), fresh, names[k], n[k].data()),
                    "artp_preprocessed_get_layer");
     for (int k = 0; k < 3; ++k) map->addLayer(names[k], n[k].data());
+    // the roadmap's re-weighting (sampleGraph's reApplyPreprocessing) works on the new map's result from here on
+    pp.use_inverse_vertex_density = params_->sampler.use_inverse_vertex_density ? 1 : 0;
+    prm_->setDensityMap(fresh, pp);
     if (pre_) artp_preprocessed_destroy(pre_);
-    pre_ = fresh;
+    pre_ = fresh_guard.release();
     map_ = std::move(map);
     // ob::RealVectorBounds of planner.cpp:146-156 (x / y: position -+ length, as the reference has it)
     low_[0] = g.position_x - g.length_x;
@@ -191,7 +193,12 @@ class Planner {
         prm_->sampleGraph(start_valid, goal_valid);
         have_roadmap_ = true;
       }
-      solved_ = prm_->solve(&path_, &cost_);
+      // LazyPRM* keeps growing its roadmap while it has planning time (lazy_prm_star_min_update.cpp:552-615);
+      // PRMMotionCost searches the graph sampleGraph built (prm_motion_cost.cpp:440-532)
+      if (params_->planner.name == "lazy_prm_star_min_update" || params_->planner.name == "lazy_prm_star")
+        solved_ = prm_->solveUntil(params_->planner.plan_time, 1000, &path_, &cost_);
+      else
+        solved_ = prm_->solve(&path_, &cost_);
     } catch (const std::exception& e) {  // "All graph edges to goal where actually invalid" (:248-253)
       std::cout << e.what() << std::endl;
       solved_ = false;

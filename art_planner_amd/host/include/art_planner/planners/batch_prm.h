@@ -54,6 +54,17 @@ class BatchPRM {
     p.max_lon_vel = params_->objectives.custom_path_length.max_lon_vel;
     p.max_lat_vel = params_->objectives.custom_path_length.max_lat_vel;
     p.max_ang_vel = params_->objectives.custom_path_length.max_ang_vel;
+    // sampleGraph's budgets and in-build re-weighting (prm_motion_cost.cpp:171-193); the re-weighting needs the
+    // preprocessing result of the installed map (setDensityMap)
+    const bool prm_motion_cost = params_->planner.name == "prm_motion_cost";  // the budgets are that planner's
+    p.max_n_edges = prm_motion_cost ? params_->planner.prm_motion_cost.max_n_edges : 0;
+    p.max_sample_time = prm_motion_cost ? params_->planner.prm_motion_cost.max_sample_time : 0.0;
+    if (prm_motion_cost && density_map_ && params_->sampler.sample_from_distribution &&
+        params_->sampler.use_inverse_vertex_density) {
+      p.recompute_density_after_n_samples = params_->planner.prm_motion_cost.recompute_density_after_n_samples;
+      p.density_map = density_map_;
+      p.density_params = &density_params_;
+    }
     const StateArray s = flatten(start), g = flatten(goal);
     throwOnError(gpu_->get(), artp_roadmap_build(gpu_->get(), &p, s.data(), g.data(), &rm_), "artp_roadmap_build");
   }
@@ -72,6 +83,38 @@ class BatchPRM {
     throwOnError(gpu_->get(), rc, "artp_roadmap_solve");
     if (cost) *cost = c;
     return true;
+  }
+
+  // LazyPRMStarMinUpdate::baseSolve (lazy_prm_star_min_update.cpp:552-615): grow while planning until plan_time is
+  // over, return the best solution found.  false = never connected (PlannerStatus::TIMEOUT).
+  bool solveUntil(double plan_time, unsigned grow_step, std::vector<StateArray>* path, double* cost = nullptr) {
+    if (!rm_) throw std::runtime_error("BatchPRM::solveUntil before sampleGraph");
+    std::vector<StateArray> buf(4096);
+    size_t n = 0;
+    double c = 0.0;
+    uint64_t stats[3] = {0, 0, 0};
+    int rc = artp_roadmap_solve_until(rm_, plan_time, grow_step, buf[0].data(), buf.size(), &n, &c, stats);
+    if (rc == ARTP_ERR_CAPACITY && n > buf.size()) {  // a longer path than the buffer: once more with room
+      buf.resize(n);
+      rc = artp_roadmap_solve_until(rm_, 0.0, 0, buf[0].data(), buf.size(), &n, &c, stats);
+    }
+    throwOnError(gpu_->get(), rc, "artp_roadmap_solve_until");
+    if (n == 0) return false;
+    buf.resize(n);
+    path->swap(buf);
+    if (cost) *cost = c;
+    return true;
+  }
+
+  // The preprocessing result of the map the context has installed (Planner::setMap): what the in-build and
+  // in-growth re-weighting of the sampling distribution is computed on.  Call it again after every map change,
+  // BEFORE the old result is destroyed (nullptr = no re-weighting).
+  void setDensityMap(artp_preprocessed* pp, const artp_preprocess_params& prm) {
+    density_map_ = pp;
+    density_params_ = prm;
+    if (rm_)
+      throwOnError(gpu_->get(), artp_roadmap_set_density_map(rm_, pp, pp ? &density_params_ : nullptr),
+                   "artp_roadmap_set_density_map");
   }
 
   // LazyPRMStarMinUpdate's roadmap maintenance (lazy_prm_star_min_update.cpp:18-217), batched: after the map
@@ -140,6 +183,8 @@ class BatchPRM {
   GpuContextPtr gpu_;
   artp_roadmap* rm_{nullptr};
   uint64_t seed_{42};
+  artp_preprocessed* density_map_{nullptr};
+  artp_preprocess_params density_params_{};
 };
 
 }  // namespace art_planner

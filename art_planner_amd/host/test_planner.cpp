@@ -43,6 +43,8 @@ int main(int argc, char** argv) {
   params->planner.start_goal_search.goal_radius = 0.3;
   params->planner.start_goal_search.n_iter = 64;
   params->planner.prm_motion_cost.max_n_vertices = 4000;
+  // the default planner name is LazyPRM*: it keeps growing the roadmap for plan_time (baseSolve's while (!ptc))
+  params->planner.plan_time = 0.05;
   std::unique_ptr<Planner> planner;
   try {
     planner.reset(new Planner(params, 0));
@@ -117,6 +119,7 @@ int main(int argc, char** argv) {
     }
     std::printf("round %d: %zu states, cost %.4f; simplified %zu states; roadmap %zu vertices %zu edges\n", round,
                 path.size(), cost, simple.size(), planner->roadmap()->numVertices(), planner->roadmap()->numEdges());
+    CHECK(planner->roadmap()->numVertices() > 4002);  // it grew while planning
   }
 
   // a start far off the map cannot be repaired by the region search (start.cpp:40-46 -> INVALID_START)

@@ -14,7 +14,10 @@ from . import _capi
 class Roadmap:
     def __init__(self, ctx, start, goal, n_milestones=10000, seed=42, first_index=0, k_neighbors=0,
                  objective=0, max_lon_vel=0.5, max_lat_vel=0.1, max_ang_vel=0.5, max_replans=1000,
-                 cost_weights=None, risk_threshold=None):
+                 cost_weights=None, risk_threshold=None, max_n_edges=0, recompute_density_after_n_samples=0,
+                 max_sample_time=0.0, density_map=None):
+        """density_map: the PreprocessedMap of the installed map (Context.preprocess_map) -- needed for the in-build
+        re-weighting of the sampling distribution (recompute_density_after_n_samples > 0)."""
         self.ctx = ctx
         self.L = _capi.load()
         p = _capi.RoadmapParams()
@@ -26,6 +29,12 @@ class Roadmap:
             p.w_energy, p.w_time, p.w_risk = cost_weights
         if risk_threshold is not None:
             p.risk_threshold = risk_threshold
+        p.max_n_edges, p.recompute_density_after_n_samples = max_n_edges, recompute_density_after_n_samples
+        p.max_sample_time = max_sample_time
+        self._density = density_map  # keeps the map (and its params) alive
+        if density_map is not None:
+            p.density_map = density_map.h
+            p.density_params = C.cast(C.pointer(density_map.params), C.c_void_p)
         s = np.ascontiguousarray(start, np.float64).reshape(7)
         g = np.ascontiguousarray(goal, np.float64).reshape(7)
         h = C.c_void_p()
@@ -48,7 +57,8 @@ class Roadmap:
         out = (C.c_uint64 * 8)()
         self.ctx._chk(self.L.artp_roadmap_stats(self.h, C.byref(out)), "artp_roadmap_stats")
         return {"vertices": out[0], "candidate_edges": out[1], "valid_edges": out[2], "removed_edges": out[3],
-                "k": out[4], "samples_drawn": out[5]}
+                "k": out[4], "samples_drawn": out[5], "reweightings": out[6],
+                "time_budget_hit": bool(out[7] & 1), "edge_budget_hit": bool(out[7] & 2)}
 
     def export(self) -> dict:
         st = self.stats()
@@ -89,6 +99,26 @@ class Roadmap:
         self.ctx._chk(self.L.artp_roadmap_simplify_path(self.h, p.ctypes.data, p.shape[0], out.ctypes.data,
                                                         C.byref(n), C.byref(cost)), "artp_roadmap_simplify_path")
         return out[:n.value].copy(), cost.value
+
+    def solve_until(self, plan_time, grow_step, cap_states=4096):
+        """LazyPRM*'s grow-while-planning loop: (path or None, cost, {"rounds", "vertices", "improved"})."""
+        path = np.empty((cap_states, 7), np.float64)
+        n, cost = C.c_size_t(0), C.c_double(0.0)
+        st = (C.c_uint64 * 3)()
+        self.ctx._chk(self.L.artp_roadmap_solve_until(self.h, plan_time, grow_step, path.ctypes.data, cap_states,
+                                                      C.byref(n), C.byref(cost), C.byref(st)), "artp_roadmap_solve_until")
+        info = {"rounds": st[0], "vertices": st[1], "improved": st[2]}
+        if n.value == 0:
+            return None, float("inf"), info
+        return path[:n.value].copy(), cost.value, info
+
+    def set_density_map(self, density_map):
+        self._density = density_map
+        if density_map is None:
+            self.ctx._chk(self.L.artp_roadmap_set_density_map(self.h, None, None), "artp_roadmap_set_density_map")
+        else:
+            self.ctx._chk(self.L.artp_roadmap_set_density_map(self.h, density_map.h, C.byref(density_map.params)),
+                          "artp_roadmap_set_density_map")
 
     def solve(self, cap_states=4096) -> Tuple[Optional[np.ndarray], float, int]:
         """(path n x 7 or None when start and goal are not connected, cost, lazy edge removals)."""

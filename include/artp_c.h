@@ -200,6 +200,8 @@ int artp_debug_partner_table(artp_ctx* ctx, int slot, uint8_t* out, size_t out_b
  * Vertex 0 = start, vertex 1 = goal, vertices 2.. = the first n_milestones accepted states of the
  * (seed, index) sample stream.  Needs both height layers, the sampler layers and artp_set_z_bounds. */
 typedef struct artp_roadmap artp_roadmap;
+struct artp_preprocessed;        /* "next" row N2 below */
+struct artp_preprocess_params;
 typedef struct artp_roadmap_params {
   uint64_t seed, first_index;  /* sample stream */
   uint32_t n_milestones;       /* Params::planner.prm_motion_cost.max_n_vertices (params.h:51) */
@@ -213,6 +215,17 @@ typedef struct artp_roadmap_params {
   double max_lon_vel, max_lat_vel, max_ang_vel; /* params.h:71-73 */
   float w_energy, w_time, w_risk; /* MotionCostObjective::getCost weights (params.h:58-62) */
   float risk_threshold;           /* MotionCostObjective::isFeasible (params.h:55) */
+  /* PRMMotionCostMaintainer::sampleGraph's budgets and its in-build re-weighting (prm_motion_cost.cpp:171-193):
+   * the graph grows until max_n_vertices (= n_milestones) OR max_n_edges candidate edges OR max_sample_time of
+   * sampling; every recompute_density_after_n_samples accepted vertices Map::reApplyPreprocessing() recomputes the
+   * sampling distribution from the inverse density of the vertices so far.  0 switches a budget / the re-weighting
+   * off.  The re-weighting needs the preprocessing result of the installed map (density_map, artp_preprocess_map_ex)
+   * and its parameters; with density_map == NULL the distribution stays fixed. */
+  uint32_t max_n_edges;                        /* params.h:52 (default 50000) */
+  uint32_t recompute_density_after_n_samples;  /* params.h:53 (default 1000) */
+  double max_sample_time;                      /* seconds, params.h:50 (default 2.0) */
+  struct artp_preprocessed* density_map;
+  const struct artp_preprocess_params* density_params;
 } artp_roadmap_params;
 void artp_roadmap_params_defaults(artp_roadmap_params* p);
 /* Samples, connects and validates.  ARTP_ERR_INVALID_ARG (artp_last_error says which) when start or goal
@@ -220,7 +233,8 @@ void artp_roadmap_params_defaults(artp_roadmap_params* p);
 int artp_roadmap_build(artp_ctx* ctx, const artp_roadmap_params* params, const double* start_se3,
                        const double* goal_se3, artp_roadmap** out);
 /* out[0] vertices, [1] candidate edges, [2] edges passing the interpolation rule, [3] edges removed by
- * the lazy path check so far, [4] k, [5] samples drawn. */
+ * the lazy path check so far, [4] k, [5] samples drawn, [6] density re-weightings during the build,
+ * [7] bit 0 = the sampling-time budget ended the build, bit 1 = the edge budget did. */
 int artp_roadmap_stats(const artp_roadmap* rm, uint64_t out[8]);
 /* Any pointer may be NULL.  verts: n_vertices x 7; knn / knn_dist: n_vertices x k (0xffffffff = none);
  * edges_uv: n_edges x 2 (u < v, sorted); edge_*: n_edges. */
@@ -232,6 +246,13 @@ int artp_roadmap_export(const artp_roadmap* rm, double* verts, uint32_t* knn, do
  * path_se3 (cap_states x 7, may be NULL) is too small. */
 int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
                        int* n_replans);
+/* LazyPRMStarMinUpdate::baseSolve (lazy_prm_star_min_update.cpp:552-615): the roadmap keeps growing while the
+ * planner has time -- solve, then grow by grow_step milestones (artp_roadmap_grow) and solve again until
+ * plan_time seconds have passed; the best solution found is returned (the reference keeps bestSolution / bestCost_
+ * the same way).  stats (may be NULL): [0] growth rounds, [1] final vertex count, [2] rounds that improved the cost.
+ * *n_path = 0 when no round connected start and goal (PlannerStatus::TIMEOUT). */
+int artp_roadmap_solve_until(artp_roadmap* rm, double plan_time, uint32_t grow_step, double* path_se3,
+                             size_t cap_states, size_t* n_path, double* cost, uint64_t stats[3]);
 /* After the map changed (artp_upload_layer / artp_update_layer_rect / artp_preprocessed_install): re-validate
  * every vertex and re-evaluate every edge against the current layers, forget earlier lazy removals -- the
  * batched form of LazyPRMStarMinUpdate's roadmap maintenance (lazy_prm_star_min_update.cpp:18-217).
@@ -253,6 +274,10 @@ int artp_roadmap_simplify_path(artp_roadmap* rm, const double* path_se3, size_t 
  * and edge verdicts are recomputed for the whole set.  out (may be NULL) = {milestones kept, milestones the
  * current map invalidated}.  Start and goal must still be valid (else ARTP_ERR_INVALID_ARG: set a new query). */
 int artp_roadmap_grow(artp_roadmap* rm, uint64_t n_more, uint64_t out[2]);
+/* The preprocessing result re-weightings are computed on (artp_roadmap_params::density_map) belongs to the map it
+ * was made from: after a map update hand the roadmap the new one (or NULL) before growing it. */
+int artp_roadmap_set_density_map(artp_roadmap* rm, struct artp_preprocessed* pp,
+                                 const struct artp_preprocess_params* params);
 void artp_roadmap_destroy(artp_roadmap* rm);
 
 /* ---- "next" row N2: the per-map preprocessing chain on the device -----------------------
@@ -309,6 +334,12 @@ int artp_preprocessed_get_layer(artp_ctx* ctx, const artp_preprocessed* pp, cons
 /* Planner::setMap (planner.cpp:135-163): make the result the context's map -- both height fields with
  * their tables, the sampler layers and the z bounds. */
 int artp_preprocessed_install(artp_ctx* ctx, const artp_preprocessed* pp);
+/* Map::reApplyPreprocessing (art_planner/src/map/map.cpp:94-96), the part that can change on an unchanged map:
+ * the sampling distribution re-weighted by the inverse density of the given roadmap vertices (DEVICE pointer,
+ * n x 7 doubles; NULL / 0 = no density term) and its CDF.  With install_sampler != 0 the context's sampler uses
+ * the new CDF from the next sample on (the height fields are untouched). */
+int artp_preprocessed_reweight_dev(artp_ctx* ctx, artp_preprocessed* pp, const struct artp_preprocess_params* params,
+                                   const double* vertex_se3_dev, size_t n_vertices, int install_sampler);
 void artp_preprocessed_destroy(artp_preprocessed* pp);
 
 /* ---- learned motion cost: MotionCostObjective::MotionCostFunc

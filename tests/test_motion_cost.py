@@ -138,9 +138,9 @@ def test_gpu_features_match_oracle_at_c3_c4_and_odd_sizes(n, F):
     c = ctx.cost_query(e)
     co = mo.fc_costs(p, ref, e, gm.res, gm.len_x, gm.len_y)
     # fp16 features (each within 2e-2 of the float32 reference) through the float32 MLP: 99 % of the edges
-    # within 2e-3 relative + 5e-3 absolute, none further than 3e-2
+    # within 2e-3 relative + 1e-2 absolute, none further than 3e-2
     cerr = np.abs(c - co) - 2e-3 * np.abs(co)
-    assert np.quantile(cerr.max(axis=1), 0.99) <= 5e-3, float(np.quantile(cerr.max(axis=1), 0.99))
+    assert np.quantile(cerr.max(axis=1), 0.99) <= 1e-2, float(np.quantile(cerr.max(axis=1), 0.99))
     assert cerr.max() <= 3e-2, float(cerr.max())
     ctx.close()
 

@@ -428,3 +428,169 @@ def test_replan_loop_example_runs():
     stats = mod.main(5, verbose=False)
     assert len(stats) >= 3 and np.isfinite(stats).all()
     assert np.median(stats.sum(axis=1)) < 100.0   # the reference's 10 Hz budget, with two orders of margin
+
+
+# ---- round 2: PRMMotionCostMaintainer::sampleGraph's budgets and in-build re-weighting, LazyPRM*'s growth loop --------
+def _preprocessed_ctx(n=250, seed=77):
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(n, 0.04, seed=seed)
+    ctx = Context(0, "yaml")
+    pm = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
+                            traversability=gm["traversability"], use_inverse_vertex_density=1)
+    pm.install()
+    se3 = ctx.sample_states(5, 0, 6000)
+    acc = se3[ctx.validate_states(se3) != 0]
+    d = np.hypot(acc[:, None, 0] - acc[None, :300, 0], acc[:, None, 1] - acc[None, :300, 1])
+    i, j = np.unravel_index(np.argmax(d), d.shape)
+    return gm, ctx, pm, acc[i], acc[j]
+
+
+def _cell_counts(gm, verts, cell=10):
+    """Vertices per (cell x cell)-cell block of the map, over the blocks the sampler can reach at all."""
+    ri = ((gm.pos_x + 0.5 * gm.len_x - verts[:, 0]) / gm.res).astype(int).clip(0, gm.rows - 1) // cell
+    ci = ((gm.pos_y + 0.5 * gm.len_y - verts[:, 1]) / gm.res).astype(int).clip(0, gm.cols - 1) // cell
+    nb = (gm.rows + cell - 1) // cell
+    return np.bincount(ri * nb + ci, minlength=nb * nb).reshape(nb, nb)
+
+
+@pytest.mark.gpu
+def test_in_build_density_reweighting_follows_the_reference_rounds():
+    """prm_motion_cost.cpp:190-193: every recompute_density_after_n_samples vertices Map::reApplyPreprocessing()
+    recomputes the sampling distribution from the inverse vertex density.  (1) the number of re-weightings is the
+    reference's floor(vertices / R) (none at the very end); (2) the FIRST R milestones are those of the fixed
+    distribution (same sample stream), later ones differ; (3) the distribution the last round sampled from equals the
+    numpy restatement of computeInverseSampleDensity over the vertices known at that point; (4) the vertex density
+    gets flatter than with a fixed distribution (that is the purpose of the re-weighting)."""
+    from art_planner_amd.roadmap import Roadmap
+    from art_planner_amd.synthetic import cumulative_distribution
+    import test_preprocess as TP
+    gm, ctx, pm, s, g = _preprocessed_ctx()
+    R, nm = 400, 1500
+    fixed = Roadmap(ctx, s, g, n_milestones=nm, seed=3)
+    vf = fixed.export()["verts"]
+    fixed.close()
+    sf = pm.layer("traversability_sample_filter")
+    rw = Roadmap(ctx, s, g, n_milestones=nm, seed=3, recompute_density_after_n_samples=R, density_map=pm)
+    st = rw.stats()
+    vr = rw.export()["verts"]
+    assert st["vertices"] == nm + 2 and st["reweightings"] == nm // R
+    assert np.array_equal(vr[:2 + R], vf[:2 + R]) and not np.array_equal(vr[2 + R:2 + 2 * R], vf[2 + R:2 + 2 * R])
+    # (3) the map now carries the distribution of the last re-weighting: the first 3 R milestones
+    known = vr[2:2 + nm // R * R]
+    tx = -((known[:, 0] - gm.pos_x) - 0.5 * gm.len_x)
+    ty = -((known[:, 1] - gm.pos_y) - 0.5 * gm.len_y)
+    cnt = np.zeros((gm.rows, gm.cols), np.float32)
+    np.add.at(cnt, ((tx / np.float64(np.float32(gm.res))).astype(int).clip(0, gm.rows - 1),
+                    (ty / np.float64(np.float32(gm.res))).astype(int).clip(0, gm.cols - 1)), 1.0)
+    prm = ctx.params
+    radius = (prm.torso_length + prm.torso_width) * 0.25
+    k = int(6 * radius / gm.res)
+    k += 1 if k % 2 == 0 else 0
+    blurred = TP._blur_reflect101(cnt, TP._gauss_taps(k, radius / gm.res))
+    got_blur = pm.layer("n_samples")
+    assert np.abs(got_blur - blurred).max() < 1e-5 * max(1.0, blurred.max())
+    prob = pm.layer("sample_probability")
+    base = (np.float32(got_blur.max()) - got_blur) * sf
+    assert np.allclose(prob / max(prob.max(), 1e-30), base / max(base.max(), 1e-30), atol=2e-5)
+    cp, _ = cumulative_distribution(prob)
+    with np.errstate(invalid="ignore"):
+        assert np.nanmax(np.abs(pm.layer("cum_prob") - cp)) < 1e-5
+    # (4) flatter: dispersion of the block counts over the reachable blocks
+    blocks = sf.reshape(gm.rows // 10, 10, gm.cols // 10, 10).sum((1, 3)) > 60   # blocks that are mostly samplable
+    cf, cr = _cell_counts(gm, vf[2:])[blocks], _cell_counts(gm, vr[2:])[blocks]
+    assert cr.std() / cr.mean() < 0.93 * cf.std() / cf.mean(), (cr.std() / cr.mean(), cf.std() / cf.mean())
+    # the kept roadmap keeps re-weighting when it grows, and survives losing its density map
+    rw.grow(500)
+    assert rw.stats()["reweightings"] > st["reweightings"]
+    rw.set_density_map(None)
+    rw.grow(100)
+    rw.close()
+    # restore the fixed distribution for whoever comes next
+    pm.reweight_dev(None)
+    pm.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_sample_graph_budgets():
+    """max_n_edges / max_sample_time of PRMMotionCostMaintainer::sampleGraph (prm_motion_cost.cpp:171-185)."""
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, pm, s, g = _preprocessed_ctx()
+    full = Roadmap(ctx, s, g, n_milestones=3000, seed=3)
+    ne_full = full.stats()["candidate_edges"]
+    full.close()
+    cut = Roadmap(ctx, s, g, n_milestones=3000, seed=3, max_n_edges=ne_full // 3)
+    st = cut.stats()
+    assert st["edge_budget_hit"] and st["candidate_edges"] <= ne_full // 3 and 3 < st["vertices"] < 3002
+    e = cut.export()
+    assert e["edges"].max() < st["vertices"]
+    # the vertices are a prefix of the unconstrained build's (same stream, the budget only stops it earlier)
+    full = Roadmap(ctx, s, g, n_milestones=3000, seed=3)
+    assert np.array_equal(e["verts"], full.export()["verts"][:st["vertices"]])
+    full.close()
+    cut.close()
+    timed = Roadmap(ctx, s, g, n_milestones=2_000_000, seed=3, max_sample_time=0.002)
+    st = timed.stats()
+    assert st["time_budget_hit"] and 10 < st["vertices"] < 2_000_000, st
+    timed.close()
+    pm.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_solve_until_grows_while_planning():
+    """LazyPRMStarMinUpdate::baseSolve (lazy_prm_star_min_update.cpp:552-615): the roadmap grows until the planning
+    time is over and the best solution found is returned -- never worse than the first one."""
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, pm, s, g = _preprocessed_ctx()
+    rm = Roadmap(ctx, s, g, n_milestones=300, seed=9)
+    p0, c0, _ = rm.solve()
+    path, cost, info = rm.solve_until(0.15, 400)
+    assert info["rounds"] >= 2 and info["vertices"] >= 302 + 400 * info["rounds"] - 5
+    assert path is not None and cost <= (c0 if p0 is not None else np.inf) + 1e-12
+    assert np.array_equal(path[0], s) and np.array_equal(path[-1], g)
+    assert ctx.validate_states(path).all() and ctx.check_motions(path[:-1], path[1:]).all()
+    # plan_time 0: exactly one solve, no growth
+    nv = rm.stats()["vertices"]
+    p1, c1, info1 = rm.solve_until(0.0, 400)
+    # (the grown graph's own optimum may differ from the best of all rounds: k-nearest connections change as
+    # the roadmap gets denser)
+    assert info1["rounds"] == 0 and rm.stats()["vertices"] == nv and p1 is not None and np.isfinite(c1)
+    rm.close()
+    pm.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_search_matches_host_astar_and_scipy():
+    """Roadmaps of >= 30 000 vertices search on the device (label-correcting relaxation): same cost as the host
+    A* of the small-roadmap path and as scipy's Dijkstra on the exported graph."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from art_planner_amd.roadmap import Roadmap
+    from art_planner_amd.context import Context
+    from art_planner_amd.synthetic import make_map
+    gm = make_map(400, 0.04, seed=1234)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    se3 = ctx.sample_states(5, 0, 8000)
+    acc = se3[ctx.validate_states(se3) != 0]
+    s = acc[np.argmin(acc[:, 0] + acc[:, 1])]
+    g = acc[np.argmax(acc[:, 0] + acc[:, 1])]
+    rm = Roadmap(ctx, s, g, n_milestones=40000, seed=11)
+    path, cost, rep = rm.solve()
+    assert path is not None
+    e = rm.export()
+    ok = (e["edge_valid"] != 0) & (e["edge_removed"] == 0) & np.isfinite(e["edge_cost"])
+    nv = len(e["verts"])
+    gr = csr_matrix((e["edge_cost"][ok], (e["edges"][ok, 0], e["edges"][ok, 1])), shape=(nv, nv))
+    d = dijkstra(gr, directed=False, indices=0)
+    assert abs(d[1] - cost) <= 1e-9 * cost
+    # the returned states are roadmap vertices joined by usable edges whose costs add up to the reported cost
+    idx = [int(np.flatnonzero((e["verts"] == p).all(1))[0]) for p in path]
+    cost_of = {(int(a), int(b)): c for (a, b), c, o in zip(e["edges"], e["edge_cost"], ok) if o}
+    tot = sum(cost_of[(min(a, b), max(a, b))] for a, b in zip(idx[:-1], idx[1:]))
+    assert abs(tot - cost) <= 1e-9 * cost
+    rm.close()
+    ctx.close()
