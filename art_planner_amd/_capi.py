@@ -30,6 +30,7 @@ SYMBOLS = [
     "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
     "artp_preprocess_map_ex", "artp_preprocessed_change",
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
+    "artp_inpaint_layer", "artp_cost_set_hole_filling",
     "artp_cost_blob_bytes", "artp_cost_load_weights", "artp_cost_update_map_layer",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features",
 ]
@@ -157,6 +158,8 @@ def load():
     L.artp_preprocessed_install.argtypes = [vp, vp]
     L.artp_preprocessed_destroy.argtypes = [vp]
     L.artp_preprocessed_destroy.restype = None
+    L.artp_inpaint_layer.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(u64)]
+    L.artp_cost_set_hole_filling.argtypes = [vp, i32]
     L.artp_cost_blob_bytes.argtypes = []
     L.artp_cost_blob_bytes.restype = sz
     L.artp_cost_load_weights.argtypes = [vp, vp, sz]

@@ -247,6 +247,18 @@ class Context:
         pm.params = p
         return pm
 
+    def inpaint_layer(self, layer, mode=0):
+        """(filled layer, number of holes): artp_inpaint_layer, mode 0 = inpaintMatrix, 1 = the cost node's."""
+        a = _f32F(layer)
+        out = np.empty(a.shape, np.float32, order="F")
+        n = C.c_uint64(0)
+        self._chk(self.L.artp_inpaint_layer(self.h, a.ctypes.data, a.shape[0], a.shape[1], mode, out.ctypes.data,
+                                            C.byref(n)), "artp_inpaint_layer")
+        return out, n.value
+
+    def cost_set_hole_filling(self, enabled=True):
+        self._chk(self.L.artp_cost_set_hole_filling(self.h, 1 if enabled else 0), "artp_cost_set_hole_filling")
+
     # ---- learned motion cost (R8 / R9) ---------------------------------------------------------
     def cost_load_weights(self, blob: bytes):
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)

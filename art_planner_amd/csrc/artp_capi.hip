@@ -84,6 +84,7 @@ struct artp_ctx {
   CostMapGeom cost_geom{};
   int feat_h = 0, feat_w = 0;
   bool have_features = false;
+  bool cost_fill_holes = false;        // artp_cost_set_hole_filling
   std::string last_error;
   std::string arch;
   std::recursive_mutex mu;  // recursive: host entry points hold it across the _dev calls they are built from
@@ -1631,6 +1632,9 @@ int artp_cost_update_map_dev(artp_ctx* c, const float* elev_xy_dev, int rows, in
 // cost_query_server.py:46-74 receives the planner's grid_map layer and stores it as
 // np.rot90(layer_as_sent, 2).transpose(); for the Eigen matrix layer(i, j) (column-major) that is the array
 // a[r][c] = layer(rows-1-r, cols-1-c): index r grows along world x, c along world y.
+int cost_update_map_layer_filled(artp_ctx* c, const float* layer, int rows, int cols, double res, double len_x,
+                                 double len_y, double pos_x, double pos_y);
+
 int artp_cost_update_map_layer(artp_ctx* c, const float* layer, int rows, int cols, double res, double len_x,
                                double len_y, double pos_x, double pos_y) {
   if (!c || !layer || rows < 1 || cols < 1) return ARTP_ERR_INVALID_ARG;
@@ -1638,9 +1642,11 @@ int artp_cost_update_map_layer(artp_ctx* c, const float* layer, int rows, int co
   for (int r = 0; r < rows; ++r)
     for (int k = 0; k < cols; ++k) {
       const float v = layer[(size_t)(rows - 1 - r) + (size_t)(cols - 1 - k) * rows];
+      if (!std::isfinite(v) && c->cost_fill_holes)
+        return cost_update_map_layer_filled(c, layer, rows, cols, res, len_x, len_y, pos_x, pos_y);
       if (!std::isfinite(v)) {
-        // the server inpaints holes with cv.inpaint (cost_query_server.py:90-111); that stays with the caller
-        c->last_error = "elevation layer has holes (NaN / inf): inpaint before artp_cost_update_map_layer";
+        // the server inpaints holes (cost_query_server.py:90-111): artp_cost_set_hole_filling(ctx, 1) does it here
+        c->last_error = "elevation layer has holes (NaN / inf): inpaint first or enable artp_cost_set_hole_filling";
         return ARTP_ERR_INVALID_ARG;
       }
       a[(size_t)r * cols + k] = v;

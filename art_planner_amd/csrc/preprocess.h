@@ -99,26 +99,27 @@ estimate_normals_kernel(const float* __restrict__ elev, PreGeom g, int n_r, int 
   stdv[t] = acc.max_dz;
 }
 
-// grey erosion (min) / dilation (max) with the disk footprint of `size`, replicated borders
+// grey erosion (min) / dilation (max) with the footprint of getCircularKernel(size) (utils.cpp:114-119), anchored at
+// (size/2, size/2) like cv::erode / cv::dilate; replicated borders (for these footprints the same as OpenCV's
+// ignored border: clamping an offset moves it towards the anchor, where the footprint is at least as wide).
+// fp: one 64-bit row mask per footprint row (bit x of row y = kernel(y, x)), `fsize` rows (<= 64).
 template <bool DILATE>
 __global__ void __launch_bounds__(256)
-morph_kernel(const float* __restrict__ in, int rows, int cols, int size, float* __restrict__ out) {
+morph_kernel(const float* __restrict__ in, int rows, int cols, int fsize, const unsigned long long* __restrict__ fp,
+             float* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * cols) return;
   const int i = t % rows, j = t / rows;
-  if (size <= 0) {
-    out[t] = in[t];
-    return;
-  }
-  const int r = size / 2;
+  const int r = fsize / 2;
   float v = DILATE ? -INFINITY : INFINITY;
-  for (int dj = -r; dj < size - r; ++dj) {
-    const int jj = min(max(j + dj, 0), cols - 1);
-    for (int di = -r; di < size - r; ++di) {
-      if (di * di + dj * dj > r * r) continue;
-      const int ii = min(max(i + di, 0), rows - 1);
-      const float x = in[ii + (size_t)jj * rows];
-      v = DILATE ? fmaxf(v, x) : fminf(v, x);
+  for (int y = 0; y < fsize; ++y) {
+    const unsigned long long m = fp[y];
+    const int jj = min(max(j + y - r, 0), cols - 1);
+    for (int x = 0; x < fsize; ++x) {
+      if (!((m >> x) & 1ull)) continue;
+      const int ii = min(max(i + x - r, 0), rows - 1);
+      const float xv = in[ii + (size_t)jj * rows];
+      v = DILATE ? fmaxf(v, xv) : fminf(v, xv);
     }
   }
   out[t] = v;
@@ -311,6 +312,92 @@ change_kernel(const float* __restrict__ elev_new, const float* __restrict__ trav
   }
 }
 
+
+// ---- hole filling: inpaintMatrix (art_planner/src/utils.cpp:13-64) / the cost node's _elvMapProcess
+// (art_planner_motion_cost/scripts/cost_query_server.py:92-111) ------------------------------------------------
+// Both quantise the WHOLE layer to 8 bit over [min, max] of its valid cells, inpaint the holes on the 8-bit image
+// (cv::inpaint, INPAINT_TELEA, radius 3) and scale back, so every cell -- hole or not -- comes out quantised.
+// mode 0 (planner): cv::Mat::convertTo(CV_8U, 255/(max-min), -min*255/(max-min)) = saturate(cvRound(x*a + b)) in
+//   float; back: q * ((max-min)/255) + min; then column 0 := column 1, row 0 := row 1 (utils.cpp:60-61).
+// mode 1 (cost node): ((x - min) * 255 / (max - min)).astype(uint8) -- truncation; back: q * (max-min) / 255 + min.
+// The quantisation and the scaling are restated exactly; the fill itself is NOT Telea's fast-marching method
+// (OpenCV is not available here: parity of the hole cells is UNPINNED): holes are closed from their rim inwards,
+// each pass giving every hole cell that has filled neighbours within radius 3 their 1/d^2-weighted mean.
+__global__ void __launch_bounds__(256)
+inpaint_quantise_kernel(const float* __restrict__ in, int n, int mode, float lo, float hi, unsigned char* __restrict__ q,
+                        unsigned char* __restrict__ known, unsigned long long* __restrict__ n_holes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned hole = 0;
+  if (i < n) {
+    const float x = in[i];
+    const bool ok = mode == 0 ? !(x != x) : ((__float_as_uint(x) & 0x7f800000u) != 0x7f800000u);
+    // planner mask = NaN cells only (cv::patchNaNs workaround, utils.cpp:27-32); the node masks every non-finite cell
+    float v;
+    if (mode == 0) {
+      const float a = 255.0f / (hi - lo), b = -lo * 255.0f / (hi - lo);
+      v = rintf(x * a + b);  // cvRound: round half to even
+      if (!(v >= -2147483648.0f && v < 2147483648.0f)) v = 0.0f;  // cvtss2si of inf / NaN = INT_MIN -> saturates to 0
+    } else {
+      v = truncf((x - lo) * 255.0f / (hi - lo));
+    }
+    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);  // saturate_cast<uchar>; NaN -> 0 (masked anyway)
+    q[i] = ok ? (unsigned char)v : 0;
+    known[i] = ok ? 1 : 0;
+    hole = ok ? 0u : 1u;
+  }
+  const unsigned long long bal = __ballot(hole != 0);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_holes, (unsigned long long)__popcll(bal));
+}
+
+// one pass: hole cells with filled cells within radius 3 get their weighted mean; reads (q, known), writes (q2, known2)
+__global__ void __launch_bounds__(256)
+inpaint_fill_pass_kernel(const unsigned char* __restrict__ q, const unsigned char* __restrict__ known, int rows, int cols,
+                         unsigned char* __restrict__ q2, unsigned char* __restrict__ known2,
+                         unsigned* __restrict__ n_left) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned left = 0;
+  if (i < rows * cols) {
+    unsigned char v = q[i], k = known[i];
+    if (!k) {
+      const int r = i % rows, c = i / rows;  // column-major rows x cols
+      float sw = 0.0f, sv = 0.0f;
+      for (int dc = -3; dc <= 3; ++dc)
+        for (int dr = -3; dr <= 3; ++dr) {
+          const int rr = r + dr, cc = c + dc, d2 = dr * dr + dc * dc;
+          if (d2 == 0 || d2 > 9 || rr < 0 || cc < 0 || rr >= rows || cc >= cols) continue;
+          const int j = rr + cc * rows;
+          if (known[j]) {
+            const float w = 1.0f / (float)d2;
+            sw += w;
+            sv += w * (float)q[j];
+          }
+        }
+      if (sw > 0.0f) {
+        v = (unsigned char)rintf(sv / sw);
+        k = 1;
+      } else {
+        left = 1;
+      }
+    }
+    q2[i] = v;
+    known2[i] = k;
+  }
+  if (__any(left != 0) && (threadIdx.x & 63) == 0) atomicAdd(n_left, 1u);
+}
+
+__global__ void __launch_bounds__(256)
+inpaint_dequantise_kernel(const unsigned char* __restrict__ q, int rows, int cols, int mode, float lo, float hi,
+                          float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int r = i % rows, c = i / rows;
+  if (mode == 0) {  // col(0) = col(1), then row(0) = row(1): cell (r, c) shows the value of (max(r,1), max(c,1))
+    if (c == 0 && cols > 1) c = 1;
+    if (r == 0 && rows > 1) r = 1;
+  }
+  const float v = (float)q[r + c * rows];
+  out[i] = mode == 0 ? v * ((hi - lo) / 255.0f) + lo : v * (hi - lo) / 255.0f + lo;
+}
 }  // namespace artp
 
 // -------------------------------------------------------------------------------------------------------
@@ -341,6 +428,43 @@ struct artp_preprocessed {
 
 
 namespace {
+// getCircularKernel(size) (utils.cpp:114-119): a size x size image, cv::circle(centre (size/2, size/2), radius size/2,
+// filled).  The fill is the midpoint circle of OpenCV's drawing.cpp (Circle(): error term err / plus / minus, for
+// every step the spans of rows centre -+ dy over [centre - dx, centre + dx] and of rows centre -+ dx over
+// [centre - dy, centre + dy]), clipped to the image -- restated from the published OpenCV source, which is not
+// installed here (parity UNPINNED).  size <= 0: cv::Mat() -> cv::erode / cv::dilate use a 3 x 3 rectangle.
+std::vector<unsigned long long> circular_footprint(int size, int* fsize) {
+  if (size <= 0) {
+    *fsize = 3;
+    return {7ull, 7ull, 7ull};
+  }
+  if (size > 64) size = 64;
+  *fsize = size;
+  std::vector<unsigned long long> rows(size, 0ull);
+  const int radius = size / 2, cx = radius, cy = radius;
+  auto hline = [&](int y, int x0, int x1) {
+    if (y < 0 || y >= size) return;
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 >= size ? size - 1 : x1;
+    for (int x = x0; x <= x1; ++x) rows[y] |= 1ull << x;
+  };
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    hline(cy - dy, cx - dx, cx + dx);
+    hline(cy + dy, cx - dx, cx + dx);
+    hline(cy - dx, cx - dy, cx + dy);
+    hline(cy + dx, cx - dy, cx + dy);
+    ++dy;
+    err += plus;
+    plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+  return rows;
+}
+
 // The sampling distribution of a preprocessed map (planner.cpp:43-56): [inverse vertex density] * sample filter
 // [capped unknown share], then the CDF -- the part of the processor chain that depends on the roadmap's vertices
 // and that Map::reApplyPreprocessing() (map.cpp:94-96) re-runs while PRMMotionCostMaintainer::sampleGraph grows
@@ -514,11 +638,33 @@ int artp_preprocess_map_ex(artp_ctx* c, const artp_preprocess_inputs* in, const 
                        L(PRE_STD));
   }
   // setMaskedElevationAndTraversability                            basic.cpp:57-106
+  // footprints of this call's morphology sizes, uploaded once each (64 rows of 64 bits at most)
+  unsigned long long* d_fp = nullptr;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&d_fp), 16 * 64 * sizeof(unsigned long long)) == hipSuccess;
+  int fp_sizes[16], fp_fsize[16], n_fp = 0;
+  auto footprint = [&](int size, int* fsize) -> const unsigned long long* {
+    for (int q = 0; q < n_fp; ++q)
+      if (fp_sizes[q] == size) {
+        *fsize = fp_fsize[q];
+        return d_fp + 64 * q;
+      }
+    const std::vector<unsigned long long> rowsv = circular_footprint(size, fsize);
+    const int q = n_fp < 16 ? n_fp++ : 15;
+    fp_sizes[q] = size;
+    fp_fsize[q] = *fsize;
+    ok = ok && d_fp && hipMemcpyAsync(d_fp + 64 * q, rowsv.data(), rowsv.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess;  // rowsv dies with this call
+    return d_fp + 64 * q;
+  };
   auto erode = [&](const float* in, int size, float* o) {
-    hipLaunchKernelGGL(artp::morph_kernel<false>, grid, blk, 0, st, in, rows, cols, size, o);
+    int fs = 0;
+    const unsigned long long* fp = footprint(size, &fs);
+    if (ok) hipLaunchKernelGGL(artp::morph_kernel<false>, grid, blk, 0, st, in, rows, cols, fs, fp, o);
   };
   auto dilate = [&](const float* in, int size, float* o) {
-    hipLaunchKernelGGL(artp::morph_kernel<true>, grid, blk, 0, st, in, rows, cols, size, o);
+    int fs = 0;
+    const unsigned long long* fp = footprint(size, &fs);
+    if (ok) hipLaunchKernelGGL(artp::morph_kernel<true>, grid, blk, 0, st, in, rows, cols, fs, fp, o);
   };
   const int fh = (int)std::ceil(prm->foothold_size / res);
   const int margin = (int)std::ceil(2 * prm->foothold_margin / res);
@@ -561,6 +707,7 @@ int artp_preprocess_map_ex(artp_ctx* c, const artp_preprocess_inputs* in, const 
   ok = ok && pre_sampling_distribution(c, pp, prm, d_verts, d_verts ? in->n_vertices : 0);
   ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
   if (d_verts) (void)hipFree(d_verts);
+  if (d_fp) (void)hipFree(d_fp);
   if (!ok) {
     c->last_error = "device preprocessing failed";
     lock.unlock();
@@ -689,6 +836,108 @@ int artp_preprocessed_reweight_dev(artp_ctx* c, artp_preprocessed* pp, const art
   return upload_sampler_layers_from_device(c, pp->layer(PRE_CUM_PROB), pp->rowwise(), pp->layer(PRE_ELEV), pp->layer(PRE_NX),
                                            pp->layer(PRE_NY), pp->layer(PRE_NZ), pp->layer(PRE_STD), pp->rows, pp->cols,
                                            pp->len_x, pp->len_y, pp->pos_x, pp->pos_y);
+}
+
+
+// d_in -> d_out (both rows x cols column-major floats in HBM; may alias).  *n_holes = masked cells.  No holes: a
+// plain copy (both reference functions are only called when the layer has invalid cells).
+static int inpaint_dev(artp_ctx* c, const float* d_in, int rows, int cols, int mode, float* d_out, uint64_t* n_holes) {
+  const size_t n = (size_t)rows * cols;
+  float lo = 0.f, hi = 0.f;
+  bool any = false;
+  int rc = finite_min_max_dev(c, d_in, n, &lo, &hi, &any);
+  if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  unsigned char* buf = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&buf), 4 * n + 64));
+  unsigned char *q = buf, *known = buf + n, *q2 = buf + 2 * n, *known2 = buf + 3 * n;
+  unsigned long long* d_holes = reinterpret_cast<unsigned long long*>(c->d_count);
+  unsigned* d_left = reinterpret_cast<unsigned*>(buf + 4 * n + (8 - (4 * n) % 8) % 8);
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  auto fail = [&](int code) {
+    (void)hipFree(buf);
+    return code;
+  };
+  if (hipMemsetAsync(d_holes, 0, 8, st) != hipSuccess) return fail(ARTP_ERR_HIP);
+  if (!any || !(hi > lo)) {
+    // no valid cell at all, or a constant layer (the reference divides by max - min = 0 here): holes take the
+    // constant, nothing is quantised
+    hipLaunchKernelGGL(artp::inpaint_quantise_kernel, grid, blk, 0, st, d_in, (int)n, mode, 0.0f, 1.0f, q, known, d_holes);
+    unsigned long long h = 0;
+    if (hipMemcpyAsync(&h, d_holes, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+    if (n_holes) *n_holes = h;
+    std::vector<float> tmp(n);
+    if (hipMemcpy(tmp.data(), d_in, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ARTP_ERR_HIP);
+    for (float& v : tmp)
+      if (!std::isfinite(v)) v = any ? lo : 0.0f;
+    if (hipMemcpy(d_out, tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(ARTP_ERR_HIP);
+    return fail(ARTP_OK);
+  }
+  hipLaunchKernelGGL(artp::inpaint_quantise_kernel, grid, blk, 0, st, d_in, (int)n, mode, lo, hi, q, known, d_holes);
+  unsigned long long h = 0;
+  if (hipMemcpyAsync(&h, d_holes, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return fail(ARTP_ERR_HIP);
+  if (n_holes) *n_holes = h;
+  if (h == 0) {
+    if (d_out != d_in && hipMemcpyAsync(d_out, d_in, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(ARTP_ERR_HIP);
+    return fail(ARTP_OK);
+  }
+  for (int group = 0; group < (rows + cols) / 3 + 2; ++group) {
+    if (hipMemsetAsync(d_left, 0, 4, st) != hipSuccess) return fail(ARTP_ERR_HIP);
+    for (int p = 0; p < 4; ++p) {  // an even number of passes: the result is back in (q, known)
+      hipLaunchKernelGGL(artp::inpaint_fill_pass_kernel, grid, blk, 0, st, (const unsigned char*)q,
+                         (const unsigned char*)known, rows, cols, q2, known2, d_left);
+      hipLaunchKernelGGL(artp::inpaint_fill_pass_kernel, grid, blk, 0, st, (const unsigned char*)q2,
+                         (const unsigned char*)known2, rows, cols, q, known, d_left);
+    }
+    unsigned left = 0;
+    if (hipMemcpyAsync(&left, d_left, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+    if (!left) break;
+  }
+  hipLaunchKernelGGL(artp::inpaint_dequantise_kernel, grid, blk, 0, st, (const unsigned char*)q, rows, cols, mode, lo, hi,
+                     d_out);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(ARTP_ERR_HIP);
+  return fail(ARTP_OK);
+}
+
+int artp_inpaint_layer(artp_ctx* c, const float* layer, int rows, int cols, int mode, float* out, uint64_t* n_holes) {
+  if (!c || !layer || !out || rows < 1 || cols < 1 || mode < 0 || mode > 1) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = (size_t)rows * cols;
+  float* d = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
+  int rc = hipMemcpy(d, layer, n * 4, hipMemcpyHostToDevice) == hipSuccess ? ARTP_OK : ARTP_ERR_HIP;
+  if (rc == ARTP_OK) rc = inpaint_dev(c, d, rows, cols, mode, d, n_holes);
+  if (rc == ARTP_OK && hipMemcpy(out, d, n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = ARTP_ERR_HIP;
+  (void)hipFree(d);
+  return rc;
+}
+
+int artp_cost_set_hole_filling(artp_ctx* c, int enabled) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->cost_fill_holes = enabled != 0;
+  return ARTP_OK;
+}
+
+// artp_cost_update_map_layer for a layer with holes when hole filling is on: the node's _elvMapProcess on the device
+int cost_update_map_layer_filled(artp_ctx* c, const float* layer, int rows, int cols, double res, double len_x,
+                                 double len_y, double pos_x, double pos_y) {
+  std::vector<float> filled((size_t)rows * cols);
+  uint64_t holes = 0;
+  const int rc = artp_inpaint_layer(c, layer, rows, cols, ARTP_INPAINT_COST_NODE, filled.data(), &holes);
+  if (rc != ARTP_OK) return rc;
+  c->cost_fill_holes = false;  // the filled layer has no holes; avoid recursion
+  const int rc2 = artp_cost_update_map_layer(c, filled.data(), rows, cols, res, len_x, len_y, pos_x, pos_y);
+  c->cost_fill_holes = true;
+  return rc2;
 }
 
 }  // extern "C"

@@ -68,11 +68,10 @@ def csrc_hash():
 def pmc_child(args):
     """Only the launches to be measured: warm-up + 3 sample+validate batches of S states."""
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import map_from_device, raw_map
     dev = torch.device("cuda", 0)
-    gm = make_map(args.map, args.res, seed=1234)
     ctx = Context(0, "yaml")
-    ctx.upload_map(gm)
+    map_from_device(ctx, raw_map(args.map, args.res, seed=1234))
     ctx.use_torch_stream()
     se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
     valid = torch.empty(args.batch, dtype=torch.uint8, device=dev)
@@ -235,7 +234,7 @@ def c1_leg(local_rank):
     import oracle_py as O
     from art_planner_amd.context import Context
     from art_planner_amd.roadmap import Roadmap
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(100, 0.1, flat=True)
     rob, om, smp = O.robot("yaml"), O.OracleMap(gm), O.OracleSampler(gm)
     probe, _ = smp.sample(rob, 1, 0, 64)
@@ -341,11 +340,12 @@ def main():
 
     from art_planner_amd.context import Context
     from art_planner_amd.distributed import shard_first_index
-    from art_planner_amd.synthetic import make_map
+    from synthetic import map_from_device, raw_map
 
-    gm = make_map(args.map, args.res, seed=1234)
+    # synthetic inputs: raw terrain + traversability; every derived layer (masked elevation, normals, CDF) comes
+    # from the product's device preprocessing, installed as the context's map
     ctx = Context(local_rank, "yaml")
-    ctx.upload_map(gm)
+    gm = map_from_device(ctx, raw_map(args.map, args.res, seed=1234))
     # one explicit stream carries the kernels AND the HIP events that time them
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
@@ -632,7 +632,7 @@ def main():
         motion_cost = {"weights": "seeded random (tools/convert_weights.random_params(0))"}
         for tag, n_map, g_ in (("c3_400", gm.rows, gm), ("c4_800", 800, None)):
             if g_ is None:
-                g_ = make_map(800, 0.04, seed=77)
+                g_ = raw_map(800, 0.04, seed=77)
             elv = np.ascontiguousarray(g_["elevation"][::-1, ::-1]).astype(np.float32)  # cost_query_server.py:66-74
             ctx.cost_update_map(elv, g_.res, g_.len_x, g_.len_y)
             torch.cuda.synchronize()
@@ -707,7 +707,7 @@ def main():
             cyc.append((t4 - t0) * 1e3)
             for k_, v_ in zip(("rects", "cnn", "states", "cost"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                 stg[k_].append(v_ * 1e3)
-        ctx.upload_map(gm)  # restore
+        gm.preprocessed.install()  # restore
         ctx.cost_update_map(np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32), gm.res, gm.len_x, gm.len_y)
         c5 = {"versions": 100, "cycle_ms_median": float(np.median(cyc)), "cycle_ms_max": float(np.max(cyc)),
               "stage_ms_median": {k_: float(np.median(v_)) for k_, v_ in stg.items()},
@@ -778,10 +778,8 @@ def main():
     try:
         if args.skip_extras:
             raise RuntimeError("skipped (--skip-extras)")
-        from art_planner_amd.synthetic import RobotDims
-        gm4 = make_map(800, 0.04, seed=77, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
         ctx4 = Context(local_rank, "defaults")
-        ctx4.upload_map(gm4)
+        gm4 = map_from_device(ctx4, raw_map(800, 0.04, seed=77))
         ctx4.use_torch_stream()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ctx4.sample_and_validate_dev(seed, 0, S, se3, valid)
@@ -794,11 +792,11 @@ def main():
         c4 = {"states_per_s": S / (ms4 * 1e-3), "ms_per_batch": ms4, "valid_frac": float(valid.float().mean().item()),
               "map": "800x800@0.04", "robot": "Params defaults",
               "motion_cost_cnn": None if not motion_cost else motion_cost.get("c4_800")}
+        gm4.preprocessed.close()
         ctx4.close()
         # secondary robot of SURVEY.md 8d on the C2 map
-        gm2d = make_map(args.map, args.res, seed=1234, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
         ctx2d = Context(local_rank, "defaults")
-        ctx2d.upload_map(gm2d)
+        gm2d = map_from_device(ctx2d, raw_map(args.map, args.res, seed=1234))
         ctx2d.use_torch_stream()
         ctx2d.sample_and_validate_dev(seed, 0, S, se3, valid)
         ev0.record()
@@ -808,6 +806,7 @@ def main():
         torch.cuda.synchronize()
         c4["c2_map_defaults_robot"] = {"states_per_s": S / (ev0.elapsed_time(ev1) / 3 * 1e-3),
                                        "valid_frac": float(valid.float().mean().item())}
+        gm2d.preprocessed.close()
         ctx2d.close()
         ctx.use_torch_stream()
     except Exception as ex:  # pragma: no cover

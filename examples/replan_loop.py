@@ -13,9 +13,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # synthetic input maps live with the tests
 from art_planner_amd.context import Context  # noqa: E402
 from art_planner_amd.roadmap import Roadmap  # noqa: E402
-from art_planner_amd.synthetic import make_map  # noqa: E402
+from synthetic import make_map  # noqa: E402
 
 
 def main(cycles=10, verbose=True):

@@ -327,6 +327,15 @@ int artp_preprocess_map_ex(artp_ctx* ctx, const artp_preprocess_inputs* in, cons
  * rect = {row0, col0, nrows, ncols} bounds the updated cells of the new map (nrows = 0: none). */
 int artp_preprocessed_change(artp_ctx* ctx, artp_preprocessed* map_new, const artp_preprocessed* map_old,
                              float height_change_for_update, float* updated_out, int rect[4], uint64_t* n_updated);
+/* Hole filling of a layer (rows x cols column-major floats, host): inpaintMatrix (art_planner/src/utils.cpp:13-64,
+ * ARTP_INPAINT_PLANNER: NaN cells are the holes, cv::convertTo rounding, column 0 := column 1 / row 0 := row 1
+ * afterwards) and the cost node's _elvMapProcess (cost_query_server.py:92-111, ARTP_INPAINT_COST_NODE: non-finite
+ * cells are the holes, numpy truncation).  Like the reference the WHOLE layer comes back quantised to 8 bit over
+ * [min, max] of its valid cells -- that part is restated exactly; the fill of the hole cells is a rim-inwards
+ * distance-weighted mean (radius 3), NOT OpenCV's Telea marching (OpenCV is not available: unpinned).  A layer
+ * without holes is returned unchanged.  *n_holes (optional) = hole cells. */
+enum { ARTP_INPAINT_PLANNER = 0, ARTP_INPAINT_COST_NODE = 1 };
+int artp_inpaint_layer(artp_ctx* ctx, const float* layer, int rows, int cols, int mode, float* out, uint64_t* n_holes);
 /* name: elevation, traversability, normal_x/_y/_z, plane_fit_std_dev, traversability_thresholded_no_safety,
  * traversability_thresholded, elevation_masked, sample_probability, cum_prob, observed, n_samples (the blurred
  * vertex density), traversability_sample_filter, updated (rows x cols floats each) or cum_prob_rowwise (rows). */
@@ -363,9 +372,12 @@ int artp_cost_update_map_dev(artp_ctx* ctx, const float* elev_xy_dev, int rows, 
                              double len_y, double cx, double cy);
 /* The same from the planner's grid_map elevation layer (column-major rows x cols, as PlannerRos publishes it
  * to the cost node): applies the server's rot90(.., 2).transpose() re-indexing (cost_query_server.py:66-74).
- * Holes (NaN / inf) are an error: the server's cv.inpaint (cost_query_server.py:90-111) stays with the caller. */
+ * Holes (NaN / inf) are an error unless artp_cost_set_hole_filling is on (cost_query_server.py:90-111). */
 int artp_cost_update_map_layer(artp_ctx* ctx, const float* layer, int rows, int cols, double res, double len_x,
                                double len_y, double pos_x, double pos_y);
+/* enabled != 0: artp_cost_update_map_layer fills the holes of its layer itself (artp_inpaint_layer,
+ * ARTP_INPAINT_COST_NODE) instead of rejecting it -- the node's behaviour (cost_query_server.py:92-111). */
+int artp_cost_set_hole_filling(artp_ctx* ctx, int enabled);
 /* MotionCostFunc: edges [B][6] = target x y yaw, start x y yaw (prm_motion_cost.cpp:41-52);
  * cost [B][3] = energy, time, risk (= 1 - prob; cost_query.py:65-69). */
 int artp_cost_query(artp_ctx* ctx, const float* edges, size_t b, float* cost);

@@ -1,8 +1,8 @@
 """Per-call latency of the host-buffer validity API for small batches (the per-state isValid() of the host mirror)."""
 import time, numpy as np, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from art_planner_amd.context import Context
-from art_planner_amd.synthetic import make_map
+from synthetic import make_map
 gm = make_map(400, 0.04, seed=1234)
 ctx = Context(0, "yaml"); ctx.upload_map(gm)
 se3 = ctx.sample_states(1, 0, 4096)

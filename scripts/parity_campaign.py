@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import common  # noqa: E402
 import oracle_py as O  # noqa: E402
 from art_planner_amd.context import Context, make_params  # noqa: E402
-from art_planner_amd.synthetic import make_map  # noqa: E402
+from synthetic import make_map  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
 rng = np.random.default_rng(2024)

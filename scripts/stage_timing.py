@@ -4,9 +4,10 @@ usage: ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/stage_timi
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from art_planner_amd import _capi
 from art_planner_amd.context import Context
-from art_planner_amd.synthetic import make_map
+from synthetic import make_map
 
 gm = make_map(400, 0.04, seed=1234)
 ctx = Context(0, "yaml")

@@ -12,7 +12,7 @@ if ROOT not in sys.path:
 if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from art_planner_amd.synthetic import GridMap, make_map  # noqa: E402
+from synthetic import GridMap, make_map  # noqa: E402
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 

@@ -34,7 +34,7 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def big_map():
     """BASELINE config C2 map: 400x400 @ 0.04 m Perlin terrain + obstacles."""
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     return make_map(400, 0.04, seed=1234)
 
 

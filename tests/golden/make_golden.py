@@ -24,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import common  # noqa: E402
 import oracle_py as O  # noqa: E402
-from art_planner_amd.synthetic import make_map  # noqa: E402
+from synthetic import make_map  # noqa: E402
 
 
 def quat_dposes(pos, quat):

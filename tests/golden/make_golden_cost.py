@@ -17,11 +17,12 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, "/root/reference/art_planner_motion_cost/src/art_planner_motion_cost/predictor")
 import motion_cost_oracle as mo  # noqa: E402
 import network_light  # noqa: E402  (the reference)
-from art_planner_amd.synthetic import make_map  # noqa: E402
+from synthetic import make_map  # noqa: E402
 
 
 def main():

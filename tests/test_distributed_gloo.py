@@ -13,7 +13,7 @@ import common
 import oracle_py as O
 from art_planner_amd.distributed import (EdgeResultGatherer, ValidIndexGatherer, ValidStateGatherer, agree_capacity,
                                          shard_first_index)
-from art_planner_amd.synthetic import make_map
+from synthetic import make_map
 
 BATCH, STEPS, WORLD = 512, 3, 2
 

@@ -183,7 +183,7 @@ def test_c4_map_800_defaults_robot_labels():
     """BASELINE config C4 size (800x800 @ 0.04 m, 32 m map) with the `Params` default robot: sampler
     states -> GPU labels == oracle labels; plus the 0.5 m edge interpolation on the same map."""
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import RobotDims, make_map
+    from synthetic import RobotDims, make_map
     gm = make_map(800, 0.04, seed=77, robot=RobotDims(1.05, 0.55, 0.25, 0.1))
     ctx = Context(0, "defaults")
     ctx.upload_map(gm)
@@ -209,7 +209,7 @@ def test_c4_map_800_defaults_robot_labels():
 def test_c1_flat_map_all_exit_paths_decided_by_tables(ctx_yaml):
     """BASELINE config C1 (flat 100x100 @ 0.1 m): every box is decided by the range tables alone
     (nothing reaches the window stages), labels equal the oracle's."""
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(100, 0.1, flat=True)
     ctx_yaml.upload_map(gm)
     rng = np.random.default_rng(2)
@@ -362,7 +362,7 @@ def test_uniform_position_sampler_branch(big_map):
 
 def test_non_square_map(big_map):
     """rows != cols (the reference's grid_map need not be square): 300 x 180 crop of the C2 map."""
-    from art_planner_amd.synthetic import GridMap, cumulative_distribution
+    from synthetic import GridMap, cumulative_distribution
     i0, j0, nr, nc = 40, 150, 300, 180
     gm = GridMap(nr, nc, big_map.res)
     gm.pos_x = float(big_map.cell_x()[i0:i0 + nr].mean())
@@ -398,7 +398,7 @@ def test_tiny_and_odd_sized_maps(rows, cols):
     """Maps smaller than (or straddling) the 4/8/16/32-cell range-table blocks, with NaN / inf holes: the
     table shortcuts, the partner table and the streaming passes must clamp exactly like the reference's
     GetHeight / zone clamping (heightfield.cpp:325-384, :973-1040)."""
-    from art_planner_amd.synthetic import GridMap
+    from synthetic import GridMap
     rng = np.random.default_rng(rows * 1000 + cols)
     gm = GridMap(rows, cols, 0.08)
     gm.pos_x, gm.pos_y = 0.3, -0.2

@@ -39,7 +39,7 @@ def test_host_mirror_matches_oracle_through_the_ompl_shaped_interfaces(tmp_path)
     _build()
     import oracle_py as O
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(160, 0.04, seed=7)
     rob = O.robot("yaml")
     om = O.OracleMap(gm)
@@ -102,7 +102,7 @@ def test_planner_mirror_plans_on_a_perlin_map(tmp_path):
     re-query on the kept roadmap after another setMap, INVALID_START / INVALID_GOAL."""
     _build()
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(250, 0.04, seed=77)
     # start / goal: two valid samples of the same map under the same preprocessing (Params defaults), far apart
     ctx = Context(0, "yaml")

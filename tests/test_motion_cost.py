@@ -119,7 +119,7 @@ def test_gpu_features_match_oracle_at_c3_c4_and_odd_sizes(n, F):
     oracle (pinned on the reference network at 112^2 and 120^2), then the per-edge costs of 20 000 edges against
     the oracle fed with the ORACLE's features (whole-path parity, not the GPU's own features)."""
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(n, 0.04, seed=1234 if n == 400 else 77)
     elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float16).astype(np.float32)
     p = mo.random_params(0)

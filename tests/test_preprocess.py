@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n,res,seed", [(200, 0.04, 5), (120, 0.05, 9)])
 def test_device_preprocessing_matches_numpy_restatement(n, res, seed):
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(n, res, seed=seed)
     ctx = Context(0, "yaml")
     pp = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
@@ -38,7 +38,7 @@ def test_install_equals_host_upload():
     same states, the same sampler cells (the CDFs agree to 1e-5: a draw that close to a bin edge may land in the
     neighbouring cell)."""
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(200, 0.04, seed=5)
     a, b = Context(0, "yaml"), Context(0, "yaml")
     a.upload_map(gm)
@@ -87,7 +87,7 @@ def test_sampling_distribution_processors():
     (sample_density.cpp:12-43), base distribution, capped unknown share (probability_distribution.cpp:50-90),
     CDF -- against a numpy restatement; and unknown_space_untraversable through the "observed" layer."""
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map, cumulative_distribution
+    from synthetic import make_map, cumulative_distribution
     gm = make_map(160, 0.05, seed=12)
     ctx = Context(0, "yaml")
     rng = np.random.default_rng(4)
@@ -150,7 +150,7 @@ def test_change_detection_between_maps():
     """computeChange (change.cpp:9-51): the 'updated' layer between an old and a new map, also when the new
     map's origin moved by whole cells; the rectangle bounds the updated cells."""
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(160, 0.05, seed=12)
     ctx = Context(0, "yaml")
     old = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y, traversability=gm["traversability"])
@@ -186,4 +186,81 @@ def test_change_detection_between_maps():
     assert np.array_equal(upd2, exp2)
     for m in (old, new, sh):
         m.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_hole_filling_quantisation_matches_the_reference_arithmetic(mode):
+    """artp_inpaint_layer: inpaintMatrix (utils.cpp:13-64, mode 0) and the cost node's _elvMapProcess
+    (cost_query_server.py:92-111, mode 1).  The reference quantises the WHOLE layer to 8 bit when it has holes;
+    that arithmetic is restated exactly, so every cell that is not a hole must be bit-equal to the numpy restatement
+    (mode 0 also carries the column-0 / row-0 copy).  The fill of the hole cells is not Telea's (unpinned): they
+    must be finite and lie within the range of the valid cells around them."""
+    from art_planner_amd.context import Context
+    from synthetic import raw_map
+    gm = raw_map(160, 0.05, seed=12)
+    elev = gm["elevation"].copy()
+    rng = np.random.default_rng(3)
+    holes = np.zeros(elev.shape, bool)
+    for _ in range(14):  # blobs of missing cells, one of them wider than the fill radius
+        r, c, w = rng.integers(5, 150), rng.integers(5, 150), rng.integers(1, 9)
+        holes[r:r + w, c:c + w] = True
+    holes[100:120, 40:52] = True
+    elev[holes] = np.nan
+    ctx = Context(0, "yaml")
+    out, n = ctx.inpaint_layer(elev, mode)
+    assert n == holes.sum() and np.isfinite(out).all()
+    lo, hi = np.float32(np.nanmin(elev)), np.float32(np.nanmax(elev))
+    with np.errstate(invalid="ignore"):
+        if mode == 0:
+            a, b = np.float32(255) / (hi - lo), -lo * np.float32(255) / (hi - lo)
+            q = np.clip(np.rint(elev * a + b), 0, 255)                       # cvRound, saturate_cast<uchar>
+            ref = q.astype(np.float32) * ((hi - lo) / np.float32(255)) + lo
+        else:
+            q = np.clip(np.trunc((elev - lo) * np.float32(255) / (hi - lo)), 0, 255)   # .astype(np.uint8)
+            ref = q.astype(np.float32) * (hi - lo) / np.float32(255) + lo
+    keep = ~holes
+    if mode == 0:                       # mat_inpainted.col(0) = col(1); row(0) = row(1)
+        ref[:, 0] = ref[:, 1]
+        keep[:, 0] = keep[:, 1]
+        ref[0, :] = ref[1, :]
+        keep[0, :] = keep[1, :]
+    assert np.array_equal(out[keep], ref[keep])
+    # hole cells: between the extremes of the valid cells within the reach of the fill (the blob + 3 cells)
+    from scipy import ndimage
+    near = ndimage.binary_dilation(holes, iterations=12) & ~holes
+    assert out[holes].min() >= ref[near].min() - 1e-6 and out[holes].max() <= ref[near].max() + 1e-6
+    # a layer without holes comes back untouched (the reference only inpaints when something is missing)
+    whole, n0 = ctx.inpaint_layer(gm["elevation"], mode)
+    assert n0 == 0 and np.array_equal(whole, gm["elevation"])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_cost_map_layer_with_holes_is_filled_when_asked(big_map):
+    """N3: with artp_cost_set_hole_filling the cost map accepts a layer with holes like the cost node does --
+    same features as handing over the layer filled by artp_inpaint_layer(mode 1) -- and still refuses it without."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import convert_weights
+    from art_planner_amd._capi import ArtpError
+    from art_planner_amd.context import Context
+    ctx = Context(0, "yaml")
+    ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
+    layer = big_map["elevation"].copy()
+    layer[50:58, 200:211] = np.nan
+    layer[300, 17] = np.inf
+    with pytest.raises(ArtpError):
+        ctx.cost_update_map_layer(layer, big_map.res, big_map.len_x, big_map.len_y)
+    ctx.cost_set_hole_filling(True)
+    ctx.cost_update_map_layer(layer, big_map.res, big_map.len_x, big_map.len_y)
+    f1 = ctx.cost_features()
+    filled, n = ctx.inpaint_layer(layer, 1)
+    assert n == 8 * 11 + 1
+    ctx.cost_set_hole_filling(False)
+    ctx.cost_update_map_layer(filled, big_map.res, big_map.len_x, big_map.len_y)
+    assert np.array_equal(f1, ctx.cost_features()) and np.isfinite(f1).all()
     ctx.close()

@@ -31,7 +31,7 @@ def _valid_state_near(ctx, gm, xy, rng, tries=4000):
 @pytest.fixture(scope="module")
 def planning_setup():
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(200, 0.04, seed=5)
     ctx = Context(0, "yaml")
     ctx.upload_map(gm)
@@ -154,7 +154,7 @@ def test_flat_map_path_is_near_the_straight_line():
     straight segment; the cost is bounded below by it and, at this density, within 10 %."""
     from art_planner_amd.context import Context
     from art_planner_amd.roadmap import Roadmap
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(100, 0.1, flat=True)
     ctx = Context(0, "yaml")
     ctx.upload_map(gm)
@@ -433,7 +433,7 @@ def test_replan_loop_example_runs():
 # ---- round 2: PRMMotionCostMaintainer::sampleGraph's budgets and in-build re-weighting, LazyPRM*'s growth loop --------
 def _preprocessed_ctx(n=250, seed=77):
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(n, 0.04, seed=seed)
     ctx = Context(0, "yaml")
     pm = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
@@ -463,7 +463,7 @@ def test_in_build_density_reweighting_follows_the_reference_rounds():
     numpy restatement of computeInverseSampleDensity over the vertices known at that point; (4) the vertex density
     gets flatter than with a fixed distribution (that is the purpose of the re-weighting)."""
     from art_planner_amd.roadmap import Roadmap
-    from art_planner_amd.synthetic import cumulative_distribution
+    from synthetic import cumulative_distribution
     import test_preprocess as TP
     gm, ctx, pm, s, g = _preprocessed_ctx()
     R, nm = 400, 1500
@@ -570,7 +570,7 @@ def test_device_search_matches_host_astar_and_scipy():
     from scipy.sparse.csgraph import dijkstra
     from art_planner_amd.roadmap import Roadmap
     from art_planner_amd.context import Context
-    from art_planner_amd.synthetic import make_map
+    from synthetic import make_map
     gm = make_map(400, 0.04, seed=1234)
     ctx = Context(0, "yaml")
     ctx.upload_map(gm)
