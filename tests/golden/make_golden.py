@@ -173,6 +173,35 @@ def main():
             cm, nchk = om.check_motions(rob, a, b)
             nd = om.segment_counts(rob, a, b)
             ei, nint = om.edges_interp_valid(rob, a, b)
+            # every state either rule evaluates goes through the REFERENCE ODE (its five dPoses, the body / feet
+            # logic of validity_checker*.cpp): the edge verdicts folded from those labels must equal the oracle's
+            def ref_labels(states):
+                poses, inside = om.state_poses(rob, states)
+                hb_ = refb.check(poses[:, 0])
+                hf_ = np.stack([reff.check(poses[:, 1 + k]) for k in range(4)], 1)
+                b_ok = np.where(inside[:, 0] != 0, hb_ == 0, True)
+                f_ok = np.where(inside[:, 1:] != 0, hf_ != 0, not rob.unknown_space_untraversable)
+                return b_ok & f_ok.all(1)
+            cm_states, cm_edge, ei_states, ei_edge = [b], [np.arange(len(a))], [], []
+            for e_i in range(len(a)):
+                if nd[e_i] >= 2:   # DiscreteMotionValidator: s2, then t = j / nd, j = 1 .. nd-1
+                    ts = np.arange(1, nd[e_i]) / float(nd[e_i])
+                    cm_states.append(np.stack([O.interpolate(a[e_i], b[e_i], t) for t in ts]))
+                    cm_edge.append(np.full(len(ts), e_i))
+                if nint[e_i] >= 1:  # addValidMilestone: t = step * (1 / (n_interp + 1)), step = 1 .. n_interp
+                    div = 1.0 / (nint[e_i] + 1)
+                    ei_states.append(np.stack([O.interpolate(a[e_i], b[e_i], st * div)
+                                               for st in range(1, nint[e_i] + 1)]))
+                    ei_edge.append(np.full(nint[e_i], e_i))
+            lab = ref_labels(np.concatenate(cm_states))
+            cm_ref = np.ones(len(a), bool)
+            np.logical_and.at(cm_ref, np.concatenate(cm_edge), lab)
+            assert np.array_equal(cm_ref.astype(np.uint8), cm), (name, rname, "checkMotion vs reference ODE")
+            ei_ref = np.ones(len(a), bool)
+            if ei_states:
+                np.logical_and.at(ei_ref, np.concatenate(ei_edge), ref_labels(np.concatenate(ei_states)))
+            assert np.array_equal(ei_ref.astype(np.uint8), ei), (name, rname, "interpolation rule vs reference ODE")
+            n_checked_ode = len(lab) + sum(len(x) for x in ei_states)
             eout[f"{rname}__s1"] = a
             eout[f"{rname}__s2"] = b
             eout[f"{rname}__check_motion"] = np.packbits(cm)
@@ -183,7 +212,7 @@ def main():
             refb.close()
             reff.close()
             print(f"{name:9s} edges  {rname:9s} checkMotion={cm.mean():.3f} interp={ei.mean():.3f} "
-                  f"nd mean={nd.mean():.1f}")
+                  f"nd mean={nd.mean():.1f}; {n_checked_ode} edge states labelled by the reference ODE")
         np.savez_compressed(os.path.join(HERE, f"states_{name}.npz"), **sout)
         np.savez_compressed(os.path.join(HERE, f"edges_{name}.npz"), **eout)
 
