@@ -47,6 +47,7 @@ def variant(name):
 cases = [("plain", "yaml"), ("nan", "yaml"), ("terraced", "yaml"), ("steps", "defaults"), ("inf", "yaml"),
          ("plain", "tiny"), ("terraced", "defaults"), ("far", "yaml")]
 bad_total = 0
+lines = []
 for mapname, robot in cases:
     gm = variant(mapname)
     if robot == "tiny":
@@ -69,7 +70,19 @@ for mapname, robot in cases:
     vo = O.OracleMap(gm).states_valid(rob, se3)
     bad = int((vg != vo).sum())
     bad_total += bad
-    print(f"{mapname:9s} {robot:8s} valid={vg.mean():.3f} mismatches={bad} counters={ctx.pipeline_counters()} ({time.time() - t0:.1f}s)")
+    # the latency path (<= 16 states per call, validate_few_kernel) on a slice of the same states
+    few = np.concatenate([ctx.validate_states(se3[i:i + 16]) for i in range(0, 4096, 16)])
+    bad_few = int((few != vo[:4096]).sum())
+    bad_total += bad_few
+    lines.append(f"{mapname:9s} {robot:8s} states={n} valid={vg.mean():.3f} mismatches={bad} latency-path mismatches={bad_few}/4096 "
+                 f"counters={ctx.pipeline_counters()} ({time.time() - t0:.1f}s)")
+    print(lines[-1])
     ctx.close()
-print("TOTAL MISMATCHES", bad_total)
+lines.append(f"TOTAL MISMATCHES {bad_total} over {n * len(cases)} states (batch pipeline) + {4096 * len(cases)} (latency path)")
+print(lines[-1])
+out = os.path.join(ROOT, "gpurun_out", "parity_campaign.txt")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+with open(out, "w") as f:
+    f.write("scripts/parity_campaign.py: GPU labels (C ABI) vs CPU oracle, random states over map / robot families\n")
+    f.write("\n".join(lines) + "\n")
 sys.exit(1 if bad_total else 0)
