@@ -53,12 +53,18 @@ class RNG {
 
 namespace base {
 
+// ompl/base/State.h: not copyable, only constructible through derived state types (as in OMPL, code that wants a
+// second state allocates one and copies the VALUES over)
 class State {
- public:
+ private:
+  State(const State&) = delete;
+  State& operator=(const State&) = delete;
+
+ protected:
   State() = default;
-  State(const State&) = default;
-  State& operator=(const State&) = default;
   virtual ~State() = default;
+
+ public:
   template <class T>
   const T* as() const { return static_cast<const T*>(this); }
   template <class T>
@@ -94,6 +100,8 @@ class SO3StateSpace : public StateSpace {
  public:
   class StateType : public State {
    public:
+    StateType() = default;
+    ~StateType() override = default;
     void setIdentity() { x = y = z = 0; w = 1; }
     double x{0}, y{0}, z{0}, w{1};
   };
@@ -103,6 +111,8 @@ class SE3StateSpace : public StateSpace {
  public:
   class StateType : public State {
    public:
+    StateType() = default;
+    ~StateType() override = default;
     double getX() const { return xyz_[0]; }
     double getY() const { return xyz_[1]; }
     double getZ() const { return xyz_[2]; }
@@ -119,6 +129,8 @@ class SE3StateSpace : public StateSpace {
   };
   void setBounds(const RealVectorBounds& bounds) { bounds_ = bounds; }
   const RealVectorBounds& getBounds() const { return bounds_; }
+  State* allocState() const { return new StateType(); }
+  void freeState(State* state) const { delete state->as<StateType>(); }
 
  private:
   RealVectorBounds bounds_{3};

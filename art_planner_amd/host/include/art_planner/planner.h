@@ -33,20 +33,22 @@ namespace ob = ompl::base;
 
 namespace art_planner {
 
-// utils.h:85-88
-inline double getYawFromSO3(const ob::SO3StateSpace::StateType& s) {
-  return std::atan2(2 * (s.w * s.z + s.x * s.y), 1 - 2 * (s.y * s.y + s.z * s.z));
+// OMPL states cannot be copied (ob::State's copy constructor is deleted; the real SE3 state is a compound of
+// separately allocated parts): the planner works on flattened states x y z qx qy qz qw and only READS the caller's.
+// utils.h:85-88 on a flattened state
+inline double yawOfFlat(const double* s) {
+  return std::atan2(2 * (s[6] * s[5] + s[3] * s[4]), 1 - 2 * (s[4] * s[4] + s[5] * s[5]));
 }
 
-// utils.h:101-115
-inline void setSO3FromRPY(ob::SO3StateSpace::StateType& s, const double* rpy) {
+// utils.h:101-115 (setSO3FromRPY) into a flattened state
+inline void setFlatRotationFromRPY(double* s, const double* rpy) {
   const double r2 = rpy[0] * 0.5, p2 = rpy[1] * 0.5, y2 = rpy[2] * 0.5;
   const double cr = std::cos(r2), cp = std::cos(p2), cy = std::cos(y2);
   const double sr = std::sin(r2), sp = std::sin(p2), sy = std::sin(y2);
-  s.w = cy * cp * cr + sy * sp * sr;
-  s.x = cy * cp * sr - sy * sp * cr;
-  s.y = sy * cp * sr + cy * sp * cr;
-  s.z = sy * cp * cr - cy * sp * sr;
+  s[6] = cy * cp * cr + sy * sp * sr;
+  s[3] = cy * cp * sr - sy * sp * cr;
+  s[4] = sy * cp * sr + cy * sp * cr;
+  s[5] = sy * cp * cr - cy * sp * sr;
 }
 
 class Planner {
@@ -171,20 +173,21 @@ class Planner {
       std::cout << "Planner does not have the elevation map set, yet." << std::endl;
       return PlannerStatus::NO_MAP;
     }
+    const StateArray start_flat = BatchPRM::flatten(start);
     // enforce the goal inside the bounds (:204-221)
-    StateType goal_clipped = goal;
-    goal_clipped.setXYZ(clamp(goal.getX(), 0), clamp(goal.getY(), 1), clamp(goal.getZ(), 2));
+    StateArray goal_clipped = BatchPRM::flatten(goal);
+    for (int a = 0; a < 3; ++a) goal_clipped[a] = clamp(goal_clipped[a], a);
     // height, roll, pitch from the map (:224-238)
-    if (map_->isInside(goal_clipped.getX(), goal_clipped.getY())) {
-      double xyzrpy[6] = {goal_clipped.getX(), goal_clipped.getY(), 0, 0, 0, getYawFromSO3(goal_clipped.rotation())};
+    if (map_->isInside(goal_clipped[0], goal_clipped[1])) {
+      double xyzrpy[6] = {goal_clipped[0], goal_clipped[1], 0, 0, 0, yawOfFlat(goal_clipped.data())};
       get3DPoseFrom2D(xyzrpy);
-      goal_clipped.setZ(xyzrpy[2]);
-      setSO3FromRPY(goal_clipped.rotation(), xyzrpy + 3);
+      goal_clipped[2] = xyzrpy[2];
+      setFlatRotationFromRPY(goal_clipped.data(), xyzrpy + 3);
     }
     solved_ = false;
-    StateType start_valid = start, goal_valid = goal_clipped;
+    StateArray start_valid = start_flat, goal_valid = goal_clipped;
     const auto& sg = params_->planner.start_goal_search;
-    if (!searchValid(start, sg.start_radius, sg.n_iter, 0x5741u, &start_valid)) return PlannerStatus::INVALID_START;
+    if (!searchValid(start_flat, sg.start_radius, sg.n_iter, 0x5741u, &start_valid)) return PlannerStatus::INVALID_START;
     if (!searchValid(goal_clipped, sg.goal_radius, sg.n_iter, 0x474fu, &goal_valid)) return PlannerStatus::INVALID_GOAL;
     try {
       if (have_roadmap_) {
@@ -269,7 +272,7 @@ class Planner {
   // n_iter candidates offset uniformly in a disc of the given radius (x / y only; z and attitude are kept).
   // The reference tests them one by one; here they are ONE batch and the first valid index wins -- the same
   // answer for the same offsets.
-  bool searchValid(const StateType& center, double radius, unsigned n_iter, uint64_t salt, StateType* out) const {
+  bool searchValid(const StateArray& center, double radius, unsigned n_iter, uint64_t salt, StateArray* out) const {
     std::vector<double> se3(static_cast<size_t>(n_iter + 1) * 7);
     uint64_t x = seed_ * 0x9e3779b97f4a7c15ull + salt;
     auto next01 = [&x]() {  // splitmix64
@@ -287,13 +290,9 @@ class Planner {
         oy = r * std::sin(a);
       }
       double* s = &se3[static_cast<size_t>(i) * 7];
-      s[0] = center.getX() + ox;
-      s[1] = center.getY() + oy;
-      s[2] = center.getZ();
-      s[3] = center.rotation().x;
-      s[4] = center.rotation().y;
-      s[5] = center.rotation().z;
-      s[6] = center.rotation().w;
+      for (int k = 0; k < 7; ++k) s[k] = center[k];
+      s[0] += ox;
+      s[1] += oy;
     }
     std::vector<uint8_t> valid(n_iter + 1);
     throwOnError(gpu_->get(), artp_validate_states(gpu_->get(), se3.data(), valid.size(), valid.data(), nullptr),
@@ -301,11 +300,11 @@ class Planner {
     for (unsigned i = 0; i <= n_iter; ++i) {
       if (valid[i]) {
         *out = center;
-        out->setX(se3[static_cast<size_t>(i) * 7]);
-        out->setY(se3[static_cast<size_t>(i) * 7 + 1]);
+        (*out)[0] = se3[static_cast<size_t>(i) * 7];
+        (*out)[1] = se3[static_cast<size_t>(i) * 7 + 1];
         if (i > 0 && params_->verbose)
-          std::cout << "Found valid state offset by " << out->getX() - center.getX() << " "
-                    << out->getY() - center.getY() << std::endl;
+          std::cout << "Found valid state offset by " << (*out)[0] - center[0] << " " << (*out)[1] - center[1]
+                    << std::endl;
         return true;
       }
     }

@@ -37,6 +37,9 @@ class BatchPRM {
   // PRMMotionCostMaintainer::sampleGraph + the connection loop: (re)build the roadmap for start / goal.
   // Throws on an invalid start or goal, like the reference's INVALID_START / INVALID_GOAL statuses.
   void sampleGraph(const ob::SE3StateSpace::StateType& start, const ob::SE3StateSpace::StateType& goal) {
+    sampleGraph(flatten(start), flatten(goal));
+  }
+  void sampleGraph(const StateArray& s, const StateArray& g) {
     clear();
     artp_roadmap_params p;
     artp_roadmap_params_defaults(&p);
@@ -65,7 +68,6 @@ class BatchPRM {
       p.density_map = density_map_;
       p.density_params = &density_params_;
     }
-    const StateArray s = flatten(start), g = flatten(goal);
     throwOnError(gpu_->get(), artp_roadmap_build(gpu_->get(), &p, s.data(), g.data(), &rm_), "artp_roadmap_build");
   }
 
@@ -138,8 +140,10 @@ class BatchPRM {
 
   // new start / goal on the kept roadmap (every OMPL query adds them as milestones)
   void setQuery(const ob::SE3StateSpace::StateType& start, const ob::SE3StateSpace::StateType& goal) {
+    setQuery(flatten(start), flatten(goal));
+  }
+  void setQuery(const StateArray& s, const StateArray& g) {
     if (!rm_) throw std::runtime_error("BatchPRM::setQuery before sampleGraph");
-    const StateArray s = flatten(start), g = flatten(goal);
     throwOnError(gpu_->get(), artp_roadmap_set_query(rm_, s.data(), g.data()), "artp_roadmap_set_query");
   }
 
@@ -170,10 +174,11 @@ class BatchPRM {
   size_t numVertices() const { return stat(0); }
   size_t numEdges() const { return stat(2); }
 
- private:
   static StateArray flatten(const ob::SE3StateSpace::StateType& s) {
     return {s.getX(), s.getY(), s.getZ(), s.rotation().x, s.rotation().y, s.rotation().z, s.rotation().w};
   }
+
+ private:
   size_t stat(int i) const {
     uint64_t out[8] = {};
     if (rm_) artp_roadmap_stats(rm_, out);

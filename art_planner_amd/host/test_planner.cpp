@@ -13,14 +13,13 @@
 
 using namespace art_planner;
 
-static Planner::StateType toState(const double* s) {
-  Planner::StateType st;
-  st.setXYZ(s[0], s[1], s[2]);
-  st.rotation().x = s[3];
-  st.rotation().y = s[4];
-  st.rotation().z = s[5];
-  st.rotation().w = s[6];
-  return st;
+// OMPL states are not copyable: fill a caller-owned one
+static void toState(const double* s, Planner::StateType* st) {
+  st->setXYZ(s[0], s[1], s[2]);
+  st->rotation().x = s[3];
+  st->rotation().y = s[4];
+  st->rotation().z = s[5];
+  st->rotation().w = s[6];
 }
 
 static int fails = 0;
@@ -64,7 +63,9 @@ int main(int argc, char** argv) {
   f.read(reinterpret_cast<char*>(trav.data()), trav.size() * 4);
   f.read(reinterpret_cast<char*>(sg), sizeof(sg));
   if (!f) return 2;
-  const Planner::StateType start = toState(sg), goal = toState(sg + 7);
+  Planner::StateType start, goal;
+  toState(sg, &start);
+  toState(sg + 7, &goal);
 
   // no map yet (planner.cpp:196-199); a failed plan has no path (:268-270)
   CHECK(planner->plan(start, goal) == PlannerStatus::NO_MAP);
@@ -123,7 +124,8 @@ int main(int argc, char** argv) {
   }
 
   // a start far off the map cannot be repaired by the region search (start.cpp:40-46 -> INVALID_START)
-  Planner::StateType off = start;
+  Planner::StateType off;
+  toState(sg, &off);
   off.setX(geo[2] + 10.0 * geo[0]);
   CHECK(planner->plan(off, goal) == PlannerStatus::INVALID_START);
   threw = false;
@@ -134,7 +136,8 @@ int main(int argc, char** argv) {
   }
   CHECK(threw);
   // a goal outside the bounds is clipped to them (planner.cpp:204-221), then found invalid there
-  Planner::StateType far_goal = goal;
+  Planner::StateType far_goal;
+  toState(sg + 7, &far_goal);
   far_goal.setX(geo[2] + 10.0 * geo[0]);
   CHECK(planner->plan(start, far_goal) == PlannerStatus::INVALID_GOAL);
 
