@@ -177,11 +177,29 @@ partner_flags_clear_kernel(int nW, int cx0, int cz0, int ncx, int ncz, unsigned 
 __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int wmax = wX > wZ ? wX : wZ;
-  if (wmax > (4 << (ARTP_TABLE_LEVELS - 1))) return -1;
-  const int lc = wmax <= 4 ? 0 : (wmax <= 8 ? 1 : (wmax <= 16 ? 2 : 3));
-  const unsigned at = (unsigned)lc * t.stride + (unsigned)(b.minX + b.minZ * f.nW);
-  const float2 v = t.mm[at];
-  const unsigned fc = t.has_nonfinite ? t.fl[at] : 0u;
+  constexpr int BTOP = 4 << (ARTP_TABLE_LEVELS - 1);  // 32
+  if (wmax > 2 * BTOP) return -1;
+  float2 v;
+  unsigned fc = 0u;
+  if (wmax <= BTOP) {
+    const int lc = wmax <= 4 ? 0 : (wmax <= 8 ? 1 : (wmax <= 16 ? 2 : 3));
+    const unsigned at = (unsigned)lc * t.stride + (unsigned)(b.minX + b.minZ * f.nW);
+    v = t.mm[at];
+    if (t.has_nonfinite) fc = t.fl[at];
+  } else {
+    // torso-sized windows (33 .. 64 samples on their long side): up to 2 x 2 top-level blocks anchored at the
+    // window's low corner and at (high corner - 31) cover it -- a superset of the window again (a block may reach
+    // past a side shorter than 32 samples, or past the map edge, where the table holds the clipped block)
+    const unsigned base = (unsigned)(ARTP_TABLE_LEVELS - 1) * t.stride;
+    const int x1 = wX > BTOP ? b.maxX - BTOP + 1 : b.minX, z1 = wZ > BTOP ? b.maxZ - BTOP + 1 : b.minZ;
+    const unsigned a00 = base + (unsigned)(b.minX + b.minZ * f.nW), a10 = base + (unsigned)(x1 + b.minZ * f.nW);
+    const unsigned a01 = base + (unsigned)(b.minX + z1 * f.nW), a11 = base + (unsigned)(x1 + z1 * f.nW);
+    const float2 v00 = t.mm[a00], v10 = t.mm[a10], v01 = t.mm[a01], v11 = t.mm[a11];  // duplicates hit the same line
+    if (t.has_nonfinite) fc = (unsigned)t.fl[a00] | t.fl[a10] | t.fl[a01] | t.fl[a11];
+    const float mx0 = v10.x > v00.x ? v10.x : v00.x, mx1 = v11.x > v01.x ? v11.x : v01.x;
+    const float mn0 = v10.y < v00.y ? v10.y : v00.y, mn1 = v11.y < v01.y ? v11.y : v01.y;
+    v = make_float2(mx1 > mx0 ? mx1 : mx0, mn1 < mn0 ? mn1 : mn0);
+  }
   if (fc & 2u) return -1;  // a NaN nearby: ODE's running dMAX needs the precise path
   const float minO2 = b.aabb[2], maxO2 = b.aabb[3];
   if (minO2 - v.x > -ARTP_EPS) return 0;
