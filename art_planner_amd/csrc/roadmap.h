@@ -517,7 +517,7 @@ bool roadmap_sssp_dev(artp_roadmap* rm, std::vector<uint32_t>* path, double* cos
         hipMemcpyAsync(rm->d_euv + ne, rm->ev.data(), ne * 4, hipMemcpyHostToDevice, st) != hipSuccess)
       return false;
   }
-  if (rm->d_graph_dirty || rm->csr_dirty) {
+  if (rm->d_graph_dirty) {
     std::vector<double> w(ne);
     for (size_t e = 0; e < ne; ++e)
       w[e] = (rm->evalid[e] && !rm->eremoved[e] && std::isfinite(rm->ecost[e])) ? rm->ecost[e] : INFINITY;
@@ -1357,8 +1357,8 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
   for (;;) {
     double cst = INFINITY;
     bool found;
-    if (rm->nv() >= ARTP_SSSP_MIN_VERTICES) {
-      if (rm->csr_dirty) roadmap_build_csr(rm);  // the lazy removal below looks edges up in the CSR
+    const bool on_device = rm->nv() >= ARTP_SSSP_MIN_VERTICES;
+    if (on_device) {
       bool dev_ok = false;
       found = roadmap_sssp_dev(rm, &path, &cst, &dev_ok);
       if (!dev_ok) found = roadmap_astar(rm, &path, &cst);
@@ -1407,8 +1407,18 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
     }
     // remove edge (path[bad], path[bad+1])
     const uint32_t a = std::min(path[bad], path[bad + 1]), b = std::max(path[bad], path[bad + 1]);
-    for (uint32_t t = rm->row[a]; t < rm->row[a + 1]; ++t)
-      if (rm->adj[t] == b) rm->eremoved[rm->adj_edge[t]] = 1;  // the search skips removed edges
+    if (!rm->csr_dirty) {
+      for (uint32_t t = rm->row[a]; t < rm->row[a + 1]; ++t)
+        if (rm->adj[t] == b) rm->eremoved[rm->adj_edge[t]] = 1;  // the search skips removed edges
+    } else {
+      // no CSR (device search): the edge list is sorted by (u, v), u < v
+      size_t lo = 0, hi = rm->eu.size();
+      while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (rm->eu[mid] < a || (rm->eu[mid] == a && rm->ev[mid] < b)) lo = mid + 1; else hi = mid;
+      }
+      if (lo < rm->eu.size() && rm->eu[lo] == a && rm->ev[lo] == b) rm->eremoved[lo] = 1;
+    }
     rm->d_graph_dirty = true;
     if (++replans > (int)rm->params.max_replans) {
       c->last_error = "too many lazy edge removals";
