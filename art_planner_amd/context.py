@@ -310,6 +310,16 @@ class Context:
                                                     cost_t.data_ptr(), valid_t.shape[0], records_t.data_ptr(),
                                                     count_t.data_ptr()), "artp_pack_edge_results_dev")
 
+    def pack_valid_bits_dev(self, valid_t, bits_t):
+        """bits_t: int64 device tensor [ceil(n / 64)]."""
+        self._chk(self.L.artp_pack_valid_bits_dev(self.h, valid_t.data_ptr(), valid_t.shape[0], bits_t.data_ptr()),
+                  "artp_pack_valid_bits_dev")
+
+    def indices_from_bits_dev(self, bits_t, n, idx_t, count_t):
+        """The ascending indices of the set bits among the first n bits; idx_t int32 [>= set bits], count_t int64[1]."""
+        self._chk(self.L.artp_indices_from_bits_dev(self.h, bits_t.data_ptr(), n, idx_t.data_ptr(), count_t.data_ptr()),
+                  "artp_indices_from_bits_dev")
+
     def sample_states_at_dev(self, seed, base_index, idx_t, count_t, cap, out_t):
         self._chk(self.L.artp_sample_states_at_dev(self.h, seed, base_index, idx_t.data_ptr(), count_t.data_ptr(),
                                                    cap, out_t.data_ptr()), "artp_sample_states_at_dev")

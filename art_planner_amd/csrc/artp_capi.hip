@@ -1393,6 +1393,59 @@ int artp_pack_edge_results_dev(artp_ctx* c, const uint8_t* valid, const uint32_t
   return ARTP_OK;
 }
 
+namespace {
+// 64 labels -> one word (bit k of word w = valid[64 w + k] != 0)
+__global__ void __launch_bounds__(256)
+pack_valid_bits_kernel(const uint8_t* __restrict__ valid, size_t n, unsigned long long* __restrict__ bits) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long b = __ballot(i < n && valid[i] != 0);
+  if ((threadIdx.x & 63) == 0 && (i & ~(size_t)63) < n) bits[i >> 6] = b;
+}
+struct BitAt {
+  const unsigned long long* bits;
+  __host__ __device__ __forceinline__ uint8_t operator()(uint32_t i) const {
+    return (uint8_t)((bits[i >> 6] >> (i & 63u)) & 1ull);
+  }
+};
+}  // namespace
+
+int artp_pack_valid_bits_dev(artp_ctx* c, const uint8_t* valid, size_t n, uint64_t* bits_out) {
+  if (!c || (n && (!valid || !bits_out))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (n == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t padded = (n + 63) & ~(size_t)63;  // whole wavefronts: the ballot covers the tail
+  hipLaunchKernelGGL(pack_valid_bits_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, c->stream, valid, n,
+                     reinterpret_cast<unsigned long long*>(bits_out));
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+int artp_indices_from_bits_dev(artp_ctx* c, const uint64_t* bits, size_t n, uint32_t* out_idx, uint64_t* n_out_dev) {
+  if (!c || (n && (!bits || !out_idx)) || !n_out_dev || n >= (1ull << 31)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n == 0) {
+    HIP_TRY(c, hipMemsetAsync(n_out_dev, 0, sizeof(uint64_t), c->stream));
+    return ARTP_OK;
+  }
+  hipcub::CountingInputIterator<uint32_t> in(0u);
+  hipcub::TransformInputIterator<uint8_t, BitAt, hipcub::CountingInputIterator<uint32_t>> flags(
+      in, BitAt{reinterpret_cast<const unsigned long long*>(bits)});
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(n_out_dev);
+  size_t need = 0;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, need, in, flags, out_idx, cnt, (int)n, c->stream));
+  if (c->cub_cap < need) {
+    if (c->cub_tmp) HIP_TRY(c, hipFree(c->cub_tmp));
+    c->cub_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->cub_tmp, need + 256));
+    c->cub_cap = need + 256;
+  }
+  size_t cap = c->cub_cap;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->cub_tmp, cap, in, flags, out_idx, cnt, (int)n, c->stream));
+  return ARTP_OK;
+}
+
 int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, const uint32_t* idx,
                               const uint64_t* count_dev, size_t cap, double* se3_out) {
   if (!c || !idx || !count_dev || (cap && !se3_out)) return ARTP_ERR_INVALID_ARG;

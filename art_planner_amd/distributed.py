@@ -108,3 +108,31 @@ class EdgeResultGatherer:
             ij.append((blk[:, :2].to(torch.int64) & 0xffffffff) + shard_first_index(step, r, self.world, batch))
             cost.append(blk[:, 2:].contiguous().view(torch.float32))
         return torch.cat(ij, 0), torch.cat(cost, 0), ok
+
+
+class ValidBitmapGatherer:
+    """All-gather of the validity BITMAP of every rank's batch: one bit per candidate state (batch / 8 bytes per
+    rank: 512 KiB for 2^22 candidates) -- 20x less xGMI traffic than the index lists of ValidIndexGatherer and a
+    fixed size, whatever the acceptance rate.  bits: int64 [ceil(batch / 64)], bit k of word w = candidate 64 w + k
+    (artp_pack_valid_bits_dev); the receiving rank expands what it needs with artp_indices_from_bits_dev."""
+
+    def __init__(self, world: int, batch: int, device, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.batch, self.group = world, batch, group
+        self.words = (batch + 63) // 64
+        self.gathered = torch.empty((world, self.words), dtype=torch.int64, device=device)
+
+    def gather(self, bits: torch.Tensor):
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), bits[:self.words].reshape(-1), group=self.group)
+
+    def global_indices(self, step: int) -> torch.Tensor:
+        """Global sample indices of every accepted state of this step, in rank order (host sync; numpy)."""
+        import numpy as np
+        parts = []
+        for r in range(self.world):
+            w = self.gathered[r].cpu().numpy().view(np.uint64)
+            b = np.unpackbits(w.view(np.uint8), bitorder="little")[:self.batch]
+            parts.append(torch.from_numpy(np.flatnonzero(b).astype(np.int64)) +
+                         shard_first_index(step, r, self.world, self.batch))
+        return torch.cat(parts, 0)

@@ -370,21 +370,26 @@ def main():
     torch.cuda.synchronize()
     mat_cap = 0
     if do_gather:
-        from art_planner_amd.distributed import EdgeResultGatherer, ValidIndexGatherer, agree_capacity
+        from art_planner_amd.distributed import EdgeResultGatherer, ValidBitmapGatherer, agree_capacity
         cap = agree_capacity(cap, S, dev)
-        idx_buf = [torch.zeros(S, dtype=torch.int32, device=dev) for _ in range(2)]
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
-        gatherers = [ValidIndexGatherer(N, cap, dev), ValidIndexGatherer(N, cap, dev)]  # double-buffered
-        # every rank's accepted states, re-materialised from the gathered indices: the first mat_cap per rank and
-        # step (default 2^16 = 6.5x the reference's whole roadmap, max_n_vertices = 10^4); anything beyond is
-        # one artp_sample_states_at_dev call away because the index lists are complete
+        words = (S + 63) // 64
+        # what crosses xGMI per batch: the validity BITMAP of every rank's candidates (S / 8 bytes = 512 KiB per
+        # rank) -- a state is a pure function of (seed, index), so a bit per candidate is all another rank needs
+        bits_buf = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
+        gatherers = [ValidBitmapGatherer(N, S, dev), ValidBitmapGatherer(N, S, dev)]  # double-buffered
+        # every rank's accepted states, re-materialised from the gathered bitmaps: the first mat_cap per rank and
+        # step (default 2^16 = 6.5x the reference's whole roadmap, max_n_vertices = 10^4), looked for among the first
+        # 8 * mat_cap candidates of the rank's block; anything beyond is one artp_indices_from_bits_dev +
+        # artp_sample_states_at_dev away because the bitmaps are complete
         all_states = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)
+        idx_tmp = torch.zeros(S, dtype=torch.int32, device=dev)
+        cnt_tmp = torch.zeros(1, dtype=torch.int64, device=dev)
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         for e in done_ev:
             e.record()
         try:  # trial exchange outside the timed region; a failing collective must not lose the whole run
-            ctx.compact_valid_indices_dev(valid, idx_buf[0], counts[0])
-            gatherers[0].gather(idx_buf[0], counts[0])
+            ctx.pack_valid_bits_dev(valid, bits_buf[0])
+            gatherers[0].gather(bits_buf[0])
             torch.cuda.synchronize()
         except Exception as ex:  # pragma: no cover
             gather_error = repr(ex)
@@ -393,26 +398,27 @@ def main():
     def materialise(j):
         gb = gatherers[j & 1]
         torch.cuda.current_stream().wait_event(done_ev[j & 1])
+        prefix = S if mat_cap >= cap else min(S, 8 * mat_cap)
         for r in range(N):
-            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), gb.gathered[r], gb.counts[r:r + 1], mat_cap,
-                                     all_states[r])
+            ctx.indices_from_bits_dev(gb.gathered[r], prefix, idx_tmp, cnt_tmp)
+            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), idx_tmp, cnt_tmp, mat_cap, all_states[r])
 
     def step(i):
         ctx.sample_and_validate_dev(seed, first_index(i), S, se3, valid)
         if do_gather:
             b = i & 1
             torch.cuda.current_stream().wait_event(done_ev[b])  # buffer b free again
-            ctx.compact_valid_indices_dev(valid, idx_buf[b], counts[b])
+            ctx.pack_valid_bits_dev(valid, bits_buf[b])
             ready = torch.cuda.Event()
             ready.record()
             comm.wait_event(ready)
             with torch.cuda.stream(comm):
-                gatherers[b].gather(idx_buf[b], counts[b])     # 4 B per accepted state over xGMI
+                gatherers[b].gather(bits_buf[b])               # one bit per candidate state over xGMI
                 done_ev[b].record()
             # materialise the accepted states of every rank for the PREVIOUS step (its gather has had a
-            # whole step to complete): a state is a pure function of (seed, index).  On the main stream:
-            # the validity kernels are persistent grids with static striding, and a kernel that shares their
-            # CUs from a side stream costs them more than it hides (measured: +0.36 ms for 0.15 ms of work).
+            # whole step to complete).  On the main stream: the validity kernels are persistent grids with static
+            # striding, and a kernel that shares their CUs from a side stream costs them more than it hides
+            # (measured: +0.36 ms for 0.15 ms of work).
             if i > 0 and mat_cap > 0:
                 materialise(i - 1)
 
@@ -439,8 +445,6 @@ def main():
     # ---- the headline region -----------------------------------------------------------------------
     mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise)) if do_gather else 0
     dt = timed_region(K)
-    if do_gather:
-        assert max(int(g_.counts.max().item()) for g_ in gatherers) <= cap, "all-gather block capacity exceeded"
     value = N * S * K / dt
 
     # ---- N > 1 (or --force-dist): the other materialisation setting and the edge exchange, all ranks -------
@@ -871,7 +875,7 @@ def main():
                                "(seed 1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
                    "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}",
                    "sharding": f"sample-index ranges over {N} GPU(s)" +
-                               (", accepted-state indices all-gathered over RCCL (complete lists) + the first "
+                               (", validity bitmaps (1 bit per candidate) all-gathered over RCCL + the first "
                                 f"{'all' if args.materialise < 0 else args.materialise} accepted states of every rank per step "
                                 "re-materialised on every rank" if do_gather else "")},
         "roofline": roofline, "cpu_baseline": cpu,
@@ -881,6 +885,11 @@ def main():
         "c4_800_defaults": c4, "distributed": dist_extras,
         "device": ctx.arch, "gather_error": gather_error,
     }
+    try:  # RCCL prints a version banner through C stdio; push it out BEFORE the JSON so that the line is the last one
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out))
     sys.stdout.flush()
     if dist is not None:

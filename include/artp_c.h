@@ -172,6 +172,12 @@ int artp_compact_valid_indices_dev(artp_ctx* ctx, const uint8_t* valid, size_t n
                                    uint64_t* n_out_dev);
 int artp_sample_states_at_dev(artp_ctx* ctx, uint64_t seed, uint64_t base_index, const uint32_t* idx,
                               const uint64_t* count_dev, size_t cap, double* se3_out);
+/* The most compact form of "which states of my batch were accepted": one bit per candidate (512 KiB for 2^22
+ * candidates, against 9 MB of indices or 130 MB of states) -- what the ranks all-gather per batch.
+ * bits_out: ceil(n / 64) 64-bit words, bit k of word w = valid[64 w + k] != 0.  artp_indices_from_bits_dev turns
+ * the first n bits of a (received) bitmap back into the ascending index list artp_sample_states_at_dev takes. */
+int artp_pack_valid_bits_dev(artp_ctx* ctx, const uint8_t* valid, size_t n, uint64_t* bits_out);
+int artp_indices_from_bits_dev(artp_ctx* ctx, const uint64_t* bits, size_t n, uint32_t* out_idx, uint64_t* n_out_dev);
 /* The second exchange of SURVEY.md 8e: the edge results of a rank as fixed-size records {u32 i, u32 j,
  * f32 cost[3]} (20 bytes; i / j = the caller's vertex ids of the edge's endpoints, cost = the MotionCostFunc row
  * of artp_cost_query_dev or any 3 floats).  records_out (n x 5 u32) receives the records of the edges with

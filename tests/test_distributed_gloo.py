@@ -11,8 +11,8 @@ import torch.multiprocessing as mp
 
 import common
 import oracle_py as O
-from art_planner_amd.distributed import (EdgeResultGatherer, ValidIndexGatherer, ValidStateGatherer, agree_capacity,
-                                         shard_first_index)
+from art_planner_amd.distributed import (EdgeResultGatherer, ValidBitmapGatherer, ValidIndexGatherer,
+                                         ValidStateGatherer, agree_capacity, shard_first_index)
 from synthetic import make_map
 
 BATCH, STEPS, WORLD = 512, 3, 2
@@ -67,6 +67,7 @@ def _worker(rank, port, out_dir):
     gi = ValidIndexGatherer(WORLD, cap, dev)
     smp = O.OracleSampler(gm)
     merged = []
+    gb = ValidBitmapGatherer(WORLD, BATCH, dev)
     ge = EdgeResultGatherer(WORLD, 3 * BATCH, dev)
     all_ij, all_cost = [], []
     for step in range(STEPS):
@@ -99,6 +100,11 @@ def _worker(rank, port, out_dir):
         assert ok2
         regen = np.stack([smp.sample(rob, 42, int(k), 1)[0][0] for k in gidx.tolist()]) if len(gidx) else np.zeros((0, 7))
         assert np.array_equal(regen, m.numpy())
+        # the bitmap exchange (1 bit per candidate: what bench.py gathers) names the same global indices
+        bits = np.packbits(valid.astype(np.uint8), bitorder="little")
+        bits = np.concatenate([bits, np.zeros((-len(bits)) % 8, np.uint8)]).view(np.int64)
+        gb.gather(torch.from_numpy(bits.copy()))
+        assert torch.equal(gb.global_indices(step), gidx)
         merged.append(m.numpy().copy())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate(merged, 0))
     np.save(os.path.join(out_dir, f"edges_ij_rank{rank}.npy"), np.concatenate(all_ij, 0))

@@ -526,3 +526,35 @@ def test_edge_batches_with_non_finite_states_are_rejected(big_map, ctx_yaml):
     with pytest.raises(ArtpError):
         ctx_yaml.check_edges_interp(se3, bad)
     assert ctx_yaml.check_motions(se3, se3).shape == (8,)   # the context stays usable
+
+
+def test_validity_bitmap_round_trip(big_map, ctx_yaml):
+    """The multi-GPU exchange format: artp_pack_valid_bits_dev (one bit per candidate) and
+    artp_indices_from_bits_dev give back exactly the indices of the accepted states, also for lengths that are not
+    multiples of 64 and for a prefix of the bitmap; the states re-materialised from them are the accepted ones."""
+    import torch
+    ctx_yaml.upload_map(big_map)
+    ctx_yaml.use_torch_stream()
+    for n in (1 << 16, 50_001, 63, 64, 65):
+        se3 = torch.empty((n, 7), dtype=torch.float64, device="cuda")
+        valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctx_yaml.sample_and_validate_dev(7, 1234, n, se3, valid)
+        bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        ctx_yaml.pack_valid_bits_dev(valid, bits)
+        idx = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx_yaml.indices_from_bits_dev(bits, n, idx, cnt)
+        torch.cuda.synchronize()
+        ref = np.flatnonzero(valid.cpu().numpy())
+        assert int(cnt.item()) == len(ref) and np.array_equal(idx.cpu().numpy()[:len(ref)], ref)
+        b = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")
+        assert np.array_equal(np.flatnonzero(b[:n]), ref) and not b[n:].any()
+        if n > 1000:
+            ctx_yaml.indices_from_bits_dev(bits, 1000, idx, cnt)      # a prefix of the bitmap
+            torch.cuda.synchronize()
+            assert int(cnt.item()) == int((ref < 1000).sum())
+            ctx_yaml.indices_from_bits_dev(bits, n, idx, cnt)
+            out = torch.empty((len(ref), 7), dtype=torch.float64, device="cuda")
+            ctx_yaml.sample_states_at_dev(7, 1234, idx, cnt, len(ref), out)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), se3.cpu().numpy()[ref])
