@@ -44,6 +44,7 @@ struct artp_ctx {
   // partner table and the raw cross products it is built from
   float* table_buf[2] = {nullptr, nullptr};
   unsigned char* flag_buf[2] = {nullptr, nullptr};  // per-level non-finite / NaN block flags
+  float2* stride_buf[2] = {nullptr, nullptr};        // stride tables (TablesDev::st)
   unsigned char* partner_buf[2] = {nullptr, nullptr};
   int partner_R_built[2] = {-1, -1};
   bool conv_lds_attr_set = false;
@@ -305,6 +306,8 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
   if (c->table_elems[slot] < elems) {
     if (c->table_buf[slot]) HIP_TRY(c, hipFree(c->table_buf[slot]));
     if (c->flag_buf[slot]) HIP_TRY(c, hipFree(c->flag_buf[slot]));
+    if (c->stride_buf[slot]) HIP_TRY(c, hipFree(c->stride_buf[slot]));
+    c->stride_buf[slot] = nullptr;
     if (c->partner_buf[slot]) HIP_TRY(c, hipFree(c->partner_buf[slot]));
     if (c->tri_raw_buf[slot]) HIP_TRY(c, hipFree(c->tri_raw_buf[slot]));
     c->tri_raw_buf[slot] = nullptr;
@@ -316,6 +319,8 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
     c->partner_R_built[slot] = -1;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->table_buf[slot]), 12 * elems * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->flag_buf[slot]), 6 * elems));
+    // stride tables: (nW / s) x (nD / s) entries for s = 2, 4, 8 -- less than elems / 2 entries in all
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->stride_buf[slot]), (elems / 2 + 3 * (f.nW + f.nD) + 16) * sizeof(float2)));
     c->table_elems[slot] = elems;
   }
   float2* mm[6];
@@ -337,6 +342,19 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
   t.stride = (unsigned)elems;
   t.has_nan = f.has_nan;
   t.has_nonfinite = c->layer_has_nonfinite[slot];
+  {
+    unsigned off[ARTP_STRIDE_LEVELS + 1] = {0};
+    for (int l = 0; l < ARTP_STRIDE_LEVELS; ++l) {
+      const int s = 2 << l;
+      off[l + 1] = off[l] + (unsigned)(((f.nW + s - 1) / s) * ((f.nD + s - 1) / s));
+    }
+    t.st = c->stride_buf[slot];
+    t.st_off1 = off[1];
+    t.st_off2 = off[2];
+    hipLaunchKernelGGL(stride_tables_kernel, dim3((off[3] + 255) / 256), dim3(256), 0, c->stream, t.mm, t.fl, t.stride,
+                       f.nW, f.nD, off[1], off[2], off[3], c->stride_buf[slot]);
+    HIP_TRY(c, hipGetLastError());
+  }
   const int rc_partner = build_partner_table(c, slot, dirty);
   if (rc_partner != ARTP_OK) return rc_partner;
   t.valid = 1;
@@ -533,6 +551,7 @@ void artp_destroy(artp_ctx* c) {
   for (int s = 0; s < 2; ++s) {
     if (c->table_buf[s]) (void)hipFree(c->table_buf[s]);
     if (c->flag_buf[s]) (void)hipFree(c->flag_buf[s]);
+    if (c->stride_buf[s]) (void)hipFree(c->stride_buf[s]);
     if (c->partner_buf[s]) (void)hipFree(c->partner_buf[s]);
     if (c->tri_raw_buf[s]) (void)hipFree(c->tri_raw_buf[s]);
   }

@@ -43,7 +43,15 @@ struct TablesDev {
   int has_nan;              // the layer holds a NaN somewhere
   int has_nonfinite;        // the layer holds a NaN or an infinity somewhere (else fl is all zero)
   int valid;
+  // Stride tables: blocks of 8 / 16 / 32 samples anchored every 2 / 4 / 8 samples only (level l: block 8 << l,
+  // anchors at multiples of 2 << l), back to back in `st`.  425 KB per 400 x 400 layer instead of 5 MB of exact
+  // tables: they stay in every XCD's L2, and they are CONSERVATIVE bounds (see stride_entry) that decide most boxes
+  // before an exact table is touched.
+  const float2* st;
+  unsigned st_off1, st_off2;  // first entry of levels 1 and 2 (level 0 starts at 0)
 };
+
+#define ARTP_STRIDE_LEVELS 3
 
 // ---- table construction (map upload) ---------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -70,6 +78,39 @@ table_level_up_kernel(const float2* __restrict__ in, const unsigned char* __rest
   const float ef = (b.y < a.y) ? b.y : a.y, gh = (d.y < c.y) ? d.y : c.y;
   out[i] = make_float2((cd > ab) ? cd : ab, (gh < ef) ? gh : ef);
   fout[i] = fin[x + z * nW] | fin[x1 + z * nW] | fin[x + z1 * nW] | fin[x1 + z1 * nW];
+}
+
+// Stride-table entry {max', min'} of a block with exact statistics {mx, mn} and flags fl (bit 0 non-finite sample,
+// bit 1 NaN).  The tiers that read it only need max' >= max and min' <= min-of-finite, so the flags ride in the
+// values: a NaN block becomes {+inf, -inf} (no exit can fire on it), and "holds a non-finite sample" is the lowest
+// mantissa bit of max', rounded UP to the next float of that parity (+inf cannot carry the bit and does not need
+// it: exit (d) never fires on max' = +inf).
+__device__ __forceinline__ float2 stride_entry(float mx, float mn, unsigned fl) {
+  if (fl & 2u) return make_float2(INFINITY, -INFINITY);
+  unsigned u = __float_as_uint(mx);
+  const unsigned bit = fl & 1u;
+  if ((u & 1u) != bit && mx != INFINITY) {
+    if ((u << 1) == 0u) u = 1u;                  // +-0 -> smallest positive subnormal
+    else if (u & 0x80000000u) u -= 1u;           // negative: toward zero
+    else u += 1u;
+  }
+  return make_float2(__uint_as_float(u), mn);
+}
+
+// One thread per stride-table entry, all levels in one launch.  mm / fl = the exact tables of blocks 4, 8, 16, 32
+// (TablesDev::mm / fl); level l of the stride tables copies the exact level l + 1 at its anchors.
+__global__ void __launch_bounds__(256)
+stride_tables_kernel(const float2* __restrict__ mm, const unsigned char* __restrict__ fl, unsigned stride, int nW,
+                     int nD, unsigned off1, unsigned off2, unsigned total, float2* __restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int l = i >= off2 ? 2 : (i >= off1 ? 1 : 0);
+  const unsigned j = i - (l == 2 ? off2 : (l == 1 ? off1 : 0u));
+  const int sh = l + 1, nxs = (nW + (1 << sh) - 1) >> sh;
+  const int x = (int)(j % (unsigned)nxs) << sh, z = (int)(j / (unsigned)nxs) << sh;
+  const size_t at = (size_t)(l + 1) * stride + (size_t)x + (size_t)z * nW;
+  const float2 e = mm[at];
+  out[i] = stride_entry(e.x, e.y, fl[at]);
 }
 
 // Partner table (FieldDev::partner_flags): both triangles of a cell against every triangle of the
@@ -166,46 +207,80 @@ partner_flags_clear_kernel(int nW, int cx0, int cz0, int ncx, int ncz, unsigned 
   if (li < ncx * ncz) flags[(cx0 + li % ncx) + (size_t)(cz0 + li / ncx) * nW] = 0;
 }
 
-// One block of a coarser level that CONTAINS the window (anchored at the window's corner) bounds the window's
-// statistics from outside: max_c >= maxY, min_c <= minY, and "block all finite" implies "window all finite".
-// That decides most boxes with a single gather, exactly:
+// Conservative exits from the stride tables.  A set of blocks whose union CONTAINS the window bounds the window's
+// statistics from outside: max_c >= maxY, min_c <= minY, and "blocks all finite" implies "window all finite".
+// That decides most boxes exactly:
 //   (b) above : minO2 - max_c > -eps  =>  minO2 - maxY > -eps                       -> no contact
 //   (c) under : min_c - maxO2 > -eps  =>  minY - maxO2 > -eps (whether (b) fired first or not: both say 0)
-//   (d) spans : block finite, min_c - minO2 >= eps and maxO2 - max_c >= eps  =>  (b) and (c) cannot fire
+//   (d) spans : blocks finite, min_c - minO2 >= eps and maxO2 - max_c >= eps  =>  (b) and (c) cannot fire
 //               (maxY >= min_c >= minO2 + eps, minY <= max_c <= maxO2 - eps) and (d)'s own tests hold
-// Returns 0 / 1 = decided result, -1 = undecided (the precise statistics below take over).
+// Returns 0 / 1 = decided result, -1 = undecided.
+__device__ __forceinline__ int conservative_exits(const BoxHF& b, float max_c, float min_c, bool nonfinite) {
+  const float minO2 = b.aabb[2], maxO2 = b.aabb[3];
+  if (minO2 - max_c > -ARTP_EPS) return 0;
+  if (min_c - maxO2 > -ARTP_EPS) return 0;
+  if (!nonfinite && min_c - minO2 >= ARTP_EPS && maxO2 - max_c >= ARTP_EPS) return 1;
+  return -1;
+}
+
+__device__ __forceinline__ unsigned stride_level_offset(const TablesDev& t, int l) {
+  return l == 2 ? t.st_off2 : (l == 1 ? t.st_off1 : 0u);  // selects, not an indexed load from the kernel arguments
+}
+
+// Tier 1: ONE block that contains the window.  A block of B samples anchored at the multiple of s = B / 4 below
+// the window's corner reaches at least B - s + 1 samples past it: windows up to 7 / 13 / 25 samples use the
+// 8 / 16 / 32 blocks.
 __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int wmax = wX > wZ ? wX : wZ;
-  constexpr int BTOP = 4 << (ARTP_TABLE_LEVELS - 1);  // 32
-  if (wmax > 2 * BTOP) return -1;
-  float2 v;
-  unsigned fc = 0u;
-  if (wmax <= BTOP) {
-    const int lc = wmax <= 4 ? 0 : (wmax <= 8 ? 1 : (wmax <= 16 ? 2 : 3));
-    const unsigned at = (unsigned)lc * t.stride + (unsigned)(b.minX + b.minZ * f.nW);
-    v = t.mm[at];
-    if (t.has_nonfinite) fc = t.fl[at];
-  } else {
-    // torso-sized windows (33 .. 64 samples on their long side): up to 2 x 2 top-level blocks anchored at the
-    // window's low corner and at (high corner - 31) cover it -- a superset of the window again (a block may reach
-    // past a side shorter than 32 samples, or past the map edge, where the table holds the clipped block)
-    const unsigned base = (unsigned)(ARTP_TABLE_LEVELS - 1) * t.stride;
-    const int x1 = wX > BTOP ? b.maxX - BTOP + 1 : b.minX, z1 = wZ > BTOP ? b.maxZ - BTOP + 1 : b.minZ;
-    const unsigned a00 = base + (unsigned)(b.minX + b.minZ * f.nW), a10 = base + (unsigned)(x1 + b.minZ * f.nW);
-    const unsigned a01 = base + (unsigned)(b.minX + z1 * f.nW), a11 = base + (unsigned)(x1 + z1 * f.nW);
-    const float2 v00 = t.mm[a00], v10 = t.mm[a10], v01 = t.mm[a01], v11 = t.mm[a11];  // duplicates hit the same line
-    if (t.has_nonfinite) fc = (unsigned)t.fl[a00] | t.fl[a10] | t.fl[a01] | t.fl[a11];
-    const float mx0 = v10.x > v00.x ? v10.x : v00.x, mx1 = v11.x > v01.x ? v11.x : v01.x;
-    const float mn0 = v10.y < v00.y ? v10.y : v00.y, mn1 = v11.y < v01.y ? v11.y : v01.y;
-    v = make_float2(mx1 > mx0 ? mx1 : mx0, mn1 < mn0 ? mn1 : mn0);
+  if (wmax > 25) return -1;
+  const int l = wmax <= 7 ? 0 : (wmax <= 13 ? 1 : 2), sh = l + 1;
+  const int nxs = (f.nW + (1 << sh) - 1) >> sh;
+  const float2 v = t.st[stride_level_offset(t, l) + (unsigned)((b.minX >> sh) + (b.minZ >> sh) * nxs)];
+  return conservative_exits(b, v.x, v.y, __float_as_uint(v.x) & 1u);
+}
+
+// Tier 2: a tight cover.  Blocks of B <= min(wX, wZ) (8 at least) per axis: one at the anchor below the window's low
+// end, one at the anchor above (high end - B + 1), a third between them when the window is longer than 2 B - s: the
+// union reaches at most s - 1 = B / 4 - 1 samples past the window on each side, so it decides nearly everything the
+// exact statistics would -- out of tables that stay in L2.  Up to 3 x 3 predicated gathers in one round trip.
+__device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
+  const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
+  const int m = wX < wZ ? wX : wZ;
+  const int l = m >= 32 ? 2 : (m >= 16 ? 1 : 0), sh = l + 1, B = 8 << l, s = 1 << sh;
+  const int nxs = (f.nW + s - 1) >> sh;
+  int px[3], pz[3], nx, nz;
+  {
+    const int a0 = (b.minX >> sh) << sh;
+    const int aR = a0 + B > b.maxX ? a0 : ((b.maxX - B + s) >> sh) << sh;  // ceil to the stride of (maxX - B + 1)
+    nx = aR == a0 ? 1 : (aR <= a0 + B ? 2 : (aR <= a0 + 2 * B ? 3 : 4));
+    px[0] = a0; px[1] = nx == 3 ? a0 + B : aR; px[2] = aR;
   }
-  if (fc & 2u) return -1;  // a NaN nearby: ODE's running dMAX needs the precise path
-  const float minO2 = b.aabb[2], maxO2 = b.aabb[3];
-  if (minO2 - v.x > -ARTP_EPS) return 0;
-  if (v.y - maxO2 > -ARTP_EPS) return 0;
-  if (!(fc & 1u) && v.y - minO2 >= ARTP_EPS && maxO2 - v.x >= ARTP_EPS) return 1;
-  return -1;
+  {
+    const int a0 = (b.minZ >> sh) << sh;
+    const int aR = a0 + B > b.maxZ ? a0 : ((b.maxZ - B + s) >> sh) << sh;
+    nz = aR == a0 ? 1 : (aR <= a0 + B ? 2 : (aR <= a0 + 2 * B ? 3 : 4));
+    pz[0] = a0; pz[1] = nz == 3 ? a0 + B : aR; pz[2] = aR;
+  }
+  if (nx > 3 || nz > 3) return -1;
+  const float2* __restrict__ st = t.st + stride_level_offset(t, l);
+  float2 v[9];
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int i = u % 3, j = u / 3;
+    v[u] = make_float2(-INFINITY, INFINITY);
+    if (i < nx && j < nz) v[u] = st[(px[i] >> sh) + (pz[j] >> sh) * nxs];
+  }
+  float vmax = -INFINITY, vmin = INFINITY;
+  unsigned nf = 0u;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    // a masked-off slot holds -inf (lowest bit 0)
+    nf |= __float_as_uint(v[u].x);
+    vmax = (v[u].x > vmax) ? v[u].x : vmax;
+    vmin = (v[u].y < vmin) ? v[u].y : vmin;
+  }
+  return conservative_exits(b, vmax, vmin, nf & 1u);
 }
 
 // Exact window statistics from the tables.  Returns false when the tables cannot answer (window
@@ -409,7 +484,8 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
     WindowStats w;
     int ec;
     if (tab.valid) {
-      const int coarse = coarse_block_exit(f, tab, b);
+      int coarse = coarse_block_exit(f, tab, b);
+      if (coarse < 0) coarse = tight_cover_exit(f, tab, b);
       if (coarse >= 0) return (body ? coarse : !coarse) ? 1 : 0;
     }
     const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
