@@ -30,6 +30,14 @@ namespace artp {
 
 #define ARTP_TABLE_LEVELS 4  // block sizes 4, 8, 16, 32 samples
 
+// base[idx] with the BYTE offset formed in 32 bits: the load becomes `global_load v, v_off, s[base]` (uniform
+// base in SGPRs, one VGPR of offset) instead of a per-lane 64-bit address built with three more VALU operations.
+// Every table and layer this is used on is far smaller than 4 GB.
+template <class T>
+__device__ __forceinline__ T gather32(const T* __restrict__ base, unsigned idx) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
+}
+
 struct TablesDev {
   // {max, min-of-finite} interleaved so one 8-byte gather answers both (the lookups are random
   // accesses into tables larger than one XCD's L2: cache lines touched, not bytes, are the cost).
@@ -236,7 +244,7 @@ __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const Tables
   if (wmax > 25) return -1;
   const int l = wmax <= 7 ? 0 : (wmax <= 13 ? 1 : 2), sh = l + 1;
   const int nxs = (f.nW + (1 << sh) - 1) >> sh;
-  const float2 v = t.st[stride_level_offset(t, l) + (unsigned)((b.minX >> sh) + (b.minZ >> sh) * nxs)];
+  const float2 v = gather32(t.st, stride_level_offset(t, l) + (unsigned)((b.minX >> sh) + (b.minZ >> sh) * nxs));
   return conservative_exits(b, v.x, v.y, __float_as_uint(v.x) & 1u);
 }
 
@@ -263,13 +271,13 @@ __device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesD
     pz[0] = a0; pz[1] = nz == 3 ? a0 + B : aR; pz[2] = aR;
   }
   if (nx > 3 || nz > 3) return -1;
-  const float2* __restrict__ st = t.st + stride_level_offset(t, l);
+  const unsigned lo = stride_level_offset(t, l);
   float2 v[9];
 #pragma unroll
   for (int u = 0; u < 9; ++u) {
     const int i = u % 3, j = u / 3;
     v[u] = make_float2(-INFINITY, INFINITY);
-    if (i < nx && j < nz) v[u] = st[(px[i] >> sh) + (pz[j] >> sh) * nxs];
+    if (i < nx && j < nz) v[u] = gather32(t.st, lo + (unsigned)((px[i] >> sh) + (pz[j] >> sh) * nxs));
   }
   float vmax = -INFINITY, vmin = INFINITY;
   unsigned nf = 0u;
@@ -292,8 +300,7 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
   if (m < 4) return false;
   const int lvl = m >= 32 ? 3 : (m >= 16 ? 2 : (m >= 8 ? 1 : 0));
   const int B = 4 << lvl;
-  const float2* __restrict__ mm = t.mm + (size_t)lvl * t.stride;
-  const unsigned char* __restrict__ fl = t.fl + (size_t)lvl * t.stride;
+  const unsigned lo = (unsigned)lvl * t.stride;
   float vmax = -INFINITY, vmin = INFINITY;
   unsigned flags = 0;
   const int lastX = b.maxX - B + 1, lastZ = b.maxZ - B + 1;
@@ -313,9 +320,9 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
         fb[u] = 0u;
         if (i < nx && j < nz) {
           const int xx = b.minX + i * B, zz = b.minZ + j * B;
-          const int at = (xx < lastX ? xx : lastX) + (zz < lastZ ? zz : lastZ) * f.nW;
-          v[u] = mm[at];
-          if (t.has_nonfinite) fb[u] = fl[at];  // uniform: a fully finite layer skips the lookup
+          const unsigned at = lo + (unsigned)((xx < lastX ? xx : lastX) + (zz < lastZ ? zz : lastZ) * f.nW);
+          v[u] = gather32(t.mm, at);
+          if (t.has_nonfinite) fb[u] = gather32(t.fl, at);  // uniform: a fully finite layer skips the lookup
         }
       }
 #pragma unroll
@@ -440,7 +447,7 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const T
       z = z < b.minZ ? b.minZ : (z > b.maxZ ? b.maxZ : z);
       ix[j * N + i] = x;
       iz[j * N + i] = z;
-      h[j * N + i] = f.data[x + (size_t)z * f.nW];
+      h[j * N + i] = gather32(f.data, (unsigned)(x + z * f.nW));
       // A window with masked cells: the vertex only counts as a corner of an all-finite triangle OF THE WINDOW
       // (heightfield.cpp:1306-1441).  The 4 x 4 block anchored one sample before the vertex being all finite
       // and the vertex's neighbours lying in the window is sufficient (its ABC triangle qualifies); the flag
@@ -448,7 +455,7 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const T
       nf[j * N + i] = 0u;
       if (!window_all_finite) {
         const bool inner = x > b.minX && x < b.maxX && z > b.minZ && z < b.maxZ;
-        nf[j * N + i] = inner ? (unsigned)t.fl[(x - 1) + (size_t)(z - 1) * f.nW] : 1u;
+        nf[j * N + i] = inner ? (unsigned)gather32(t.fl, (unsigned)((x - 1) + (z - 1) * f.nW)) : 1u;
       }
     }
   }
@@ -460,15 +467,15 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const T
   return hit;
 }
 
-// Box k of a state against ITS layer: 0 = decided ok, 1 = decided failing, 2 = undecided (exits known not
-// to fire), 3 = undecided (tables could not answer).  `b` is complete whenever the result is >= 2.
+// Box k of a state against ITS layer, first half: pose, AABB, index window and the conservative exits of the stride
+// tables.  0 = decided ok, 1 = decided failing, ARTP_CODE_OPEN = not decided yet (`b` is complete).
 // Called with the body layer for k = 0 and the feet layer for k = 1..4 from separate call sites:
 // selecting the FieldDev / TablesDev kernel arguments by a per-lane index would force both structs into
 // per-lane scratch memory (240 B/lane of HBM traffic).
-__device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
-                                            const RobotDev& rb, const float t[3], const float R[9],
-                                            const float bR[9], int k, BoxHF& b, bool& all_finite) {
-  all_finite = false;
+#define ARTP_CODE_OPEN 4
+__device__ __forceinline__ int classify_head(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
+                                             const RobotDev& rb, const float t[3], const float R[9],
+                                             const float bR[9], int k, BoxHF& b) {
   const bool body = (k == 0);
   float pose[16];
   state_box_pose(rb, t, R, k, pose);
@@ -479,30 +486,36 @@ __device__ __forceinline__ int classify_box(const FieldDev& f, const TablesDev& 
   }
   setup_box_rotated(f, pose, bR, body ? rb.torso[0] : rb.foot[0], body ? rb.torso[1] : rb.foot[1],
                     body ? rb.torso[2] : rb.foot[2], b);
-  int hit = 0;
-  if (b.on_field) {
-    WindowStats w;
-    int ec;
-    if (tab.valid) {
-      int coarse = coarse_block_exit(f, tab, b);
-      if (coarse < 0) coarse = tight_cover_exit(f, tab, b);
-      if (coarse >= 0) return (body ? coarse : !coarse) ? 1 : 0;
-    }
-    const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
-    all_finite = have_stats && w.allFinite;
-    if (!(have_stats && decide_exits(b, w, hit, ec))) {
-      // feet only: 3/5 of the undecided foot boxes hold a vertex and the 2 x 2 probe finds most of them;
-      // torso hits sit at the rim of the box (a 3 x 3 probe caught 1 in 4) and do not pay for the probe
-      if (have_stats && !body && probe_vertices_inside<2>(f, tab, b, 0.33f, all_finite)) return 0;  // exit (f): the foot touches
-      return have_stats ? 2 : 3;
-    }
+  if (!b.on_field) return body ? 0 : 1;  // AABB off the field: no contact (heightfield.cpp:1868-1877)
+  if (tab.valid) {
+    int coarse = coarse_block_exit(f, tab, b);
+    if (coarse < 0) coarse = tight_cover_exit(f, tab, b);
+    if (coarse >= 0) return (body ? coarse : !coarse) ? 1 : 0;
+  }
+  return ARTP_CODE_OPEN;
+}
+
+// Second half, for the boxes the stride tables left open: exact window statistics, exits (b)-(e), and for feet
+// the vertex probe.  0 = decided ok, 1 = decided failing, 2 = undecided (exits known not to fire), 3 = undecided
+// (tables could not answer).
+__device__ __forceinline__ int classify_tail(const FieldDev& f, const TablesDev& tab, const BoxHF& b, bool body,
+                                             bool& all_finite) {
+  WindowStats w;
+  int hit = 0, ec;
+  const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
+  all_finite = have_stats && w.allFinite;
+  if (!(have_stats && decide_exits(b, w, hit, ec))) {
+    // feet only: 3/5 of the undecided foot boxes hold a vertex and the 2 x 2 probe finds most of them;
+    // torso hits sit at the rim of the box (a 3 x 3 probe caught 1 in 4) and do not pay for the probe
+    if (have_stats && !body && probe_vertices_inside<2>(f, tab, b, 0.33f, all_finite)) return 0;  // exit (f): the foot touches
+    return have_stats ? 2 : 3;
   }
   return (body ? hit : !hit) ? 1 : 0;
 }
 
-// Queue record of a box into the LDS staging slot dst[0..5].
-__device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned state, bool exits_negative,
-                                             bool all_finite, float4* dst) {
+// Queue record of a box into the LDS slot dst[0..5].  dst[5].z carries the classify stage's own bookkeeping (the
+// lane the box came from); consumers ignore it.
+__device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned state, unsigned origin, float4* dst) {
   dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
   dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
   dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
@@ -510,54 +523,62 @@ __device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned
   const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
   const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
   dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
-  const unsigned kind = (body ? 0u : 1u) | (exits_negative ? ARTP_REC_EXITS_NEGATIVE : 0u) |
-                        (exits_negative && all_finite ? ARTP_REC_ALL_FINITE : 0u);
-  dst[5] = make_float4(__uint_as_float(state), __uint_as_float(kind), 0.0f, 0.0f);
+  dst[5] = make_float4(__uint_as_float(state), __uint_as_float(body ? 0u : 1u), __uint_as_float(origin), 0.0f);
 }
 
-// ---- stage 1: one lane per (state, box) ---------------------------------------------------------------
-// A workgroup owns SUB x 64 consecutive states and runs 5 x SUB wavefronts: wavefront w handles box
-// k = w / SUB (0 torso, 1..4 feet) of the 64 states of sub-block w % SUB.  The box index is therefore
-// wave-uniform (no divergence between torso and foot geometry, the layer is picked by a uniform branch)
-// and the five table-lookup latency chains of one state run in five different wavefronts instead of
-// back to back in one lane.  The five verdicts meet in LDS; a state with a decided failing box is
-// finished (label 0) and queues nothing.  Queue slots: ONE atomic per queue per workgroup (a single word
-// sustains only ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue"); every wavefront
-// writes one contiguous run of records, staged in LDS and copied out as full coalesced 16-byte lanes
+__device__ __forceinline__ unsigned record_kind(bool body, bool exits_negative, bool all_finite) {
+  return (body ? 0u : 1u) | (exits_negative ? ARTP_REC_EXITS_NEGATIVE : 0u) |
+         (exits_negative && all_finite ? ARTP_REC_ALL_FINITE : 0u);
+}
+
+// ---- stage 1: one lane per (state, box), then one lane per OPEN box ---------------------------------------
+// A workgroup owns SUB x 64 consecutive states and runs 5 x SUB wavefronts.
+// Phase A: wavefront w handles box k = w / SUB (0 torso, 1..4 feet) of the 64 states of sub-block w % SUB, so the
+// box index is wave-uniform (no divergence between torso and foot geometry, the layer is picked by a uniform
+// branch) and the five table-lookup latency chains of one state run in five different wavefronts.  classify_head
+// decides ~6 of 7 boxes out of the stride tables.
+// Phase B: the boxes still open -- of states none of whose boxes has failed yet -- are compacted through LDS, in
+// the queue's record format, into a torso list and a foot list, and ONE LANE PER LIST ENTRY runs classify_tail.
+// A wavefront executes every branch one of its lanes takes: left in place, the ~1 in 7 open lanes made all ten
+// wavefronts of the workgroup issue the exact-statistics / probe code (a third of the kernel's VALU instructions);
+// compacted, two or three wavefronts do.
+// Phase C: the five verdicts of a state meet in LDS; a state with a decided failing box is finished (label 0) and
+// queues nothing.  Records still pending are already in LDS in queue format: every wavefront of phase B takes its
+// queue slots with one atomic (sub-queue blockIdx % ARTP_NSUB: a single counter word sustains only ~88 returning
+// atomics per microsecond, MI355X_MICROARCH.md "dequeue") and copies them out as full coalesced 16-byte lanes
 // (scattered 16-byte stores into 96-byte records cost ~7x the bytes in partial-line write traffic).
 #define ARTP_CLASSIFY_SUB 2
-#ifdef ARTP_STAGE_TIMING
-__device__ unsigned long long g_classify_cycles[2][8];  // [torso waves | foot waves][phase]
-#define ARTP_C_MARK(slot) do { const long long n_ = clock64(); c_acc[slot] = (unsigned long long)(n_ - c_prev); c_prev = n_; } while (0)
-#else
-#define ARTP_C_MARK(slot) do { } while (0)
-#endif
 #define ARTP_CLASSIFY_THREADS (64 * 5 * ARTP_CLASSIFY_SUB)
+#define ARTP_CLASSIFY_CAP_T 64   // open torso boxes a workgroup lists (of 128; typically ~15 are open)
+#define ARTP_CLASSIFY_CAP_F 192  // open foot boxes it lists (of 512; typically ~80)
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_classify_cycles[2][8];  // kept for the timing build's readout; not written any more
+#endif
 
-__global__ void __launch_bounds__(ARTP_CLASSIFY_THREADS)
+__global__ void __launch_bounds__(ARTP_CLASSIFY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, MapGeom g, RobotDev rb,
                        const PoseRec* __restrict__ recs, size_t n, uint8_t* __restrict__ valid,
                        PipelineQueues q) {
-  constexpr int SUB = ARTP_CLASSIFY_SUB;
+  constexpr int SUB = ARTP_CLASSIFY_SUB, CAP_T = ARTP_CLASSIFY_CAP_T, CAP_F = ARTP_CLASSIFY_CAP_F;
+  constexpr int WAVES_T = CAP_T / 64, WAVES_B = (CAP_T + CAP_F) / 64;  // phase B: torso list, then foot list
   // The PoseRecs of the workgroup's SUB * 64 states come in ONCE, cooperatively (one 16-byte chunk per lane, fully
   // coalesced), and are handed to the five box wavefronts of each state through LDS: five wavefronts pulling
-  // the same 64-byte line per lane through the L1 were half of the kernel's L1 accesses, and the L1's miss queue
-  // is what bounds this kernel (TCP_PENDING_STALL ~70 % of its cycles).  80-byte stride: conflict-free b128 reads.
-  __shared__ float4 prec[SUB * 64 * 5];
-  __shared__ float4 stage[5 * SUB][32 * 6];
+  // the same 64-byte line per lane through the L1 were half of the kernel's L1 accesses.  80-byte stride:
+  // conflict-free b128 reads.
+  // The open-box records reuse the PoseRecs' LDS (the last PoseRec read is two barriers before the first record
+  // write): 24 KB per workgroup, so LDS never limits how many workgroups a CU holds.
+  static_assert((CAP_T + CAP_F) * 6 >= SUB * 64 * 5, "the record area also holds the PoseRecs");
+  __shared__ float4 open_recs[(CAP_T + CAP_F) * 6];
+  float4* prec = open_recs;
+  __shared__ unsigned short plist[CAP_T + CAP_F];
   __shared__ uint8_t codes[SUB][5][64];
   __shared__ unsigned cnts[5 * SUB];
-  __shared__ unsigned long long bases[2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k = wave / SUB, sub = wave % SUB;
   const bool body = (k == 0);
   const size_t i_raw = ((size_t)blockIdx.x * SUB + sub) * 64 + lane;
   const bool live = i_raw < n;
   const size_t i = live ? i_raw : n - 1;  // dead lanes shadow the last state and write nothing
-#ifdef ARTP_STAGE_TIMING
-  unsigned long long c_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long c_prev = clock64();
-#endif
   // the state's PoseRec: float pose + the box rotation in the field frame (shared by its five boxes)
   if (threadIdx.x < SUB * 64 * 4) {
     const int sl = threadIdx.x >> 2, part = threadIdx.x & 3;
@@ -566,77 +587,142 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     prec[sl * 5 + part] = reinterpret_cast<const float4*>(recs + gi)[part];
   }
   __syncthreads();
-  const float4* rp = &prec[(sub * 64 + lane) * 5];
-  const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-  const float t[3] = {r0.x, r0.y, r0.z};
-  const float bR[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-  float R[9];
-  rot_from_quat(r0.w, r1.x, r1.y, r1.z, R);
-  ARTP_C_MARK(0);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int rank = 0;
+  bool open;
   BoxHF b;
-  int code;
-  bool all_finite;
-  if (body)
-    code = classify_box(fb, tb, g, rb, t, R, bR, 0, b, all_finite);
-  else
-    code = classify_box(ff, tf, g, rb, t, R, bR, k, b, all_finite);
-  ARTP_C_MARK(1);
-  codes[sub][k][lane] = (uint8_t)code;
-  __syncthreads();
-  ARTP_C_MARK(2);
-  bool ok = true;
+  {
+    const float4* rp = &prec[(sub * 64 + lane) * 5];
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    const float t[3] = {r0.x, r0.y, r0.z};
+    const float bR[9] = {r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    float R[9];
+    rot_from_quat(r0.w, r1.x, r1.y, r1.z, R);
+    int code;
+    if (body)
+      code = classify_head(fb, tb, g, rb, t, R, bR, 0, b);
+    else
+      code = classify_head(ff, tf, g, rb, t, R, bR, k, b);
+    if (!live) code = 0;
+    codes[sub][k][lane] = (uint8_t)code;
+    __syncthreads();
+    bool ok = true;
 #pragma unroll
-  for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
-  if (body && live) valid[i] = (uint8_t)ok;
-  const bool pending = live && ok && code >= 2;
-  const unsigned long long bal = __ballot(pending);
-  const int cnt = __popcll(bal);
-  if (lane == 0) cnts[wave] = (unsigned)cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned tot_t = 0, tot_f = 0;
-#pragma unroll
-    for (int w = 0; w < 5 * SUB; ++w) {
-      if (w < SUB) tot_t += cnts[w];
-      else tot_f += cnts[w];
-    }
-    const int sq = blockIdx.x % ARTP_NSUB;
-    bases[0] = sub_base(q, 0, sq) + (tot_t ? atomicAdd(sub_counter(q, 0, sq), (unsigned long long)tot_t) : 0ull);
-    bases[1] = sub_base(q, 1, sq) + (tot_f ? atomicAdd(sub_counter(q, 1, sq), (unsigned long long)tot_f) : 0ull);
+    for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
+    open = ok && code == ARTP_CODE_OPEN;
+    const unsigned long long bal = __ballot(open);
+    rank = __popcll(bal & lt_mask);
+    if (lane == 0) cnts[wave] = (unsigned)__popcll(bal);
   }
   __syncthreads();
-  ARTP_C_MARK(3);
-#ifdef ARTP_STAGE_TIMING
-  if (cnt == 0) {
-    if (lane == 0) {
-      for (int p = 0; p < 4; ++p) atomicAdd(&g_classify_cycles[body ? 0 : 1][p], c_acc[p]);
-      atomicAdd(&g_classify_cycles[body ? 0 : 1][7], 1ull);
+  int n_t = 0, n_f = 0;
+#pragma unroll
+  for (int w = 0; w < 5 * SUB; ++w) {
+    const int c = (int)cnts[w];
+    if (w < SUB) {
+      if (body && w < wave) rank += c;
+      n_t += c;
+    } else {
+      if (!body && w < wave) rank += c;
+      n_f += c;
+    }
+  }
+  // rank = position of this lane's box in its list (valid where `open`)
+  if (n_t + n_f == 0) {
+    if (body && live) {
+      bool ok = true;
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
+      valid[i] = (uint8_t)ok;
     }
     return;
   }
-#endif
-  if (cnt == 0) return;  // wave-uniform; no barrier below
-  unsigned long long base = body ? bases[0] : bases[1];
-  for (int w = body ? 0 : SUB; w < wave; ++w) base += cnts[w];
-  float4* stg = stage[wave];
-  float4* out = reinterpret_cast<float4*>(q.q1 + base);
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int rank = __popcll(bal & lt_mask);
-  // two rounds of up to 32 records: half the staging LDS, twice the resident wavefronts
-  for (int r0 = 0; r0 < cnt; r0 += 32) {
-    if (pending && rank >= r0 && rank < r0 + 32) stage_record(b, body, (unsigned)i, code == 2, all_finite, stg + 6 * (rank - r0));
-    wave_lds_sync();
-    const int m = (cnt - r0 < 32 ? cnt - r0 : 32) * 6;
-    for (int j = lane; j < m; j += 64) out[r0 * 6 + j] = stg[j];
-    wave_lds_sync();
+  if (open) {
+    const int cap = body ? CAP_T : CAP_F;
+    if (rank < cap) {
+      stage_record(b, body, (unsigned)i, threadIdx.x, open_recs + 6 * ((body ? 0 : CAP_T) + rank));
+    } else {
+      // more open boxes than the list holds (it takes a map the stride tables cannot decide much on): the box goes
+      // to the queue as it is, marked "tables could not answer", and the scan stages evaluate its exits.  One
+      // atomic and six scattered 16-byte stores per box.
+      float4 r6[6];
+      stage_record(b, body, (unsigned)i, 0u, r6);
+      const int sq = blockIdx.x % ARTP_NSUB, kind = body ? 0 : 1;
+      float4* out = reinterpret_cast<float4*>(q.q1 + sub_base(q, kind, sq) + atomicAdd(sub_counter(q, kind, sq), 1ull));
+#pragma unroll
+      for (int j = 0; j < 6; ++j) out[j] = r6[j];
+      codes[sub][k][lane] = 3;
+    }
   }
-#ifdef ARTP_STAGE_TIMING
-  ARTP_C_MARK(4);
-  if (lane == 0) {
-    for (int p = 0; p < 5; ++p) atomicAdd(&g_classify_cycles[body ? 0 : 1][p], c_acc[p]);
-    atomicAdd(&g_classify_cycles[body ? 0 : 1][7], 1ull);
+  if (n_t > CAP_T) n_t = CAP_T;
+  if (n_f > CAP_F) n_f = CAP_F;
+  __syncthreads();
+  // Wavefronts without a list leave here: S_BARRIER waits on the surviving wavefronts of a workgroup only, and the
+  // wave slots they free let the next workgroup start while this one's tail (two dependent trips to the exact
+  // tables, then the queue atomic) is in flight.
+  if (wave >= WAVES_B) return;
+  // phase B: waves [0, WAVES_T) walk the torso list, waves [WAVES_T, WAVES_B) the foot list
+  const bool list_t = wave < WAVES_T;
+  const int slot = (int)threadIdx.x;  // list entry = record slot: torso [0, CAP_T), feet [CAP_T, CAP_T + CAP_F)
+  const bool have = list_t ? slot < n_t : slot - CAP_T < n_f;
+  int code2 = 0;
+  bool all_finite = false;
+  unsigned origin = 0, state = 0;
+  if (have) {
+    PendingBox rec;
+    const float4* src = open_recs + 6 * slot;
+    float4* dst = reinterpret_cast<float4*>(&rec);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[j] = src[j];
+    BoxHF bb;
+    box_from_record(rec, rb, bb);
+    state = rec.state;
+    origin = rec.pad[0];
+    if (list_t)
+      code2 = classify_tail(fb, tb, bb, true, all_finite);
+    else
+      code2 = classify_tail(ff, tf, bb, false, all_finite);
+    codes[(origin >> 6) % SUB][(origin >> 6) / SUB][origin & 63] = (uint8_t)code2;
   }
-#endif
+  __syncthreads();
+  // phase C
+  {
+    bool pending = have && code2 >= 2;
+    if (pending) {
+      const int os = (origin >> 6) % SUB, ol = origin & 63;
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) pending = pending && (codes[os][kk][ol] != 1);
+    }
+    const unsigned long long pbal = __ballot(pending);
+    const int pc = __popcll(pbal);
+    if (pc) {  // wave-uniform
+      if (pending) {
+        // the record's last 16 bytes with the verdict flags; its slot goes on the wavefront's copy list
+        open_recs[6 * slot + 5] = make_float4(__uint_as_float(state), __uint_as_float(record_kind(list_t, code2 == 2, all_finite)), 0.0f, 0.0f);
+        plist[wave * 64 + __popcll(pbal & lt_mask)] = (unsigned short)slot;
+      }
+      unsigned long long base = 0;
+      if (lane == 0) {
+        const int sq = blockIdx.x % ARTP_NSUB;
+        base = sub_base(q, list_t ? 0 : 1, sq) + atomicAdd(sub_counter(q, list_t ? 0 : 1, sq), (unsigned long long)pc);
+      }
+      base = __shfl(base, 0);
+      wave_lds_sync();
+      float4* out = reinterpret_cast<float4*>(q.q1 + base);
+      const unsigned short* pl = plist + wave * 64;
+      for (int j = lane; j < pc * 6; j += 64) {
+        const int e = j / 6;
+        out[j] = open_recs[6 * (int)pl[e] + (j - 6 * e)];
+      }
+    }
+  }
+  // verdicts: every code is final (the open ones were replaced in phase B, in front of a barrier)
+  if (body && live) {
+    bool ok = true;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
+    valid[i] = (uint8_t)ok;
+  }
 }
 
 // ---- fallback stage: foot boxes without a table verdict (queue 4), one LANE per box ---------------------

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 run() {
   rm -rf /tmp/pm; mkdir -p /tmp/pm
-  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pm -o t -- python $GRAFT_REPO_ROOT/bench.py --pmc-child > /tmp/pm/log 2>&1 || tail -3 /tmp/pm/log
+  timeout 150 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pm -o t -- python $GRAFT_REPO_ROOT/bench.py --pmc-child > /tmp/pm/log 2>&1 || tail -3 /tmp/pm/log
   python - <<PY
 import glob, sqlite3
 dbs = glob.glob("/tmp/pm/**/*_results.db", recursive=True)
@@ -14,8 +14,13 @@ if dbs:
             print("  %-42s %-40s %16.0f" % (kn.split("(")[0][-42:], cn, mx))
 PY
 }
-run TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum
-run TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
-run TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum
-run TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TCC_WRITE_REQ_sum
-run TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum GRBM_GUI_ACTIVE
+# each pass under its own timeout (a TA / TD pass once hung the box until gpurun's limit); PASSES="1 3" selects
+PASSES=${PASSES:-1 2 3}
+for p in $PASSES; do
+  case $p in
+    1) run TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum ;;
+    2) run FETCH_SIZE ;;
+    3) run SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU ;;
+    4) run SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE ;;
+  esac
+done

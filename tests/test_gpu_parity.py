@@ -558,3 +558,29 @@ def test_validity_bitmap_round_trip(big_map, ctx_yaml):
             ctx_yaml.sample_states_at_dev(7, 1234, idx, cnt, len(ref), out)
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), se3.cpu().numpy()[ref])
+
+
+def test_nan_speckled_layers_overflow_the_open_box_lists(big_map):
+    """A NaN in every 8 x 8 block of the foot layer: no stride-table block can decide a foot box, so all 512 foot
+    boxes of a classify workgroup stay open -- more than its LDS list holds; the overflow goes to the queue as
+    'tables could not answer' and the lane-scan stage finishes it.  Labels must still equal the oracle's."""
+    import copy
+    gm = copy.deepcopy(common.crop_map(big_map, 40, 70, 160))
+    rng = np.random.default_rng(77)
+    for name, step in (("elevation_masked", 6), ("elevation", 16)):
+        a = np.array(gm[name], dtype=np.float32, order="F")
+        jj, ii = np.meshgrid(np.arange(0, a.shape[1], step), np.arange(0, a.shape[0], step))
+        ii = np.clip(ii + rng.integers(0, step, ii.shape), 0, a.shape[0] - 1)
+        jj = np.clip(jj + rng.integers(0, step, jj.shape), 0, a.shape[1] - 1)
+        a[ii, jj] = np.nan
+        gm.layers[name] = np.asfortranarray(a)
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm, sampler=False)
+    se3 = common.random_states(gm, 40000, rng, z_off=(0.02, 0.12), tilt=0.15, spread=0.45)
+    vg = ctx.validate_states(se3)
+    cnt = ctx.pipeline_counters()
+    vo = O.OracleMap(gm).states_valid(O.robot("yaml"), se3)
+    assert np.array_equal(vg, vo), f"{(vg != vo).sum()} mismatches"
+    assert cnt["feet_queued"] > 1.5 * len(se3), cnt  # the foot boxes of every state whose torso is clear were queued
+    assert 0.05 < vg.mean() < 0.95
+    ctx.close()
