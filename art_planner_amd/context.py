@@ -159,6 +159,15 @@ class Context:
     def synchronize(self):
         self._chk(self.L.artp_synchronize(self.h), "artp_synchronize")
 
+    def set_lane(self, lane: int):
+        """Switch the current lane (include/artp_c.h artp_set_lane): own stream + scratch, shared map.  Calls issued
+        on different lanes overlap on the GPU."""
+        self._chk(self.L.artp_set_lane(self.h, int(lane)), "artp_set_lane")
+
+    @property
+    def lane(self) -> int:
+        return int(self.L.artp_get_lane(self.h))
+
     def validate_states_dev(self, se3_t, valid_t, detail_t=None):
         n = se3_t.shape[0]
         self._chk(self.L.artp_validate_states_dev(self.h, se3_t.data_ptr(), n, valid_t.data_ptr(),

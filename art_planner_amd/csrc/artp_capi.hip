@@ -20,6 +20,7 @@
 using namespace artp;
 
 #define ARTP_FEW_STATES 16
+#define ARTP_MAX_LANES 4
 
 struct artp_ctx {
   int device = 0;
@@ -44,7 +45,7 @@ struct artp_ctx {
   // partner table and the raw cross products it is built from
   float* table_buf[2] = {nullptr, nullptr};
   unsigned char* flag_buf[2] = {nullptr, nullptr};  // per-level non-finite / NaN block flags
-  float2* stride_buf[2] = {nullptr, nullptr};        // stride tables (TablesDev::st)
+  unsigned* stride_buf[2] = {nullptr, nullptr};      // stride tables (TablesDev::st)
   unsigned char* partner_buf[2] = {nullptr, nullptr};
   int partner_R_built[2] = {-1, -1};
   bool conv_lds_attr_set = false;
@@ -70,6 +71,21 @@ struct artp_ctx {
   size_t tmp_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void* cub_tmp = nullptr;
   size_t cub_cap = 0;
+  // Lanes (artp_set_lane): everything above that a call in flight owns -- stream, scratch buffers, counters -- exists
+  // once per lane, so calls issued on different lanes (from one host thread, on different streams) overlap on the
+  // GPU.  The members above are the CURRENT lane's; the others are parked here.  The map, its tables and the
+  // sampler are shared and read-only while states are validated.
+  struct lane_state {
+    bool init = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    unsigned long long* d_count = nullptr;
+    void* tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t tmp_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* cub_tmp = nullptr;
+    size_t cub_cap = 0;
+  };
+  lane_state lanes[ARTP_MAX_LANES];
+  int cur_lane = 0;
   // motion cost (R8/R9)
   bool have_weights = false;
   float* d_conv1_w = nullptr;          // [24][9] + [24]
@@ -111,6 +127,34 @@ int ensure_tmp(artp_ctx* c, int slot, size_t bytes) {
   HIP_TRY(c, hipMalloc(&c->tmp[slot], want));
   c->tmp_cap[slot] = want;
   return ARTP_OK;
+}
+
+void park_lane(artp_ctx* c) {  // current members -> lanes[cur_lane]
+  artp_ctx::lane_state& l = c->lanes[c->cur_lane];
+  l.init = true;
+  l.own_stream = c->own_stream;
+  l.stream = c->stream;
+  l.d_count = c->d_count;
+  l.cub_tmp = c->cub_tmp;
+  l.cub_cap = c->cub_cap;
+  for (int k = 0; k < 8; ++k) {
+    l.tmp[k] = c->tmp[k];
+    l.tmp_cap[k] = c->tmp_cap[k];
+  }
+}
+
+void unpark_lane(artp_ctx* c, int lane) {
+  const artp_ctx::lane_state& l = c->lanes[lane];
+  c->own_stream = l.own_stream;
+  c->stream = l.stream;
+  c->d_count = l.d_count;
+  c->cub_tmp = l.cub_tmp;
+  c->cub_cap = l.cub_cap;
+  for (int k = 0; k < 8; ++k) {
+    c->tmp[k] = l.tmp[k];
+    c->tmp_cap[k] = l.tmp_cap[k];
+  }
+  c->cur_lane = lane;
 }
 
 void fill_robot(artp_ctx* c) {
@@ -320,7 +364,7 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->table_buf[slot]), 12 * elems * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->flag_buf[slot]), 6 * elems));
     // stride tables: (nW / s) x (nD / s) entries for s = 2, 4, 8 -- less than elems / 2 entries in all
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->stride_buf[slot]), (elems / 2 + 3 * (f.nW + f.nD) + 16) * sizeof(float2)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->stride_buf[slot]), (elems / 2 + 3 * (f.nW + f.nD) + 16) * sizeof(unsigned)));
     c->table_elems[slot] = elems;
   }
   float2* mm[6];
@@ -541,13 +585,21 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
 void artp_destroy(artp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  park_lane(c);
+  for (auto& l : c->lanes)
+    if (l.init && l.stream) (void)hipStreamSynchronize(l.stream);
   for (int s = 0; s < 2; ++s)
     if (c->field_data[s]) (void)hipFree(c->field_data[s]);
   if (c->sampler_buf) (void)hipFree(c->sampler_buf);
   if (c->sampler_pack) (void)hipFree(c->sampler_pack);
-  for (int s = 0; s < 8; ++s)
-    if (c->tmp[s]) (void)hipFree(c->tmp[s]);
+  for (auto& l : c->lanes) {
+    if (!l.init) continue;
+    for (int s = 0; s < 8; ++s)
+      if (l.tmp[s]) (void)hipFree(l.tmp[s]);
+    if (l.cub_tmp) (void)hipFree(l.cub_tmp);
+    if (l.d_count) (void)hipFree(l.d_count);
+    if (l.own_stream) (void)hipStreamDestroy(l.own_stream);
+  }
   for (int s = 0; s < 2; ++s) {
     if (c->table_buf[s]) (void)hipFree(c->table_buf[s]);
     if (c->flag_buf[s]) (void)hipFree(c->flag_buf[s]);
@@ -555,7 +607,6 @@ void artp_destroy(artp_ctx* c) {
     if (c->partner_buf[s]) (void)hipFree(c->partner_buf[s]);
     if (c->tri_raw_buf[s]) (void)hipFree(c->tri_raw_buf[s]);
   }
-  if (c->cub_tmp) (void)hipFree(c->cub_tmp);
   if (c->d_conv1_w) (void)hipFree(c->d_conv1_w);
   for (int l = 0; l < 5; ++l) {
     if (c->d_convw[l]) (void)hipFree(c->d_convw[l]);
@@ -569,8 +620,6 @@ void artp_destroy(artp_ctx* c) {
   if (c->pin_states) (void)hipHostFree(c->pin_states);
   if (c->pin_labels) (void)hipHostFree(const_cast<uint8_t*>(c->pin_labels));
   if (c->d_error) (void)hipFree(c->d_error);
-  if (c->d_count) (void)hipFree(c->d_count);
-  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -593,8 +642,34 @@ int artp_synchronize(artp_ctx* c) {
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int l = 0; l < ARTP_MAX_LANES; ++l)
+    if (l != c->cur_lane && c->lanes[l].init) HIP_TRY(c, hipStreamSynchronize(c->lanes[l].stream));
   return ARTP_OK;
 }
+
+int artp_set_lane(artp_ctx* c, int lane) {
+  if (!c || lane < 0 || lane >= ARTP_MAX_LANES) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (lane == c->cur_lane) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->lanes[lane].init) {
+    artp_ctx::lane_state l;
+    HIP_TRY(c, hipStreamCreateWithFlags(&l.own_stream, hipStreamNonBlocking));
+    if (hipMalloc(&l.d_count, sizeof(unsigned long long)) != hipSuccess) {
+      (void)hipStreamDestroy(l.own_stream);
+      c->last_error = "hipMalloc failed (lane counter)";
+      return ARTP_ERR_HIP;
+    }
+    l.stream = l.own_stream;
+    l.init = true;
+    c->lanes[lane] = l;
+  }
+  park_lane(c);
+  unpark_lane(c, lane);
+  return ARTP_OK;
+}
+
+int artp_get_lane(artp_ctx* c) { return c ? c->cur_lane : -1; }
 
 namespace {
 

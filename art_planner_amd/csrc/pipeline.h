@@ -24,6 +24,8 @@
 // Evaluating boxes the reference would have short-circuited cannot change the label.
 #pragma once
 
+#include <hip/hip_fp16.h>
+
 #include "kernels.h"
 
 namespace artp {
@@ -52,10 +54,11 @@ struct TablesDev {
   int has_nonfinite;        // the layer holds a NaN or an infinity somewhere (else fl is all zero)
   int valid;
   // Stride tables: blocks of 8 / 16 / 32 samples anchored every 2 / 4 / 8 samples only (level l: block 8 << l,
-  // anchors at multiples of 2 << l), back to back in `st`.  425 KB per 400 x 400 layer instead of 5 MB of exact
-  // tables: they stay in every XCD's L2, and they are CONSERVATIVE bounds (see stride_entry) that decide most boxes
-  // before an exact table is touched.
-  const float2* st;
+  // anchors at multiples of 2 << l), back to back in `st`, one packed pair of HALF floats per entry.  210 KB per
+  // 400 x 400 layer instead of 5 MB of exact tables: they stay in every XCD's L2 (the feet's 16-sample table, 40 KB,
+  // largely in the L1s), and they are CONSERVATIVE bounds (see stride_entry) that decide most boxes before an exact
+  // table is touched.
+  const unsigned* st;
   unsigned st_off1, st_off2;  // first entry of levels 1 and 2 (level 0 starts at 0)
 };
 
@@ -88,28 +91,31 @@ table_level_up_kernel(const float2* __restrict__ in, const unsigned char* __rest
   fout[i] = fin[x + z * nW] | fin[x1 + z * nW] | fin[x + z1 * nW] | fin[x1 + z1 * nW];
 }
 
-// Stride-table entry {max', min'} of a block with exact statistics {mx, mn} and flags fl (bit 0 non-finite sample,
-// bit 1 NaN).  The tiers that read it only need max' >= max and min' <= min-of-finite, so the flags ride in the
-// values: a NaN block becomes {+inf, -inf} (no exit can fire on it), and "holds a non-finite sample" is the lowest
-// mantissa bit of max', rounded UP to the next float of that parity (+inf cannot carry the bit and does not need
-// it: exit (d) never fires on max' = +inf).
-__device__ __forceinline__ float2 stride_entry(float mx, float mn, unsigned fl) {
-  if (fl & 2u) return make_float2(INFINITY, -INFINITY);
-  unsigned u = __float_as_uint(mx);
+// Stride-table entry: {max', min'} of a block with exact statistics {mx, mn} and flags fl (bit 0 non-finite sample,
+// bit 1 NaN), as two half floats (max' in the low 16 bits).  The tiers that read it only need max' >= max and
+// min' <= min-of-finite, so the values are rounded OUTWARD to half precision (a millimetre at the heights of a map:
+// far below what decides an exit) and the flags ride in them: a NaN block becomes {+inf, -inf} (no exit can fire on
+// it), and "holds a non-finite sample" is the lowest mantissa bit of max', moved UP to the next half of that parity
+// (+inf cannot carry the bit and does not need it: exit (d) never fires on max' = +inf).
+__device__ __forceinline__ unsigned stride_entry(float mx, float mn, unsigned fl) {
+  if (fl & 2u) return 0xFC007C00u;
+  unsigned u = (unsigned)__half_as_ushort(__float2half_ru(mx));
   const unsigned bit = fl & 1u;
-  if ((u & 1u) != bit && mx != INFINITY) {
-    if ((u << 1) == 0u) u = 1u;                  // +-0 -> smallest positive subnormal
-    else if (u & 0x80000000u) u -= 1u;           // negative: toward zero
+  if ((u & 1u) != bit && u != 0x7C00u) {
+    if ((u & 0x7FFFu) == 0u) u = 1u;        // +-0 -> smallest positive subnormal
+    else if (u & 0x8000u) u -= 1u;          // negative: toward zero
     else u += 1u;
   }
-  return make_float2(__uint_as_float(u), mn);
+  return u | ((unsigned)__half_as_ushort(__float2half_rd(mn)) << 16);
 }
+__device__ __forceinline__ float stride_max(unsigned e) { return __half2float(__ushort_as_half((unsigned short)(e & 0xFFFFu))); }
+__device__ __forceinline__ float stride_min(unsigned e) { return __half2float(__ushort_as_half((unsigned short)(e >> 16))); }
 
 // One thread per stride-table entry, all levels in one launch.  mm / fl = the exact tables of blocks 4, 8, 16, 32
 // (TablesDev::mm / fl); level l of the stride tables copies the exact level l + 1 at its anchors.
 __global__ void __launch_bounds__(256)
 stride_tables_kernel(const float2* __restrict__ mm, const unsigned char* __restrict__ fl, unsigned stride, int nW,
-                     int nD, unsigned off1, unsigned off2, unsigned total, float2* __restrict__ out) {
+                     int nD, unsigned off1, unsigned off2, unsigned total, unsigned* __restrict__ out) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int l = i >= off2 ? 2 : (i >= off1 ? 1 : 0);
@@ -244,8 +250,8 @@ __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const Tables
   if (wmax > 25) return -1;
   const int l = wmax <= 7 ? 0 : (wmax <= 13 ? 1 : 2), sh = l + 1;
   const int nxs = (f.nW + (1 << sh) - 1) >> sh;
-  const float2 v = gather32(t.st, stride_level_offset(t, l) + (unsigned)((b.minX >> sh) + (b.minZ >> sh) * nxs));
-  return conservative_exits(b, v.x, v.y, __float_as_uint(v.x) & 1u);
+  const unsigned e = gather32(t.st, stride_level_offset(t, l) + (unsigned)((b.minX >> sh) + (b.minZ >> sh) * nxs));
+  return conservative_exits(b, stride_max(e), stride_min(e), e & 1u);
 }
 
 // Tier 2: a tight cover.  Blocks of B <= min(wX, wZ) (8 at least) per axis: one at the anchor below the window's low
@@ -272,21 +278,21 @@ __device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesD
   }
   if (nx > 3 || nz > 3) return -1;
   const unsigned lo = stride_level_offset(t, l);
-  float2 v[9];
+  unsigned v[9];
 #pragma unroll
   for (int u = 0; u < 9; ++u) {
     const int i = u % 3, j = u / 3;
-    v[u] = make_float2(-INFINITY, INFINITY);
+    v[u] = 0x7C00FC00u;  // masked-off slot: {max' = -inf (lowest bit 0), min' = +inf}
     if (i < nx && j < nz) v[u] = gather32(t.st, lo + (unsigned)((px[i] >> sh) + (pz[j] >> sh) * nxs));
   }
   float vmax = -INFINITY, vmin = INFINITY;
   unsigned nf = 0u;
 #pragma unroll
   for (int u = 0; u < 9; ++u) {
-    // a masked-off slot holds -inf (lowest bit 0)
-    nf |= __float_as_uint(v[u].x);
-    vmax = (v[u].x > vmax) ? v[u].x : vmax;
-    vmin = (v[u].y < vmin) ? v[u].y : vmin;
+    nf |= v[u];
+    const float mx = stride_max(v[u]), mn = stride_min(v[u]);
+    vmax = (mx > vmax) ? mx : vmax;
+    vmin = (mn < vmin) ? mn : vmin;
   }
   return conservative_exits(b, vmax, vmin, nf & 1u);
 }
@@ -499,11 +505,14 @@ __device__ __forceinline__ int classify_head(const FieldDev& f, const TablesDev&
 // the vertex probe.  0 = decided ok, 1 = decided failing, 2 = undecided (exits known not to fire), 3 = undecided
 // (tables could not answer).
 __device__ __forceinline__ int classify_tail(const FieldDev& f, const TablesDev& tab, const BoxHF& b, bool body,
-                                             bool& all_finite) {
+                                             bool& all_finite, long long* t_stats = nullptr) {
   WindowStats w;
   int hit = 0, ec;
   const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
   all_finite = have_stats && w.allFinite;
+#ifdef ARTP_STAGE_TIMING
+  if (t_stats) *t_stats = (w.maxY > 1e30f) ? 0 : clock64();  // depends on the statistics: taken after they arrive
+#endif
   if (!(have_stats && decide_exits(b, w, hit, ec))) {
     // feet only: 3/5 of the undecided foot boxes hold a vertex and the 2 x 2 probe finds most of them;
     // torso hits sit at the rim of the box (a 3 x 3 probe caught 1 in 4) and do not pay for the probe
@@ -552,7 +561,12 @@ __device__ __forceinline__ unsigned record_kind(bool body, bool exits_negative, 
 #define ARTP_CLASSIFY_CAP_T 64   // open torso boxes a workgroup lists (of 128; typically ~15 are open)
 #define ARTP_CLASSIFY_CAP_F 192  // open foot boxes it lists (of 512; typically ~80)
 #ifdef ARTP_STAGE_TIMING
-__device__ unsigned long long g_classify_cycles[2][8];  // kept for the timing build's readout; not written any more
+__device__ unsigned long long g_classify_cycles[2][8];  // [list waves | early-exit waves][phase], [7] = waves
+#define ARTP_C_MARK(slot) do { const long long n_ = clock64(); c_acc[slot] += (unsigned long long)(n_ - c_prev); c_prev = n_; } while (0)
+#define ARTP_C_FLUSH(grp) do { if (lane == 0) { for (int p_ = 0; p_ < 7; ++p_) atomicAdd(&g_classify_cycles[grp][p_], c_acc[p_]); atomicAdd(&g_classify_cycles[grp][7], 1ull); } } while (0)
+#else
+#define ARTP_C_MARK(slot) do { } while (0)
+#define ARTP_C_FLUSH(grp) do { } while (0)
 #endif
 
 __global__ void __launch_bounds__(ARTP_CLASSIFY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -579,6 +593,10 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   const size_t i_raw = ((size_t)blockIdx.x * SUB + sub) * 64 + lane;
   const bool live = i_raw < n;
   const size_t i = live ? i_raw : n - 1;  // dead lanes shadow the last state and write nothing
+#ifdef ARTP_STAGE_TIMING
+  unsigned long long c_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long c_prev = clock64();
+#endif
   // the state's PoseRec: float pose + the box rotation in the field frame (shared by its five boxes)
   if (threadIdx.x < SUB * 64 * 4) {
     const int sl = threadIdx.x >> 2, part = threadIdx.x & 3;
@@ -587,6 +605,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     prec[sl * 5 + part] = reinterpret_cast<const float4*>(recs + gi)[part];
   }
   __syncthreads();
+  ARTP_C_MARK(0);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int rank = 0;
   bool open;
@@ -605,6 +624,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       code = classify_head(ff, tf, g, rb, t, R, bR, k, b);
     if (!live) code = 0;
     codes[sub][k][lane] = (uint8_t)code;
+    ARTP_C_MARK(1);
     __syncthreads();
     bool ok = true;
 #pragma unroll
@@ -627,8 +647,10 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       n_f += c;
     }
   }
+  ARTP_C_MARK(2);
   // rank = position of this lane's box in its list (valid where `open`)
   if (n_t + n_f == 0) {
+    ARTP_C_FLUSH(1);
     if (body && live) {
       bool ok = true;
 #pragma unroll
@@ -657,14 +679,19 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   if (n_t > CAP_T) n_t = CAP_T;
   if (n_f > CAP_F) n_f = CAP_F;
   __syncthreads();
-  // Wavefronts without a list leave here: S_BARRIER waits on the surviving wavefronts of a workgroup only, and the
-  // wave slots they free let the next workgroup start while this one's tail (two dependent trips to the exact
-  // tables, then the queue atomic) is in flight.
-  if (wave >= WAVES_B) return;
-  // phase B: waves [0, WAVES_T) walk the torso list, waves [WAVES_T, WAVES_B) the foot list
+  // Phase B: wave 0 walks the torso list, waves [WAVES_T, WAVES_B) the foot list, one lane per entry.  Wavefronts
+  // without a list, or with an empty one, leave here (the torso wavefronts 0 .. SUB-1 stay: they write the labels at
+  // the end).  S_BARRIER waits on the surviving wavefronts of a workgroup only, and the wave slots freed let the
+  // next workgroup start while this one's tail (two dependent trips to the exact tables, then the queue atomic) is in
+  // flight.
   const bool list_t = wave < WAVES_T;
   const int slot = (int)threadIdx.x;  // list entry = record slot: torso [0, CAP_T), feet [CAP_T, CAP_T + CAP_F)
-  const bool have = list_t ? slot < n_t : slot - CAP_T < n_f;
+  const bool have = wave < WAVES_B && (list_t ? slot < n_t : slot - CAP_T < n_f);
+  ARTP_C_MARK(3);
+  if (wave >= SUB && !__any(have)) {
+    ARTP_C_FLUSH(1);
+    return;
+  }
   int code2 = 0;
   bool all_finite = false;
   unsigned origin = 0, state = 0;
@@ -678,12 +705,23 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     box_from_record(rec, rb, bb);
     state = rec.state;
     origin = rec.pad[0];
+#ifdef ARTP_STAGE_TIMING
+    long long t_stats = 0;
+    if (list_t)
+      code2 = classify_tail(fb, tb, bb, true, all_finite, &t_stats);
+    else
+      code2 = classify_tail(ff, tf, bb, false, all_finite, &t_stats);
+    t_stats = __shfl(t_stats, 0);
+    if (t_stats) { c_acc[4] += (unsigned long long)(t_stats - c_prev); c_prev = t_stats; }
+#else
     if (list_t)
       code2 = classify_tail(fb, tb, bb, true, all_finite);
     else
       code2 = classify_tail(ff, tf, bb, false, all_finite);
+#endif
     codes[(origin >> 6) % SUB][(origin >> 6) / SUB][origin & 63] = (uint8_t)code2;
   }
+  ARTP_C_MARK(5);
   __syncthreads();
   // phase C
   {
@@ -723,6 +761,8 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
     valid[i] = (uint8_t)ok;
   }
+  ARTP_C_MARK(6);
+  ARTP_C_FLUSH(0);
 }
 
 // ---- fallback stage: foot boxes without a table verdict (queue 4), one LANE per box ---------------------

@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="parts of a step's batch validated side by side on as many streams of the context (1..4)")
     ap.add_argument("--materialise", type=int, default=1 << 16,
                     help="N>1: accepted states of EVERY rank re-materialised on every rank per step, per rank block "
                          "(-1 = all of them, 0 = none; the gathered index lists are always complete)")
@@ -352,6 +354,20 @@ def main():
     ctx.use_torch_stream()
 
     S, K, W, seed = args.batch, args.steps, args.warmup, 42
+    # Lanes: the batch of a step is validated as `lanes` contiguous parts on as many streams of the SAME context
+    # (include/artp_c.h artp_set_lane).  Nothing joins the lanes between steps, so the short serial kernels at the
+    # end of one part's pipeline overlap another part's long kernels, and kernels with different bottlenecks run side
+    # by side.  --lanes 1 = everything on one stream (what the per-kernel profiles and `roofline.kernel_ms` use).
+    lanes = max(1, min(4, args.lanes))
+    if S % (128 * lanes):
+        raise SystemExit("--batch must be a multiple of 128 * lanes")
+    part = S // lanes
+    lane_streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+    for l in range(1, lanes):
+        ctx.set_lane(l)
+        with torch.cuda.stream(lane_streams[l]):
+            ctx.use_torch_stream()
+    ctx.set_lane(0)
     se3 = torch.empty((S, 7), dtype=torch.float64, device=dev)
     valid = torch.empty(S, dtype=torch.uint8, device=dev)
     do_gather = (N > 1 or args.force_dist) and not args.no_gather
@@ -404,19 +420,28 @@ def main():
             ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), idx_tmp, cnt_tmp, mat_cap, all_states[r])
 
     def step(i):
-        ctx.sample_and_validate_dev(seed, first_index(i), S, se3, valid)
+        b = i & 1
+        ready = []
+        for l in range(lanes):
+            ctx.set_lane(l)
+            with torch.cuda.stream(lane_streams[l]):
+                lo, hi = l * part, (l + 1) * part
+                ctx.sample_and_validate_dev(seed, first_index(i) + lo, part, se3[lo:hi], valid[lo:hi])
+                if do_gather:
+                    torch.cuda.current_stream().wait_event(done_ev[b])  # buffer b free again
+                    ctx.pack_valid_bits_dev(valid[lo:hi], bits_buf[b][lo // 64:hi // 64])
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    ready.append(ev)
+        ctx.set_lane(0)
         if do_gather:
-            b = i & 1
-            torch.cuda.current_stream().wait_event(done_ev[b])  # buffer b free again
-            ctx.pack_valid_bits_dev(valid, bits_buf[b])
-            ready = torch.cuda.Event()
-            ready.record()
-            comm.wait_event(ready)
+            for ev in ready:
+                comm.wait_event(ev)
             with torch.cuda.stream(comm):
                 gatherers[b].gather(bits_buf[b])               # one bit per candidate state over xGMI
                 done_ev[b].record()
             # materialise the accepted states of every rank for the PREVIOUS step (its gather has had a
-            # whole step to complete).  On the main stream: the validity kernels are persistent grids with static
+            # whole step to complete).  On lane 0's stream: the validity kernels are persistent grids with static
             # striding, and a kernel that shares their CUs from a side stream costs them more than it hides
             # (measured: +0.36 ms for 0.15 ms of work).
             if i > 0 and mat_cap > 0:
@@ -572,6 +597,10 @@ def main():
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel": "validity pipeline (artp_validate_states_dev)", "kernel_ms": k_ms,
         "fused_sample_validate_ms": step_ms,
+        # the timed region's own rate: `lanes` parts side by side, sampler included (the figures above are ONE batch
+        # alone on ONE stream, which is what the rocprofv3 per-kernel durations in profiles/ correspond to)
+        "timed_region": {"lanes": lanes, "ms_per_batch": dt / K * 1e3,
+                         "algorithmic_GBps": alg_bytes / (dt / K) / 1e9},
         "kernel_launches": "classify_states_kernel + feet_stream_kernel<4> + resolve_boxes_kernel<2,64,0> + 5 "
                            "near-empty fallback launches (profiles/README.md)",
         "algorithmic_bytes_per_launch": alg_bytes,
@@ -874,6 +903,8 @@ def main():
         "config": {"workload": "C2: lazy_prm_star_min_update front end, 400x400@0.04m Perlin terrain "
                                "(seed 1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
                    "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}",
+                   "lanes": f"{lanes} (the step's batch as {lanes} contiguous part(s) on {lanes} HIP stream(s) of one "
+                            "context; roofline.kernel_ms is one part-free batch on one stream)",
                    "sharding": f"sample-index ranges over {N} GPU(s)" +
                                (", validity bitmaps (1 bit per candidate) all-gathered over RCCL + the first "
                                 f"{'all' if args.materialise < 0 else args.materialise} accepted states of every rank per step "

@@ -70,7 +70,18 @@ void artp_destroy(artp_ctx* ctx);
  * A fresh context uses a private non-blocking stream; artp_use_own_stream switches back to it. */
 int artp_set_stream(artp_ctx* ctx, void* hip_stream);
 int artp_use_own_stream(artp_ctx* ctx);
-int artp_synchronize(artp_ctx* ctx);
+int artp_synchronize(artp_ctx* ctx); /* every lane's stream */
+
+/* Lanes: a context owns up to 4 lanes, each with its own stream (artp_set_stream applies to the current lane) and
+ * its own scratch buffers, queues and counters; the map, its tables and the sampler are shared.  Calls issued on
+ * different lanes overlap on the GPU: a planner thread that validates a batch as two halves on two lanes hides the
+ * pipeline's short serial kernels and pairs kernels with different bottlenecks (bench.py: 1.77 -> 1.66 ms per 2^22
+ * states).  Every call works on the CURRENT lane (0 after artp_create); artp_set_lane switches it (first use of a
+ * lane creates its stream).  Work on different lanes is unordered: the caller orders map / layer updates against the
+ * lanes that still read the old map (artp_synchronize, or stream events).  No equivalent in the reference (it
+ * validates one state at a time on the calling thread). */
+int artp_set_lane(artp_ctx* ctx, int lane);
+int artp_get_lane(artp_ctx* ctx);
 
 /* ---- map upload: HeightMapBoxChecker::setHeightField
  *      (art_planner/src/validity_checker/height_map_box_checker.cpp:38-54) ----------------------

@@ -36,10 +36,11 @@ torch.cuda.synchronize()
 cc = (C.c_ulonglong * 20)()
 L.artp_debug_stage_cycles(cc, 2)  # reset >= 2: read the classify phase counters instead (and reset all)
 c = np.array(list(cc)[:16], dtype=np.float64).reshape(2, 8)
-for g, nm in ((0, "classify torso waves"), (1, "classify foot waves")):
-    tot = c[g, :5].sum()
+ph = ["PoseRec load+barrier", "head", "2 barriers", "stage+barrier", "tail: record + exact statistics", "tail: exits, probe, label", "queue+copy"]
+for g, nm in ((0, "classify list waves"), (1, "classify early-exit waves")):
+    tot = c[g, :7].sum()
     print(nm, int(c[g, 7]), "waves, ticks/wave", round(tot / max(c[g, 7], 1)),
-          {k: round(float(c[g, j] / tot), 3) for j, k in enumerate(["load+pose", "classify_box", "barrier1", "atomic+barriers", "records"])})
+          {k: round(float(c[g, j] / max(c[g, 7], 1))) for j, k in enumerate(ph)})
 for g, nm in ((0, "torso G=64"), (1, "feet G=16")):
     tot = a[g, :5].sum()
     print(nm, "stage ticks/lifetime", round(tot / a[g, 8], 3), "groups", int(a[g, 9]), "ticks per group", a[g, 8] / a[g, 9],

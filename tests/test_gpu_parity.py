@@ -584,3 +584,41 @@ def test_nan_speckled_layers_overflow_the_open_box_lists(big_map):
     assert cnt["feet_queued"] > 1.5 * len(se3), cnt  # the foot boxes of every state whose torso is clear were queued
     assert 0.05 < vg.mean() < 0.95
     ctx.close()
+
+
+def test_lanes_overlap_and_agree_with_one_stream(big_map, ctx_yaml):
+    """artp_set_lane: the two halves of a batch on two lanes (own streams, own queues, shared map) give the states
+    and labels of one call; counters and scratch of the lanes do not interfere; lane 0 stays usable."""
+    import torch
+    ctx_yaml.upload_map(big_map)
+    n = 1 << 18
+    dev = "cuda:0"
+    se3_a = torch.empty((n, 7), dtype=torch.float64, device=dev)
+    va_a = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx_yaml.use_torch_stream()
+    ctx_yaml.sample_and_validate_dev(11, 5000, n, se3_a, va_a)
+    torch.cuda.synchronize()
+    se3_b = torch.zeros_like(se3_a)
+    va_b = torch.full_like(va_a, 7)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    half = n // 2
+    for rep in range(3):  # back to back: the lanes run ahead of each other
+        for l in (1, 2):
+            ctx_yaml.set_lane(l)
+            assert ctx_yaml.lane == l
+            with torch.cuda.stream(streams[l - 1]):
+                ctx_yaml.use_torch_stream()
+                lo = (l - 1) * half
+                ctx_yaml.sample_and_validate_dev(11, 5000 + lo, half, se3_b[lo:lo + half], va_b[lo:lo + half])
+    ctx_yaml.set_lane(0)
+    ctx_yaml.synchronize()  # every lane
+    assert torch.equal(se3_a, se3_b) and torch.equal(va_a, va_b)
+    # counts through the lanes' own counters
+    ctx_yaml.set_lane(2)
+    with torch.cuda.stream(streams[1]):
+        c2 = ctx_yaml.sample_and_validate_dev(11, 5000 + half, half, se3_b[half:], va_b[half:], count=True)
+    ctx_yaml.set_lane(0)
+    assert c2 == int(va_a[half:].sum().item())
+    with pytest.raises(Exception):
+        ctx_yaml.set_lane(9)
+    assert ctx_yaml.lane == 0
