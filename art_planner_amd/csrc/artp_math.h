@@ -50,6 +50,14 @@ struct FieldDev {
 };
 
 // Box in heightfield frame, ready for the zone test.
+// base[idx] with the BYTE offset formed in 32 bits: the load becomes `global_load v, v_off, s[base]` (uniform
+// base in SGPRs, one VGPR of offset) instead of a per-lane 64-bit address built with three more VALU operations.
+// Every table and layer this is used on is far smaller than 4 GB.
+template <class T>
+ARTP_HD T gather32(const T* __restrict__ base, unsigned idx) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
+}
+
 struct BoxHF {
   float pos[3];
   float R[9];  // row-major 3x3 (R1 = Rt^T * R)

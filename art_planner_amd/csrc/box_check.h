@@ -200,7 +200,7 @@ __device__ __forceinline__ void grp_scan_window(const FieldDev& f, const BoxHF& 
   const int qz = G / numX, rx = G - qz * numX;  // advance of (xl, zl) per G elements
   {
     int xl = gl % numX, zl = gl / numX;
-    const float* base = f.data + b.minX + (size_t)b.minZ * f.nW;
+    const unsigned base = (unsigned)(b.minX + b.minZ * f.nW);  // sample index: 32-bit offsets from the uniform f.data
     // 8 independent loads in flight per lane before the first use (the window comes from L2: a
     // dependent load per step would pay the full L2 latency 17 times for a torso window)
     constexpr int U = 8;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void grp_scan_window(const FieldDev& f, const BoxHF& 
       for (int u = 0; u < U; ++u) {
         xs[u] = xl;
         zs[u] = zl;
-        hv[u] = (e0 + G * u < total) ? base[xl + zl * f.nW] : 0.0f;
+        hv[u] = (e0 + G * u < total) ? gather32(f.data, base + (unsigned)(xl + zl * f.nW)) : 0.0f;
         xl += rx;
         zl += qz;
         if (xl >= numX) {
@@ -351,7 +351,7 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
   const int qz = G / inX, rx = G - qz * inX;
   int xl = gl % inX, zl = gl / inX;  // position in the inner grid; window-local = (x0 + xl, z0 + zl)
   const int nW = f.nW;
-  const float* base = f.data + (b.minX + x0) + (size_t)(b.minZ + z0) * nW;
+  const unsigned base = (unsigned)((b.minX + x0) + (b.minZ + z0) * nW);
   bool hit = false;
   for (int e0 = gl; e0 < total; e0 += G * U) {
     float hv[U];
@@ -360,7 +360,7 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
     for (int u = 0; u < U; ++u) {
       xs[u] = xl;
       zs[u] = zl;
-      hv[u] = (e0 + G * u < total) ? base[xl + zl * nW] : -INFINITY;
+      hv[u] = (e0 + G * u < total) ? gather32(f.data, base + (unsigned)(xl + zl * nW)) : -INFINITY;
       xl += rx;
       zl += qz;
       if (xl >= inX) {
@@ -376,7 +376,7 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
         if (all_finite) {
           hit = true;
         } else {
-          const float* c = base + xs[u] + zs[u] * nW;
+          const float* c = f.data + base + xs[u] + zs[u] * nW;
           const int wx = x0 + xs[u], wz = z0 + zs[u];  // window-local: the triangles counted are the window's
           const bool xm = wx > 0, xp = wx < cellsX, zm = wz > 0, zp = wz < cellsZ;
           const bool f_xp = xp && is_finite(c[1]);
@@ -693,9 +693,17 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
     float craw[3] = {0.0f, 0.0f, 0.0f};
     if (is_cand) {
       // GLOBAL_H: no LDS tile was staged (fast mode only), read the four samples of the cell from the map
-      const float* hp = GLOBAL_H ? f.data + (b.minX + cx) + (size_t)(b.minZ + cz) * f.nW : s.h + cz * numX + cx;
-      const int hstride = GLOBAL_H ? f.nW : numX;
-      const float hA = hp[0], hB = hp[1], hC = hp[hstride], hD = hp[hstride + 1];
+      float hA, hB, hC, hD;
+      if (GLOBAL_H) {
+        const unsigned at = (unsigned)((b.minX + cx) + (b.minZ + cz) * f.nW);
+        hA = gather32(f.data, at);
+        hB = gather32(f.data, at + 1u);
+        hC = gather32(f.data, at + (unsigned)f.nW);
+        hD = gather32(f.data, at + (unsigned)f.nW + 1u);
+      } else {
+        const float* hp = s.h + cz * numX + cx;
+        hA = hp[0], hB = hp[1], hC = hp[numX], hD = hp[numX + 1];
+      }
       const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
       const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
       bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
@@ -710,7 +718,7 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
       is_cand = kept;
       if (kept && fast)
         maybe_partner = maybe_partner || !window_covered ||
-                        ((f.partner_flags[(b.minX + cx) + (size_t)(b.minZ + cz) * f.nW] >> (c_up ? 0 : 1)) & 1);
+                        ((gather32(f.partner_flags, (unsigned)((b.minX + cx) + (b.minZ + cz) * f.nW)) >> (c_up ? 0 : 1)) & 1);
       if (kept) {
         const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
         const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;

@@ -32,14 +32,6 @@ namespace artp {
 
 #define ARTP_TABLE_LEVELS 4  // block sizes 4, 8, 16, 32 samples
 
-// base[idx] with the BYTE offset formed in 32 bits: the load becomes `global_load v, v_off, s[base]` (uniform
-// base in SGPRs, one VGPR of offset) instead of a per-lane 64-bit address built with three more VALU operations.
-// Every table and layer this is used on is far smaller than 4 GB.
-template <class T>
-__device__ __forceinline__ T gather32(const T* __restrict__ base, unsigned idx) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
-}
-
 struct TablesDev {
   // {max, min-of-finite} interleaved so one 8-byte gather answers both (the lookups are random
   // accesses into tables larger than one XCD's L2: cache lines touched, not bytes, are the cost).
