@@ -372,6 +372,13 @@ struct PipelineQueues {
 __device__ __forceinline__ unsigned long long* sub_counter(const PipelineQueues& q, int kind, int s) {
   return q.sub + (size_t)(kind * ARTP_NSUB + s) * 16;
 }
+// Consumer cursor of a sub-queue (same 128-byte line as its slot counter, which is final by then): the streaming
+// kernels take their boxes in chunks through it instead of a static stride.  A group's 55 boxes cost anywhere
+// between an early vertex hit and a full corner stage, and with a static stride the kernel lasts as long as its
+// unluckiest group.
+__device__ __forceinline__ unsigned long long* sub_cursor(const PipelineQueues& q, int kind, int s) {
+  return sub_counter(q, kind, s) + 1;
+}
 // first record of sub-queue s of the torso (kind 0) / foot (kind 1) queue
 __device__ __forceinline__ unsigned long long sub_base(const PipelineQueues& q, int kind, int s) {
   return kind ? q.feet_base + (unsigned long long)s * 4ull * q.seg_t : (unsigned long long)s * q.seg_t;
@@ -766,6 +773,12 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 // plane stage) are compacted into queue 3 for the lane-group stage, one atomic per wavefront.
 #define ARTP_LANE_THREADS 256
 #define ARTP_STREAM_WAVES 4
+#ifndef ARTP_FEET_CHUNK
+#define ARTP_FEET_CHUNK 32
+#endif
+#ifndef ARTP_TORSO_CHUNK
+#define ARTP_TORSO_CHUNK 8
+#endif
 
 __global__ void __launch_bounds__(ARTP_LANE_THREADS)
 feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
@@ -864,41 +877,52 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
   const int sq = blockIdx.x % ARTP_NSUB;  // this workgroup's foot sub-queue
   const unsigned long long count = *sub_counter(q, 1, sq);
   const unsigned long long first = sub_base(q, 1, sq);
-  const unsigned long long stride = (unsigned long long)(gridDim.x / ARTP_NSUB) * WAVES * GPW;
-  for (unsigned long long it = (unsigned long long)(blockIdx.x / ARTP_NSUB) * WAVES * GPW + unit_in_block; it < count;
-       it += stride) {
-    const unsigned long long item = first + it;
-    const PendingBox rec = q.q1[item];
-    if (valid[rec.state] == 0) continue;  // another box of this state already failed
-    if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) {
-      if (gl == 0) q.q4[atomicAdd(&q.counters[7], 1ull)] = (unsigned)item;
-      continue;
-    }
-    BoxHF b;
-    box_from_record(rec, rb, b);
+  // every wavefront takes ARTP_FEET_CHUNK boxes at a time from the sub-queue's cursor (4 rounds of its 4 groups)
+  unsigned long long* cursor = sub_cursor(q, 1, sq);
+  for (;;) {
+    unsigned long long chunk = 0;
+    if (lane == 0) chunk = atomicAdd(cursor, (unsigned long long)ARTP_FEET_CHUNK);
+    chunk = __shfl(chunk, 0);
+    if (chunk >= count) break;
+    for (int r = 0; r < ARTP_FEET_CHUNK / GPW; ++r) {
+      const unsigned long long it = chunk + (unsigned long long)(r * GPW + lane / G);
+      if (it < count) {
+        const unsigned long long item = first + it;
+        const PendingBox rec = q.q1[item];
+        if (valid[rec.state] != 0) {  // else another box of this state already failed
+          if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) {
+            if (gl == 0) q.q4[atomicAdd(&q.counters[7], 1ull)] = (unsigned)item;
+          } else {
+            BoxHF b;
+            box_from_record(rec, rb, b);
 #ifdef ARTP_STAGE_TIMING
-    const long long tf0 = clock64();
+            const long long tf0 = clock64();
 #endif
-    const bool touches = grp_vertex_stream<G, 6>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);  // ~80 samples
+            const bool touches = grp_vertex_stream<G, 6>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);  // ~80 samples
 #ifdef ARTP_STAGE_TIMING
-    const long long tf1 = clock64();
-    if (gl == 0) atomicAdd(&g_feet_cycles[0], (unsigned long long)(tf1 - tf0));
+            const long long tf1 = clock64();
+            if (gl == 0) atomicAdd(&g_feet_cycles[0], (unsigned long long)(tf1 - tf0));
 #endif
-    if (touches) continue;
-    const int r = grp_plane_stage_corners<G, true>(ff, b, s, lane, 0, true);
+            if (!touches) {
+              const int rr = grp_plane_stage_corners<G, true>(ff, b, s, lane, 0, true);
 #ifdef ARTP_STAGE_TIMING
-    if (gl == 0) {
-      atomicAdd(&g_feet_cycles[1], (unsigned long long)(clock64() - tf1));
-      atomicAdd(&g_feet_cycles[2], 1ull);
-    }
+              if (gl == 0) {
+                atomicAdd(&g_feet_cycles[1], (unsigned long long)(clock64() - tf1));
+                atomicAdd(&g_feet_cycles[2], 1ull);
+              }
 #endif
-    if (gl == 0) {
-      if (r == 2)
-        q.q5[atomicAdd(&q.counters[6], 1ull)] = (unsigned)item;
-      else if (r == 0)
-        valid[rec.state] = 0;  // a foot that touches nothing fails the state
+              if (gl == 0) {
+                if (rr == 2)
+                  q.q5[atomicAdd(&q.counters[6], 1ull)] = (unsigned)item;
+                else if (rr == 0)
+                  valid[rec.state] = 0;  // a foot that touches nothing fails the state
+              }
+            }
+          }
+        }
+      }
+      wave_lds_sync();
     }
-    wave_lds_sync();
   }
 }
 
@@ -945,7 +969,24 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = clock64();
 #endif
-  for (unsigned long long it = blk * WAVES * GPW + unit_in_block; it < count; it += stride) {
+  // PASS 0: every wavefront takes ARTP_TORSO_CHUNK boxes at a time from the sub-queue's cursor (see sub_cursor);
+  // the other passes stride statically over their short index queues
+  unsigned long long next = PASS == 0 ? 0ull : blk * WAVES * GPW + unit_in_block, chunk_end = 0ull;
+  for (;;) {
+    if constexpr (PASS == 0) {
+      if (next >= chunk_end) {
+        unsigned long long c0 = 0;
+        if (lane == 0) c0 = atomicAdd(sub_cursor(q, 0, sq), (unsigned long long)ARTP_TORSO_CHUNK);
+        c0 = __shfl(c0, 0);
+        if (c0 >= count) break;
+        next = c0;
+        chunk_end = c0 + ARTP_TORSO_CHUNK < count ? c0 + ARTP_TORSO_CHUNK : count;
+      }
+    } else {
+      if (next >= count) break;
+    }
+    const unsigned long long it = next;
+    next += PASS == 0 ? 1ull : stride;
     const unsigned long long item =
         PASS == 0 ? first + it : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : q.q6[it]));
 #ifdef ARTP_STAGE_TIMING
