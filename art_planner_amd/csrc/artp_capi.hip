@@ -56,6 +56,7 @@ struct artp_ctx {
   ScratchCaps caps_full{0, 0, 0, 0};  // window tile + triangle list + hash table (1 wave / block)
   ScratchCaps caps_scan{0, 0, 0, 0};  // torso resolve stage: window tile + short triangle list, per wave
   ScratchCaps caps_feet{0, 0, 0, 0};  // foot resolve stage: per 16-lane group
+  ScratchCaps caps_feet_wave{0, 0, 0, 0};  // foot list pass: a whole wavefront per box
   ScratchCaps caps_foot_full{0, 0, 0, 0};  // validate_few_kernel: a foot wavefront's full zone-test scratch
   int n_cus = 256;
   // latency path (<= ARTP_FEW_STATES states per call): mapped pinned host memory, read / written by the kernel
@@ -240,6 +241,7 @@ int size_scratch(artp_ctx* c) {
     long ft = (2L * (fdim - 1) * (fdim - 1) + 7) & ~7L;
     if (ft > 1024) ft = 1024;
     c->caps_feet = ScratchCaps{32 * 36, (int)fv, (int)ft, 0};
+    c->caps_feet_wave = ScratchCaps{64 * 36, (int)fv, (int)ft, 0};
     // a whole wavefront per foot box (validate_few_kernel): full list + hash table like caps_full
     long ftf = (2L * (fdim - 1) * (fdim - 1) + 7) & ~7L;
     if (ftf > 4096) ftf = 4096;
@@ -259,6 +261,7 @@ int size_scratch(artp_ctx* c) {
 size_t lds_full(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_full); }
 size_t lds_scan(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_scan) * ARTP_WAVES_PER_BLOCK; }
 size_t lds_feet(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_feet) * 4 * ARTP_WAVES_PER_BLOCK; }
+size_t lds_feet_wave(const artp_ctx* c) { return scratch_bytes_per_wave(c->caps_feet_wave) * ARTP_WAVES_PER_BLOCK; }
 size_t lds_few(const artp_ctx* c) {
   return scratch_bytes_per_wave(c->caps_full) + 4 * scratch_bytes_per_wave(c->caps_foot_full);
 }
@@ -277,8 +280,8 @@ int set_kernel_lds(artp_ctx* c) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet(c)));
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_feet_wave(c)));
   return ARTP_OK;
 }
 
@@ -469,9 +472,10 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 1>), dim3(grid_scan(c, lds_feet(c))),
                      dim3(64 * ARTP_WAVES_PER_BLOCK), lds_feet(c), c->stream, c->field[1], c->robot, q, valid,
                      c->caps_feet, c->d_error);
-  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 16, 2>), dim3(grid_scan(c, lds_feet(c))),
-                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_feet(c), c->stream, c->field[1], c->robot, q, valid,
-                     c->caps_feet, c->d_error);
+  // list pass: few boxes (dozens on natural terrain), each a long chain -> a whole wavefront per box
+  hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 2>), dim3(grid_scan(c, lds_feet_wave(c))),
+                     dim3(64 * ARTP_WAVES_PER_BLOCK), lds_feet_wave(c), c->stream, c->field[1], c->robot, q, valid,
+                     c->caps_feet_wave, c->d_error);
   hipLaunchKernelGGL(plane_stage_kernel<1>, dim3(grid_full(c, 0)), dim3(64), lds_full(c), c->stream,
                      c->field[0], c->field[1], c->robot, q, valid, c->caps_full, c->d_error);
   HIP_TRY(c, hipGetLastError());

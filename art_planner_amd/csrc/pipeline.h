@@ -956,7 +956,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   const int gl = lane & (G - 1);
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
-  const bool feet = (G != 64);  // feet: only the boxes the lane-per-box stages handed over (queue 3)
+  const bool feet = (PASS == 1 || PASS == 2);  // feet: only the boxes the lane-per-box stages handed over
   // PASS 0 walks torso sub-queue blockIdx % ARTP_NSUB; the other passes walk their (short) index queues
   const int sq = blockIdx.x % ARTP_NSUB;
   const unsigned long long count =

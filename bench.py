@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 peak, same guide
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 PIPELINE = ["classify_states_kernel", "feet_stream_kernel", "feet_lane_kernel", "resolve_boxes_kernel<2, 64, 0>",
-            "resolve_boxes_kernel<2, 64, 3>", "resolve_boxes_kernel<2, 16, 1>", "resolve_boxes_kernel<2, 16, 2>",
+            "resolve_boxes_kernel<2, 64, 3>", "resolve_boxes_kernel<2, 16, 1>", "resolve_boxes_kernel<2, 64, 2>",
             "plane_stage_kernel", "sample_states_kernel", "sample_classify_kernel"]
 PMC_PASSES = [
     ["FETCH_SIZE"],

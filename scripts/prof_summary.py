@@ -11,7 +11,7 @@ import sqlite3
 import sys
 
 PIPELINE = ["classify_states_kernel", "feet_stream_kernel", "feet_lane_kernel", "resolve_boxes_kernel<2, 64, 0>",
-            "resolve_boxes_kernel<2, 64, 3>", "resolve_boxes_kernel<2, 16, 1>", "resolve_boxes_kernel<2, 16, 2>",
+            "resolve_boxes_kernel<2, 64, 3>", "resolve_boxes_kernel<2, 16, 1>", "resolve_boxes_kernel<2, 64, 2>",
             "plane_stage_kernel"]
 
 
