@@ -1022,8 +1022,8 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
 // The derived sampler tables (SamplerDev::cum_prob_t / pivots / cells) from the six layers in c->sampler_buf.
 static int pack_sampler_tables(artp_ctx* c, int rows, int cols) {
   const size_t e = (size_t)rows * cols;
-  const int npiv = (cols + 15) / 16, pitch = npiv * 16;
-  const size_t floats = (size_t)rows * pitch + (size_t)rows * npiv + 8 * e + 64;
+  const int npiv = (cols + 15) / 16, pitch = npiv * 16, ppitch = (npiv + 3) & ~3;
+  const size_t floats = (size_t)rows * pitch + (size_t)rows * ppitch + 8 * e + 64;
   if (c->sampler_pack) HIP_TRY(c, hipFree(c->sampler_pack));
   c->sampler_pack = nullptr;
   HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_pack), floats * sizeof(float)));
@@ -1033,6 +1033,7 @@ static int pack_sampler_tables(artp_ctx* c, int rows, int cols) {
   float* piv = cdf_t + (size_t)rows * pitch;
   c->sampler.npiv = npiv;
   c->sampler.pitch = pitch;
+  c->sampler.ppitch = ppitch;
   hipLaunchKernelGGL(sampler_pack_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, c->stream, c->sampler, rows,
                      cols, cdf_t, piv, reinterpret_cast<float4*>(cells));
   HIP_TRY(c, hipGetLastError());

@@ -41,10 +41,11 @@ struct SamplerDev {
   // per sample, not by arithmetic: the per-row CDF contiguous (row-major), one pivot per 16 columns, and the five
   // per-cell numbers of a sample in one 32-byte record -- 4 requests per sample instead of 14.
   const float* cum_prob_t;        // row-major, rows x pitch floats (pitch = cols rounded up to 16: aligned groups)
-  const float* pivots;            // rows x npiv: cum_prob(row, min(16 j + 15, cols - 1))
+  const float* pivots;            // rows x ppitch: cum_prob(row, 16 j + 15) for j < npiv - 1, +inf behind them
   const float4* cells;            // 2 float4 per cell (index row + col * rows): {elev, nx, ny, nz}, {std, -, -, -}
   int npiv;
   int pitch;
+  int ppitch;                     // floats per pivot row (npiv rounded up to 4: aligned 16-byte loads)
 };
 
 // one lane per cell: transposed CDF, pivots, packed cell records
@@ -56,8 +57,13 @@ sampler_pack_kernel(SamplerDev sm, int rows, int cols, float* __restrict__ cum_p
   const int row = i % rows, col = i / rows;
   const float v = sm.cum_prob[i];
   cum_prob_t[(size_t)row * sm.pitch + col] = v;
-  const int npiv = (cols + 15) / 16;
-  if ((col & 15) == 15 || col == cols - 1) pivots[(size_t)row * npiv + (col >> 4)] = v;
+  // the last pivot of a row is never looked at ("first of [0, cols-2] that exceeds u, else cols-1"): it and the
+  // padding behind it hold +inf, so "number of pivots that do not exceed u" is the group index
+  if (col == cols - 1) {
+    for (int j = col >> 4; j < sm.ppitch; ++j) pivots[(size_t)row * sm.ppitch + j] = INFINITY;
+  } else if ((col & 15) == 15) {
+    pivots[(size_t)row * sm.ppitch + (col >> 4)] = v;
+  }
   cells[2 * (size_t)i] = make_float4(sm.elevation[i], sm.normal_x[i], sm.normal_y[i], sm.normal_z[i]);
   cells[2 * (size_t)i + 1] = make_float4(sm.plane_fit_std_dev[i], 0.0f, 0.0f, 0.0f);
 }
@@ -426,24 +432,48 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
     // "first column of [0, cols-2] whose cumulative value exceeds u, else cols-1" in two levels (the CDF of a row
     // is non-decreasing, so the first group of 16 columns whose LAST value exceeds u holds the answer):
     // the pivots of the row (<= 2 cache lines), then the group's 16 values (one line, one request).
-    const float* prow = sm.pivots + (size_t)row * sm.npiv;
-    lo = 0;
-    hi = sm.npiv - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((double)prow[mid] > samp_col) hi = mid; else lo = mid + 1;
+    // pivots of the row: all of them in one round trip (<= 8 aligned 16-byte loads, two cache lines for a 400-column
+    // map) and a count, instead of a binary search's five dependent requests -- the kernel is bound by its L2
+    // requests times their latency (the L1's miss queue), not by arithmetic
+    const float* prow = sm.pivots + (size_t)row * sm.ppitch;
+    const int nch = sm.ppitch >> 2;
+    if (nch <= 8) {
+      // (double)p > u  <=>  p > (u rounded DOWN to float): between two neighbouring floats every u compares the same
+      const float uf = __double2float_rd(samp_col);
+      const float4* p4 = reinterpret_cast<const float4*>(prow);
+      lo = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // two batches of four loads: eight float4 in flight at once spill registers
+        float4 pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * h + k < nch) pv[k] = p4[4 * h + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * h + k < nch)
+            lo += (!(pv[k].x > uf) ? 1 : 0) + (!(pv[k].y > uf) ? 1 : 0) + (!(pv[k].z > uf) ? 1 : 0) +
+                  (!(pv[k].w > uf) ? 1 : 0);
+      }
+    } else {
+      lo = 0;
+      hi = sm.npiv - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((double)prow[mid] > samp_col) hi = mid; else lo = mid + 1;
+      }
     }
     const int c0 = lo << 4;
     const int c1 = (c0 + 15 < g.cols - 1) ? c0 + 15 : g.cols - 1;
     const float4* grp = reinterpret_cast<const float4*>(sm.cum_prob_t + (size_t)row * sm.pitch + c0);
     int below = 0;  // values of the group that do not exceed u (they come first)
+    const float uf_col = __double2float_rd(samp_col);  // (double)v > u  <=>  v > u rounded down to float
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const float4 v = grp[q4];
-      below += (c0 + 4 * q4 + 0 <= c1 && !((double)v.x > samp_col)) ? 1 : 0;
-      below += (c0 + 4 * q4 + 1 <= c1 && !((double)v.y > samp_col)) ? 1 : 0;
-      below += (c0 + 4 * q4 + 2 <= c1 && !((double)v.z > samp_col)) ? 1 : 0;
-      below += (c0 + 4 * q4 + 3 <= c1 && !((double)v.w > samp_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 0 <= c1 && !(v.x > uf_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 1 <= c1 && !(v.y > uf_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 2 <= c1 && !(v.z > uf_col)) ? 1 : 0;
+      below += (c0 + 4 * q4 + 3 <= c1 && !(v.w > uf_col)) ? 1 : 0;
     }
     const int col = (c0 + below < c1) ? c0 + below : c1;
     cell_row = row;
