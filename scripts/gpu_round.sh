@@ -32,7 +32,9 @@ except Exception as e:
 PY
 mkdir -p $OUT/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $OUT/prof_$TAG/trace.log 2>&1
+# --lanes 1: one batch at a time on one stream, the configuration of roofline.kernel_ms (rocprofv3 serialises the
+# kernels of concurrent streams anyway)
+rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $OUT/prof_$TAG/trace.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/prof_summary.py $OUT/prof_$TAG > $OUT/prof_$TAG/summary.txt 2>&1
 rm -f $OUT/prof_$TAG/*/*.db $OUT/prof_$TAG/*/*/*.db
 head -30 $OUT/prof_$TAG/summary.txt
