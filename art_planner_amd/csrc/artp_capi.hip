@@ -451,17 +451,14 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
                      dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, (const PoseRec*)recs, n,
                      valid, q);
-  {
-    const size_t lds = (size_t)CandCap<16>::value * 36 * 4 * ARTP_STREAM_WAVES;
-    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, 5)), dim3(64 * ARTP_STREAM_WAVES), lds,
-                       c->stream, c->field[1], c->robot, q, valid);
-  }
+  hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, 5)), dim3(64 * ARTP_STREAM_WAVES), 0,
+                     c->stream, c->field[1], c->robot, q, valid);
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);
   {
-    // streaming pass: only the corner-candidate scratch; the staged pass behind it takes the rest
-    const ScratchCaps caps_stream{64 * 36, 0, 0, 0};
-    const size_t lds_stream = (size_t)64 * 36 * ARTP_WAVES_PER_BLOCK;
+    // streaming pass: no LDS at all; the staged pass behind it takes the window tile and the list
+    const ScratchCaps caps_stream{0, 0, 0, 0};
+    const size_t lds_stream = 0;
     hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_sub(c, 10)),
                        dim3(64 * ARTP_WAVES_PER_BLOCK), lds_stream, c->stream, c->field[0], c->robot, q, valid,
                        caps_stream, c->d_error);

@@ -809,6 +809,72 @@ __device__ __forceinline__ int grp_plane_stage_corners(const FieldDev& f, const 
   return grp_any<G>(hit, lane) ? 1 : 0;
 }
 
+// The corner stage of the streaming kernels: no LDS tile, no kept-triangle list, no candidate arrays.  The lane that
+// nominates a (corner, triangle) pair reads the cell's four samples from the map, forms the plane and tests its
+// contacts right there; when the map's partner table cannot rule out a partner for some kept candidate the box
+// needs the list (2).  Same candidates, same planes and same contact tests as grp_plane_stage_corners in fast mode
+// (a triangle nominated by two corners is tested twice: harmless).
+template <int G>
+__device__ __forceinline__ int grp_corner_stage_direct(const FieldDev& f, const BoxHF& b, int lane) {
+  const int gl = grp_lane<G>(lane);
+  const int cellsX = b.maxX - b.minX, cellsZ = b.maxZ - b.minZ;
+  const float minO2 = b.aabb[2];
+  const float margin = 1.0e-4f;  // see grp_plane_stage_corners
+  const bool window_covered = f.partner_flags != nullptr && cellsX <= f.partner_R && cellsZ <= f.partner_R;
+  const int base_slot = gl & 15;
+  const int corner = base_slot >> 1;
+  const bool c_up = !(base_slot & 1);
+  const float s0 = (corner & 1) ? 0.5f : -0.5f, s1 = (corner & 2) ? 0.5f : -0.5f, s2 = (corner & 4) ? 0.5f : -0.5f;
+  const float px = b.pos[0] + s0 * b.side[0] * b.R[0] + s1 * b.side[1] * b.R[1] + s2 * b.side[2] * b.R[2];
+  const float py = b.pos[1] + s0 * b.side[0] * b.R[3] + s1 * b.side[1] * b.R[4] + s2 * b.side[2] * b.R[5];
+  const float pz = b.pos[2] + s0 * b.side[0] * b.R[6] + s1 * b.side[1] * b.R[7] + s2 * b.side[2] * b.R[8];
+  const float reach = 2.0f * margin * fmaxf(f.inv_w, f.inv_d);
+  const int cxa = (int)floorf((px - margin) * f.inv_w), cxb = (int)floorf((px + margin) * f.inv_w);
+  const int cza = (int)floorf((pz - margin) * f.inv_d), czb = (int)floorf((pz + margin) * f.inv_d);
+  bool maybe_partner = false, hit = false;
+  for (int r = 0; r < 4; ++r) {
+    const int off = (G == 64) ? (gl >> 4) : r;
+    const int dx = off & 1, dz = off >> 1;
+    const bool wanted = (cxa + dx <= cxb) && (cza + dz <= czb);
+    if (G != 64 && r > 0 && !grp_any<G>(wanted, lane)) continue;
+    const int cx = cxa + dx - b.minX, cz = cza + dz - b.minZ;  // window-local cell
+    if (wanted && cx >= 0 && cz >= 0 && cx < cellsX && cz < cellsZ) {
+      const unsigned at = (unsigned)((b.minX + cx) + (b.minZ + cz) * f.nW);
+      const float hA = gather32(f.data, at), hB = gather32(f.data, at + 1u);
+      const float hC = gather32(f.data, at + (unsigned)f.nW), hD = gather32(f.data, at + (unsigned)f.nW + 1u);
+      const bool fA = is_finite(hA), fB = is_finite(hB), fC = is_finite(hC), fD = is_finite(hD);
+      const bool kA = fA && hA > minO2, kB = fB && hB > minO2, kC = fC && hC > minO2, kD = fD && hD > minO2;
+      bool kept = c_up ? ((kA || kB || kC) && (fA && fB && fC)) : ((kB || kC || kD) && (fB && fC && fD));
+      if (kept) {
+        const float h0 = c_up ? hA : hD;
+        const float h4 = (hB + hC) - h0;
+        const float top = fmaxf(fmaxf(h0, h4), fmaxf(hB, hC));
+        const float spread = fabsf(hB - h0) + fabsf(hC - h0);
+        kept = !(py > top + spread * reach + 1.0e-3f);
+      }
+      if (kept) {
+        maybe_partner = maybe_partner || !window_covered || ((gather32(f.partner_flags, at) >> (c_up ? 0 : 1)) & 1);
+        const float xA = (float)(b.minX + cx) * f.sample_w, xB = (float)(b.minX + cx + 1) * f.sample_w;
+        const float zA = (float)(b.minZ + cz) * f.sample_d, zC = (float)(b.minZ + cz + 1) * f.sample_d;
+        float cpl[4];
+        if (c_up)
+          triangle_plane(xA, hA, zA, xB, hB, zA, xA, hC, zC, true, cpl);
+        else
+          triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, cpl);
+        const int gx = b.minX + cx + (c_up ? 0 : 1), gz = b.minZ + cz + (c_up ? 0 : 1);
+        float cpos[4][3];
+        const int nc = box_plane_contacts(b, cpl[0], cpl[1], cpl[2], cpl[3], 10, cpos);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nc) hit = hit || is_on_heightfield2(f, gx, gz, cpos[i][0], cpos[i][2], c_up);
+      }
+    }
+    if (G == 64) break;  // the four offsets were handled side by side
+  }
+  if (grp_any<G>(maybe_partner, lane)) return 2;
+  return grp_any<G>(hit, lane) ? 1 : 0;
+}
+
 __device__ __forceinline__ int wave_plane_stage_corners(const FieldDev& f, const BoxHF& b,
                                                         const WaveScratch& s, int lane, int T) {
   return grp_plane_stage_corners<64>(f, b, s, lane, T);

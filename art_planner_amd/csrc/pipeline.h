@@ -867,13 +867,9 @@ __device__ unsigned long long g_feet_cycles[4];  // stream cycles, corner cycles
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
 feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, GPW = 4;
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
-  const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
-  const ScratchCaps caps{CandCap<G>::value * 36, 0, 0, 0};
-  const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
   const int sq = blockIdx.x % ARTP_NSUB;  // this workgroup's foot sub-queue
   const unsigned long long count = *sub_counter(q, 1, sq);
   const unsigned long long first = sub_base(q, 1, sq);
@@ -904,7 +900,7 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
             if (gl == 0) atomicAdd(&g_feet_cycles[0], (unsigned long long)(tf1 - tf0));
 #endif
             if (!touches) {
-              const int rr = grp_plane_stage_corners<G, true>(ff, b, s, lane, 0, true);
+              const int rr = grp_corner_stage_direct<G>(ff, b, lane);
 #ifdef ARTP_STAGE_TIMING
               if (gl == 0) {
                 atomicAdd(&g_feet_cycles[1], (unsigned long long)(clock64() - tf1));
@@ -921,7 +917,6 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
           }
         }
       }
-      wave_lds_sync();
     }
   }
 }
@@ -1011,7 +1006,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
           decided = true;
         } else {
           ARTP_T_MARK(2);
-          const int r = grp_plane_stage_corners<G, true>(fld, b, s, lane, 0, true);
+          const int r = grp_corner_stage_direct<G>(fld, b, lane);
           if (r != 2) {
             result = r;
             decided = true;
@@ -1024,7 +1019,6 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
       } else if (gl == 0 && result != 0) {
         valid[rec.state] = 0;  // the torso touches
       }
-      wave_lds_sync();
       continue;
     }
     const int total = (b.maxX - b.minX + 1) * (b.maxZ - b.minZ + 1);
