@@ -555,10 +555,16 @@ __device__ __forceinline__ unsigned record_kind(bool body, bool exits_negative, 
 // queue slots with one atomic (sub-queue blockIdx % ARTP_NSUB: a single counter word sustains only ~88 returning
 // atomics per microsecond, MI355X_MICROARCH.md "dequeue") and copies them out as full coalesced 16-byte lanes
 // (scattered 16-byte stores into 96-byte records cost ~7x the bytes in partial-line write traffic).
-#define ARTP_CLASSIFY_SUB 2
+// 64 states and five wavefronts per workgroup: smaller workgroups start and drain faster than 128-state ones
+// (2^22 states: 0.555 -> 0.49 ms), and their open-box lists still fill most of a wavefront
+#ifndef ARTP_CLASSIFY_SUB
+#define ARTP_CLASSIFY_SUB 1
+#endif
 #define ARTP_CLASSIFY_THREADS (64 * 5 * ARTP_CLASSIFY_SUB)
-#define ARTP_CLASSIFY_CAP_T 64   // open torso boxes a workgroup lists (of 128; typically ~15 are open)
-#define ARTP_CLASSIFY_CAP_F 192  // open foot boxes it lists (of 512; typically ~80)
+#ifndef ARTP_CLASSIFY_CAP_T
+#define ARTP_CLASSIFY_CAP_T 64   // open torso boxes a workgroup lists (all of its 64; typically ~8 are open)
+#define ARTP_CLASSIFY_CAP_F 128  // open foot boxes it lists (of 256; typically ~40)
+#endif
 #ifdef ARTP_STAGE_TIMING
 __device__ unsigned long long g_classify_cycles[2][8];  // [list waves | early-exit waves][phase], [7] = waves
 #define ARTP_C_MARK(slot) do { const long long n_ = clock64(); c_acc[slot] += (unsigned long long)(n_ - c_prev); c_prev = n_; } while (0)
@@ -579,7 +585,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   // the same 64-byte line per lane through the L1 were half of the kernel's L1 accesses.  80-byte stride:
   // conflict-free b128 reads.
   // The open-box records reuse the PoseRecs' LDS (the last PoseRec read is two barriers before the first record
-  // write): 24 KB per workgroup, so LDS never limits how many workgroups a CU holds.
+  // write): 18 KB per workgroup, so LDS never limits how many workgroups a CU holds.
   static_assert((CAP_T + CAP_F) * 6 >= SUB * 64 * 5, "the record area also holds the PoseRecs");
   __shared__ float4 open_recs[(CAP_T + CAP_F) * 6];
   float4* prec = open_recs;
