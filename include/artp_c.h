@@ -78,8 +78,10 @@ int artp_synchronize(artp_ctx* ctx); /* every lane's stream */
  * pipeline's short serial kernels and pairs kernels with different bottlenecks (bench.py: 1.77 -> 1.66 ms per 2^22
  * states).  Every call works on the CURRENT lane (0 after artp_create); artp_set_lane switches it (first use of a
  * lane creates its stream).  Work on different lanes is unordered: the caller orders map / layer updates against the
- * lanes that still read the old map (artp_synchronize, or stream events).  No equivalent in the reference (it
- * validates one state at a time on the calling thread). */
+ * lanes that still read the old map (artp_synchronize, or stream events).  The current lane is state of the
+ * context, not of the calling thread: lanes are for ONE host thread that keeps several batches in flight (threads
+ * that share a context would switch each other's lane; give each thread its own context).  No equivalent in the
+ * reference (it validates one state at a time on the calling thread). */
 int artp_set_lane(artp_ctx* ctx, int lane);
 int artp_get_lane(artp_ctx* ctx);
 
