@@ -353,7 +353,9 @@ struct __attribute__((aligned(16))) PendingBox {  // 96 bytes
 // 128-byte line: a workgroup of the classify stage takes its slots from sub-queue blockIdx % ARTP_NSUB.  One
 // counter word for all 32 768 workgroups of a 2^22-state batch serialised them on one L2 atomic unit (0.14 ms of
 // the stage); the consumers walk sub-queue blockIdx % ARTP_NSUB, so their launch grids are multiples of ARTP_NSUB.
+#ifndef ARTP_NSUB
 #define ARTP_NSUB 16
+#endif
 
 struct PipelineQueues {
   PendingBox* q1;                // undecided boxes: torso sub-queue s at [s * seg_t, ...), foot sub-queue s at
