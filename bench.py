@@ -314,8 +314,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="parts of a step's batch validated side by side on as many streams of the context (1..4)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="parts of a step's batch validated side by side on as many streams of the context (1..4); "
+                         "2 was worth 6 %% before the stream kernels balanced their own load, -0.7 %% on the final build")
     ap.add_argument("--materialise", type=int, default=1 << 16,
                     help="N>1: accepted states of EVERY rank re-materialised on every rank per step, per rank block "
                          "(-1 = all of them, 0 = none; the gathered index lists are always complete)")
@@ -354,10 +355,10 @@ def main():
     ctx.use_torch_stream()
 
     S, K, W, seed = args.batch, args.steps, args.warmup, 42
-    # Lanes: the batch of a step is validated as `lanes` contiguous parts on as many streams of the SAME context
+    # Lanes: the batch of a step can be validated as `lanes` contiguous parts on as many streams of the SAME context
     # (include/artp_c.h artp_set_lane).  Nothing joins the lanes between steps, so the short serial kernels at the
-    # end of one part's pipeline overlap another part's long kernels, and kernels with different bottlenecks run side
-    # by side.  --lanes 1 = everything on one stream (what the per-kernel profiles and `roofline.kernel_ms` use).
+    # end of one part's pipeline overlap another part's long kernels.  Default 1 = everything on one stream (what the
+    # per-kernel profiles and `roofline.kernel_ms` use): on the final kernels a second lane no longer pays.
     lanes = max(1, min(4, args.lanes))
     if S % (128 * lanes):
         raise SystemExit("--batch must be a multiple of 128 * lanes")
