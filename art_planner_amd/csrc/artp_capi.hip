@@ -451,7 +451,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
                      dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, (const PoseRec*)recs, n,
                      valid, q);
-  hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, 5)), dim3(64 * ARTP_STREAM_WAVES), 0,
+  hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, ARTP_FEET_WAVES_PER_SIMD)), dim3(64 * ARTP_STREAM_WAVES), 0,
                      c->stream, c->field[1], c->robot, q, valid);
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);

@@ -781,6 +781,9 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 // plane stage) are compacted into queue 3 for the lane-group stage, one atomic per wavefront.
 #define ARTP_LANE_THREADS 256
 #define ARTP_STREAM_WAVES 4
+#ifndef ARTP_FEET_U
+#define ARTP_FEET_U 4  // loads in flight per lane in the feet vertex stream (a 10 x 10 window is 6 per lane in all)
+#endif
 #ifndef ARTP_FEET_CHUNK
 #define ARTP_FEET_CHUNK 32
 #endif
@@ -868,12 +871,15 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
 // NaN or is thinner than the smallest table block): (f) streamed from the map, then the list-free corner
 // stage.  Decides everything except boxes whose corner candidates may have partners (-> queue 5, list
 // pass).  Records without table verdict go to queue 4 (sequential lane scan with the running-dMAX quirk).
-// 5 wavefronts per SIMD (96 VGPRs, 5 of them spilled) beat 4 at 100 VGPRs by 4 %; 6 (24 spills) lose 20 %
+// 5 wavefronts per SIMD (96 VGPRs, 14 spilled in the corner stage) beat 4 at 128 VGPRs by 1-2 %; 6 and more lose 70 %
 #ifdef ARTP_STAGE_TIMING
 __device__ unsigned long long g_feet_cycles[4];  // stream cycles, corner cycles, boxes that reached the corners
 #endif
+#ifndef ARTP_FEET_WAVES_PER_SIMD
+#define ARTP_FEET_WAVES_PER_SIMD 5
+#endif
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 5)))
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(ARTP_FEET_WAVES_PER_SIMD, ARTP_FEET_WAVES_PER_SIMD)))
 feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid) {
   constexpr int G = 16, GPW = 4;
   const int lane = threadIdx.x & 63;
@@ -902,7 +908,7 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
 #ifdef ARTP_STAGE_TIMING
             const long long tf0 = clock64();
 #endif
-            const bool touches = grp_vertex_stream<G, 6>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);  // ~80 samples
+            const bool touches = grp_vertex_stream<G, ARTP_FEET_U>(ff, b, lane, (rec.kind & ARTP_REC_ALL_FINITE) != 0);  // ~80 samples
 #ifdef ARTP_STAGE_TIMING
             const long long tf1 = clock64();
             if (gl == 0) atomicAdd(&g_feet_cycles[0], (unsigned long long)(tf1 - tf0));
