@@ -459,7 +459,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
     // streaming pass: no LDS at all; the staged pass behind it takes the window tile and the list
     const ScratchCaps caps_stream{0, 0, 0, 0};
     const size_t lds_stream = 0;
-    hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_sub(c, 10)),
+    hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_sub(c, ARTP_TORSO_WGS_PER_CU)),
                        dim3(64 * ARTP_WAVES_PER_BLOCK), lds_stream, c->stream, c->field[0], c->robot, q, valid,
                        caps_stream, c->d_error);
   }

@@ -781,6 +781,12 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 // plane stage) are compacted into queue 3 for the lane-group stage, one atomic per wavefront.
 #define ARTP_LANE_THREADS 256
 #define ARTP_STREAM_WAVES 4
+#ifndef ARTP_TORSO_WGS_PER_CU
+#define ARTP_TORSO_WGS_PER_CU 12  // 2 wavefronts each: 6 per SIMD (79 VGPRs with 6 loads in flight; 8 loads = 88 VGPRs = 5 per SIMD: +3 %)
+#endif
+#ifndef ARTP_TORSO_U
+#define ARTP_TORSO_U 6  // loads in flight per lane in the torso vertex stream (~14 per lane in all)
+#endif
 #ifndef ARTP_FEET_U
 #define ARTP_FEET_U 4  // loads in flight per lane in the feet vertex stream (a 10 x 10 window is 6 per lane in all)
 #endif
@@ -1015,7 +1021,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
       // finite) goes to queue 6 for the staged pass (PASS 3) -- keeping that code out of this kernel keeps
       // its register count down.
       if (fld.partner_flags != nullptr && (rec.kind & ARTP_REC_ALL_FINITE)) {
-        if (grp_vertex_stream<G>(fld, b, lane, true)) {
+        if (grp_vertex_stream<G, ARTP_TORSO_U>(fld, b, lane, true)) {
           result = 1;
           decided = true;
         } else {
