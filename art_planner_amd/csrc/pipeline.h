@@ -250,6 +250,10 @@ __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const Tables
 // end, one at the anchor above (high end - B + 1), a third between them when the window is longer than 2 B - s: the
 // union reaches at most s - 1 = B / 4 - 1 samples past the window on each side, so it decides nearly everything the
 // exact statistics would -- out of tables that stay in L2.  Up to 3 x 3 predicated gathers in one round trip.
+// N = the most blocks per axis the caller is willing to gather (N x N predicated loads are issued whether a lane
+// needs them or not: a foot window takes 2 x 2 of the 8-sample blocks, a torso window up to 3 x 3 of the 16s); a
+// window that needs more stays undecided here.
+template <int N>
 __device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int m = wX < wZ ? wX : wZ;
@@ -268,19 +272,22 @@ __device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesD
     nz = aR == a0 ? 1 : (aR <= a0 + B ? 2 : (aR <= a0 + 2 * B ? 3 : 4));
     pz[0] = a0; pz[1] = nz == 3 ? a0 + B : aR; pz[2] = aR;
   }
-  if (nx > 3 || nz > 3) return -1;
+  if (nx > N || nz > N) return -1;
   const unsigned lo = stride_level_offset(t, l);
-  unsigned v[9];
+  unsigned v[N * N];
 #pragma unroll
-  for (int u = 0; u < 9; ++u) {
-    const int i = u % 3, j = u / 3;
+  for (int u = 0; u < N * N; ++u) {
+    const int i = u % N, j = u / N;
     v[u] = 0x7C00FC00u;  // masked-off slot: {max' = -inf (lowest bit 0), min' = +inf}
-    if (i < nx && j < nz) v[u] = gather32(t.st, lo + (unsigned)((px[i] >> sh) + (pz[j] >> sh) * nxs));
+    // block i of an axis with n <= N blocks: the first, [the middle one,] the last
+    const int xi = (i == 0) ? px[0] : ((i == nx - 1) ? px[2] : px[1]);
+    const int zj = (j == 0) ? pz[0] : ((j == nz - 1) ? pz[2] : pz[1]);
+    if (i < nx && j < nz) v[u] = gather32(t.st, lo + (unsigned)((xi >> sh) + (zj >> sh) * nxs));
   }
   float vmax = -INFINITY, vmin = INFINITY;
   unsigned nf = 0u;
 #pragma unroll
-  for (int u = 0; u < 9; ++u) {
+  for (int u = 0; u < N * N; ++u) {
     nf |= v[u];
     const float mx = stride_max(v[u]), mn = stride_min(v[u]);
     vmax = (mx > vmax) ? mx : vmax;
@@ -496,7 +503,7 @@ __device__ __forceinline__ int classify_head(const FieldDev& f, const TablesDev&
   if (!b.on_field) return body ? 0 : 1;  // AABB off the field: no contact (heightfield.cpp:1868-1877)
   if (tab.valid) {
     int coarse = coarse_block_exit(f, tab, b);
-    if (coarse < 0) coarse = tight_cover_exit(f, tab, b);
+    if (coarse < 0) coarse = body ? tight_cover_exit<3>(f, tab, b) : tight_cover_exit<2>(f, tab, b);
     if (coarse >= 0) return (body ? coarse : !coarse) ? 1 : 0;
   }
   return ARTP_CODE_OPEN;
