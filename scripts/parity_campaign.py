@@ -45,16 +45,21 @@ def variant(name):
 
 
 cases = [("plain", "yaml"), ("nan", "yaml"), ("terraced", "yaml"), ("steps", "defaults"), ("inf", "yaml"),
-         ("plain", "tiny"), ("terraced", "defaults"), ("far", "yaml")]
+         ("plain", "tiny"), ("terraced", "defaults"), ("far", "yaml"), ("plain", "huge"), ("nan", "huge")]
 bad_total = 0
 lines = []
 for mapname, robot in cases:
     gm = variant(mapname)
-    if robot == "tiny":
+    if robot in ("tiny", "huge"):
         prm = make_params("yaml")
-        prm.torso_length, prm.torso_width, prm.torso_height = 0.3, 0.2, 0.1
-        prm.feet_off_x, prm.feet_off_y = 0.1, 0.06
-        prm.reach_x = prm.reach_y = prm.reach_z = 0.06
+        if robot == "tiny":
+            prm.torso_length, prm.torso_width, prm.torso_height = 0.3, 0.2, 0.1
+            prm.feet_off_x, prm.feet_off_y = 0.1, 0.06
+            prm.reach_x = prm.reach_y = prm.reach_z = 0.06
+        else:  # torso windows of ~55 samples, foot windows of ~20: the largest table levels, three-block covers
+            prm.torso_length, prm.torso_width, prm.torso_height = 1.9, 1.0, 0.3
+            prm.feet_off_x, prm.feet_off_y, prm.feet_off_z = 0.7, 0.45, -0.6
+            prm.reach_x, prm.reach_y, prm.reach_z = 0.6, 0.35, 0.25
         ctx = Context(0, prm)
         rob = O.Robot()
         for f, _ in O.Robot._fields_:

@@ -622,3 +622,29 @@ def test_lanes_overlap_and_agree_with_one_stream(big_map, ctx_yaml):
     with pytest.raises(Exception):
         ctx_yaml.set_lane(9)
     assert ctx_yaml.lane == 0
+
+
+def test_huge_robot_uses_the_largest_table_levels(big_map):
+    """A robot twice the size of ANYmal: torso windows of ~55 samples (32-sample blocks, three per axis), foot
+    windows of ~20 (the feet's 2 x 2 tight cover of 16-sample blocks, or none) -- labels equal the oracle's."""
+    from art_planner_amd.context import make_params
+    prm = make_params("yaml")
+    prm.torso_length, prm.torso_width, prm.torso_height = 1.9, 1.0, 0.3
+    prm.feet_off_x, prm.feet_off_y, prm.feet_off_z = 0.7, 0.45, -0.6
+    prm.reach_x, prm.reach_y, prm.reach_z = 0.6, 0.35, 0.25
+    rob = O.Robot()
+    for f, _ in O.Robot._fields_:
+        if hasattr(prm, f):
+            setattr(rob, f, getattr(prm, f))
+    gm = common.crop_map(big_map, 20, 40, 300)
+    ctx = _ctx(prm)
+    ctx.upload_map(gm, sampler=False)
+    rng = np.random.default_rng(5)
+    se3 = common.random_states(gm, 30000, rng, z_off=(0.0, 0.1), tilt=0.2, spread=0.4)
+    vg = ctx.validate_states(se3)
+    vo = O.OracleMap(gm).states_valid(rob, se3)
+    assert np.array_equal(vg, vo), f"{(vg != vo).sum()} mismatches"
+    assert 0.01 < vg.mean() < 0.99
+    few = np.concatenate([ctx.validate_states(se3[i:i + 16]) for i in range(0, 512, 16)])
+    assert np.array_equal(few, vo[:512])
+    ctx.close()
