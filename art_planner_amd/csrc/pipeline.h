@@ -789,7 +789,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 #define ARTP_LANE_THREADS 256
 #define ARTP_STREAM_WAVES 4
 #ifndef ARTP_TORSO_WGS_PER_CU
-#define ARTP_TORSO_WGS_PER_CU 12  // 2 wavefronts each: 6 per SIMD (79 VGPRs with 6 loads in flight; 8 loads = 88 VGPRs = 5 per SIMD: +3 %)
+#define ARTP_TORSO_WGS_PER_CU 14  // 2 wavefronts each: 7 per SIMD (69 VGPRs with 6 loads in flight)
 #endif
 #ifndef ARTP_TORSO_U
 #define ARTP_TORSO_U 6  // loads in flight per lane in the torso vertex stream (~14 per lane in all)
@@ -884,12 +884,13 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
 // NaN or is thinner than the smallest table block): (f) streamed from the map, then the list-free corner
 // stage.  Decides everything except boxes whose corner candidates may have partners (-> queue 5, list
 // pass).  Records without table verdict go to queue 4 (sequential lane scan with the running-dMAX quirk).
-// 5 wavefronts per SIMD (96 VGPRs, 14 spilled in the corner stage) beat 4 at 128 VGPRs by 1-2 %; 6 and more lose 70 %
+// 6 wavefronts per SIMD (82 VGPRs -> 80, a handful spilled): -2 % against 5; 7 lose it again.  (With LLVM's SLP pass on,
+// the kernel needed 96 VGPRs + 14 spills for 5 wavefronts and 6 were out of reach.)
 #ifdef ARTP_STAGE_TIMING
 __device__ unsigned long long g_feet_cycles[4];  // stream cycles, corner cycles, boxes that reached the corners
 #endif
 #ifndef ARTP_FEET_WAVES_PER_SIMD
-#define ARTP_FEET_WAVES_PER_SIMD 5
+#define ARTP_FEET_WAVES_PER_SIMD 6
 #endif
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(ARTP_FEET_WAVES_PER_SIMD, ARTP_FEET_WAVES_PER_SIMD)))

@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out", "isa")
 os.makedirs(out, exist_ok=True)
 asm = os.path.join(out, "artp.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
                 "-Wno-unused-function", "-Wno-unused-command-line-argument", "-S", "--cuda-device-only", "-o", asm,
                 os.path.join(root, "art_planner_amd/csrc/artp_capi.hip")] + [a for a in sys.argv[1:] if a.startswith("-D")], check=True)
 want = [a for a in sys.argv[1:] if not a.startswith("-D")] or ["classify_states", "feet_stream", "resolve_boxes", "sample_states"]
