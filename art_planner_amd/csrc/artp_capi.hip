@@ -1105,8 +1105,11 @@ static int finite_min_max_dev(artp_ctx* c, const float* d_layer, size_t n, float
 
 // recs != nullptr: also emit the PoseRecs of the validity pipeline (fused sample + validate)
 static int launch_sampler(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out, PoseRec* recs) {
-  size_t blocks = (n + 255) / 256;
-  if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+  const size_t blocks = (n + 255) / 256;  // one wavefront per 64 states
+  if (blocks > 0x7fffffffull) {
+    c->last_error = "batch too large for one sampler launch";
+    return ARTP_ERR_INVALID_ARG;
+  }
   if (c->sampler.from_distribution)
     hipLaunchKernelGGL(sample_states_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->sampler,
                        c->geom, c->robot, seed, first_index, n, se3_out, c->field[0], recs);

@@ -580,30 +580,32 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
   const float* row_cdf = stage_row_cdf(sm, g, row_cdf_lds);
   const int lane = threadIdx.x & 63;
   double* sw = stage[threadIdx.x >> 6];
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); i0 < n; i0 += stride) {  // wave-uniform
-    const size_t i = i0 + lane;
-    if (i < n) {
-      double st[7];
-      sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st, row_cdf);
+  // One wavefront = 64 consecutive states, no grid-stride loop: in a loop the compiler hoists the f64 polynomial
+  // constants of acos / atan2 / sincos out of it into SGPRs, runs out of them and parks them in VGPR lanes
+  // (v_writelane / v_readlane were 11 % of the kernel's VALU instructions); straight-line code takes them as
+  // literals on the scalar unit.
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane);  // wave-uniform
+  if (i0 >= n) return;
+  const size_t i = i0 + lane;
+  if (i < n) {
+    double st[7];
+    sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st, row_cdf);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) sw[lane * 7 + k] = st[k];
-      if (recs) {
-        float4 r[4];
-        make_pose_rec(f, st, r);
-        float4* dst = reinterpret_cast<float4*>(recs + i);  // one whole 64-byte line per lane
+    for (int k = 0; k < 7; ++k) sw[lane * 7 + k] = st[k];
+    if (recs) {
+      float4 r[4];
+      make_pose_rec(f, st, r);
+      float4* dst = reinterpret_cast<float4*>(recs + i);  // one whole 64-byte line per lane
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dst[k] = r[k];
-      }
+      for (int k = 0; k < 4; ++k) dst[k] = r[k];
     }
-    wave_lds_sync();
-    const size_t cnt = (n - i0 < 64 ? n - i0 : 64) * 7;
-    double* out = se3_out + 7 * i0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k)
-      if ((size_t)(k * 64 + lane) < cnt) out[k * 64 + lane] = sw[k * 64 + lane];
-    wave_lds_sync();
   }
+  wave_lds_sync();
+  const size_t cnt = (n - i0 < 64 ? n - i0 : 64) * 7;
+  double* out = se3_out + 7 * i0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+    if ((size_t)(k * 64 + lane) < cnt) out[k * 64 + lane] = sw[k * 64 + lane];
 }
 
 // States of the global sample stream at explicit indices base + idx[j], j < *count (device counter):
