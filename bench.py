@@ -613,6 +613,9 @@ def main():
         # the bound that binds: instruction issue, from this run's PMC passes
         "binding": None if not pmc else {
             "bound": "valu_issue", "valu_busy_time_weighted": pmc["valu_busy_time_weighted"],
+            "valu_busy_note": "SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * GRBM_GUI_ACTIVE / 8).  A value of 1.0 - 1.1 "
+                              "means saturated: instructions that issue with an empty EXEC mask (16-lane groups of a "
+                              "wavefront on different branches) retire in fewer than the four cycles the formula charges",
             "lds_busy_time_weighted": pmc["lds_busy_time_weighted"],
             "hbm_traffic_frac_of_peak": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "per_kernel": pmc["kernels"],
