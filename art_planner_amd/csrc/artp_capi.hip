@@ -461,7 +461,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
     const size_t lds_stream = 0;
     hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 0>), dim3(grid_sub(c, ARTP_TORSO_WGS_PER_CU)),
                        dim3(64 * ARTP_WAVES_PER_BLOCK), lds_stream, c->stream, c->field[0], c->robot, q, valid,
-                       caps_stream, c->d_error);
+                       caps_stream, c->d_error, c->tables[0].valid ? c->tables[0].mm : (const float2*)nullptr);
   }
   hipLaunchKernelGGL((resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 3>), dim3(grid_scan(c, lds_scan(c))),
                      dim3(64 * ARTP_WAVES_PER_BLOCK), lds_scan(c), c->stream, c->field[0], c->robot, q, valid,

@@ -395,6 +395,79 @@ __device__ __forceinline__ bool grp_vertex_stream(const FieldDev& f, const BoxHF
   return false;
 }
 
+// (f) for a torso box in an all-finite window, block form.  Only a vertex above the box's lowest point (h > minO2)
+// can lie inside it, and under a torso that is 1 vertex in 15 of the ~900 of its window, in a few clusters.  The exact
+// range table of 4 x 4 blocks (any anchor) says which blocks hold such a vertex at all: the wavefront looks up the
+// maxima of the window's ~80 blocks (the last block of a row / column is pulled back inside the window), packs the
+// ids of the blocks with max > minO2 into `hot` (LDS) and streams only their vertices -- the same vertices the full
+// scan would have passed on to point_in_box (max <= minO2 means none of the 16 passes the pre-filter), a few of
+// them twice where pulled-back blocks overlap.  Existence test: order and repeats do not matter.
+#define ARTP_HOT_BLOCKS 512
+template <int U>
+__device__ __forceinline__ bool wave_vertex_stream_blocks(const FieldDev& f, const float2* __restrict__ mm4,
+                                                          const BoxHF& b, unsigned short* hot, int lane) {
+  constexpr int G = 64;
+  const int numX = b.maxX - b.minX + 1;
+  const int numZ = b.maxZ - b.minZ + 1;
+  const float minO2 = b.aabb[2];
+  const float slack = 1.0e-5f;  // see grp_vertex_stream
+  const int x0 = ((float)b.minX * f.sample_w < b.aabb[0] - slack) ? 1 : 0;
+  const int x1 = ((float)b.maxX * f.sample_w > b.aabb[1] + slack) ? 1 : 0;
+  const int z0 = ((float)b.minZ * f.sample_d < b.aabb[4] - slack) ? 1 : 0;
+  const int z1 = ((float)b.maxZ * f.sample_d > b.aabb[5] + slack) ? 1 : 0;
+  const int inX = numX - x0 - x1, inZ = numZ - z0 - z1;
+  const int nbx = (inX + 3) >> 2, nbz = (inZ + 3) >> 2, nb = nbx * nbz;
+  if (mm4 == nullptr || inX < 4 || inZ < 4 || nb > ARTP_HOT_BLOCKS) return grp_vertex_stream<G, U>(f, b, lane, true);
+  const int xs0 = b.minX + x0, zs0 = b.minZ + z0;              // first inner sample
+  const int xl0 = xs0 + inX - 4, zl0 = zs0 + inZ - 4;          // last admissible block anchor
+  const int nW = f.nW;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int nhot = 0;
+  for (int j0 = 0; j0 < nb; j0 += G) {  // uniform
+    const int j = j0 + lane;
+    bool is_hot = false;
+    const int bx = j % nbx, bz = j / nbx;
+    if (j < nb) {
+      const int ax = min(xs0 + 4 * bx, xl0), az = min(zs0 + 4 * bz, zl0);
+      is_hot = gather32(mm4, (unsigned)(ax + az * nW)).x > minO2;
+    }
+    const unsigned long long m = __ballot(is_hot);
+    if (is_hot) hot[nhot + __popcll(m & lt_mask)] = (unsigned short)(bx | (bz << 8));
+    nhot += __popcll(m);
+  }
+  if (nhot == 0) return false;
+  wave_lds_sync();
+  const int total = nhot * 16;
+  bool hit = false;
+  for (int e0 = lane; e0 - lane < total; e0 += G * U) {  // uniform trip count
+    float hv[U];
+    int ix[U], iz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + G * u;
+      hv[u] = -INFINITY;
+      ix[u] = 0;
+      iz[u] = 0;
+      if (e < total) {
+        const int j = hot[e >> 4], v = e & 15;
+        const int bx = j & 255, bz = j >> 8;
+        ix[u] = min(xs0 + 4 * bx, xl0) + (v & 3);
+        iz[u] = min(zs0 + 4 * bz, zl0) + (v >> 2);
+        hv[u] = gather32(f.data, (unsigned)(ix[u] + iz[u] * nW));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float h = hv[u];
+      if (is_finite(h) && h > minO2 && !hit &&
+          point_in_box(b, (float)ix[u] * f.sample_w, h, (float)iz[u] * f.sample_d))
+        hit = true;
+    }
+    if (__any(hit)) return true;
+  }
+  return false;
+}
+
 // Kept triangles of the window in the reference's buffer order (x_local outer, z_local inner, ABC
 // before DBC; :1306-1441).  With WRITE_LIST the ids go to s.tri; returns T, or -1 on list overflow.
 template <int G, bool WRITE_LIST>

@@ -972,7 +972,7 @@ __device__ unsigned long long g_stage_cycles[2][10];
 template <int WAVES, int G, int PASS>
 __global__ void __launch_bounds__(64 * WAVES)
 resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __restrict__ valid,
-                     ScratchCaps caps, int* __restrict__ error_flag) {
+                     ScratchCaps caps, int* __restrict__ error_flag, const float2* __restrict__ mm4 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int GPW = 64 / G;  // groups per wavefront
   const int lane = threadIdx.x & 63;
@@ -1029,7 +1029,8 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
       // finite) goes to queue 6 for the staged pass (PASS 3) -- keeping that code out of this kernel keeps
       // its register count down.
       if (fld.partner_flags != nullptr && (rec.kind & ARTP_REC_ALL_FINITE)) {
-        if (grp_vertex_stream<G, ARTP_TORSO_U>(fld, b, lane, true)) {
+        __shared__ unsigned short hot_blocks[WAVES][ARTP_HOT_BLOCKS];
+        if (wave_vertex_stream_blocks<ARTP_TORSO_U>(fld, mm4, b, hot_blocks[threadIdx.x >> 6], lane)) {
           result = 1;
           decided = true;
         } else {
