@@ -789,10 +789,10 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 #define ARTP_LANE_THREADS 256
 #define ARTP_STREAM_WAVES 4
 #ifndef ARTP_TORSO_WGS_PER_CU
-#define ARTP_TORSO_WGS_PER_CU 14  // 2 wavefronts each: 7 per SIMD (69 VGPRs with 6 loads in flight)
+#define ARTP_TORSO_WGS_PER_CU 14  // 2 wavefronts each: 7 per SIMD (65 VGPRs)
 #endif
 #ifndef ARTP_TORSO_U
-#define ARTP_TORSO_U 6  // loads in flight per lane in the torso vertex stream (~14 per lane in all)
+#define ARTP_TORSO_U 2  // loads in flight per lane in the torso vertex stream (the hot blocks are ~3 steps of 64 vertices)
 #endif
 #ifndef ARTP_FEET_U
 #define ARTP_FEET_U 4  // loads in flight per lane in the feet vertex stream (a 10 x 10 window is 6 per lane in all)
