@@ -612,6 +612,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   long long c_prev = clock64();
 #endif
   // the state's PoseRec: float pose + the box rotation in the field frame (shared by its five boxes)
+  if (threadIdx.x < 2) cnts[threadIdx.x] = 0u;  // open torso / foot boxes of the workgroup (visible after the barrier)
   if (threadIdx.x < SUB * 64 * 4) {
     const int sl = threadIdx.x >> 2, part = threadIdx.x & 3;
     const size_t gi_raw = (size_t)blockIdx.x * SUB * 64 + sl;
@@ -644,35 +645,18 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
     open = ok && code == ARTP_CODE_OPEN;
+    // list slots: one LDS atomic per wavefront and list (no second barrier for a cross-wavefront prefix sum; the
+    // order of the list, and so of the queue, is whatever order the wavefronts arrive in -- labels do not depend on it)
     const unsigned long long bal = __ballot(open);
     rank = __popcll(bal & lt_mask);
-    if (lane == 0) cnts[wave] = (unsigned)__popcll(bal);
-  }
-  __syncthreads();
-  int n_t = 0, n_f = 0;
-#pragma unroll
-  for (int w = 0; w < 5 * SUB; ++w) {
-    const int c = (int)cnts[w];
-    if (w < SUB) {
-      if (body && w < wave) rank += c;
-      n_t += c;
-    } else {
-      if (!body && w < wave) rank += c;
-      n_f += c;
+    if (bal) {
+      unsigned base_w = 0;
+      if (lane == 0) base_w = atomicAdd(&cnts[body ? 0 : 1], (unsigned)__popcll(bal));
+      rank += (int)__shfl(base_w, 0);
     }
   }
   ARTP_C_MARK(2);
   // rank = position of this lane's box in its list (valid where `open`)
-  if (n_t + n_f == 0) {
-    ARTP_C_FLUSH(1);
-    if (body && live) {
-      bool ok = true;
-#pragma unroll
-      for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
-      valid[i] = (uint8_t)ok;
-    }
-    return;
-  }
   if (open) {
     const int cap = body ? CAP_T : CAP_F;
     if (rank < cap) {
@@ -690,9 +674,20 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       codes[sub][k][lane] = 3;
     }
   }
+  __syncthreads();
+  int n_t = (int)cnts[0], n_f = (int)cnts[1];
+  if (n_t + n_f == 0) {  // uniform: nothing open in this workgroup
+    ARTP_C_FLUSH(1);
+    if (body && live) {
+      bool ok = true;
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) ok = ok && (codes[sub][kk][lane] != 1);
+      valid[i] = (uint8_t)ok;
+    }
+    return;
+  }
   if (n_t > CAP_T) n_t = CAP_T;
   if (n_f > CAP_F) n_f = CAP_F;
-  __syncthreads();
   // Phase B: wave 0 walks the torso list, waves [WAVES_T, WAVES_B) the foot list, one lane per entry.  Wavefronts
   // without a list, or with an empty one, leave here (the torso wavefronts 0 .. SUB-1 stay: they write the labels at
   // the end).  S_BARRIER waits on the surviving wavefronts of a workgroup only, and the wave slots freed let the
