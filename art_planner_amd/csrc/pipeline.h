@@ -256,8 +256,13 @@ __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const Tables
 template <int N>
 __device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
-  const int m = wX < wZ ? wX : wZ;
-  const int l = m >= 32 ? 2 : (m >= 16 ? 1 : 0), sh = l + 1, B = 8 << l, s = 1 << sh;
+  const int m = wX < wZ ? wX : wZ, wl = wX > wZ ? wX : wZ;
+  // block size by the short side, but large enough that N blocks span the long side (N B - s samples at least): a
+  // torso window of 33 x 15 samples takes three 16-sample blocks by one, not five 8-sample blocks it may not gather
+  int l = m >= 32 ? 2 : (m >= 16 ? 1 : 0);
+  if (l < 2 && wl > N * (8 << l) - (2 << l)) ++l;
+  if (l < 2 && wl > N * (8 << l) - (2 << l)) ++l;
+  const int sh = l + 1, B = 8 << l, s = 1 << sh;
   const int nxs = (f.nW + s - 1) >> sh;
   int px[3], pz[3], nx, nz;
   {
