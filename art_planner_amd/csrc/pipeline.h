@@ -884,7 +884,7 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
 // NaN or is thinner than the smallest table block): (f) streamed from the map, then the list-free corner
 // stage.  Decides everything except boxes whose corner candidates may have partners (-> queue 5, list
 // pass).  Records without table verdict go to queue 4 (sequential lane scan with the running-dMAX quirk).
-// 6 wavefronts per SIMD (82 VGPRs -> 80, a handful spilled): -2 % against 5; 7 lose it again.  (With LLVM's SLP pass on,
+// 6 wavefronts per SIMD (80 VGPRs, nothing spilled): -2 % against 5; 7 lose it again.  (With LLVM's SLP pass on,
 // the kernel needed 96 VGPRs + 14 spills for 5 wavefronts and 6 were out of reach.)
 #ifdef ARTP_STAGE_TIMING
 __device__ unsigned long long g_feet_cycles[4];  // stream cycles, corner cycles, boxes that reached the corners
