@@ -648,3 +648,29 @@ def test_huge_robot_uses_the_largest_table_levels(big_map):
     few = np.concatenate([ctx.validate_states(se3[i:i + 16]) for i in range(0, 512, 16)])
     assert np.array_equal(few, vo[:512])
     ctx.close()
+
+
+def test_labels_are_deterministic_across_repeats(big_map, ctx_yaml):
+    """The same batch validated 40 times gives the same labels every time: the queue order of the pipeline is not
+    deterministic (list slots and queue slots are handed out by atomics), the labels must be."""
+    import torch
+    ctx_yaml.upload_map(big_map)
+    n = 1 << 20
+    dev = "cuda:0"
+    se3 = torch.empty((n, 7), dtype=torch.float64, device=dev)
+    va = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx_yaml.use_torch_stream()
+    ctx_yaml.sample_and_validate_dev(3, 77777, n, se3, va)
+    torch.cuda.synchronize()
+    ref = va.clone()
+    c0 = ctx_yaml.pipeline_counters()
+    for rep in range(40):
+        va.fill_(9)
+        if rep % 2:
+            ctx_yaml.validate_states_dev(se3, va)       # PoseRecs from the states
+        else:
+            ctx_yaml.sample_and_validate_dev(3, 77777, n, se3, va)  # fused
+        torch.cuda.synchronize()
+        assert torch.equal(va, ref), f"repeat {rep}: {(va != ref).sum().item()} labels differ"
+    c1 = ctx_yaml.pipeline_counters()
+    assert c0["torso_queued"] == c1["torso_queued"] and c0["feet_queued"] == c1["feet_queued"]
