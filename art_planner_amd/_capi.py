@@ -14,7 +14,7 @@ if os.environ.get("ARTP_LIB"):  # tuning builds (e.g. libartp_timing.so); never 
 SYMBOLS = [
     "artp_params_defaults", "artp_params_yaml", "artp_status_string", "artp_last_error",
     "artp_device_arch", "artp_create", "artp_destroy", "artp_set_stream", "artp_use_own_stream",
-    "artp_synchronize", "artp_set_lane", "artp_get_lane",
+    "artp_synchronize", "artp_set_lane", "artp_get_lane", "artp_map_version",
     "artp_upload_layer", "artp_update_layer_rect", "artp_check_boxes", "artp_check_boxes_dev",
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
@@ -119,7 +119,9 @@ def load():
     for name in ("artp_sample_states", "artp_sample_states_dev"):
         getattr(L, name).argtypes = [vp, u64, u64, sz, vp]
     L.artp_sample_and_validate_dev.argtypes = [vp, u64, u64, sz, vp, vp, C.POINTER(sz)]
-    L.artp_sample_and_validate.argtypes = [vp, u64, u64, sz, vp, vp]
+    L.artp_sample_and_validate.argtypes = [vp, u64, u64, sz, vp, vp, vp]
+    L.artp_map_version.argtypes = [vp]
+    L.artp_map_version.restype = C.c_uint64
     L.artp_set_z_bounds.argtypes = [vp, dbl, dbl]
     for name in ("artp_check_motions_last_valid", "artp_check_motions_last_valid_dev"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, vp]

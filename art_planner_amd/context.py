@@ -132,12 +132,17 @@ class Context:
                                                        t.ctypes.data, st.ctypes.data), "artp_check_motions_last_valid")
         return valid, t, st
 
-    def sample_and_validate(self, seed, first_index, n):
+    def sample_and_validate(self, seed, first_index, n, with_version=False):
         se3 = np.empty((n, 7), np.float64)
         valid = np.empty(n, np.uint8)
-        self._chk(self.L.artp_sample_and_validate(self.h, seed, first_index, n, se3.ctypes.data, valid.ctypes.data),
-                  "artp_sample_and_validate")
-        return se3, valid
+        ver = C.c_uint64(0)
+        self._chk(self.L.artp_sample_and_validate(self.h, seed, first_index, n, se3.ctypes.data, valid.ctypes.data,
+                                                  C.addressof(ver)), "artp_sample_and_validate")
+        return (se3, valid, int(ver.value)) if with_version else (se3, valid)
+
+    def map_version(self):
+        """artp_map_version: bumped by every call that changes a layer, its tables or the sampler tables."""
+        return int(self.L.artp_map_version(self.h))
 
     def check_edges_interp(self, s1, s2):
         s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)

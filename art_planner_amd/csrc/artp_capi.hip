@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,8 @@ struct artp_ctx {
   RobotDev robot{};
   MapGeom geom{};
   bool have_geom = false;
+  // artp_map_version(): bumped (under `mu`) by everything that changes a layer, its tables or the sampler tables
+  std::atomic<uint64_t> map_version{0};
   FieldDev field[2]{};
   float* field_data[2] = {nullptr, nullptr};
   size_t field_elems[2] = {0, 0};
@@ -38,6 +41,7 @@ struct artp_ctx {
   SamplerDev sampler{};
   float* sampler_buf = nullptr;
   float* sampler_pack = nullptr;  // derived tables: packed cells, row-major CDF, pivots
+  int sampler_rows = 0, sampler_cols = 0;  // grid size sampler_buf / sampler_pack were allocated for
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
@@ -80,6 +84,7 @@ struct artp_ctx {
     bool init = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
     unsigned long long* d_count = nullptr;
+    int* d_error = nullptr;  // per lane: a capacity overflow is reported to the caller of the batch that raised it
     void* tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t tmp_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void* cub_tmp = nullptr;
@@ -136,6 +141,7 @@ void park_lane(artp_ctx* c) {  // current members -> lanes[cur_lane]
   l.own_stream = c->own_stream;
   l.stream = c->stream;
   l.d_count = c->d_count;
+  l.d_error = c->d_error;
   l.cub_tmp = c->cub_tmp;
   l.cub_cap = c->cub_cap;
   for (int k = 0; k < 8; ++k) {
@@ -149,6 +155,7 @@ void unpark_lane(artp_ctx* c, int lane) {
   c->own_stream = l.own_stream;
   c->stream = l.stream;
   c->d_count = l.d_count;
+  c->d_error = l.d_error;
   c->cub_tmp = l.cub_tmp;
   c->cub_cap = l.cub_cap;
   for (int k = 0; k < 8; ++k) {
@@ -599,6 +606,7 @@ void artp_destroy(artp_ctx* c) {
       if (l.tmp[s]) (void)hipFree(l.tmp[s]);
     if (l.cub_tmp) (void)hipFree(l.cub_tmp);
     if (l.d_count) (void)hipFree(l.d_count);
+    if (l.d_error) (void)hipFree(l.d_error);
     if (l.own_stream) (void)hipStreamDestroy(l.own_stream);
   }
   for (int s = 0; s < 2; ++s) {
@@ -620,8 +628,7 @@ void artp_destroy(artp_ctx* c) {
   if (c->d_map_f32) (void)hipFree(c->d_map_f32);
   if (c->pin_states) (void)hipHostFree(c->pin_states);
   if (c->pin_labels) (void)hipHostFree(const_cast<uint8_t*>(c->pin_labels));
-  if (c->d_error) (void)hipFree(c->d_error);
-  delete c;
+  delete c;  // d_error / d_count of every lane went with the lanes above
 }
 
 int artp_set_stream(artp_ctx* c, void* hip_stream) {
@@ -656,9 +663,12 @@ int artp_set_lane(artp_ctx* c, int lane) {
   if (!c->lanes[lane].init) {
     artp_ctx::lane_state l;
     HIP_TRY(c, hipStreamCreateWithFlags(&l.own_stream, hipStreamNonBlocking));
-    if (hipMalloc(&l.d_count, sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc(&l.d_count, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&l.d_error, sizeof(int)) != hipSuccess || hipMemset(l.d_error, 0, sizeof(int)) != hipSuccess) {
+      if (l.d_count) (void)hipFree(l.d_count);
+      if (l.d_error) (void)hipFree(l.d_error);
       (void)hipStreamDestroy(l.own_stream);
-      c->last_error = "hipMalloc failed (lane counter)";
+      c->last_error = "hipMalloc failed (lane counters)";
       return ARTP_ERR_HIP;
     }
     l.stream = l.own_stream;
@@ -671,6 +681,8 @@ int artp_set_lane(artp_ctx* c, int lane) {
 }
 
 int artp_get_lane(artp_ctx* c) { return c ? c->cur_lane : -1; }
+
+uint64_t artp_map_version(const artp_ctx* c) { return c ? c->map_version.load(std::memory_order_acquire) : 0; }
 
 namespace {
 
@@ -758,6 +770,7 @@ int finish_layer(artp_ctx* c, int slot, int rows, int cols, double len_x, double
   if (rc != ARTP_OK) return rc;
   rc = set_kernel_lds(c);
   if (rc != ARTP_OK) return rc;
+  c->map_version.fetch_add(1, std::memory_order_release);  // even when the tables fail: the samples did change
   rc = build_tables(c, slot);
   if (rc != ARTP_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -834,6 +847,7 @@ int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, 
   if (row0 < 0 || col0 < 0 || nrows <= 0 || ncols <= 0 || row0 + nrows > rows || col0 + ncols > cols)
     return ARTP_ERR_INVALID_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
+  c->map_version.fetch_add(1, std::memory_order_release);
   std::vector<float>& host = c->field_host[slot];
   // grid column j maps to ODE z = cols-1-j; copy each touched z-row segment (contiguous in x)
   for (int jj = 0; jj < ncols; ++jj) {
@@ -977,6 +991,31 @@ int artp_validate_states(artp_ctx* c, const double* se3, size_t n, uint8_t* vali
 
 static int pack_sampler_tables(artp_ctx* c, int rows, int cols);
 
+// Sampler layer + derived-table storage.  Reused while the grid size stays the same (the in-build re-weighting of
+// artp_roadmap_build / _grow re-uploads the distribution every recompute_density_after_n_samples vertices: no
+// hipFree / hipMalloc per round, and no free that is unordered against another lane still sampling).  On a size
+// change every lane's stream is drained before the old buffers go.
+static int ensure_sampler_storage(artp_ctx* c, int rows, int cols) {
+  if (c->sampler_buf && c->sampler_pack && c->sampler_rows == rows && c->sampler_cols == cols) return ARTP_OK;
+  const size_t e = (size_t)rows * cols;
+  const int npiv = (cols + 15) / 16, pitch = npiv * 16, ppitch = (npiv + 3) & ~3;
+  const size_t floats = (size_t)rows * pitch + (size_t)rows * ppitch + 8 * e + 64;
+  for (int l = 0; l < ARTP_MAX_LANES; ++l)
+    if (l != c->cur_lane && c->lanes[l].init) HIP_TRY(c, hipStreamSynchronize(c->lanes[l].stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_sampler = false;
+  if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
+  c->sampler_buf = nullptr;
+  if (c->sampler_pack) HIP_TRY(c, hipFree(c->sampler_pack));
+  c->sampler_pack = nullptr;
+  c->sampler_rows = c->sampler_cols = 0;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_buf), (6 * e + rows) * sizeof(float)));
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_pack), floats * sizeof(float)));
+  c->sampler_rows = rows;
+  c->sampler_cols = cols;
+  return ARTP_OK;
+}
+
 int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* cum_prob_rowwise,
                                const float* elevation, const float* normal_x, const float* normal_y,
                                const float* normal_z, const float* plane_fit_std_dev, int rows,
@@ -987,9 +1026,11 @@ int artp_upload_sampler_layers(artp_ctx* c, const float* cum_prob, const float* 
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t e = (size_t)rows * cols;
-  if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
-  c->sampler_buf = nullptr;
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_buf), (6 * e + rows) * sizeof(float)));
+  c->map_version.fetch_add(1, std::memory_order_release);
+  {
+    const int rcs = ensure_sampler_storage(c, rows, cols);
+    if (rcs != ARTP_OK) return rcs;
+  }
   float* p = c->sampler_buf;
   const float* src[6] = {cum_prob, elevation, normal_x, normal_y, normal_z, plane_fit_std_dev};
   const float** dst[6] = {&c->sampler.cum_prob, &c->sampler.elevation, &c->sampler.normal_x,
@@ -1021,9 +1062,7 @@ static int pack_sampler_tables(artp_ctx* c, int rows, int cols) {
   const size_t e = (size_t)rows * cols;
   const int npiv = (cols + 15) / 16, pitch = npiv * 16, ppitch = (npiv + 3) & ~3;
   const size_t floats = (size_t)rows * pitch + (size_t)rows * ppitch + 8 * e + 64;
-  if (c->sampler_pack) HIP_TRY(c, hipFree(c->sampler_pack));
-  c->sampler_pack = nullptr;
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_pack), floats * sizeof(float)));
+  // storage from ensure_sampler_storage (same size for the same rows x cols)
   HIP_TRY(c, hipMemsetAsync(c->sampler_pack, 0, floats * sizeof(float), c->stream));
   float* cells = c->sampler_pack;                       // 8 floats per cell, 32-byte aligned
   float* cdf_t = cells + 8 * e;
@@ -1049,9 +1088,11 @@ static int upload_sampler_layers_from_device(artp_ctx* c, const float* cum_prob,
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t e = (size_t)rows * cols;
-  if (c->sampler_buf) HIP_TRY(c, hipFree(c->sampler_buf));
-  c->sampler_buf = nullptr;
-  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->sampler_buf), (6 * e + rows) * sizeof(float)));
+  c->map_version.fetch_add(1, std::memory_order_release);
+  {
+    const int rcs = ensure_sampler_storage(c, rows, cols);
+    if (rcs != ARTP_OK) return rcs;
+  }
   float* p = c->sampler_buf;
   const float* src[6] = {cum_prob, elevation, normal_x, normal_y, normal_z, plane_fit_std_dev};
   const float** dst[6] = {&c->sampler.cum_prob, &c->sampler.elevation, &c->sampler.normal_x,
@@ -1194,10 +1235,11 @@ int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_inde
 // Host-buffer form of the fused rejection-sampling step: states AND labels come back, so a caller that hands the
 // states out one at a time (SE3FromSE2Sampler::sampleUniform of the host mirror) already knows their labels.
 int artp_sample_and_validate(artp_ctx* c, uint64_t seed, uint64_t first_index, size_t n, double* se3_out,
-                             uint8_t* valid_out) {
+                             uint8_t* valid_out, uint64_t* map_version) {
   if (!c || (n && (!se3_out || !valid_out))) return ARTP_ERR_INVALID_ARG;
-  if (n == 0) return ARTP_OK;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (map_version) *map_version = c->map_version.load(std::memory_order_acquire);  // fixed while `mu` is held
+  if (n == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = ensure_tmp(c, 0, n * 7 * sizeof(double));
   if (rc) return rc;

@@ -520,7 +520,10 @@ bool roadmap_sssp_dev(artp_roadmap* rm, std::vector<uint32_t>* path, double* cos
   if (rm->d_graph_dirty) {
     std::vector<double> w(ne);
     for (size_t e = 0; e < ne; ++e)
-      w[e] = (rm->evalid[e] && !rm->eremoved[e] && std::isfinite(rm->ecost[e])) ? rm->ecost[e] : INFINITY;
+      // negative weights (a learned cost below 0) would break the atomicMin on the bit pattern of the distances, which
+      // orders non-negative doubles only: such an edge is not traversable here (the reference's costs are >= 0)
+      w[e] = (rm->evalid[e] && !rm->eremoved[e] && std::isfinite(rm->ecost[e]) && rm->ecost[e] >= 0.0) ? rm->ecost[e]
+                                                                                                           : INFINITY;
     if (hipMemcpyAsync(rm->d_w, w.data(), ne * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
@@ -573,6 +576,14 @@ bool roadmap_sssp_dev(artp_roadmap* rm, std::vector<uint32_t>* path, double* cos
     if (v == 0) break;
     v = pred[v];
     if (v == 0xffffffffu) return false;  // cannot happen at the fixed point
+  }
+  if (path->back() != 0) {
+    // zero-weight edges (coincident vertices, a learned cost of 0) make dist[u] + 0 == dist[v] true in both
+    // directions, so the predecessor chain can close a cycle that never reaches the start: no path from here --
+    // the caller falls back to the host A*, which cannot cycle
+    path->clear();
+    *ok = false;
+    return false;
   }
   std::reverse(path->begin(), path->end());
   *cost = dg;

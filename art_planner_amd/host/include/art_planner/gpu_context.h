@@ -20,7 +20,10 @@ namespace art_planner {
 // launch that sampled them (artp_sample_and_validate).  The planners' rejection loops call
 // `do sampler_->sampleUniform(s); while (!si_->isValid(s))` (prm_motion_cost.cpp:174-186,
 // lazy_prm_star_min_update.cpp:552-554): with the block pre-validated, that isValid() is a lookup instead of a
-// kernel launch.  A block dies with the map it was validated on (mapChanged()).
+// kernel launch.  A block carries the artp_map_version() it was validated on and is only ever served while the
+// context still reports that version: whichever entry point changed the map (a mirror class, artp_update_layer_rect or
+// artp_preprocessed_install straight through GpuContext::get()), the very next isValid() sees the new map -- the
+// guarantee of StateValidityChecker::updateHeightField (validity_checker.cpp:26-29).
 class ValidatedStateBlock {
  public:
   ValidatedStateBlock(std::vector<double>&& se3, std::vector<uint8_t>&& labels, uint64_t epoch, bool validated)
@@ -107,27 +110,25 @@ class GpuContext {
   artp_ctx* get() const { return ctx_; }
 
   // ---- validated-state blocks (see ValidatedStateBlock) ----
-  // every map upload (checker, sampler, box checker) ends the validity of the blocks
+  // The epoch of a block is the map version INSIDE the artp_ctx (artp_map_version): every upload, rectangle update,
+  // install or sampler re-weighting bumps it, whoever issued it.  mapChanged() only drops the dead blocks early.
   void mapChanged() {
     std::lock_guard<std::mutex> lock(blocks_mutex_);
-    ++map_epoch_;
     for (auto& b : blocks_) b.reset();
   }
-  uint64_t mapEpoch() const {
-    std::lock_guard<std::mutex> lock(blocks_mutex_);
-    return map_epoch_;
-  }
+  uint64_t mapEpoch() const { return artp_map_version(ctx_); }
   // a sampler publishes its current block in its own slot (slot = -1: take a free one); returns the slot
   int publishBlock(int slot, const std::shared_ptr<ValidatedStateBlock>& block) {
     std::lock_guard<std::mutex> lock(blocks_mutex_);
     if (slot < 0) slot = next_slot_++ % kBlockSlots;
-    blocks_[slot] = (block->validated() && block->epoch() == map_epoch_) ? block : nullptr;
+    blocks_[slot] = (block->validated() && block->epoch() == artp_map_version(ctx_)) ? block : nullptr;
     return slot;
   }
   bool lookupLabel(const double s[7], uint8_t* label) const {
     std::lock_guard<std::mutex> lock(blocks_mutex_);
+    const uint64_t now = artp_map_version(ctx_);
     for (const auto& b : blocks_)
-      if (b && b->epoch() == map_epoch_ && b->lookup(s, label)) return true;
+      if (b && b->epoch() == now && b->lookup(s, label)) return true;
     return false;
   }
   // isValid() / checkMotion() never throw (ob::StateValidityChecker contract): a failing call is remembered here
@@ -150,7 +151,6 @@ class GpuContext {
   artp_ctx* ctx_{nullptr};
   mutable std::mutex blocks_mutex_;
   std::shared_ptr<ValidatedStateBlock> blocks_[kBlockSlots];
-  uint64_t map_epoch_{1};
   int next_slot_{0};
   mutable std::string last_error_;
   mutable size_t n_errors_{0};

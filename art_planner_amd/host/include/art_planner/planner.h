@@ -121,6 +121,9 @@ class Planner {
     std::unique_ptr<artp_preprocessed, void (*)(artp_preprocessed*)> fresh_guard(fresh_raw, artp_preprocessed_destroy);
     artp_preprocessed* fresh = fresh_raw;
     throwOnError(gpu_->get(), artp_preprocessed_install(gpu_->get(), fresh), "artp_preprocessed_install");
+    // the install bumped artp_map_version(): labels cached on the previous map can no longer be served by any mirror
+    // class on this context; drop them now rather than at their next lookup
+    gpu_->mapChanged();
     // the normals of get3DPoseFrom2D (map.cpp:77-90) come back from the device once per map
     const size_t cells = static_cast<size_t>(g.rows) * g.cols;
     std::vector<float> n[3] = {std::vector<float>(cells), std::vector<float>(cells), std::vector<float>(cells)};

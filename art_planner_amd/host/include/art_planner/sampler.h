@@ -167,8 +167,9 @@ class SE3FromSE2Sampler : public ob::StateSampler {
   void refill() {
     std::vector<double> se3(block_ * 7);
     std::vector<uint8_t> labels(block_);
-    const uint64_t epoch = gpu_->mapEpoch();
-    int rc = artp_sample_and_validate(gpu_->get(), seed_, next_index_, block_, se3.data(), labels.data());
+    uint64_t epoch = gpu_->mapEpoch();
+    // the version the labels were computed on comes back from the call itself (taken under the context's lock)
+    int rc = artp_sample_and_validate(gpu_->get(), seed_, next_index_, block_, se3.data(), labels.data(), &epoch);
     const bool validated = rc == ARTP_OK;
     if (rc == ARTP_ERR_NO_MAP)  // height fields not uploaded (yet): plain sampling, isValid() launches
       rc = artp_sample_states(gpu_->get(), seed_, next_index_, block_, se3.data());

@@ -5,7 +5,10 @@
 //          float32 elevation_masked, cum_prob, cum_prob_rowwise_hack, normal_x, normal_y, normal_z,
 //          plane_fit_std_dev (rows*cols each); float64 z_low, z_high; int32 n; float64 se3[n*7]; uint8 expected[n]
 //          (oracle labels); int32 m; float64 s1[m*7], s2[m*7]; uint8 motion_ok[m]; float64 last_t[m],
-//          last_state[m*7] (oracle, DiscreteMotionValidator::checkMotion(s1, s2, lastValid))
+//          last_state[m*7] (oracle, DiscreteMotionValidator::checkMotion(s1, s2, lastValid));
+//          stale-label case: int32 nb; uint64 seed_b; uint8 old_labels[nb], new_labels[nb] (oracle labels of the
+//          states sample(seed_b, 0..nb) on the map as uploaded / after the rectangle update); int32 row0, col0,
+//          nrows, ncols; float32 patch[nrows*ncols] (col-major, new body-layer samples)
 // Exit code 0 = every label (single-state isValid AND batch), every checkMotion verdict and every lastValid pair
 // equals the oracle's.  Without a GPU the context constructor must throw (no CPU fallback): exit code 3.
 #include <chrono>
@@ -85,6 +88,16 @@ int main(int argc, char** argv) {
   f.read(reinterpret_cast<char*>(motion_ok.data()), m);
   f.read(reinterpret_cast<char*>(last_t.data()), m * 8);
   f.read(reinterpret_cast<char*>(last_state.data()), last_state.size() * 8);
+  int32_t nb = 0, rect[4] = {0, 0, 0, 0};
+  uint64_t seed_b = 0;
+  f.read(reinterpret_cast<char*>(&nb), 4);
+  f.read(reinterpret_cast<char*>(&seed_b), 8);
+  std::vector<uint8_t> old_labels(nb), new_labels(nb);
+  f.read(reinterpret_cast<char*>(old_labels.data()), nb);
+  f.read(reinterpret_cast<char*>(new_labels.data()), nb);
+  f.read(reinterpret_cast<char*>(rect), 16);
+  std::vector<float> patch(static_cast<size_t>(rect[2]) * rect[3]);
+  f.read(reinterpret_cast<char*>(patch.data()), patch.size() * 4);
   if (!f) return 2;
 
   auto si = std::make_shared<ob::SpaceInformation>();
@@ -196,6 +209,45 @@ int main(int argc, char** argv) {
     bad += gpu->lookupLabel(fl, &lab) ? 1 : 0;
     bad += checker.isValid(&st) ? 0 : 1;  // same map data: still valid, now through a launch
   }
+  // The label cache follows the map version INSIDE the artp_ctx: a rectangle update issued straight through
+  // GpuContext::get() (what INTEGRATION.md tells a 10 Hz integrator to call) -- no mirror class involved -- must
+  // take effect for the very next isValid() on a sampler-issued state (validity_checker.cpp:26-29: updateHeightField
+  // is effective immediately in the reference).  Labels before / after against the oracle on the old / new map.
+  int stale_flips = 0;
+  {
+    SE3FromSE2Sampler fresh(&space, map, params, gpu, seed_b, static_cast<size_t>(nb));
+    std::vector<double> issued(static_cast<size_t>(nb) * 7);
+    const uint64_t v0 = artp_map_version(gpu->get());
+    for (int i = 0; i < nb; ++i) {
+      fresh.sampleUniform(&st);
+      flattenSE3(&st, &issued[7 * i]);
+      uint8_t lab = 2;
+      bad += gpu->lookupLabel(&issued[7 * i], &lab) ? 0 : 1;  // pre-validated: a lookup, not a launch
+      bad += lab != old_labels[i];
+      bad += checker.isValid(&st) != (old_labels[i] != 0);
+    }
+    bad += artp_update_layer_rect(gpu->get(), ARTP_SLOT_BODY, patch.data(), rect[0], rect[1], rect[2], rect[3]) != ARTP_OK;
+    bad += artp_map_version(gpu->get()) == v0 ? 1 : 0;
+    for (int i = 0; i < nb; ++i) {
+      uint8_t lab = 2;
+      bad += gpu->lookupLabel(&issued[7 * i], &lab) ? 1 : 0;  // the block died with its map version
+      toState(&issued[7 * i], &st);
+      bad += checker.isValid(&st) != (new_labels[i] != 0);
+      stale_flips += old_labels[i] != new_labels[i];
+    }
+    bad += stale_flips < 20 ? 1 : 0;  // the fixture must have teeth
+    // a block sampled on the new map is served again, with the new map's labels
+    SE3FromSE2Sampler again(&space, map, params, gpu, seed_b, static_cast<size_t>(nb));
+    for (int i = 0; i < nb; ++i) {
+      again.sampleUniform(&st);
+      double fl[7];
+      flattenSE3(&st, fl);
+      uint8_t lab = 2;
+      bad += gpu->lookupLabel(fl, &lab) ? 0 : 1;
+      bad += lab != new_labels[i];
+    }
+    checker.updateHeightField();  // back to the fixture's map for what follows
+  }
   // sampleUniformNear / sampleGaussian (sampler.cpp:135-187): inside the bounds, yaw-only rotation
   {
     ob::SE3StateSpace::StateType near, out;
@@ -235,8 +287,9 @@ int main(int argc, char** argv) {
     bad += (threw || prm.numVertices() != 302) ? 1 : 0;
   }
   std::printf("host mirror: %d states batch + %d single (%.1f us per isValid on arbitrary states), %d motions (%d lastValid "
-              "mismatches), rejection loop %d attempts / %d accepted at %.3f us per sampleUniform+isValid, %d mismatches\n",
-              n, n_single, us_single, m, bad_last, attempts, accepted, us_loop, bad);
+              "mismatches), rejection loop %d attempts / %d accepted at %.3f us per sampleUniform+isValid, %d labels flipped by a "
+              "direct artp_update_layer_rect and served fresh, %d mismatches\n",
+              n, n_single, us_single, m, bad_last, attempts, accepted, us_loop, stale_flips, bad);
   if (argc > 2) {
     std::ofstream o(argv[2]);
     o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"sampler_loop_us_per_state\": " << us_loop

@@ -42,7 +42,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 peak, same guide
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 PIPELINE = ["classify_states_kernel", "feet_stream_kernel", "feet_lane_kernel", "resolve_boxes_kernel<2, 64, 0>",
             "resolve_boxes_kernel<2, 64, 3>", "resolve_boxes_kernel<2, 16, 1>", "resolve_boxes_kernel<2, 64, 2>",
-            "plane_stage_kernel", "sample_states_kernel", "sample_classify_kernel"]
+            "plane_stage_kernel", "sample_states_kernel"]
 PMC_PASSES = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
@@ -300,6 +300,23 @@ def pair_edges(acc, want, max_gap=3):
     return np.concatenate(ii)[:want], np.concatenate(jj)[:want]
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with no launcher around it: re-exec under torch.distributed.run, one rank per GPU
+    of this node over RCCL (what the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` does from outside).  Returns the exit code."""
+    import socket
+    found = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if found < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: needs {n_gpus} GPUs on this node, found {found}")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,12 +343,23 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
 
+    N = args.gpus
+    if N < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if N > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: spawn the N ranks ourselves (rank 0 of the child job prints the JSON line on our stdout)
+        raise SystemExit(self_launch(N, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    N = args.gpus
-    assert world == N or (N == 1 and world == 1), f"--gpus {N} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if world != N:
+        raise SystemExit(f"bench.py --gpus {N} was launched with WORLD_SIZE={world}: start it as `python bench.py --gpus {N}` "
+                         f"(it spawns its own ranks) or under `python -m torch.distributed.run --nproc-per-node {N} "
+                         f"bench.py --gpus {N}`")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py --gpus {N}: needs {N} GPUs on this node, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -386,8 +414,16 @@ def main():
         cap = max(cap, c)
     torch.cuda.synchronize()
     mat_cap = 0
-    if do_gather:
-        from art_planner_amd.distributed import EdgeResultGatherer, ValidBitmapGatherer, agree_capacity
+    bits_buf = gatherers = all_states = idx_tmp = cnt_tmp = done_ev = None
+    rccl_ranks_seen = None
+
+    def setup_gather():
+        """Buffers of the exchange step + one trial all-gather (outside any timed region)."""
+        nonlocal cap, bits_buf, gatherers, all_states, idx_tmp, cnt_tmp, done_ev, do_gather, gather_error, rccl_ranks_seen
+        from art_planner_amd.distributed import ValidBitmapGatherer, agree_capacity
+        ones = torch.ones(1, device=dev, dtype=torch.int64)
+        dist.all_reduce(ones)                                     # the rank count RCCL itself sees
+        rccl_ranks_seen = int(ones.item())
         cap = agree_capacity(cap, S, dev)
         words = (S + 63) // 64
         # what crosses xGMI per batch: the validity BITMAP of every rank's candidates (S / 8 bytes = 512 KiB per
@@ -411,6 +447,9 @@ def main():
         except Exception as ex:  # pragma: no cover
             gather_error = repr(ex)
             do_gather = False
+
+    if do_gather:
+        setup_gather()
 
     def materialise(j):
         gb = gatherers[j & 1]
@@ -473,19 +512,41 @@ def main():
     dt = timed_region(K)
     value = N * S * K / dt
 
-    # ---- N > 1 (or --force-dist): the other materialisation setting and the edge exchange, all ranks -------
+    # ---- the exchange step under the other materialisation settings and the edge exchange, all ranks; at N = 1
+    # without --force-dist a one-rank RCCL group is brought up AFTER the headline so that every N reports the block ----
+    headline_gathers = do_gather
     dist_extras = None
+    if N == 1 and dist is None and not args.no_gather and not args.skip_extras:
+        try:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            comm = torch.cuda.Stream(device=dev)
+            do_gather = True
+            setup_gather()
+        except Exception as ex:  # pragma: no cover
+            gather_error = repr(ex)
+            do_gather = False
+            dist = None
     if do_gather:
-        dist_extras = {"materialise_default": args.materialise, "states_per_s_default": value}
         k2 = max(3, min(K, 20))
+        mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise))
+        dist_extras = {"world_size": world, "rccl_ranks_seen": rccl_ranks_seen, "backend": dist.get_backend(),
+                       "headline_includes_exchange": bool(headline_gathers),
+                       "materialise_default": args.materialise,
+                       "states_per_s_default": value if headline_gathers else N * S * k2 / timed_region(k2)}
         for name, mc in (("states_per_s_materialise_all", cap), ("states_per_s_materialise_none", 0)):
             mat_cap = mc
             dist_extras[name] = N * S * k2 / timed_region(k2)
         mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise))
+        dist_extras["per_gpu_states_per_s"] = {k_: v_ / N for k_, v_ in dist_extras.items()
+                                                 if k_.startswith("states_per_s_")}
         # edges follow the GPU that owns the source state: every rank validates E edges between its
         # own accepted states (0.5 m interpolation rule), scores them with the learned cost when weights are
         # there (else the length triple), packs the valid ones as {u32 i, u32 j, f32 cost[3]} and all-gathers them
         try:
+            from art_planner_amd.distributed import EdgeResultGatherer
             ctx.sample_and_validate_dev(seed, first_index(2000000), S, se3, valid)
             torch.cuda.synchronize()
             st_h = se3.cpu().numpy()
@@ -712,45 +773,77 @@ def main():
     except Exception as ex:  # pragma: no cover
         motion_cost = {"error": repr(ex)}
 
-    # ---- C5: persistent HBM map, 100 map versions, each changing ~5 % of the cells in 3 rectangles; per cycle =
-    # dirty-rectangle upload + table refresh + feature-map refresh + 2^18 states + 50 000 cost edges
+    # ---- C5 (BASELINE configs[4] as written): params.planner.elevation_layer = "upper_bound" -- body checker, sampler
+    # and the whole preprocessing read `upper_bound` (validity_checker_body.cpp:52-55, basic.cpp:45-104) -- on a
+    # persistent HBM map; 100 map versions, each changing ~5 % of the cells in 3 rectangles of that layer (body slot)
+    # and of the masked layer derived from it (feet slot); per cycle = dirty-rectangle upload + table refresh +
+    # feature-map refresh + 2^18 states + 50 000 cost edges.  Labels after the last version are checked
+    # against the CPU oracle on the updated layers (outside the timed cycles).
     c5 = None
     try:
         if args.skip_extras or E == 0:
             raise RuntimeError("skipped (--skip-extras)")
+        ctx5 = Context(local_rank, "yaml")
+        gm5 = map_from_device(ctx5, raw_map(args.map, args.res, seed=1234, with_upper_bound=True), body_layer="upper_bound")
+        ctx5.use_torch_stream()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import convert_weights
+        ctx5.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
         rng5 = np.random.default_rng(55)
-        elev5 = gm["elevation"].copy()
+        ub5 = gm5["upper_bound"].copy(order="F")
+        mk5 = gm5["elevation_masked"].copy(order="F")
         n5, cyc, stg = 1 << 18, [], {"rects": [], "cnn": [], "states": [], "cost": []}
         se5 = torch.empty((n5, 7), dtype=torch.float64, device=dev)
         va5 = torch.empty(n5, dtype=torch.uint8, device=dev)
         rows5 = torch.from_numpy(np.ascontiguousarray(edge_rows(a, b)[:50000])).to(dev)
         cost5 = torch.empty((rows5.shape[0], 3), dtype=torch.float32, device=dev)
-        side = int(round(np.sqrt(0.05 * gm.rows * gm.cols / 3)))  # 3 squares = 5 % of the cells
+        side = int(round(np.sqrt(0.05 * gm5.rows * gm5.cols / 3)))  # 3 squares = 5 % of the cells
+        ctx5.cost_update_map(np.ascontiguousarray(ub5[::-1, ::-1]), gm5.res, gm5.len_x, gm5.len_y)
+        ctx5.sample_and_validate_dev(seed, 0, n5, se5, va5)
+        torch.cuda.synchronize()
+        ver0 = ctx5.map_version()
         for c_i in range(100):
             t0 = time.perf_counter()
             for _ in range(3):
-                r0, c0 = int(rng5.integers(0, gm.rows - side)), int(rng5.integers(0, gm.cols - side))
-                elev5[r0:r0 + side, c0:c0 + side] += np.float32(rng5.normal(0, 0.01))
-                ctx.update_layer_rect(0, elev5[r0:r0 + side, c0:c0 + side], r0, c0)  # dirty cells -> HBM + tables
+                r0, c0 = int(rng5.integers(0, gm5.rows - side)), int(rng5.integers(0, gm5.cols - side))
+                ub5[r0:r0 + side, c0:c0 + side] += np.float32(rng5.normal(0, 0.01))
+                m_ = mk5[r0:r0 + side, c0:c0 + side]
+                mk5[r0:r0 + side, c0:c0 + side] = np.where(np.isfinite(m_), ub5[r0:r0 + side, c0:c0 + side], m_)
+                ctx5.update_layer_rect(0, ub5[r0:r0 + side, c0:c0 + side], r0, c0)  # dirty cells -> HBM + tables
+                ctx5.update_layer_rect(1, mk5[r0:r0 + side, c0:c0 + side], r0, c0)
             t1 = time.perf_counter()
-            ctx.cost_update_map(np.ascontiguousarray(elev5[::-1, ::-1]), gm.res, gm.len_x, gm.len_y)  # features
+            ctx5.cost_update_map(np.ascontiguousarray(ub5[::-1, ::-1]), gm5.res, gm5.len_x, gm5.len_y)  # features
             t2 = time.perf_counter()
-            ctx.sample_and_validate_dev(seed, 7_000_000 + c_i * n5, n5, se5, va5)
+            ctx5.sample_and_validate_dev(seed, 7_000_000 + c_i * n5, n5, se5, va5)
             torch.cuda.synchronize()
             t3 = time.perf_counter()
-            ctx.cost_query_dev(rows5, cost5)
+            ctx5.cost_query_dev(rows5, cost5)
             torch.cuda.synchronize()
             t4 = time.perf_counter()
             cyc.append((t4 - t0) * 1e3)
             for k_, v_ in zip(("rects", "cnn", "states", "cost"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                 stg[k_].append(v_ * 1e3)
-        gm.preprocessed.install()  # restore
-        ctx.cost_update_map(np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32), gm.res, gm.len_x, gm.len_y)
-        c5 = {"versions": 100, "cycle_ms_median": float(np.median(cyc)), "cycle_ms_max": float(np.max(cyc)),
+        c5 = {"versions": 100, "elevation_layer": "upper_bound (body slot + sampler + preprocessing; feet slot = the "
+                                                  "masked layer derived from it)",
+              "cycle_ms_median": float(np.median(cyc)), "cycle_ms_max": float(np.max(cyc)),
               "stage_ms_median": {k_: float(np.median(v_)) for k_, v_ in stg.items()},
               "states_per_cycle": n5, "cost_edges_per_cycle": int(rows5.shape[0]), "dirty_rects_per_cycle": 3,
-              "cells_changed_per_cycle": 3 * side * side, "budget_ms_at_10hz": 100.0,
+              "layers_updated_per_rect": 2, "cells_changed_per_cycle": 3 * side * side, "budget_ms_at_10hz": 100.0,
+              "map_versions_seen": ctx5.map_version() - ver0,
               "sustained_states_per_s": n5 / (float(np.median(cyc)) * 1e-3)}
+        if not args.no_cpu_baseline:  # the checker, outside the timed cycles
+            import oracle_py as O
+            g5 = type(gm5)(gm5.rows, gm5.cols, gm5.res, gm5.pos_x, gm5.pos_y)
+            g5.add("upper_bound", ub5)
+            g5.add("elevation_masked", mk5)
+            m5 = 16384
+            st5 = se5[:m5].cpu().numpy()
+            ref5 = O.OracleMap(g5, body_layer="upper_bound").states_valid(O.robot("yaml"), st5)
+            c5["labels_match_oracle_after_last_version"] = bool(np.array_equal(ref5, va5[:m5].cpu().numpy()))
+            c5["labels_checked"] = m5
+        gm5.preprocessed.close()
+        ctx5.close()
+        ctx.use_torch_stream()
     except Exception as ex:  # pragma: no cover
         c5 = {"error": repr(ex)}
 

@@ -97,6 +97,13 @@ int artp_upload_layer(artp_ctx* ctx, int slot, const float* layer_colmajor, int 
  * previously uploaded layer; `patch` is column-major nrows x ncols. */
 int artp_update_layer_rect(artp_ctx* ctx, int slot, const float* patch, int row0, int col0,
                            int nrows, int ncols);
+/* Map version of the context: a counter that every call which changes what isValid() / the sampler would answer
+ * increments -- artp_upload_layer, artp_update_layer_rect, artp_upload_sampler_layers, artp_preprocessed_install,
+ * artp_preprocessed_reweight_dev (when it installs the new distribution).  The reference's guarantee that
+ * StateValidityChecker::updateHeightField (validity_checker.cpp:26-29) takes effect for the very next isValid() is
+ * what a host-side label cache has to honour: it stamps cached labels with the version they were computed on
+ * (artp_sample_and_validate reports it) and compares with artp_map_version() before serving one.  Lock-free read. */
+uint64_t artp_map_version(const artp_ctx* ctx);
 
 /* ---- HeightMapBoxChecker::checkCollision (height_map_box_checker.cpp:58-72) -------------------
  * hit[i] = (dCollide(box, field, 1, ...) != 0) for pose i.  exit_codes (optional, may be NULL)
@@ -141,9 +148,11 @@ int artp_sample_states_dev(artp_ctx* ctx, uint64_t seed, uint64_t first_index, s
 int artp_sample_and_validate_dev(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n,
                                  double* se3_out, uint8_t* valid_out, size_t* n_valid);
 /* Host-buffer form: states and labels come back together, so a sampler that hands the states out one at a
- * time (ob::StateSampler::sampleUniform) already holds the label the following isValid() will ask for. */
+ * time (ob::StateSampler::sampleUniform) already holds the label the following isValid() will ask for.
+ * map_version (optional): the artp_map_version() the states were sampled and validated on (the context's lock is
+ * held for the whole call, so it is the version of every label of the batch). */
 int artp_sample_and_validate(artp_ctx* ctx, uint64_t seed, uint64_t first_index, size_t n, double* se3_out,
-                             uint8_t* valid_out);
+                             uint8_t* valid_out, uint64_t* map_version);
 
 /* ---- ob::MotionValidator::checkMotion (OMPL DiscreteMotionValidator; call sites
  *      prm_motion_cost.cpp:652, lazy_prm_star_min_update.cpp:725), batched -----------------------

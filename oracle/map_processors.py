@@ -144,13 +144,14 @@ def cumulative_distribution(prob: np.ndarray):
 
 def add_derived_layers(gm, robot, trav_thres: float = 0.15, foothold_margin: float = 0.3, hole_size_m: float = 0.3,
                        max_drop: float = 0.3, drop_search_radius: float = 0.16, min_step: float = 0.3,
-                       foothold_size: float = 0.1):
+                       foothold_size: float = 0.1, elevation_layer: str = "elevation"):
     """processors::Basic + the CDF on a map that carries `elevation` and `traversability`: adds normal_{x,y,z},
     plane_fit_std_dev, traversability_thresholded, elevation_masked, sample_probability, cum_prob and
     cum_prob_rowwise (column 0 of cum_prob_rowwise_hack).  robot: an object with torso_length, torso_width,
-    reach_x, reach_y."""
+    reach_x, reach_y.  elevation_layer = params.planner.elevation_layer: the layer every derived layer comes from
+    (basic.cpp:45-47,75,104; "upper_bound" in BASELINE config 5)."""
     res = gm.res
-    elev, trav = gm["elevation"], gm["traversability"]
+    elev, trav = gm[elevation_layer], gm["traversability"]
     nx, ny, nz, std = estimate_normals(gm, elev, (robot.torso_length + robot.torso_width) * 0.25)
     gm.add("normal_x", nx)
     gm.add("normal_y", ny)

@@ -132,9 +132,10 @@ def make_map(n: int = 400, res: float = 0.04, seed: int = 1234, flat: bool = Fal
              trav_thres: float = 0.15, robot: RobotDims = RobotDims(),
              foothold_margin: float = 0.3, hole_size_m: float = 0.3, max_drop: float = 0.3,
              drop_search_radius: float = 0.16, min_step: float = 0.3, foothold_size: float = 0.1,
-             with_upper_bound: bool = False) -> GridMap:
+             with_upper_bound: bool = False, elevation_layer: str = "elevation") -> GridMap:
     """Build a GridMap with every layer the hot path reads (CPU: derived layers from the oracle's restatement of
-    the reference preprocessing).
+    the reference preprocessing).  elevation_layer = params.planner.elevation_layer (params.h:18): the layer the body
+    checker, the sampler and the whole preprocessing read -- "upper_bound" for BASELINE config 5.
 
     Layers: elevation, traversability, elevation_masked, normal_{x,y,z}, plane_fit_std_dev,
     sample_probability, cum_prob, cum_prob_rowwise (column 0 of cum_prob_rowwise_hack) and optionally
@@ -147,7 +148,7 @@ def make_map(n: int = 400, res: float = 0.04, seed: int = 1234, flat: bool = Fal
     gm = raw_map(n, res, seed, flat, trav_thres, robot, foothold_margin, hole_size_m, max_drop, drop_search_radius,
                  min_step, foothold_size, with_upper_bound)
     return map_processors.add_derived_layers(gm, robot, trav_thres, foothold_margin, hole_size_m, max_drop,
-                                             drop_search_radius, min_step, foothold_size)
+                                             drop_search_radius, min_step, foothold_size, elevation_layer)
 
 
 def cumulative_distribution(prob):

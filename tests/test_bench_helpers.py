@@ -58,3 +58,21 @@ def test_committed_pmc_profile_is_only_used_for_the_same_kernel_sources(tmp_path
     (tmp_path / "art_planner_amd" / "csrc" / "k.h").write_text("// v2\n")
     d, note = bench.load_committed_pmc()
     assert d is None and "STALE" in note
+
+
+def test_bench_multi_gpu_launch_fails_with_a_clear_message_not_an_assertion():
+    """`python bench.py --gpus N` spawns its own ranks.  On a box without N GPUs it must say so; under
+    a launcher with another world size it must say how to start it."""
+    import subprocess
+    import sys
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", str(have + 2)], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and f"needs {have + 2} GPUs on this node, found {have}" in r.stderr, r.stderr
+    assert "AssertionError" not in r.stderr and "Traceback" not in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "4"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "torch.distributed.run" in r.stderr
+    assert "Traceback" not in r.stderr

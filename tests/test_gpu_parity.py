@@ -674,3 +674,67 @@ def test_labels_are_deterministic_across_repeats(big_map, ctx_yaml):
         assert torch.equal(va, ref), f"repeat {rep}: {(va != ref).sum().item()} labels differ"
     c1 = ctx_yaml.pipeline_counters()
     assert c0["torso_queued"] == c1["torso_queued"] and c0["feet_queued"] == c1["feet_queued"]
+
+
+def test_c5_upper_bound_layer_with_rectangle_updates():
+    """BASELINE config 5 as written (README.md:120, validity_checker_body.cpp:52-55): params.planner.elevation_layer =
+    "upper_bound" -- the body checker binds `upper_bound`, the sampler takes z / normals from it, the feet layer
+    `elevation_masked` and the sampling distribution are derived from it -- on a persistent HBM map that then sees
+    map versions changing ~5 % of the cells in 3 rectangles each.  After every version: labels of fresh sampler
+    states == the CPU oracle on the updated layers (body AND feet slot), and the device preprocessing fed with
+    `upper_bound` == the oracle's preprocessing fed with `upper_bound`."""
+    from synthetic import make_map, map_from_device, raw_map
+    rob = O.robot("yaml")
+    gm = make_map(400, 0.04, seed=1234, with_upper_bound=True, elevation_layer="upper_bound")
+    assert (gm["upper_bound"] > gm["elevation"]).mean() > 0.3            # a different layer, not a renamed one
+    ctx = _ctx("yaml")
+    # (1) the product's own preprocessing with upper_bound as the elevation layer
+    gd = map_from_device(ctx, raw_map(400, 0.04, seed=1234, with_upper_bound=True), body_layer="upper_bound")
+    assert np.array_equal(gd["elevation_masked"], gm["elevation_masked"])
+    assert np.array_equal(gd["cum_prob"], gm["cum_prob"])
+    gd.preprocessed.close()
+    # (2) Planner::setMap with the layer names of config 5
+    ctx.upload_map(gm, body_layer="upper_bound")
+    st = ctx.sample_states(42, 0, 60000)
+    so, _ = O.OracleSampler(gm, elevation_layer="upper_bound").sample(rob, 42, 0, 60000)
+    assert np.abs(st - so).max() <= 1e-12
+    lab = ctx.validate_states(st)
+    ref = O.OracleMap(gm, body_layer="upper_bound").states_valid(rob, st)
+    assert np.array_equal(lab, ref) and 0.2 < lab.mean() < 0.8
+    # the body slot really holds upper_bound: torso boxes near the surface hit it where they miss `elevation`
+    P = common.random_dposes(gm, 20000, np.random.default_rng(3), (0.2, 0.1), tilt=0.3)
+    hit = ctx.check_boxes(0, rob.torso, P)
+    assert np.array_equal(hit, O.OracleField(gm["upper_bound"], gm.len_x, gm.len_y).check_boxes(rob.torso, P))
+    assert (hit != O.OracleField(gm["elevation"], gm.len_x, gm.len_y).check_boxes(rob.torso, P)).mean() > 0.02
+    # (3) map versions: rectangles of upper_bound (body slot) and of the masked layer derived from it (feet slot)
+    rng = np.random.default_rng(55)
+    ub = gm["upper_bound"].copy(order="F")
+    masked = gm["elevation_masked"].copy(order="F")
+    side = int(round(np.sqrt(0.05 * gm.rows * gm.cols / 3)))
+    v0 = ctx.map_version()
+    for version in range(8):
+        for _ in range(3):
+            r0, c0 = int(rng.integers(0, gm.rows - side)), int(rng.integers(0, gm.cols - side))
+            ub[r0:r0 + side, c0:c0 + side] += np.float32(rng.normal(0, 0.03))
+            m = masked[r0:r0 + side, c0:c0 + side]
+            masked[r0:r0 + side, c0:c0 + side] = np.where(np.isfinite(m), ub[r0:r0 + side, c0:c0 + side], m)
+            ctx.update_layer_rect(0, ub[r0:r0 + side, c0:c0 + side], r0, c0)
+            ctx.update_layer_rect(1, masked[r0:r0 + side, c0:c0 + side], r0, c0)
+        g2 = common.GridMap(gm.rows, gm.cols, gm.res, gm.pos_x, gm.pos_y)
+        g2.add("upper_bound", ub)
+        g2.add("elevation_masked", masked)
+        st = ctx.sample_states(42, 1_000_000 * (version + 1), 12000)
+        ref = O.OracleMap(g2, body_layer="upper_bound").states_valid(rob, st)
+        assert np.array_equal(ctx.validate_states(st), ref), f"version {version}"
+        few = ctx.validate_states(st[:16])                                # latency path on the updated map
+        assert np.array_equal(few, ref[:16])
+    assert ctx.map_version() == v0 + 8 * 6                                # every rectangle bumped the map version
+    # (4) persistent map == fresh upload of the final layers (tables, partner flags included)
+    ctx2 = _ctx("yaml")
+    g2.layers.update({k: gm[k] for k in ("cum_prob", "normal_x", "normal_y", "normal_z", "plane_fit_std_dev")})
+    g2.layers["cum_prob_rowwise"] = gm.layers["cum_prob_rowwise"]
+    ctx2.upload_map(g2, body_layer="upper_bound")
+    big = ctx.sample_states(7, 0, 400000)
+    assert np.array_equal(ctx.validate_states(big), ctx2.validate_states(big))
+    ctx.close()
+    ctx2.close()
