@@ -52,7 +52,6 @@ struct artp_ctx {
   unsigned* stride_buf[2] = {nullptr, nullptr};      // stride tables (TablesDev::st)
   unsigned char* partner_buf[2] = {nullptr, nullptr};
   int partner_R_built[2] = {-1, -1};
-  bool conv_lds_attr_set = false;
   int layer_has_nonfinite[2] = {1, 1};
   float4* tri_raw_buf[2] = {nullptr, nullptr};
   size_t table_elems[2] = {0, 0};
@@ -94,9 +93,10 @@ struct artp_ctx {
   int cur_lane = 0;
   // motion cost (R8/R9)
   bool have_weights = false;
-  float* d_conv1_w = nullptr;          // [24][9] + [24]
-  half8* d_convw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // packed B fragments, layers 2..6
+  half8* d_convw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: the 15 x 15 layer's B fragments, per-row packing
   float* d_convb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* d_c12 = nullptr;              // conv1 o conv2 composed: [24][25] + [24] (conv12_pool_kernel)
+  half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   half_t* d_act[2] = {nullptr, nullptr};
   size_t act_cap = 0;
@@ -616,12 +616,14 @@ void artp_destroy(artp_ctx* c) {
     if (c->partner_buf[s]) (void)hipFree(c->partner_buf[s]);
     if (c->tri_raw_buf[s]) (void)hipFree(c->tri_raw_buf[s]);
   }
-  if (c->d_conv1_w) (void)hipFree(c->d_conv1_w);
   for (int l = 0; l < 5; ++l) {
     if (c->d_convw[l]) (void)hipFree(c->d_convw[l]);
     if (c->d_convb[l]) (void)hipFree(c->d_convb[l]);
   }
   if (c->d_fc) (void)hipFree(c->d_fc);
+  if (c->d_c12) (void)hipFree(c->d_c12);
+  for (int l = 0; l < 3; ++l)
+    if (c->d_convw_chunk[l]) (void)hipFree(c->d_convw_chunk[l]);
   for (int l = 0; l < 2; ++l)
     if (c->d_act[l]) (void)hipFree(c->d_act[l]);
   if (c->d_feat) (void)hipFree(c->d_feat);
@@ -1666,16 +1668,14 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
   }
   HIP_TRY(c, hipSetDevice(c->device));
   const float* w = reinterpret_cast<const float*>(p + 8);
-  if (!c->d_conv1_w) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_conv1_w), (216 + 24) * sizeof(float)));
-  HIP_TRY(c, hipMemcpy(c->d_conv1_w, w, (216 + 24) * sizeof(float), hipMemcpyHostToDevice));
-  w += 216 + 24;
+  w += 216 + 24;  // conv1 (composed with conv2 below)
   for (int l = 0; l < 5; ++l) {
     const ConvSpec& s = kConv[l];
     const int krow = s.kw * s.cin, ksteps = (krow + 31) / 32;
-    const size_t nfrag = (size_t)s.kh * ksteps * s.nt * 64;
+    const size_t nfrag = l == 4 ? (size_t)s.kh * ksteps * s.nt * 64 : 0;  // per-row packing: the 15 x 15 layer only
     std::vector<uint16_t> packed(nfrag * 8, 0);
     // B fragment of v_mfma_f32_16x16x32_f16: lane l holds B[k = (l>>4)*8 + j][n = l&15]
-    for (int kh = 0; kh < s.kh; ++kh)
+    for (int kh = 0; l == 4 && kh < s.kh; ++kh)
       for (int ks = 0; ks < ksteps; ++ks)
         for (int nt = 0; nt < s.nt; ++nt)
           for (int l = 0; l < 64; ++l)
@@ -1691,14 +1691,72 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
             }
     w += (size_t)s.cout * s.cin * s.kh * s.kw;
     if (c->d_convw[l]) HIP_TRY(c, hipFree(c->d_convw[l]));
+    c->d_convw[l] = nullptr;
     if (c->d_convb[l]) HIP_TRY(c, hipFree(c->d_convb[l]));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convw[l]), packed.size() * 2));
+    c->d_convb[l] = nullptr;
+    if (l == 4) {
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convw[l]), packed.size() * 2));
+      HIP_TRY(c, hipMemcpy(c->d_convw[l], packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convb[l]), 64 * sizeof(float)));
-    HIP_TRY(c, hipMemcpy(c->d_convw[l], packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     float bias[64] = {0};
     std::memcpy(bias, w, s.cout * sizeof(float));
     HIP_TRY(c, hipMemcpy(c->d_convb[l], bias, sizeof(bias), hipMemcpyHostToDevice));
     w += s.cout;
+  }
+  {
+    // conv1 (+BN) followed by conv2 (+BN) without an activation in between (network_light.py:84-87) is one 5 x 5
+    // convolution: Wc[co][a+c][b+d] += W2[co][ci][a][b] * W1[ci][c][d], bias b2[co] + sum W2[co][ci][a][b] * b1[ci]
+    const float* base = reinterpret_cast<const float*>(p + 8);
+    const float* w1 = base;            // [24][3][3]
+    const float* b1 = base + 216;      // [24]
+    const float* w2 = base + 240;      // [24][24][3][3]
+    const float* b2 = w2 + 24 * 24 * 9;
+    double wc[24][25], bc[24];
+    for (int co = 0; co < 24; ++co) {
+      for (int k = 0; k < 25; ++k) wc[co][k] = 0.0;
+      bc[co] = b2[co];
+      for (int ci = 0; ci < 24; ++ci)
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) {
+            const double v2 = w2[((co * 24 + ci) * 3 + a) * 3 + b];
+            bc[co] += v2 * b1[ci];
+            for (int cc = 0; cc < 3; ++cc)
+              for (int d = 0; d < 3; ++d) wc[co][(a + cc) * 5 + (b + d)] += v2 * (double)w1[ci * 9 + cc * 3 + d];
+          }
+    }
+    float h12[24 * 25 + 24];
+    for (int co = 0; co < 24; ++co) {
+      for (int k = 0; k < 25; ++k) h12[co * 25 + k] = (float)wc[co][k];
+      h12[600 + co] = (float)bc[co];
+    }
+    if (!c->d_c12) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_c12), sizeof(h12)));
+    HIP_TRY(c, hipMemcpy(c->d_c12, h12, sizeof(h12), hipMemcpyHostToDevice));
+    // conv3..5 for conv345_kernel: K walked in 16-byte chunks over the whole (kh, kw, cin) window; fragment
+    // [ks][nt][lane][8]: lane l, element j holds B[k][n] with chunk q = 4 ks + (l >> 4), k = 8 q + j, n = 16 nt + (l & 15)
+    const float* wl = w2 + 24 * 24 * 9 + 24;
+    for (int l = 0; l < 3; ++l) {
+      const ConvSpec& s = kConv[l + 1];
+      const int cpr = 3 * s.cin / 8, q_tot = 3 * cpr, ks_tot = (q_tot + 3) / 4;
+      std::vector<uint16_t> packed((size_t)ks_tot * 3 * 64 * 8, 0);
+      for (int ks = 0; ks < ks_tot; ++ks)
+        for (int nt = 0; nt < 3; ++nt)
+          for (int ln = 0; ln < 64; ++ln)
+            for (int j = 0; j < 8; ++j) {
+              const int q = ks * 4 + (ln >> 4), co = nt * 16 + (ln & 15);
+              float v = 0.f;
+              if (q < q_tot && co < s.cout) {
+                const int kh = q / cpr, i = (q % cpr) * 8 + j, kw = i / s.cin, ci = i % s.cin;
+                v = wl[(((size_t)co * s.cin + ci) * 3 + kh) * 3 + kw];
+              }
+              packed[(((size_t)ks * 3 + nt) * 64 + ln) * 8 + j] = f32_to_f16_bits(v);
+            }
+      if (c->d_convw_chunk[l]) HIP_TRY(c, hipFree(c->d_convw_chunk[l]));
+      c->d_convw_chunk[l] = nullptr;
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convw_chunk[l]), packed.size() * 2));
+      HIP_TRY(c, hipMemcpy(c->d_convw_chunk[l], packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+      wl += (size_t)s.cout * s.cin * 9 + s.cout;
+    }
   }
   if (!c->d_fc) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_fc), FcWeights::TOTAL * sizeof(float)));
   HIP_TRY(c, hipMemcpy(c->d_fc, w, FcWeights::TOTAL * sizeof(float), hipMemcpyHostToDevice));
@@ -1706,7 +1764,7 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
   return ARTP_OK;
 }
 
-static int cost_run_cnn(artp_ctx* c, int H, int W) {
+static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
   // shapes: network_light.py:84-107
   const int h1 = H - 2, w1 = W - 2, h2 = h1 - 2, w2 = w1 - 2, hp = h2 / 2, wpp = w2 / 2;
   const int h3 = hp - 2, w3 = wpp - 2, h4 = h3 - 2, w4 = w3 - 2, hq = h4 - 2, wq = w4 - 2;
@@ -1735,46 +1793,63 @@ static int cost_run_cnn(artp_ctx* c, int H, int W) {
   half_t* A = c->d_act[0];
   half_t* Bf = c->d_act[1];
   hipStream_t st = c->stream;
-  // input fp16 lives at the tail of buffer B while conv1 writes buffer A
-  half_t* in16 = Bf;
   {
-    const size_t n = (size_t)H * W;
-    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       (const float*)c->d_map_f32, n, in16);
-    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)(((size_t)h1 * w1 + 255) / 256)), dim3(256), 0, st,
-                       (const half_t*)in16, H, W, (const float*)c->d_conv1_w, (const float*)(c->d_conv1_w + 216), A);
+    // round 3: three launches.  (A) conv1 o conv2 + lrelu + pool2 straight from the f32 map -> A [hp][wpp][24];
+    // (B) conv3 -> conv4 -> pool3 -> conv5 with LDS-resident halo tiles -> Bf [h5][w5][48]; (C) the 15 x 15 layer.
+    const unsigned blocks_a = (unsigned)(((wpp + C12_PT - 1) / C12_PT) * ((hp + C12_PT - 1) / C12_PT));
+    hipLaunchKernelGGL(conv12_pool_kernel, dim3(blocks_a), dim3(256), 0, st, d_map, H, W,
+                       (const float*)c->d_c12, (const float*)(c->d_c12 + 600), A);
+    // tile edge of (B): one workgroup per CU, and a partly filled last round costs a full round -- rounds x patch
+    // area decides (400 x 400: 144 tiles of 16 = one round; 800 x 800: 484 tiles of 18 = two rounds against three of 16)
+    auto rounds_cost = [&](int t) {
+      const long tiles = (long)((w5 + t - 1) / t) * ((h5 + t - 1) / t);
+      return ((tiles + c->n_cus - 1) / c->n_cus) * (long)(t + 8) * (t + 8);
+    };
+    auto launch_b = [&](auto k345, int lds, int t) -> int {
+      HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k345), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      const unsigned blocks_b = (unsigned)(((w5 + t - 1) / t) * ((h5 + t - 1) / t));
+      hipLaunchKernelGGL(k345, dim3(blocks_b), dim3(C345_NT), lds, st, (const half_t*)A, hp, wpp,
+                         (const half8*)c->d_convw_chunk[0], (const float*)c->d_convb[1], (const half8*)c->d_convw_chunk[1],
+                         (const float*)c->d_convb[2], (const half8*)c->d_convw_chunk[2], (const float*)c->d_convb[3], Bf);
+      return ARTP_OK;
+    };
+    const int rcb = rounds_cost(18) < rounds_cost(16) ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
+                                                      : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16);
+    if (rcb != ARTP_OK) return rcb;
+    HIP_TRY(c, hipGetLastError());
+    A = Bf;  // the 15 x 15 layer below reads conv5's output
   }
-  auto grid_for = [](int hout, int wout, int mt) {
-    const size_t waves = (size_t)((wout + 16 * mt - 1) / (16 * mt)) * hout;
-    return dim3((unsigned)((waves + 3) / 4));
-  };
-  // conv2 + BN + lrelu (A -> B), maxpool 2/2 (B -> A)
-  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 24, 24, 2, 2, true>), grid_for(h2, w2, 2), dim3(256), 0, st,
-                     (const half_t*)A, h1, w1, (const half8*)c->d_convw[0], (const float*)c->d_convb[0], Bf);
-  hipLaunchKernelGGL((maxpool_kernel<2, 2>), dim3((unsigned)(((size_t)hp * wpp * 24 + 255) / 256)), dim3(256), 0, st,
-                     (const half_t*)Bf, h2, w2, 24, A);
-  // conv3 (A -> B), conv4 (B -> A), maxpool 3/1 (A -> B)
-  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 24, 48, 3, 2, true>), grid_for(h3, w3, 2), dim3(256), 0, st,
-                     (const half_t*)A, hp, wpp, (const half8*)c->d_convw[1], (const float*)c->d_convb[1], Bf);
-  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 48, 48, 3, 2, true>), grid_for(h4, w4, 2), dim3(256), 0, st,
-                     (const half_t*)Bf, h3, w3, (const half8*)c->d_convw[2], (const float*)c->d_convb[2], A);
-  hipLaunchKernelGGL((maxpool_kernel<3, 1>), dim3((unsigned)(((size_t)hq * wq * 48 + 255) / 256)), dim3(256), 0, st,
-                     (const half_t*)A, h4, w4, 48, Bf);
-  // conv5 (B -> A), flatten 15x15 (A -> features)
-  hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 48, 48, 3, 2, true>), grid_for(h5, w5, 2), dim3(256), 0, st,
-                     (const half_t*)Bf, hq, wq, (const half8*)c->d_convw[3], (const float*)c->d_convb[3], A);
   {
-    using Cfg = ConvLdsCfg<15, 15, 48, 48, 3, true>;
-    using KCfg = ConvKsplitCfg<15, 15, 48, 48, 3, true>;
-    auto kfn = conv_ksplit_kernel<15, 15, 48, 48, 3, true>;
-    if (!c->conv_lds_attr_set) {
-      HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     KCfg::LDS_BYTES));
-      c->conv_lds_attr_set = true;
+    // Tile height of the 15 x 15 layer: two workgroups per CU run at once, and the launch's last, partly filled
+    // round costs a full round's time.  Take the candidate height with the fewest output rows computed per CU
+    // (rounds x height); ties go to the smaller tile (less padding).
+    const int slots = 2 * c->n_cus;
+    const int cands[3] = {8, 9, 10};
+    int best = 8;
+    long best_cost = -1;
+    for (int tr : cands) {
+      const long tiles = (long)((wf + 15) / 16) * ((hf + tr - 1) / tr);
+      const long cost = ((tiles + slots - 1) / slots) * tr;
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        best = tr;
+      }
     }
-    const unsigned blocks = (unsigned)(((wf + Cfg::TP - 1) / Cfg::TP) * ((hf + Cfg::TR - 1) / Cfg::TR));
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), KCfg::LDS_BYTES, st, (const half_t*)A, h5, w5,
-                       (const half8*)c->d_convw[4], (const float*)c->d_convb[4], c->d_feat);
+    auto launch = [&](auto kfn, int lds, int tr) -> int {
+      HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      const unsigned blocks = (unsigned)(((wf + 15) / 16) * ((hf + tr - 1) / tr));
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw[4],
+                         (const float*)c->d_convb[4], c->d_feat);
+      return ARTP_OK;
+    };
+    int rcl;
+    if (best == 9)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9>::LDS_BYTES, 9);
+    else if (best == 10)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 10>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 10>::LDS_BYTES, 10);
+    else
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8>::LDS_BYTES, 8);
+    if (rcl != ARTP_OK) return rcl;
   }
   HIP_TRY(c, hipGetLastError());
   c->feat_h = hf;
@@ -1789,15 +1864,18 @@ static int cost_update_map_impl(artp_ctx* c, const float* elev_xy, bool on_devic
   if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t n = (size_t)rows * cols;
-  if (c->map_cap < n) {
-    if (c->d_map_f32) HIP_TRY(c, hipFree(c->d_map_f32));
-    c->d_map_f32 = nullptr;
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_map_f32), n * sizeof(float)));
-    c->map_cap = n;
+  const float* d_map = elev_xy;  // a device array is read where it lies (stream-ordered, like every _dev argument)
+  if (!on_device) {
+    if (c->map_cap < n) {
+      if (c->d_map_f32) HIP_TRY(c, hipFree(c->d_map_f32));
+      c->d_map_f32 = nullptr;
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_map_f32), n * sizeof(float)));
+      c->map_cap = n;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_map_f32, elev_xy, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    d_map = c->d_map_f32;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_map_f32, elev_xy, n * sizeof(float),
-                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-  const int rc = cost_run_cnn(c, rows, cols);
+  const int rc = cost_run_cnn(c, d_map, rows, cols);
   if (rc) return rc;
   // CostQuery.setMapParams (cost_query.py:26-35): featureResFactor = 2, mapClip = 24
   CostMapGeom& g = c->cost_geom;
@@ -1916,6 +1994,11 @@ extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (reset) {
     unsigned long long z4[4] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_feet_cycles), z4, sizeof(z4)) != hipSuccess) return -1;
+  }
+  if (reset == 4) {  // the feature extractor's phase counters (read + reset)
+    if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_cnn_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z16[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(artp::g_cnn_cycles), z16, sizeof(z16)) == hipSuccess ? 0 : -1;
   }
   if (out20 && reset == 2 &&
       hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_classify_cycles), 16 * sizeof(unsigned long long)) != hipSuccess)

@@ -2,11 +2,12 @@
 //
 // R8  network.CNNpart (art_planner_motion_cost/.../predictor/network_light.py:78-110): six un-padded
 //     convolutions with eval-mode BatchNorm, leaky-ReLU(0.3) and two max-pools, fp16.  BatchNorm is
-//     folded into the weights/bias on the host.  Activations live in HBM as NHWC fp16, so for a fixed
-//     kernel row the (kw, cin) taps of an output pixel are ONE contiguous run of KW*Cin halfs: the
-//     implicit GEMM walks K = (kh, [kw, cin]) in 32-wide steps that are single 16-byte loads per lane
-//     and feeds v_mfma_f32_16x16x32_f16 (fp32 accumulate).  Weights are pre-packed on the host in
-//     exactly the B-fragment order.  The first layer (Cin = 1, K = 9) is plain VALU.
+//     folded into the weights/bias on the host.  Three launches: conv12_pool_kernel (conv1 o conv2 composed into one
+//     5 x 5 layer + pool, VALU), conv345_kernel (conv3 -> conv4 -> pool -> conv5 on LDS-resident halo tiles, MFMA),
+//     conv_ksplit_kernel (the 15 x 15 layer, 85 % of the FLOPs, MFMA).  Activations are NHWC fp16, so for a
+//     fixed kernel row the (kw, cin) taps of an output pixel are ONE contiguous run of KW*Cin halfs: the
+//     implicit GEMMs walk K in 32-wide steps that are single 16-byte reads per lane and feed
+//     v_mfma_f32_16x16x32_f16 (fp32 accumulate).  Weights are pre-packed on the host in fragment order.
 // R9  CostQuery.__call__ + network.FCpart (cost_query.py:39-69, network_light.py:113-165): per edge,
 //     gather the 48 features of the start cell, build the 10 geometric inputs, 1x1-conv MLP with three
 //     heads -> (energy, time, 1 - prob).  One lane per edge, fp32 math, weights broadcast from LDS.
@@ -21,115 +22,15 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// ---- layer 1: 1 -> 24 channels, 3x3, BN folded, no activation (network_light.py:84-85) --------------
-// in: [H][W] fp16; out: NHWC [H-2][W-2][24] fp16.  One lane per output pixel.
-__global__ void __launch_bounds__(256)
-conv1_kernel(const half_t* __restrict__ in, int H, int W, const float* __restrict__ w /*[24][9]*/,
-             const float* __restrict__ bias /*[24]*/, half_t* __restrict__ out) {
-  __shared__ float sw[24 * 9 + 24];
-  for (int i = threadIdx.x; i < 24 * 9 + 24; i += blockDim.x) sw[i] = i < 216 ? w[i] : bias[i - 216];
-  __syncthreads();
-  const int Ho = H - 2, Wo = W - 2;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= Ho * Wo) return;
-  const int oy = p / Wo, ox = p - oy * Wo;
-  float x[9];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) x[ky * 3 + kx] = (float)in[(oy + ky) * W + ox + kx];
-  half_t o[24];
-#pragma unroll
-  for (int c = 0; c < 24; ++c) {
-    float a = sw[216 + c];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a = fmaf(x[k], sw[c * 9 + k], a);
-    o[c] = (half_t)a;
-  }
-  half8* dst = reinterpret_cast<half8*>(out + (size_t)p * 24);
-#pragma unroll
-  for (int v = 0; v < 3; ++v) {
-    half8 t;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = o[v * 8 + j];
-    dst[v] = t;
-  }
-}
-
-// ---- generic un-padded convolution as implicit GEMM on the matrix cores -------------------------------
-// in : NHWC fp16 [Hin][Win][CIN]           (CIN = 24 or 48; rows of KW*CIN halfs are contiguous)
-// wp : packed fp16 B fragments [KH][KSTEPS][NT][64 lanes][8]   (K padded with zeros to 32*KSTEPS)
-// out: NHWC fp16 [Hout][Wout][COUT], y = lrelu?(acc + bias)
-// One wavefront computes MT x 16 consecutive output pixels of one row for all NT*16 (>= COUT) channels.
-template <int KH, int KW, int CIN, int COUT, int NT, int MT, bool LRELU>
-__global__ void __launch_bounds__(256)
-conv_mfma_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
-                 const float* __restrict__ bias, half_t* __restrict__ out) {
-  constexpr int KROW = KW * CIN;             // contiguous K run per kernel row
-  constexpr int KSTEPS = (KROW + 31) / 32;   // 32-wide MFMA steps per kernel row
-  const int Hout = Hin - KH + 1, Wout = Win - KW + 1;
-  const int tiles_x = (Wout + 16 * MT - 1) / (16 * MT);
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wave >= tiles_x * Hout) return;
-  const int oy = wave / tiles_x;
-  const int ox0 = (wave - oy * tiles_x) * 16 * MT;
-  const int li = lane & 15, kg = lane >> 4;
-
-  floatx4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  for (int kh = 0; kh < KH; ++kh) {
-    const half_t* row = in + ((size_t)(oy + kh) * Win + ox0) * CIN + kg * 8;
-    const half8* wrow = wp + (size_t)kh * KSTEPS * NT * 64 + lane;
-#pragma unroll 2
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      half8 a[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        a[m] = *reinterpret_cast<const half8*>(row + (size_t)(m * 16 + li) * CIN + ks * 32);
-      half8 b[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = wrow[(size_t)(ks * NT + n) * 64];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
-  }
-  // C/D layout of 16x16 MFMA: column (channel in tile) = lane & 15, row (pixel) = (lane >> 4) * 4 + r
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int ch = n * 16 + li;
-    if (ch >= COUT) continue;
-    const float bv = bias[ch];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ox = ox0 + m * 16 + kg * 4 + r;
-        if (ox < Wout) {
-          float v = acc[m][n][r] + bv;
-          if (LRELU) v = v > 0.f ? v : 0.3f * v;
-          out[((size_t)oy * Wout + ox) * COUT + ch] = (half_t)v;
-        }
-      }
-  }
-}
-
 // ---- the same implicit GEMM for large kernels (the 15 x 15 flatten layer): LDS-staged input patch ---------
-// A workgroup of 4 wavefronts computes an 8-row x 16-pixel output tile for all channels from a
-// (8+KH-1) x (16+KW) pixel input patch staged once in LDS (NHWC, 2*CIN bytes per pixel: with CIN = 48 the 16
+// A workgroup of 4 wavefronts computes a TR-row x 16-pixel output tile for all channels from a
+// (TR+KH-1) x (16+KW) pixel input patch staged once in LDS (NHWC, 2*CIN bytes per pixel: with CIN = 48 the 16
 // lanes of a ds_read_b128 group fall into 16 distinct bank quads, no padding needed; PMC: 0 conflicts).
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU>
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR_ = 8>
 struct ConvLdsCfg {
   static constexpr int KROW = KW * CIN;
   static constexpr int KSTEPS = (KROW + 31) / 32;
-  static constexpr int TR = 8, TP = 16;
+  static constexpr int TR = TR_, TP = 16;
   static constexpr int PR = TR + KH - 1;
   static constexpr int XPAD = (KSTEPS * 32 - KROW + CIN - 1) / CIN;  // pixels the zero-padded K tail reaches into
   static constexpr int PPX = TP + KW - 1 + XPAD;
@@ -140,35 +41,42 @@ struct ConvLdsCfg {
 };
 
 // ---- K-split variant: the workgroup's four wavefronts split the k-steps, not the pixels -------------------
-// Every wavefront accumulates the WHOLE 8-row x 16-pixel x COUT tile (8 x NT accumulators) over the
+// Every wavefront accumulates the WHOLE TR-row x 16-pixel x COUT tile (TR x NT accumulators) over the
 // k-steps ks = wave, wave+4, ... of every kernel row; the four partial tiles meet in LDS at the end.
-//  * B fragments are used by exactly one wavefront of the group: they go global -> VGPR (prefetched two
-//    steps ahead), never through LDS: no staging stores, no barrier inside the main loop.
-//  * For a fixed ks the A fragments of kernel row kh are patch rows kh .. kh+7 -- kernel row kh+1 needs
-//    ONE new row.  A register ring of 8 fragments turns 8 LDS reads per step into 1.
-//  * Per step: 1 ds_read_b128 + NT global loads feed 8*NT MFMAs (384 cycles for NT = 3).
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU>
+//  * B fragments are used by exactly one wavefront of the group: they go global -> VGPR (a ring prefetched two
+//    steps ahead that never drains), never through LDS: no staging stores, no barrier inside the main loop.
+//  * For a fixed ks the A fragments of kernel row kh are patch rows kh .. kh+TR-1 -- kernel row kh+1 needs
+//    ONE new row.  A register ring of TR fragments turns TR LDS reads per step into 1.
+//  * Per step: 1 ds_read_b128 + NT global loads feed TR*NT MFMAs (384 cycles for TR = 8, NT = 3).
+//  * Two workgroups per CU (LDS <= 80 KB, <= 256 registers): one's patch load / reduction runs under the other's
+//    MFMAs.  The partial tiles meet FOUR ROWS at a time (48 KB of LDS instead of 96) and the finished tile is staged
+//    right behind them (the patch is dead by then).
+//  * TR is chosen per launch (cost_run_cnn): the launch's last, partly filled round of workgroups costs a full
+//    round's time, so at 800 x 800 (376 x 376 outputs) 9-row tiles -- 1008 workgroups = 2 rounds of 512 -- beat
+//    8-row tiles -- 1128 = 2.2 rounds -- by a tenth although each tile is an eighth bigger.
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR = 8>
 struct ConvKsplitCfg {
-  using P = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU>;
-  static constexpr int RED_BYTES = 4 * P::TR * NT * 1024;  // four partial tiles of floatx4 per lane
-  static constexpr int STAGE_BYTES = P::TR * P::TP * COUT * 2;  // finished NHWC tile
-  static constexpr int LDS_BYTES = (P::A_BYTES > RED_BYTES ? P::A_BYTES : RED_BYTES) + STAGE_BYTES;
+  using P = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
+  static constexpr int RED_BYTES = 4 * 4 * NT * 1024;           // four wavefronts' partial rows, four rows at a time
+  static constexpr int STAGE_BYTES = TR * P::TP * COUT * 2;     // finished NHWC tile
+  static constexpr int STAGE_OFF = RED_BYTES;
+  static constexpr int LDS_BYTES = P::A_BYTES > RED_BYTES + STAGE_BYTES ? P::A_BYTES : RED_BYTES + STAGE_BYTES;
+  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
   static_assert((COUT * 2) % 16 == 0, "a pixel is a whole number of 16-byte chunks");
 };
 
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU>
-__global__ void __launch_bounds__(256)
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR>
+__global__ void __launch_bounds__(256, 2)
 conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
                    const float* __restrict__ bias, half_t* __restrict__ out) {
-  using Cfg = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU>;
-  static_assert(Cfg::TR == 8, "the fragment ring below holds 8 rows");
+  using Cfg = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
   constexpr int KSTEPS = Cfg::KSTEPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;
   const int Hout = Hin - KH + 1, Wout = Win - KW + 1;
   const int tiles_x = (Wout + Cfg::TP - 1) / Cfg::TP;
   const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-  const int oy0 = by * Cfg::TR, ox0 = bx * Cfg::TP;
+  const int oy0 = by * TR, ox0 = bx * Cfg::TP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
 
@@ -198,109 +106,488 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   }
   __syncthreads();
 
-  floatx4 acc[8][NT];
+  floatx4 acc[TR][NT];
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
+  for (int m = 0; m < TR; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   const char* a_lane = As + li * Cfg::PIX_B + kg * 16;
-  for (int ks = wave; ks < KSTEPS; ks += 4) {
-    const char* a_ks = a_lane + ks * 64;
-    const half8* b_ks = wp + (size_t)ks * NT * 64 + lane;  // + kh * KSTEPS * NT * 64
-    half8 a[8];      // ring: slot (r & 7) holds patch row r
-    half8 b[3][NT];  // ring over kernel rows, two ahead
+  // which k-steps a wavefront takes, and in which order, rotates with the workgroup index (the workgroups of a launch
+  // stream the same 1 MB of B fragments; no two neighbours in the same order)
+  const int ks_first = (wave + (int)(blockIdx.x & 3u)) & 3;
+  const int nj = (KSTEPS - ks_first + 3) / 4;
+  const int j0 = (int)((blockIdx.x >> 2) % (unsigned)nj);
+  static_assert(KH % 3 == 0 || KH == 1, "the B ring (3 slots) runs on across k-steps: slot = (step index) % 3");
+  auto ks_of = [&](int jj) {
+    const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
+    return ks_first + 4 * j;
+  };
+  half8 b[3][NT];  // ring over (k-step, kernel row), two ahead -- it never drains: the last two kernel rows of a k-step
+                   // prefetch the first two of the wavefront's next k-step
+  {
+    const half8* b0 = wp + (size_t)ks_of(0) * NT * 64 + lane;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      b[0][n] = b_ks[n * 64];
-      if (KH > 1) b[1][n] = b_ks[(size_t)KSTEPS * NT * 64 + n * 64];
+      b[0][n] = b0[n * 64];
+      if (KH > 1) b[1][n] = b0[(size_t)KSTEPS * NT * 64 + n * 64];
     }
+  }
+  for (int jj = 0; jj < nj; ++jj) {
+    const int ks = ks_of(jj);
+    const char* a_ks = a_lane + ks * 64;
+    const half8* b_ks = wp + (size_t)ks * NT * 64 + lane;  // + kh * KSTEPS * NT * 64
+    const half8* b_nx = wp + (size_t)ks_of(jj + 1 < nj ? jj + 1 : jj) * NT * 64 + lane;  // the next k-step's (or a harmless re-read)
+    half8 a[TR];     // ring: slot (r % TR) holds patch row r
 #pragma unroll
-    for (int r = 0; r < 7; ++r) a[r] = *reinterpret_cast<const half8*>(a_ks + r * Cfg::ROW_B);
+    for (int r = 0; r < TR - 1; ++r) a[r] = *reinterpret_cast<const half8*>(a_ks + r * Cfg::ROW_B);
 #pragma unroll
     for (int kh = 0; kh < KH; ++kh) {
-      a[(kh + 7) & 7] = *reinterpret_cast<const half8*>(a_ks + (kh + 7) * Cfg::ROW_B);
-      if (kh + 2 < KH) {
+      a[(kh + TR - 1) % TR] = *reinterpret_cast<const half8*>(a_ks + (kh + TR - 1) * Cfg::ROW_B);
+      {
+        const half8* src = kh + 2 < KH ? b_ks + (size_t)(kh + 2) * KSTEPS * NT * 64 : b_nx + (size_t)(kh + 2 - KH) * KSTEPS * NT * 64;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[(kh + 2) % 3][n] = b_ks[(size_t)(kh + 2) * KSTEPS * NT * 64 + n * 64];
+        for (int n = 0; n < NT; ++n) b[(kh + 2) % 3][n] = src[n * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 8; ++m)  // m = 7 uses the row requested just above: it goes last
+      for (int m = 0; m < TR; ++m)  // m = TR - 1 uses the row requested just above: it goes last
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(kh + m) & 7], b[kh % 3][n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[kh % 3][n], a[(kh + m) % TR], acc[m][n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  // the four partial tiles -> LDS (the patch is dead), wavefront w finishes rows 2w, 2w+1
-  __syncthreads();
+  // The product is computed TRANSPOSED (weights = first MFMA operand): column (lane & 15) = pixel of the 16-pixel
+  // row segment, row ((lane >> 4) * 4 + r) = channel, so a lane holds four consecutive channels of one pixel.
+  // The four partial tiles meet in LDS four rows at a time (the patch is dead); wavefront w finishes row 4 h + w.
+  // The finished halfs are staged as the NHWC tile [TR][16][COUT] behind the partial rows, then leave as whole
+  // 16-byte lanes (a tile row is one contiguous 16*COUT*2-byte run of the output image).
+  using KCfg = ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
+  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
   floatx4* red = reinterpret_cast<floatx4*>(smem);
+  char* stage = smem + KCfg::STAGE_OFF;
+  constexpr int NPASS = (TR + 3) / 4;
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
+  for (int h = 0; h < NPASS; ++h) {
+    __syncthreads();
 #pragma unroll
-    for (int n = 0; n < NT; ++n) red[((wave * 8 + m) * NT + n) * 64 + lane] = acc[m][n];
-  __syncthreads();
-  // C/D layout of 16x16 MFMA: column (channel in tile) = lane & 15, row (pixel) = (lane >> 4) * 4 + r.
-  // The finished halfs are staged as the NHWC tile [8][16][COUT] behind the partial tiles, then leave as
-  // whole 16-byte lanes (a tile row is one contiguous 16*COUT*2-byte run of the output image).
-  half_t* stage = reinterpret_cast<half_t*>(smem + ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU>::RED_BYTES);
+    for (int mm = 0; mm < 4; ++mm)
+      if (4 * h + mm < TR) {
 #pragma unroll
-  for (int mm = 0; mm < 2; ++mm) {
-    const int m = 2 * wave + mm;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      floatx4 v = red[((0 * 8 + m) * NT + n) * 64 + lane];
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const floatx4 p = red[((w * 8 + m) * NT + n) * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p[r];
+        for (int n = 0; n < NT; ++n) red[((wave * 4 + mm) * NT + n) * 64 + lane] = acc[4 * h + mm][n];
       }
-      const int ch = n * 16 + li;
-      if (ch >= COUT) continue;
-      const float bv = bias[ch];
+    __syncthreads();
+    const int m = 4 * h + wave;
+    if (m < TR) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float y = v[r] + bv;
-        if (LRELU) y = y > 0.f ? y : 0.3f * y;
-        stage[(m * 16 + kg * 4 + r) * COUT + ch] = (half_t)y;
+      for (int n = 0; n < NT; ++n) {
+        floatx4 v = red[((0 * 4 + wave) * NT + n) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const floatx4 p = red[((w * 4 + wave) * NT + n) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p[r];
+        }
+        const int ch = n * 16 + kg * 4;
+        if (ch >= COUT) continue;
+        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+        half4_t y4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = v[r] + bv[r];
+          if (LRELU) y = fmaxf(y, 0.3f * y);
+          y4[r] = (half_t)y;
+        }
+        *reinterpret_cast<half4_t*>(stage + ((m * 16 + li) * COUT + ch) * 2) = y4;
       }
     }
   }
   __syncthreads();
   {
     constexpr int CPR = 16 * COUT * 2 / 16;  // 16-byte chunks per tile row
-    for (int c = tid; c < 8 * CPR; c += 256) {
+    for (int c = tid; c < TR * CPR; c += 256) {
       const int m = c / CPR, cc = c - m * CPR;
       const int px = (cc * 16) / (COUT * 2);
       if (oy0 + m < Hout && ox0 + px < Wout)
         *reinterpret_cast<half8*>(reinterpret_cast<char*>(out) + ((size_t)(oy0 + m) * Wout + ox0) * COUT * 2 + cc * 16) =
-            *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(stage) + m * CPR * 16 + cc * 16);
+            *reinterpret_cast<const half8*>(stage + m * CPR * 16 + cc * 16);
     }
   }
 }
 
-// max_pool2d NHWC, window P, stride S (network_light.py:89,97)
-template <int P, int S>
+// ======================================================================================================
+// Fused front of the feature extractor (round 3): the eight launch-/latency-bound launches in front of the
+// 15 x 15 layer become two kernels whose intermediate activations never leave the CU.
+//
+// (A) conv12_pool_kernel: init_conv1 + BN -> init_conv2 + BN -> leaky-ReLU -> max_pool 2/2
+//     (network_light.py:84-89).  There is NO activation between conv1's BatchNorm and conv2, so the two
+//     un-padded 3 x 3 convolutions are ONE 5 x 5 convolution 1 -> 24 whose kernel is the full correlation of the two
+//     (composed on the host in double, like the BatchNorm folding: artp_cost_load_weights) plus a constant bias
+//     b2 + sum W2 * b1 (no padding: every conv2 output sees all nine taps of b1).  600 MACs per conv2 output
+//     instead of 216 + 5184, no 24-channel intermediate.  K = 25 with a single input channel is no MFMA shape:
+//     plain f32 VALU, weights as scalar (SGPR) operands, one lane per POOLED pixel (2 x 2 conv outputs from a
+//     6 x 6 input window in registers), leaky-ReLU after the max (monotone: max(lrelu(x)) = lrelu(max(x))).
+//     The f32 map is rounded to fp16 on the way in (predictor.py:33 `.half()`).
+// (B) conv345_kernel: init_conv3 -> init_conv4 -> max_pool 3/1 -> init_conv5 (network_light.py:91-102), each
+//     + BN + leaky-ReLU, as implicit GEMMs on v_mfma_f32_16x16x32_f16 from LDS-resident NHWC halo tiles: a workgroup
+//     owns a T x T tile of conv5 outputs and computes the (T+6)^2 / (T+4)^2 / (T+2)^2 halo regions of the layers
+//     in front of it from a (T+8)^2 input patch; nothing but the patch is read and nothing but the conv5 tile is
+//     written.  K is walked in 16-byte CHUNKS across the whole 3 x 3 window (kh, kw, cin), 4 chunks per MFMA:
+//     27 chunks = 7 steps for Cin 24, 54 = 14 steps for Cin 48 (per-row padding would take 9 / 15).  A wavefront
+//     keeps the accumulators of ALL its (<= 8) 16-pixel tiles live, so a B fragment is fetched from L2 once per
+//     wavefront and layer (the conv_ksplit scheme) and the k-steps are software-pipelined (next step's 3 B
+//     fragments + 8 A fragments in flight under the current 24 MFMAs).
+// ======================================================================================================
+
+constexpr int C12_PT = 8;              // pooled pixels per tile edge: one wavefront's 64 lanes
+constexpr int C12_IN = 2 * C12_PT + 4; // input window of a tile
+constexpr int C12_RS = 24;             // LDS row stride in floats: the four pooled rows of a 32-lane group land 16 banks apart
+constexpr int C12_CG = 6;              // channels per wavefront (4 wavefronts x 6 = 24)
+
+// Workgroup = an 8 x 8 tile of pooled pixels; wavefront w computes channels 6 w .. 6 w + 5 of all 64 (weights are
+// wave-uniform), lane = pooled pixel.  625 workgroups at C3, 2500 at C4: several wavefronts per SIMD hide the scalar
+// weight loads that one big tile per CU (first version: 12.8 us at C3) left exposed.
 __global__ void __launch_bounds__(256)
-maxpool_kernel(const half_t* __restrict__ in, int Hin, int Win, int C, half_t* __restrict__ out) {
-  const int Ho = (Hin - P) / S + 1, Wo = (Win - P) / S + 1;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)Ho * Wo * C) return;
-  const int c = (int)(i % C);
-  const size_t p = i / C;
-  const int ox = (int)(p % Wo), oy = (int)(p / Wo);
-  float m = -INFINITY;
+conv12_pool_kernel(const float* __restrict__ in, int H, int W, const float* __restrict__ w /*[24][25]*/,
+                   const float* __restrict__ bias /*[24]*/, half_t* __restrict__ out /*[hp][wp][24]*/) {
+  __shared__ float tile[C12_IN * C12_RS];
+  const int hp = (H - 4) / 2, wp = (W - 4) / 2;
+  const int tiles_x = (wp + C12_PT - 1) / C12_PT;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int iy0 = by * 2 * C12_PT, ix0 = bx * 2 * C12_PT;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C12_IN * C12_IN; i += 256) {
+    const int r = i / C12_IN, c = i - r * C12_IN;
+    const int y = iy0 + r, x = ix0 + c;
+    tile[r * C12_RS + c] = (y < H && x < W) ? (float)(half_t)in[(size_t)y * W + x] : 0.0f;
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform channel group: weight addresses stay scalar
+  const int py = lane >> 3, px = lane & 7;
+  // The two conv outputs of a row pair share a weight: packed f32 FMAs (v_pk_fma_f32, two lanes of math per issue
+  // slot; the kernel is bound by VALU issue) on (x[kx], x[kx+1]) pairs.  xe[r][i] = (x[r][2i], x[r][2i+1]) come straight
+  // from the 8-byte LDS reads, xo[r][i] = (x[r][2i+1], x[r][2i+2]) are the odd-aligned pairs.
+  typedef float float2_t __attribute__((ext_vector_type(2)));
+  float2_t xe[6][3], xo[6][2];
 #pragma unroll
-  for (int dy = 0; dy < P; ++dy)
+  for (int r = 0; r < 6; ++r) {
 #pragma unroll
-    for (int dx = 0; dx < P; ++dx) {
-      const float v = (float)in[((size_t)(oy * S + dy) * Win + ox * S + dx) * C + c];
-      m = v > m ? v : m;
+    for (int i = 0; i < 3; ++i)
+      xe[r][i] = *reinterpret_cast<const float2_t*>(&tile[(2 * py + r) * C12_RS + 2 * px + 2 * i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xo[r][i] = float2_t{xe[r][i][1], xe[r][i + 1][0]};
+  }
+  const float* __restrict__ wg = w + cg * C12_CG * 25;
+  const float* __restrict__ bg = bias + cg * C12_CG;
+  half_t o[C12_CG];
+#pragma unroll
+  for (int co = 0; co < C12_CG; ++co) {
+    const float b = bg[co];
+    float2_t a0 = float2_t{b, b}, a1 = float2_t{b, b};   // (a00, a01), (a10, a11)
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const float wv = wg[co * 25 + ky * 5 + kx];  // wave-uniform: a scalar load, an SGPR operand
+        const float2_t w2 = float2_t{wv, wv};
+        const float2_t p0 = (kx & 1) ? xo[ky][kx >> 1] : xe[ky][kx >> 1];
+        const float2_t p1 = (kx & 1) ? xo[ky + 1][kx >> 1] : xe[ky + 1][kx >> 1];
+        a0 = __builtin_elementwise_fma(p0, w2, a0);
+        a1 = __builtin_elementwise_fma(p1, w2, a1);
+      }
+    float m = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(a1[0], a1[1]));
+    m = m > 0.f ? m : 0.3f * m;
+    o[co] = (half_t)m;
+  }
+  const int gy = by * C12_PT + py, gx = bx * C12_PT + px;
+  if (gy < hp && gx < wp) {
+    // 6 halfs = 12 bytes at byte offset 12 cg of the pixel's 48: three dword stores
+    unsigned* dst = reinterpret_cast<unsigned*>(out + ((size_t)gy * wp + gx) * 24 + cg * C12_CG);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+      half2_t t;
+      t[0] = o[2 * v];
+      t[1] = o[2 * v + 1];
+      dst[v] = __builtin_bit_cast(unsigned, t);
     }
-  out[i] = (half_t)m;
+  }
+}
+
+// ---- (B) conv3 -> conv4 -> pool3 -> conv5 ------------------------------------------------------------------
+template <int T>
+struct C345Cfg {
+  static constexpr int RI = T + 8, R3 = T + 6, R4 = T + 4, RP = T + 2;
+  static constexpr int IN_B = RI * RI * 48, C3_B = R3 * R3 * 96, C4_B = R4 * R4 * 96, P_B = RP * RP * 96,
+                       OUT_B = T * T * 96;
+  static constexpr int X_B = ((IN_B > C4_B ? IN_B : C4_B) + 255) & ~255;   // input patch, then conv4's region, then the out tile
+  static constexpr int Y_B = ((C3_B > P_B ? C3_B : P_B) + 255) & ~255;     // conv3's region, then the pooled region
+  static constexpr int W_B = 14 * 3 * 1024;   // conv4's, then conv5's B fragments (14 k-steps x 3 x 64 lanes x 16 bytes)
+  // conv3's (7 k-steps) get a region of their own when it fits: conv4's weights can then be committed without
+  // waiting for every wavefront to leave conv3 (one barrier less); T = 18 shares the region
+  static constexpr bool SEP_W3 = X_B + Y_B + W_B + 7 * 3 * 1024 <= 160 * 1024;
+  static constexpr int W3_B = SEP_W3 ? 7 * 3 * 1024 : 0;
+  static constexpr int LDS_BYTES = X_B + Y_B + W3_B + W_B;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+  static_assert(OUT_B <= X_B, "the finished tile is staged over conv4's region");
+};
+
+constexpr int C345_NW = 8;               // wavefronts per workgroup: two per SIMD, so that one's LDS / VALU / barrier
+constexpr int C345_NT = 64 * C345_NW;    // latencies run under the other's MFMAs (one per SIMD: 46 k cycles per tile
+                                         // against 11 k of MFMA work, every phase serial)
+
+// A layer's B fragments ([KS][3][64 lanes] x 16 bytes, chunk order) are the same for all the workgroup's
+// wavefronts (they split the pixels): they come in ONCE per workgroup -- global -> registers a whole phase ahead of
+// their use (w_prefetch), registers -> LDS once the previous layer is done with the region (w_commit) -- and every
+// wavefront reads its fragments from LDS.  (Each wavefront fetching them itself moved 420 KB per tile through the
+// L1 against 27 KB of input.)
+template <int KS>
+struct WRegs { half8 v[(KS * 192 + C345_NT - 1) / C345_NT]; };
+template <int KS>
+__device__ __forceinline__ void w_prefetch(const half8* __restrict__ wp, WRegs<KS>& r, int tid) {
+  constexpr int NCH = KS * 192, NIT = (NCH + C345_NT - 1) / C345_NT;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = tid + it * C345_NT;
+    r.v[it] = wp[c < NCH ? c : NCH - 1];
+  }
+}
+template <int KS>
+__device__ __forceinline__ void w_commit(char* __restrict__ W, const WRegs<KS>& r, int tid) {
+  constexpr int NCH = KS * 192, NIT = (NCH + C345_NT - 1) / C345_NT;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = tid + it * C345_NT;
+    if (c < NCH) *reinterpret_cast<half8*>(W + c * 16) = r.v[it];
+  }
+}
+
+// One un-padded 3 x 3 layer of the fused kernel: region of NPO = RWO x RWO output pixels (row-major, linear pixel
+// index p) from an input region of width RWI (pixel stride CIN * 2 bytes) in LDS.  The workgroup's wavefronts
+// take the 16-pixel m-tiles round robin (m-tile = NW * m + wave); acc[m][n] holds m-tile m, channels 16 n .. 16 n + 15.
+// The WEIGHTS are the MFMA's first operand and the pixels its second, i.e. the product is computed transposed:
+// column (lane & 15) = pixel, row ((lane >> 4) * 4 + r) = channel, so a lane ends up with FOUR CONSECUTIVE CHANNELS
+// of one pixel -- one 8-byte store into the NHWC region instead of four 2-byte stores that collide 8-fold on the
+// LDS banks (first version: the three epilogues cost more cycles than the three MFMA loops).
+// W: the layer's B fragments [KS][3][64] in LDS, chunk order (packed by artp_cost_load_weights).
+// bv: the layer's bias, bv[n][r] = channel 16 n + 4 (lane >> 4) + r; it rides in the accumulator.
+template <int CIN, int RWI, int RWO, int MTW, int KS>
+__device__ __forceinline__ void conv3x3_lds_mfma(const char* __restrict__ in, const char* __restrict__ W,
+                                                 const floatx4 (&bv)[3], floatx4 (&acc)[MTW][3], int wave, int lane) {
+  constexpr int PIXB = CIN * 2;
+  constexpr int CPR = 3 * CIN / 8;      // 16-byte chunks per kernel row (kw, cin)
+  constexpr int Q = 3 * CPR;            // chunks of the whole window
+  static_assert(KS == (Q + 3) / 4, "MFMA k-steps: 4 chunks = 32 k");
+  constexpr int NPO = RWO * RWO;
+  const int li = lane & 15, kg = lane >> 4;
+  int base[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    int p = (m * C345_NW + wave) * 16 + li;
+    p = p < NPO ? p : NPO - 1;          // clamped: the lanes of a partial tile read a valid pixel, their results are dropped
+    const int y = p / RWO, x = p - y * RWO;
+    base[m] = (y * RWI + x) * PIXB;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) acc[m][n] = bv[n];
+  }
+  auto chunk_off = [&](int ks) {
+    int q = ks * 4 + kg;
+    q = q < Q ? q : Q - 1;              // zero weights there, but the operand must be finite data
+    const int r = (q >= CPR) + (q >= 2 * CPR);
+    return r * (RWI * PIXB - CPR * 16) + q * 16;   // r * RWI * PIXB + (q - r * CPR) * 16
+  };
+  half8 a[2][MTW], b[2][3];
+  const char* wl = W + lane * 16;
+  {
+    const int off = chunk_off(0);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) b[0][n] = *reinterpret_cast<const half8*>(wl + n * 1024);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) a[0][m] = *reinterpret_cast<const half8*>(in + base[m] + off);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int cur = ks & 1, nxt = cur ^ 1;
+    if (ks + 1 < KS) {
+      const int off = chunk_off(ks + 1);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) b[nxt][n] = *reinterpret_cast<const half8*>(wl + ((ks + 1) * 3 + n) * 1024);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) a[nxt][m] = *reinterpret_cast<const half8*>(in + base[m] + off);
+    }
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+      if (m < MTW - 1 || (m * C345_NW + wave) * 16 < NPO) {  // wave-uniform: a wavefront without a last m-tile skips it
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[cur][n], a[cur][m], acc[m][n], 0, 0, 0);
+      }
+  }
+}
+
+// leaky-ReLU + fp16 of a layer's accumulators (bias included) into an LDS region (linear pixel index, 96 bytes per
+// pixel).  Transposed product (see above): lane = pixel (lane & 15) of the m-tile, acc[m][n][r] = channel 16 n + 4 (lane >> 4) + r.
+template <int NPO, int MTW>
+__device__ __forceinline__ void store_region_lds(char* __restrict__ out, const floatx4 (&acc)[MTW][3], int wave,
+                                                 int lane) {
+  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+  const int li = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int p = (m * C345_NW + wave) * 16 + li;
+    if (p < NPO) {
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        half4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)fmaxf(acc[m][n][r], 0.3f * acc[m][n][r]);  // lrelu(v) = max(v, 0.3 v)
+        *reinterpret_cast<half4_t*>(out + p * 96 + (n * 16 + kg * 4) * 2) = h;
+      }
+    }
+  }
+}
+
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_cnn_cycles[16];  // conv345 phases (cycles of wavefront 0, summed over workgroups), [15] = workgroups
+#define ARTP_CNN_MARK(slot) do { if (tid == 0) { const long long n_ = clock64(); atomicAdd(&g_cnn_cycles[slot], (unsigned long long)(n_ - t_prev)); t_prev = n_; } } while (0)
+#else
+#define ARTP_CNN_MARK(slot) do { } while (0)
+#endif
+
+template <int T>
+__global__ void __launch_bounds__(C345_NT)
+conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Win,
+               const half8* __restrict__ w3, const float* __restrict__ b3, const half8* __restrict__ w4,
+               const float* __restrict__ b4, const half8* __restrict__ w5, const float* __restrict__ b5,
+               half_t* __restrict__ out /*[Hin-8][Win-8][48]*/) {
+  using Cfg = C345Cfg<T>;
+  constexpr int NW = C345_NW, NT_ = C345_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* X = smem;
+  char* Y = smem + Cfg::X_B;
+  char* W3 = smem + Cfg::X_B + Cfg::Y_B;
+  char* Wl = W3 + Cfg::W3_B;
+  const int Hout = Hin - 8, Wout = Win - 8;
+  const int tiles_x = (Wout + T - 1) / T;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int oy0 = by * T, ox0 = bx * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ARTP_STAGE_TIMING
+  long long t_prev = clock64();
+  if (tid == 0) atomicAdd(&g_cnn_cycles[15], 1ull);
+#endif
+  // the three layers' biases (transposed product: four consecutive channels per lane) up front: a global load in
+  // front of a layer's first MFMA would sit in its critical path
+  floatx4 bv3[3], bv4[3], bv5[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    bv3[n] = *reinterpret_cast<const floatx4*>(b3 + n * 16 + (lane >> 4) * 4);
+    bv4[n] = *reinterpret_cast<const floatx4*>(b4 + n * 16 + (lane >> 4) * 4);
+    bv5[n] = *reinterpret_cast<const floatx4*>(b5 + n * 16 + (lane >> 4) * 4);
+  }
+  WRegs<7> rw3;
+  w_prefetch<7>(w3, rw3, tid);  // conv3's weights travel with the patch
+  // input patch (T+8)^2 x 24 channels -> X; rows are contiguous byte runs of the NHWC image, zeros outside it
+  {
+    constexpr int CPR = Cfg::RI * 48 / 16;  // 16-byte chunks per patch row
+    constexpr int NCH = Cfg::RI * CPR;
+    constexpr int NIT = (NCH + NT_ - 1) / NT_;
+    const long row_bytes = (long)Win * 48;
+    half8 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * NT_;
+      const int r = c / CPR, cc = c - r * CPR;
+      const long off = (long)ox0 * 48 + (long)cc * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = (half_t)0;
+      if (c < NCH && oy0 + r < Hin && off + 16 <= row_bytes)
+        v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + r) * row_bytes + off);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * NT_;
+      if (c < NCH) *reinterpret_cast<half8*>(X + c * 16) = v[it];
+    }
+  }
+  w_commit<7>(W3, rw3, tid);
+  __syncthreads();
+  ARTP_CNN_MARK(0);
+  WRegs<14> rw;
+  w_prefetch<14>(w4, rw, tid);  // conv4's weights travel under conv3
+  {  // conv3: X (24 ch) -> Y
+    constexpr int MTW = (Cfg::R3 * Cfg::R3 + 16 * NW - 1) / (16 * NW);
+    floatx4 acc[MTW][3];
+    conv3x3_lds_mfma<24, Cfg::RI, Cfg::R3, MTW, 7>(X, W3, bv3, acc, wave, lane);
+    ARTP_CNN_MARK(1);
+    store_region_lds<Cfg::R3 * Cfg::R3, MTW>(Y, acc, wave, lane);
+    ARTP_CNN_MARK(2);
+  }
+  if (!Cfg::SEP_W3) __syncthreads();  // shared region: every wavefront must be done with conv3's weights
+  w_commit<14>(Wl, rw, tid);          // (own region: no wavefront reads it before the barrier)
+  __syncthreads();
+  ARTP_CNN_MARK(3);
+  w_prefetch<14>(w5, rw, tid);   // conv5's weights travel under conv4
+  {  // conv4: Y -> X (the patch is dead)
+    constexpr int MTW = (Cfg::R4 * Cfg::R4 + 16 * NW - 1) / (16 * NW);
+    floatx4 acc[MTW][3];
+    conv3x3_lds_mfma<48, Cfg::R3, Cfg::R4, MTW, 14>(Y, Wl, bv4, acc, wave, lane);
+    ARTP_CNN_MARK(4);
+    store_region_lds<Cfg::R4 * Cfg::R4, MTW>(X, acc, wave, lane);
+    ARTP_CNN_MARK(5);
+  }
+  __syncthreads();               // conv4's weights are dead, X is complete
+  w_commit<14>(Wl, rw, tid);
+  ARTP_CNN_MARK(6);
+  {  // max_pool 3 / 1: X -> Y.  A thread owns (column x, 8-channel chunk c, a quarter of the rows) and walks down the
+     // column with the horizontal 3-max of the last three rows in registers: 3 reads per output instead of 9.
+    constexpr int RP = Cfg::RP, R4 = Cfg::R4, PARTS = NT_ / 128, ROWS = (RP + PARTS - 1) / PARTS;
+    const int strip = tid / PARTS, part = tid - strip * PARTS;
+    if (strip < RP * 6) {
+      const int x = strip / 6, c = strip - x * 6;
+      const int y0 = part * ROWS, y1 = (y0 + ROWS < RP) ? y0 + ROWS : RP;
+      auto hmax = [&](int y) {
+        const char* src = X + ((y * R4 + x) * 96 + c * 16);
+        const half8 v0 = *reinterpret_cast<const half8*>(src), v1 = *reinterpret_cast<const half8*>(src + 96),
+                    v2 = *reinterpret_cast<const half8*>(src + 192);
+        return __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), v2);
+      };
+      if (y0 < y1) {
+        half8 r0 = hmax(y0), r1 = hmax(y0 + 1);
+        for (int y = y0; y < y1; ++y) {
+          const half8 r2 = hmax(y + 2);
+          *reinterpret_cast<half8*>(Y + (y * RP + x) * 96 + c * 16) = __builtin_elementwise_max(__builtin_elementwise_max(r0, r1), r2);
+          r0 = r1;
+          r1 = r2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  ARTP_CNN_MARK(7);
+  {  // conv5: Y -> the finished tile, staged in X, then whole 16-byte lanes to the NHWC image
+    constexpr int MTW = (T * T + 16 * NW - 1) / (16 * NW);
+    floatx4 acc[MTW][3];
+    conv3x3_lds_mfma<48, Cfg::RP, T, MTW, 14>(Y, Wl, bv5, acc, wave, lane);
+    ARTP_CNN_MARK(8);
+    store_region_lds<T * T, MTW>(X, acc, wave, lane);
+  }
+  __syncthreads();
+  ARTP_CNN_MARK(9);
+  {
+    constexpr int CPR = T * 96 / 16;  // chunks per tile row
+    for (int c = tid; c < T * CPR; c += NT_) {
+      const int r = c / CPR, cc = c - r * CPR;
+      const int px = (cc * 16) / 96;
+      if (oy0 + r < Hout && ox0 + px < Wout)
+        *reinterpret_cast<half8*>(reinterpret_cast<char*>(out) + ((size_t)(oy0 + r) * Wout + ox0) * 96 + cc * 16) =
+            *reinterpret_cast<const half8*>(X + c * 16);
+    }
+  }
+  ARTP_CNN_MARK(10);
 }
 
 // ---- R9: per-edge cost ---------------------------------------------------------------------------------
@@ -410,12 +697,6 @@ fc_cost_kernel(const float* __restrict__ edges, size_t B, const half_t* __restri
   cost[3 * e + 0] = power;
   cost[3 * e + 1] = tim;
   cost[3 * e + 2] = 1.0f - prob;  // cost_query.py:65-69 returns cost[3] = 1 - prob
-}
-
-__global__ void __launch_bounds__(256)
-f32_to_f16_kernel(const float* __restrict__ in, size_t n, half_t* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (half_t)in[i];
 }
 
 }  // namespace artp

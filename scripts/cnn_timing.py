@@ -1,0 +1,30 @@
+"""Phase cycles of conv345_kernel (timing build: make -C art_planner_amd/csrc timing).
+usage: ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/cnn_timing.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import convert_weights
+from art_planner_amd import _capi
+from art_planner_amd.context import Context
+from synthetic import raw_map
+L = _capi.load()
+ctx = Context(0, "yaml")
+ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
+names = ["patch load+barrier", "conv3 mfma", "conv3 store", "barrier", "conv4 mfma", "conv4 store", "barrier", "pool+barrier",
+         "conv5 mfma", "conv5 store+barrier", "tile store"]
+for n, seed in ((400, 1234), (800, 77)):
+    g = raw_map(n, 0.04, seed=seed)
+    elv = np.ascontiguousarray(g["elevation"][::-1, ::-1]).astype(np.float32)
+    ctx.cost_update_map(elv, g.res, g.len_x, g.len_y)
+    out = (C.c_ulonglong * 20)()
+    L.artp_debug_stage_cycles(out, 4)
+    ctx.cost_update_map(elv, g.res, g.len_x, g.len_y)
+    L.artp_debug_stage_cycles(out, 4)
+    a = np.array(list(out)[:16], dtype=np.float64)
+    wg = a[15]
+    print(f"map {n}: {int(wg)} workgroups, cycles per workgroup (wavefront 0): total {a[:11].sum() / wg:.0f}")
+    for k, nm in enumerate(names):
+        print(f"   {nm:24s} {a[k] / wg:9.0f}")
+ctx.close()

@@ -12,6 +12,8 @@ import bench
 def test_cnn_flops_match_the_survey_figures():
     assert abs(bench.cnn_flops(400) / 1e9 - 37.66) < 0.02      # 37.66 GFLOP at C2
     assert 165 < bench.cnn_flops(800) / 1e9 < 175              # "~170 GFLOP" at C4
+    # conv1 o conv2 composed: 0.068 + 1.626 GFLOP become 2 * 25 * 24 * 396^2 = 0.188 GFLOP at C2
+    assert abs((bench.cnn_flops(400) - bench.cnn_flops_executed(400)) / 1e9 - (0.068 + 1.626 - 0.188)) < 0.01
 
 
 def test_pair_edges_follow_the_8d_rule():
