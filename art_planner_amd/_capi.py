@@ -15,7 +15,7 @@ SYMBOLS = [
     "artp_params_defaults", "artp_params_yaml", "artp_status_string", "artp_last_error",
     "artp_device_arch", "artp_create", "artp_destroy", "artp_set_stream", "artp_use_own_stream",
     "artp_synchronize", "artp_set_lane", "artp_get_lane", "artp_map_version",
-    "artp_upload_layer", "artp_update_layer_rect", "artp_check_boxes", "artp_check_boxes_dev",
+    "artp_upload_layer", "artp_update_layer_rect", "artp_update_layer_rects", "artp_check_boxes", "artp_check_boxes_dev",
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_sample_and_validate", "artp_check_motions_last_valid", "artp_check_motions_last_valid_dev",
@@ -111,6 +111,7 @@ def load():
     L.artp_get_lane.argtypes = [vp]
     L.artp_upload_layer.argtypes = [vp, i32, vp, i32, i32, dbl, dbl, dbl, dbl]
     L.artp_update_layer_rect.argtypes = [vp, i32, vp, i32, i32, i32, i32]
+    L.artp_update_layer_rects.argtypes = [vp, i32, i32, vp, vp]
     for name in ("artp_check_boxes", "artp_check_boxes_dev"):
         getattr(L, name).argtypes = [vp, i32, vp, vp, sz, vp, vp]
     for name in ("artp_validate_states", "artp_validate_states_dev"):

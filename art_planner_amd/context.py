@@ -65,6 +65,14 @@ class Context:
         self._chk(self.L.artp_update_layer_rect(self.h, slot, patch.ctypes.data, row0, col0,
                                                 patch.shape[0], patch.shape[1]), "artp_update_layer_rect")
 
+    def update_layer_rects(self, slot, patches, origins):
+        """artp_update_layer_rects: patches = list of 2-D arrays, origins = list of (row0, col0)."""
+        ps = [_f32F(p) for p in patches]
+        ptrs = (C.c_void_p * len(ps))(*[p.ctypes.data for p in ps])
+        rects = np.array([[r0, c0, p.shape[0], p.shape[1]] for p, (r0, c0) in zip(ps, origins)], np.int32)
+        self._chk(self.L.artp_update_layer_rects(self.h, slot, len(ps), C.addressof(ptrs), rects.ctypes.data),
+                  "artp_update_layer_rects")
+
     def upload_map(self, gm, body_layer="elevation", feet_layer="elevation_masked", sampler=True):
         """Planner::setMap (planner.cpp:135-163): both height fields, the sampler layers and the
         z bounds (min/max finite elevation -/+ reach.z/2)."""

@@ -817,13 +817,16 @@ def main():
         ver0 = ctx5.map_version()
         for c_i in range(100):
             t0 = time.perf_counter()
+            org5 = []
             for _ in range(3):
                 r0, c0 = int(rng5.integers(0, gm5.rows - side)), int(rng5.integers(0, gm5.cols - side))
                 ub5[r0:r0 + side, c0:c0 + side] += np.float32(rng5.normal(0, 0.01))
                 m_ = mk5[r0:r0 + side, c0:c0 + side]
                 mk5[r0:r0 + side, c0:c0 + side] = np.where(np.isfinite(m_), ub5[r0:r0 + side, c0:c0 + side], m_)
-                ctx5.update_layer_rect(0, ub5[r0:r0 + side, c0:c0 + side], r0, c0)  # dirty cells -> HBM + tables
-                ctx5.update_layer_rect(1, mk5[r0:r0 + side, c0:c0 + side], r0, c0)
+                org5.append((r0, c0))
+            # dirty cells -> HBM + tables: the version's rectangles of a slot in one (asynchronous) call
+            ctx5.update_layer_rects(0, [ub5[r0:r0 + side, c0:c0 + side] for r0, c0 in org5], org5)
+            ctx5.update_layer_rects(1, [mk5[r0:r0 + side, c0:c0 + side] for r0, c0 in org5], org5)
             t1 = time.perf_counter()
             ctx5.cost_update_map(np.ascontiguousarray(ub5[::-1, ::-1]), gm5.res, gm5.len_x, gm5.len_y)  # features
             t2 = time.perf_counter()
@@ -843,6 +846,8 @@ def main():
               "states_per_cycle": n5, "cost_edges_per_cycle": int(rows5.shape[0]), "dirty_rects_per_cycle": 3,
               "layers_updated_per_rect": 2, "cells_changed_per_cycle": 3 * side * side, "budget_ms_at_10hz": 100.0,
               "map_versions_seen": ctx5.map_version() - ver0,
+              "stage_note": "the rectangle updates are asynchronous: `rects` is their host time, their device time is "
+                            "inside the stage that synchronises next (`cnn`, a host-buffer call)",
               "sustained_states_per_s": n5 / (float(np.median(cyc)) * 1e-3)}
         if not args.no_cpu_baseline:  # the checker, outside the timed cycles
             import oracle_py as O

@@ -97,6 +97,12 @@ int artp_upload_layer(artp_ctx* ctx, int slot, const float* layer_colmajor, int 
  * previously uploaded layer; `patch` is column-major nrows x ncols. */
 int artp_update_layer_rect(artp_ctx* ctx, int slot, const float* patch, int row0, int col0,
                            int nrows, int ncols);
+/* Several rectangles of one slot in one call (what computeChange, change.cpp:9-51, yields per map update):
+ * patches[k] is column-major nrows x ncols, rects = n_rects x {row0, col0, nrows, ncols}.  One staged copy, the range
+ * tables rebuilt once, the partner table per rectangle.  Both forms are ASYNCHRONOUS on the context's stream: the
+ * patches are copied to a pinned staging buffer before the call returns (the caller's buffers are free again), the
+ * device work is ordered in front of whatever the stream runs next. */
+int artp_update_layer_rects(artp_ctx* ctx, int slot, int n_rects, const float* const* patches, const int* rects);
 /* Map version of the context: a counter that every call which changes what isValid() / the sampler would answer
  * increments -- artp_upload_layer, artp_update_layer_rect, artp_upload_sampler_layers, artp_preprocessed_install,
  * artp_preprocessed_reweight_dev (when it installs the new distribution).  The reference's guarantee that

@@ -713,13 +713,21 @@ def test_c5_upper_bound_layer_with_rectangle_updates():
     side = int(round(np.sqrt(0.05 * gm.rows * gm.cols / 3)))
     v0 = ctx.map_version()
     for version in range(8):
+        origins = []
         for _ in range(3):
             r0, c0 = int(rng.integers(0, gm.rows - side)), int(rng.integers(0, gm.cols - side))
             ub[r0:r0 + side, c0:c0 + side] += np.float32(rng.normal(0, 0.03))
             m = masked[r0:r0 + side, c0:c0 + side]
             masked[r0:r0 + side, c0:c0 + side] = np.where(np.isfinite(m), ub[r0:r0 + side, c0:c0 + side], m)
-            ctx.update_layer_rect(0, ub[r0:r0 + side, c0:c0 + side], r0, c0)
-            ctx.update_layer_rect(1, masked[r0:r0 + side, c0:c0 + side], r0, c0)
+            origins.append((r0, c0))
+        if version & 1:   # one rectangle per call ...
+            for r0, c0 in origins:
+                ctx.update_layer_rect(0, ub[r0:r0 + side, c0:c0 + side], r0, c0)
+                ctx.update_layer_rect(1, masked[r0:r0 + side, c0:c0 + side], r0, c0)
+        else:             # ... or the version's rectangles of a slot in one call (they may overlap: last one wins, and
+            #               the patches are cut from the final layer, so any order gives the same samples)
+            ctx.update_layer_rects(0, [ub[r0:r0 + side, c0:c0 + side] for r0, c0 in origins], origins)
+            ctx.update_layer_rects(1, [masked[r0:r0 + side, c0:c0 + side] for r0, c0 in origins], origins)
         g2 = common.GridMap(gm.rows, gm.cols, gm.res, gm.pos_x, gm.pos_y)
         g2.add("upper_bound", ub)
         g2.add("elevation_masked", masked)
@@ -728,7 +736,7 @@ def test_c5_upper_bound_layer_with_rectangle_updates():
         assert np.array_equal(ctx.validate_states(st), ref), f"version {version}"
         few = ctx.validate_states(st[:16])                                # latency path on the updated map
         assert np.array_equal(few, ref[:16])
-    assert ctx.map_version() == v0 + 8 * 6                                # every rectangle bumped the map version
+    assert ctx.map_version() == v0 + 4 * 6 + 4 * 2                        # every update call bumped the map version
     # (4) persistent map == fresh upload of the final layers (tables, partner flags included)
     ctx2 = _ctx("yaml")
     g2.layers.update({k: gm[k] for k in ("cum_prob", "normal_x", "normal_y", "normal_z", "plane_fit_std_dev")})
