@@ -22,6 +22,7 @@ SYMBOLS = [
     "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_pack_edge_results_dev", "artp_cost_update_map_dev", "artp_pack_valid_bits_dev", "artp_indices_from_bits_dev",
+    "artp_materialise_from_bits_dev",
     "artp_algorithmic_vertices_dev",
     "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_roadmap_params_defaults",
     "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
@@ -133,6 +134,7 @@ def load():
     L.artp_compact_valid_dev.argtypes = [vp, vp, vp, sz, vp, vp]
     L.artp_compact_valid_indices_dev.argtypes = [vp, vp, sz, vp, vp]
     L.artp_sample_states_at_dev.argtypes = [vp, u64, u64, vp, vp, sz, vp]
+    L.artp_materialise_from_bits_dev.argtypes = [vp, u64, vp, i32, sz, sz, vp, sz, vp, vp]
     L.artp_pack_edge_results_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
     L.artp_pack_valid_bits_dev.argtypes = [vp, vp, sz, vp]
     L.artp_indices_from_bits_dev.argtypes = [vp, vp, sz, vp, vp]

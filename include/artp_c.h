@@ -205,6 +205,14 @@ int artp_sample_states_at_dev(artp_ctx* ctx, uint64_t seed, uint64_t base_index,
  * bits_out: ceil(n / 64) 64-bit words, bit k of word w = valid[64 w + k] != 0.  artp_indices_from_bits_dev turns
  * the first n bits of a (received) bitmap back into the ascending index list artp_sample_states_at_dev takes. */
 int artp_pack_valid_bits_dev(artp_ctx* ctx, const uint8_t* valid, size_t n, uint64_t* bits_out);
+/* The receiving side in one call for ALL ranks: bits = n_ranks bitmaps of words_per_rank words each (the all-gather's
+ * output), base_index[r] (host array) = first global sample index of rank r's batch.  For every rank the first
+ * min(count, cap) accepted states among its first prefix_bits candidates are re-sampled into
+ * se3_out[r * cap .. ) (n_ranks x cap x 7 doubles, device); counts_dev[r] (device) = accepted states among the
+ * prefix.  Two launches whatever n_ranks is (<= 16). */
+int artp_materialise_from_bits_dev(artp_ctx* ctx, uint64_t seed, const uint64_t* bits, int n_ranks,
+                                   size_t words_per_rank, size_t prefix_bits, const uint64_t* base_index, size_t cap,
+                                   double* se3_out, uint64_t* counts_dev);
 int artp_indices_from_bits_dev(artp_ctx* ctx, const uint64_t* bits, size_t n, uint32_t* out_idx, uint64_t* n_out_dev);
 /* The second exchange of SURVEY.md 8e: the edge results of a rank as fixed-size records {u32 i, u32 j,
  * f32 cost[3]} (20 bytes; i / j = the caller's vertex ids of the edge's endpoints, cost = the MotionCostFunc row

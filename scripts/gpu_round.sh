@@ -36,5 +36,11 @@ cd /tmp && export TMPDIR=/tmp
 # kernels of concurrent streams anyway)
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $OUT/prof_$TAG/trace.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/prof_summary.py $OUT/prof_$TAG > $OUT/prof_$TAG/summary.txt 2>&1
+# the headline workloads ALONE (bench.py --pmc-child <mode>: 4 batches and nothing else), so that a kernel's avg column
+# IS its per-launch time: states = fused sample + validate of 2^22 states; check_motion = 2^18 edges; sampler alone
+for MODE in states check_motion sampler; do
+  rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/child_$MODE -o trace -- python $GRAFT_REPO_ROOT/bench.py --pmc-child $MODE > $OUT/prof_$TAG/child_$MODE.log 2>&1
+done
+python $GRAFT_REPO_ROOT/scripts/prof_summary.py $OUT/prof_$TAG > $OUT/prof_$TAG/summary_all.txt 2>&1
 rm -f $OUT/prof_$TAG/*/*.db $OUT/prof_$TAG/*/*/*.db
 head -30 $OUT/prof_$TAG/summary.txt

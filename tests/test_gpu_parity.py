@@ -52,6 +52,32 @@ def test_validate_states_golden(name, rname):
 
 
 @pytest.mark.parametrize("name", golden_io.MAPS)
+def test_bulk_reference_golden(name):
+    """SURVEY.md 8c volumes on the GPU box: 20 000 dPoses per (map, box), 20 000 states and 2 000 edges per (map,
+    robot) against the real patched ODE's labels (tests/golden/bulk_*.npz; ~320 k box poses, 120 k states, 12 k edges
+    = 1.3 M edge states in all): hit bits and exit codes, state labels through the batch pipeline AND the per-box
+    detail kernel, both edge rules."""
+    gm, boxes, states, edges = golden_io.load_bulk(name)
+    ctx = _ctx("yaml")
+    for cname, c in boxes.items():
+        ctx.upload_layer(0, gm[c["layer"]], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+        hit, ec = ctx.check_boxes(0, c["side"], c["poses"], want_exit_codes=True)
+        assert np.array_equal(hit, c["hit"]), f"{name}/{cname}: {(hit != c['hit']).sum()} label mismatches"
+        assert np.array_equal(ec, c["exit"]), f"{name}/{cname}: exit paths differ"
+    ctx.close()
+    for rname in ("yaml", "defaults"):
+        ctx = _ctx(rname)
+        ctx.upload_map(gm, sampler=False)
+        s, e = states[rname], edges[rname]
+        assert np.array_equal(ctx.validate_states(s["se3"]), s["valid"]), f"{name}/{rname}: batch pipeline"
+        assert np.array_equal(ctx.validate_states(s["se3"], want_detail=True)[0], s["valid"]), f"{name}/{rname}: detail kernel"
+        assert np.array_equal(ctx.check_motions(e["s1"], e["s2"]), e["check_motion"]), f"{name}/{rname}: checkMotion"
+        ei, nint = ctx.check_edges_interp(e["s1"], e["s2"])
+        assert np.array_equal(nint, e["n_interp"]) and np.array_equal(ei, e["interp_valid"]), f"{name}/{rname}: 0.5 m rule"
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", golden_io.MAPS)
 def test_edges_golden(name):
     gm, _ = golden_io.load_boxes(name)
     for rname, e in golden_io.load_edges(name).items():
@@ -558,6 +584,40 @@ def test_validity_bitmap_round_trip(big_map, ctx_yaml):
             ctx_yaml.sample_states_at_dev(7, 1234, idx, cnt, len(ref), out)
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), se3.cpu().numpy()[ref])
+
+
+def test_materialise_all_ranks_from_gathered_bitmaps(big_map, ctx_yaml):
+    """artp_materialise_from_bits_dev: the receiving side of the bitmap exchange for ALL ranks in one call (two launches
+    whatever the world size).  Three "ranks" with different batches on one GPU: for every rank the first min(count, cap)
+    accepted states among the first prefix_bits candidates, bit-identical to the states that rank sampled, the counts
+    equal to the accepted states in the prefix; prefixes that end inside a word, caps below and above the count."""
+    import torch
+    ctx_yaml.upload_map(big_map)
+    ctx_yaml.use_torch_stream()
+    n, ranks = 40_000, 3
+    words = (n + 63) // 64
+    gathered = torch.zeros((ranks, words), dtype=torch.int64, device="cuda")
+    bases = [5_000_000 + 1_000_003 * r for r in range(ranks)]
+    states, labels = [], []
+    for r in range(ranks):
+        se3 = torch.empty((n, 7), dtype=torch.float64, device="cuda")
+        valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctx_yaml.sample_and_validate_dev(7, bases[r], n, se3, valid)
+        ctx_yaml.pack_valid_bits_dev(valid, gathered[r])
+        states.append(se3.cpu().numpy())
+        labels.append(valid.cpu().numpy())
+    for prefix, cap in ((n, n), (n, 5000), (12_345, 20_000), (64, 64), (1, 8)):
+        out = torch.full((ranks, cap, 7), np.nan, dtype=torch.float64, device="cuda")
+        counts = torch.zeros(ranks, dtype=torch.int64, device="cuda")
+        ctx_yaml.materialise_from_bits_dev(7, gathered, prefix, bases, cap, out, counts)
+        torch.cuda.synchronize()
+        o, c = out.cpu().numpy(), counts.cpu().numpy()
+        for r in range(ranks):
+            acc = np.flatnonzero(labels[r][:prefix])
+            assert c[r] == len(acc), (prefix, cap, r)
+            k = min(len(acc), cap)
+            assert np.array_equal(o[r, :k], states[r][acc[:k]]), (prefix, cap, r)
+            assert np.isnan(o[r, k:]).all()                       # nothing written past the rank's last state
 
 
 def test_nan_speckled_layers_overflow_the_open_box_lists(big_map):

@@ -43,6 +43,32 @@ def test_oracle_edges_match_golden(name):
         assert np.array_equal(nint, e["n_interp"])
 
 
+@pytest.mark.parametrize("name", golden_io.MAPS)
+def test_oracle_matches_bulk_reference_golden(name):
+    """SURVEY.md 8c volumes: 20 000 dPoses per (map, box) (hit bits AND exit codes), 20 000 states and 2 000 edges per
+    (map, robot), all labelled by the real patched ODE (tests/golden/make_golden_bulk.py); inputs regenerated from
+    seeds and checksum-verified by golden_io.load_bulk."""
+    gm, boxes, states, edges = golden_io.load_bulk(name)
+    assert len(boxes) >= 4
+    for cname, c in boxes.items():
+        assert len(c["poses"]) == golden_io.BULK_POSES
+        hit, ec, _ = O.OracleField(gm[c["layer"]], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y).check_boxes(c["side"], c["poses"], True)
+        assert np.array_equal(hit, c["hit"]), f"{name}/{cname}: {(hit != c['hit']).sum()} label mismatches"
+        assert np.array_equal(ec, c["exit"]), f"{name}/{cname}: exit codes changed"
+    om = O.OracleMap(gm)
+    for rname in ("yaml", "defaults"):
+        rob = O.robot(rname)
+        assert len(states[rname]["se3"]) == golden_io.BULK_STATES
+        assert np.array_equal(om.states_valid(rob, states[rname]["se3"]), states[rname]["valid"]), f"{name}/{rname}"
+        e = edges[rname]
+        assert len(e["s1"]) == golden_io.BULK_EDGES
+        ei, nint = om.edges_interp_valid(rob, e["s1"], e["s2"])
+        assert np.array_equal(ei, e["interp_valid"]) and np.array_equal(nint, e["n_interp"])
+        assert np.array_equal(om.segment_counts(rob, e["s1"], e["s2"]), e["nd"])
+        cm, _ = om.check_motions(rob, e["s1"][:400], e["s2"][:400])   # ~50 states per edge: a slice keeps the CPU suite short
+        assert np.array_equal(cm, e["check_motion"][:400])
+
+
 def test_flat_field_known_answers():
     """Known answers established on the real ODE during the survey: flat field,
     box half-height 0.1: hit for centre z in {0.09, 0, -0.09}; no hit for +-0.11, +-0.5, 0.1
