@@ -13,7 +13,7 @@ Prints ONE JSON line on rank 0 (see the repo prompt's bench contract) incl. `roo
 `cpu_baseline`.  `roofline.pmc` is measured IN THIS RUN: bench.py re-launches itself (`--pmc-child`, a few
 sample+validate batches and nothing else) under `rocprofv3 --kernel-trace --pmc ...`, one pass per counter
 group (PMC is never combined with other trace domains), and derives HBM traffic, VALU / LDS busy and L2 hit rate
-per pipeline kernel.  If rocprofv3 is not usable it falls back to the committed profiles/pmc_r02.json -- only
+per pipeline kernel.  If rocprofv3 is not usable it falls back to the committed profiles/pmc_r03.json -- only
 when that file was measured on the very kernel sources of this checkout (hash of art_planner_amd/csrc).
 """
 import argparse
@@ -201,8 +201,8 @@ def summarise_pmc(per_kernel, extra_kernels=()):
 
 
 def load_committed_pmc():
-    """profiles/pmc_r02.json, only if it was measured on THIS checkout's kernel sources."""
-    path = os.path.join(ROOT, "profiles", "pmc_r02.json")
+    """profiles/pmc_r03.json, only if it was measured on THIS checkout's kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_r03.json")
     if not os.path.exists(path):
         return None, "no committed PMC profile"
     try:
@@ -211,7 +211,7 @@ def load_committed_pmc():
         return None, f"unreadable committed PMC profile: {ex!r}"
     if d.get("csrc_hash") != csrc_hash():
         return None, f"committed PMC profile is STALE (measured on csrc {d.get('csrc_hash')}, checkout is {csrc_hash()})"
-    return d, "committed profiles/pmc_r02.json (same kernel sources)"
+    return d, "committed profiles/pmc_r03.json (same kernel sources)"
 
 
 # ---------------------------------------------------------------------------------------------------------

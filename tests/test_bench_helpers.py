@@ -54,7 +54,7 @@ def test_committed_pmc_profile_is_only_used_for_the_same_kernel_sources(tmp_path
     os.makedirs(tmp_path / "art_planner_amd" / "csrc")
     (tmp_path / "art_planner_amd" / "csrc" / "k.h").write_text("// v1\n")
     h = bench.csrc_hash()
-    json.dump({"csrc_hash": h, "validity_hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / "pmc_r02.json", "w"))
+    json.dump({"csrc_hash": h, "validity_hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / "pmc_r03.json", "w"))
     d, note = bench.load_committed_pmc()
     assert d is not None and "same kernel sources" in note
     (tmp_path / "art_planner_amd" / "csrc" / "k.h").write_text("// v2\n")
