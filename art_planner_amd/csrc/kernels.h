@@ -526,22 +526,19 @@ __device__ __forceinline__ void sample_one(const SamplerDev& sm, const MapGeom& 
   double sy2s, sy2c, qw, qz;
   sincos_half_angle(0.5 * rpy2, &sy2s, &sy2c);
   {
-    // normal_b = Quaterniond(AngleAxisd(yaw, Z)).inverse() * normal_w (sampler.cpp:120-123)
+    // normal_b = Quaterniond(AngleAxisd(yaw, Z)).inverse() * normal_w (sampler.cpp:120-123).  The quaternion is
+    // (cos(yaw/2), 0, 0, sin(yaw/2)): its inverse divides by |q|^2 = 1 +- 1e-16 and the rotation of a vector by it is
+    // the plane rotation by -yaw -- written out, four f64 divisions and two thirds of the multiplications fall away
+    // (the sampler is bound by its f64 instruction count).  Against the literal form (oracle/artp_oracle.c) the
+    // result moves in the 16th digit; the sampler's parity bar is 1e-12 ("same seed" contract).
     qw = sy2c;
     qz = sy2s;
-    const double n2 = qw * qw + qz * qz;
-    const double iw = qw / n2, ix = -0.0 / n2, iy = -0.0 / n2, iz = -qz / n2;
-    double uv0 = iy * nwz - iz * nwy;
-    double uv1 = iz * nwx - ix * nwz;
-    double uv2 = ix * nwy - iy * nwx;
-    uv0 += uv0;
-    uv1 += uv1;
-    uv2 += uv2;
-    const double nbx = nwx + iw * uv0 + (iy * uv2 - iz * uv1);
-    const double nby = nwy + iw * uv1 + (iz * uv0 - ix * uv2);
-    const double nbz = nwz + iw * uv2 + (ix * uv1 - iy * uv0);
-    rpy0 = -atan2(nby, nbz) + rpy0 * rb.max_roll_pert / 1.57079632679489661923;
-    rpy1 = atan2(nbx, nbz) + rpy1 * rb.max_pitch_pert / 0.78539816339744830962;
+    const double cyaw = qw * qw - qz * qz, syaw = (qw + qw) * qz;
+    const double nbx = cyaw * nwx + syaw * nwy;
+    const double nby = cyaw * nwy - syaw * nwx;
+    const double nbz = nwz;
+    rpy0 = -atan2(nby, nbz) + rpy0 * (rb.max_roll_pert * (1.0 / 1.57079632679489661923));
+    rpy1 = atan2(nbx, nbz) + rpy1 * (rb.max_pitch_pert * (1.0 / 0.78539816339744830962));
   }
   {  // setSO3FromRPY (utils.h:101-115)
     double cr, cp, sr, sp;
