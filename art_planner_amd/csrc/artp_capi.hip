@@ -1945,7 +1945,7 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     // round costs a full round's time.  Take the candidate height with the fewest output rows computed per CU
     // (rounds x height); ties go to the smaller tile (less padding).
     const int slots = 2 * c->n_cus;
-    const int cands[3] = {8, 9, 10};
+    const int cands[3] = {8, 9, 10};  // (4- and 6-row tiles were measured at 400^2: 54.5 / 60.0 us against 52.7 for 8)
     int best = 8;
     long best_cost = -1;
     for (int tr : cands) {

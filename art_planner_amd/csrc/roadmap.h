@@ -1033,6 +1033,9 @@ static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, co
     nv_use = m;
     budget_flags |= 2u;
   }
+  // the prefix search is bounded (12 reconnections): a graph still over the edge budget after that says so (bit 2)
+  // instead of passing silently
+  if (prm->max_n_edges && rm->eu.size() > prm->max_n_edges) budget_flags |= 4u;
   rm->samples_drawn = next - first_new;
   rm->n_reweights = n_reweights;
   rm->budget_flags = budget_flags;

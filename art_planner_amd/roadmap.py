@@ -58,7 +58,8 @@ class Roadmap:
         self.ctx._chk(self.L.artp_roadmap_stats(self.h, C.byref(out)), "artp_roadmap_stats")
         return {"vertices": out[0], "candidate_edges": out[1], "valid_edges": out[2], "removed_edges": out[3],
                 "k": out[4], "samples_drawn": out[5], "reweightings": out[6],
-                "time_budget_hit": bool(out[7] & 1), "edge_budget_hit": bool(out[7] & 2)}
+                "time_budget_hit": bool(out[7] & 1), "edge_budget_hit": bool(out[7] & 2),
+                "edge_budget_exceeded": bool(out[7] & 4)}
 
     def export(self) -> dict:
         st = self.stats()

@@ -276,7 +276,8 @@ int artp_roadmap_build(artp_ctx* ctx, const artp_roadmap_params* params, const d
                        const double* goal_se3, artp_roadmap** out);
 /* out[0] vertices, [1] candidate edges, [2] edges passing the interpolation rule, [3] edges removed by
  * the lazy path check so far, [4] k, [5] samples drawn, [6] density re-weightings during the build,
- * [7] bit 0 = the sampling-time budget ended the build, bit 1 = the edge budget did. */
+ * [7] bit 0 = the sampling-time budget ended the build, bit 1 = the edge budget cut the vertex set back, bit 2 = the
+ * graph is STILL over max_n_edges (the bounded prefix search gave up: treat the budget as not honoured). */
 int artp_roadmap_stats(const artp_roadmap* rm, uint64_t out[8]);
 /* Any pointer may be NULL.  verts: n_vertices x 7; knn / knn_dist: n_vertices x k (0xffffffff = none);
  * edges_uv: n_edges x 2 (u < v, sorted); edge_*: n_edges. */

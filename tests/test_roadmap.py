@@ -523,6 +523,7 @@ def test_sample_graph_budgets():
     cut = Roadmap(ctx, s, g, n_milestones=3000, seed=3, max_n_edges=ne_full // 3)
     st = cut.stats()
     assert st["edge_budget_hit"] and st["candidate_edges"] <= ne_full // 3 and 3 < st["vertices"] < 3002
+    assert not st["edge_budget_exceeded"]
     e = cut.export()
     assert e["edges"].max() < st["vertices"]
     # the vertices are a prefix of the unconstrained build's (same stream, the budget only stops it earlier)
