@@ -935,11 +935,13 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
   c->field[slot].has_nan = has_nan;
   c->layer_has_nonfinite[slot] = has_nonfinite;
   HIP_TRY(c, hipMemcpyAsync(c->rect_stage_dev, c->rect_stage_host, need, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipEventRecord(c->rect_stage_done, c->stream));
   hipLaunchKernelGGL(scatter_rects_kernel, dim3((unsigned)((max_cells + 255) / 256), (unsigned)n_rects), dim3(256), 0, c->stream,
                      reinterpret_cast<const float*>(static_cast<const char*>(c->rect_stage_dev) + rec_bytes),
                      static_cast<const RectDev*>(c->rect_stage_dev), n_rects, rows, cols, c->field_data[slot]);
   HIP_TRY(c, hipGetLastError());
+  // both staging buffers are free again once the scatter has run: the next update (whatever stream the context is on
+  // by then) waits for this event before it touches them
+  HIP_TRY(c, hipEventRecord(c->rect_stage_done, c->stream));
   // range / stride tables once (the whole map is ~1 MB: rebuilding beats tracking dirty blocks); the partner table
   // only recomputes each dirty rectangle plus its margin
   std::vector<int> dirty((size_t)4 * n_rects);

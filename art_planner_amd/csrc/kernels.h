@@ -572,7 +572,7 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
   // touches 28 cache lines with 8 useful bytes in each 56.  The wavefront's 64 states go through LDS instead and
   // leave as seven fully coalesced 512-byte rows.  recs (may be null): the per-state PoseRec of the validity
   // pipeline, produced here while the state is in registers (fused sample + validate).
-  __shared__ double stage[4][64 * 7];
+  __shared__ double stage[4][64 * 8];  // 64 states x 7 doubles, then 64 PoseRecs x 64 bytes
   __shared__ float row_cdf_lds[ARTP_ROW_CDF_LDS];
   const float* row_cdf = stage_row_cdf(sm, g, row_cdf_lds);
   const int lane = threadIdx.x & 63;
@@ -584,25 +584,37 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane);  // wave-uniform
   if (i0 >= n) return;
   const size_t i = i0 + lane;
+  float4 r[4];
   if (i < n) {
     double st[7];
     sample_one<FROM_DIST>(sm, g, rb, seed, first_index + i, st, row_cdf);
 #pragma unroll
     for (int k = 0; k < 7; ++k) sw[lane * 7 + k] = st[k];
-    if (recs) {
-      float4 r[4];
-      make_pose_rec(f, st, r);
-      float4* dst = reinterpret_cast<float4*>(recs + i);  // one whole 64-byte line per lane
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dst[k] = r[k];
-    }
+    if (recs) make_pose_rec(f, st, r);
   }
   wave_lds_sync();
-  const size_t cnt = (n - i0 < 64 ? n - i0 : 64) * 7;
+  const size_t live = n - i0 < 64 ? n - i0 : 64;
+  const size_t cnt = live * 7;
   double* out = se3_out + 7 * i0;
 #pragma unroll
   for (int k = 0; k < 7; ++k)
     if ((size_t)(k * 64 + lane) < cnt) out[k * 64 + lane] = sw[k * 64 + lane];
+  if (recs) {
+    // the PoseRecs leave the same way: a lane storing its own 64-byte record issues four 16-byte stores 64 bytes apart
+    // (each store instruction touches 64 half-written lines: the L2 fetched 270 MB per batch to merge them); through
+    // the staging area (the states are out) the wavefront's 4 KB go as four fully coalesced 1 KB rows
+    wave_lds_sync();
+    float4* rw = reinterpret_cast<float4*>(sw);
+    if (i < n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rw[lane * 4 + k] = r[k];
+    }
+    wave_lds_sync();
+    float4* dst = reinterpret_cast<float4*>(recs + i0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((size_t)(k * 64 + lane) < live * 4) dst[k * 64 + lane] = rw[k * 64 + lane];
+  }
 }
 
 // States of the global sample stream at explicit indices base + idx[j], j < *count (device counter):
