@@ -1412,15 +1412,17 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   size_t eb = ((size_t)total + 255) / 256;
   if (eb > (size_t)c->n_cus * 32) eb = (size_t)c->n_cus * 32;
   if (total != 0) {
-    rc = ensure_tmp(c, 3, (size_t)total * (7 * sizeof(double) + sizeof(uint32_t) + 1) + 64);
+    // tmp[3]: edge_of (total u32) | ex_valid (total bytes); the interior states themselves only exist as PoseRecs (tmp[7])
+    rc = ensure_tmp(c, 3, (size_t)total * (sizeof(uint32_t) + 1) + 64);
     if (rc) return rc;
-    double* ex_states = static_cast<double*>(c->tmp[3]);
-    uint32_t* edge_of = reinterpret_cast<uint32_t*>(ex_states + (size_t)7 * total);
+    rc = ensure_recs(c, total);
+    if (rc) return rc;
+    uint32_t* edge_of = static_cast<uint32_t*>(c->tmp[3]);
     uint8_t* ex_valid = reinterpret_cast<uint8_t*>(edge_of + total);
-    hipLaunchKernelGGL(expand_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream, mode, s1, s2, n,
-                       (const uint32_t*)offsets, (const uint32_t*)aux, ex_states, edge_of);
+    hipLaunchKernelGGL(expand_edges_recs_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream, c->field[0], mode, s1, s2, n,
+                       (const uint32_t*)offsets, (const uint32_t*)aux, static_cast<PoseRec*>(c->tmp[7]), edge_of);
     HIP_TRY(c, hipGetLastError());
-    rc = launch_validate_pipeline(c, ex_states, total, ex_valid);
+    rc = launch_validate_pipeline(c, nullptr, total, ex_valid, true);
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_edges_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream,
                        (const uint8_t*)ex_valid, (const uint32_t*)edge_of, (const uint32_t*)offsets, n, valid);

@@ -182,18 +182,52 @@ __device__ __forceinline__ void make_pose_rec(const FieldDev& f, const double* s
   out[3] = make_float4(bR[5], bR[6], bR[7], bR[8]);
 }
 
+// A wavefront's 64 PoseRecs through LDS: lane l parks the four 16-byte chunks of its record, then the wavefront
+// writes the 4 KB block as four fully coalesced 1 KB rows.  Chunk k of lane l sits at slot 4 l + ((k + (l >> 2)) & 3):
+// un-skewed, lanes l and l + 4 of one 8-lane ds_write_b128 group would hit the same banks.
+__device__ __forceinline__ int rec_stage_slot(int l, int k) { return 4 * l + ((k + (l >> 2)) & 3); }
+__device__ __forceinline__ void stage_pose_rec(float4* rw, int lane, const float4 r[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rw[rec_stage_slot(lane, k)] = r[k];
+}
+// live = records of this wavefront that exist (64 except at the tail); call between two wave_lds_sync()
+__device__ __forceinline__ void flush_pose_recs(const float4* rw, int lane, size_t live, PoseRec* __restrict__ dst_recs) {
+  float4* dst = reinterpret_cast<float4*>(dst_recs);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = k * 64 + lane;  // chunk j of the block = chunk (j & 3) of lane j >> 2
+    if ((size_t)j < live * 4) dst[j] = rw[rec_stage_slot(j >> 2, j & 3)];
+  }
+}
+
 __global__ void __launch_bounds__(256)
 pose_rec_kernel(FieldDev f, const double* __restrict__ se3, size_t n, PoseRec* __restrict__ recs) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double st[7];
+  // both directions through LDS: a wavefront's 64 states are seven coalesced 512-byte rows on the way in (a lane
+  // reading its own 56 bytes touches 28 lines per load instruction), its 64 PoseRecs four 1 KB rows on the way out
+  __shared__ double stage[4][64 * 8];
+  const int lane = threadIdx.x & 63;
+  double* sw = stage[threadIdx.x >> 6];
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane);  // wave-uniform
+  if (i0 >= n) return;
+  const size_t live = n - i0 < 64 ? n - i0 : 64;
+  const double* in = se3 + 7 * i0;
 #pragma unroll
-  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
+  for (int k = 0; k < 7; ++k)
+    if ((size_t)(k * 64 + lane) < live * 7) sw[k * 64 + lane] = in[k * 64 + lane];
+  wave_lds_sync();
   float4 r[4];
-  make_pose_rec(f, st, r);
-  float4* dst = reinterpret_cast<float4*>(recs + i);
+  const bool have = (size_t)lane < live;
+  if (have) {
+    double st[7];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dst[j] = r[j];
+    for (int j = 0; j < 7; ++j) st[j] = sw[lane * 7 + j];
+    make_pose_rec(f, st, r);
+  }
+  wave_lds_sync();
+  float4* rw = reinterpret_cast<float4*>(sw);
+  if (have) stage_pose_rec(rw, lane, r);
+  wave_lds_sync();
+  flush_pose_recs(rw, lane, live, recs + i0);
 }
 
 // One full StateValidityChecker::isValid for the state held (wave-uniformly) in se3[7].
@@ -605,15 +639,9 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
     // the staging area (the states are out) the wavefront's 4 KB go as four fully coalesced 1 KB rows
     wave_lds_sync();
     float4* rw = reinterpret_cast<float4*>(sw);
-    if (i < n) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) rw[lane * 4 + k] = r[k];
-    }
+    if (i < n) stage_pose_rec(rw, lane, r);
     wave_lds_sync();
-    float4* dst = reinterpret_cast<float4*>(recs + i0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if ((size_t)(k * 64 + lane) < live * 4) dst[k * 64 + lane] = rw[k * 64 + lane];
+    flush_pose_recs(rw, lane, live, recs + i0);
   }
 }
 
@@ -857,41 +885,55 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
   if (my_overflow) atomicExch(overflow, 1);
 }
 
-// offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  One lane per wave-task:
-// writes the interpolated state of (edge, k) and remembers its edge.
+// offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  One lane per task (edge e, interior state k):
+// the interpolated state of DiscreteMotionValidator::checkMotion (mode 0: k = 0 is s2, then t = k / nd) or of
+// addValidMilestone's 0.5 m rule (mode 1: t = (k + 1) / (n_interp + 1)), and the edge it belongs to.
+// The interpolated state never leaves the registers: the validity pipeline only reads its PoseRec, so
+// the kernel emits that (coalesced through LDS) instead of 56 bytes of f64 state per lane for pose_rec_kernel to read
+// back (13 M states per 2^18 checkMotion edges: 0.74 GB written with 56-byte strides, read again, and a launch).
 __global__ void __launch_bounds__(256)
-expand_edges_kernel(int mode, const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
-                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
-                    double* __restrict__ states_out, uint32_t* __restrict__ edge_of) {
+expand_edges_recs_kernel(FieldDev f, int mode, const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
+                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
+                         PoseRec* __restrict__ recs, uint32_t* __restrict__ edge_of) {
+  __shared__ float4 stage[4][64 * 4];
+  const int lane = threadIdx.x & 63;
+  float4* rw = stage[threadIdx.x >> 6];
   const size_t total = offsets[n];
-  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
-       w += (size_t)gridDim.x * blockDim.x) {
-    size_t lo = 0, hi = n;  // edge e with offsets[e] <= w < offsets[e+1]
-    while (hi - lo > 1) {
-      const size_t mid = (lo + hi) >> 1;
-      if (offsets[mid] <= w) lo = mid; else hi = mid;
-    }
-    const size_t e = lo;
-    const uint32_t k = (uint32_t)(w - offsets[e]);
-    const double* a = s1 + 7 * e;
-    const double* b = s2 + 7 * e;
-    double st[7];
-    if (mode == 0) {
-      if (k == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) st[i] = b[i];
-      } else {
-        const uint32_t nd = aux[e];
-        se3_interpolate(a, b, (double)k / (double)nd, st);
+  for (size_t w0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); w0 < total;
+       w0 += (size_t)gridDim.x * blockDim.x) {  // w0: wave-uniform
+    const size_t w = w0 + lane;
+    if (w < total) {
+      size_t lo = 0, hi = n;  // edge e with offsets[e] <= w < offsets[e+1]
+      while (hi - lo > 1) {
+        const size_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= w) lo = mid; else hi = mid;
       }
-    } else {
-      const uint32_t n_interp = aux[e];
-      const double n_interp_div = 1.0 / (n_interp + 1);
-      se3_interpolate(a, b, (k + 1) * n_interp_div, st);
-    }
+      const size_t e = lo;
+      const uint32_t k = (uint32_t)(w - offsets[e]);
+      const double* a = s1 + 7 * e;
+      const double* b = s2 + 7 * e;
+      double st[7];
+      if (mode == 0) {
+        if (k == 0) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) states_out[7 * w + i] = st[i];
-    edge_of[w] = (uint32_t)e;
+          for (int i = 0; i < 7; ++i) st[i] = b[i];
+        } else {
+          const uint32_t nd = aux[e];
+          se3_interpolate(a, b, (double)k / (double)nd, st);
+        }
+      } else {
+        const uint32_t n_interp = aux[e];
+        const double n_interp_div = 1.0 / (n_interp + 1);
+        se3_interpolate(a, b, (k + 1) * n_interp_div, st);
+      }
+      float4 r[4];
+      make_pose_rec(f, st, r);
+      stage_pose_rec(rw, lane, r);
+      edge_of[w] = (uint32_t)e;
+    }
+    wave_lds_sync();
+    flush_pose_recs(rw, lane, total - w0 < 64 ? total - w0 : 64, recs + w0);
+    wave_lds_sync();
   }
 }
 

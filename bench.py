@@ -65,7 +65,7 @@ def csrc_hash():
 # ---------------------------------------------------------------------------------------------------------
 # PMC: child workload + parent-side collection
 # ---------------------------------------------------------------------------------------------------------
-EDGE_KERNELS = ["motion_plan_kernel", "expand_edges_kernel", "reduce_edges_kernel", "pose_rec_kernel"]
+EDGE_KERNELS = ["motion_plan_kernel", "expand_edges_recs_kernel", "reduce_edges_kernel"]
 
 
 def pmc_child(args):
