@@ -196,7 +196,12 @@ __device__ __forceinline__ void flush_pose_recs(const float4* rw, int lane, size
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int j = k * 64 + lane;  // chunk j of the block = chunk (j & 3) of lane j >> 2
-    if ((size_t)j < live * 4) dst[j] = rw[rec_stage_slot(j >> 2, j & 3)];
+    // streamed once, read once by the next kernel: non-temporal, so that 0.27 GB of records per batch do not push the
+    // sampler's 6 MB of tables out of the L2s
+    typedef float native_f4 __attribute__((ext_vector_type(4)));
+    if ((size_t)j < live * 4)
+      __builtin_nontemporal_store(reinterpret_cast<const native_f4*>(rw)[rec_stage_slot(j >> 2, j & 3)],
+                                  reinterpret_cast<native_f4*>(dst) + j);
   }
 }
 
@@ -632,7 +637,7 @@ sample_states_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, uint6
   double* out = se3_out + 7 * i0;
 #pragma unroll
   for (int k = 0; k < 7; ++k)
-    if ((size_t)(k * 64 + lane) < cnt) out[k * 64 + lane] = sw[k * 64 + lane];
+    if ((size_t)(k * 64 + lane) < cnt) __builtin_nontemporal_store(sw[k * 64 + lane], &out[k * 64 + lane]);
   if (recs) {
     // the PoseRecs leave the same way: a lane storing its own 64-byte record issues four 16-byte stores 64 bytes apart
     // (each store instruction touches 64 half-written lines: the L2 fetched 270 MB per batch to merge them); through

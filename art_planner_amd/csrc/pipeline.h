@@ -622,7 +622,10 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     const int sl = threadIdx.x >> 2, part = threadIdx.x & 3;
     const size_t gi_raw = (size_t)blockIdx.x * SUB * 64 + sl;
     const size_t gi = gi_raw < n ? gi_raw : n - 1;
-    prec[sl * 5 + part] = reinterpret_cast<const float4*>(recs + gi)[part];
+    // read once, 268 MB per batch: non-temporal, so that the records do not evict the 10 MB of exact tables from the L2s
+    typedef float native_f4 __attribute__((ext_vector_type(4)));
+    const native_f4 pv = __builtin_nontemporal_load(reinterpret_cast<const native_f4*>(recs + gi) + part);
+    prec[sl * 5 + part] = make_float4(pv[0], pv[1], pv[2], pv[3]);
   }
   __syncthreads();
   ARTP_C_MARK(0);
@@ -764,7 +767,8 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       const unsigned short* pl = plist + wave * 64;
       for (int j = lane; j < pc * 6; j += 64) {
         const int e = j / 6;
-        out[j] = open_recs[6 * (int)pl[e] + (j - 6 * e)];
+        out[j] = open_recs[6 * (int)pl[e] + (j - 6 * e)];  // plain stores: the stream kernels find the records in L2 / MALL
+        //                                                     (non-temporal: classify -11 us, the two stream kernels +18)
       }
     }
   }
