@@ -74,7 +74,8 @@ class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
                 ("w_energy", C.c_float), ("w_time", C.c_float), ("w_risk", C.c_float),
                 ("risk_threshold", C.c_float),
                 ("max_n_edges", C.c_uint32), ("recompute_density_after_n_samples", C.c_uint32),
-                ("max_sample_time", C.c_double), ("density_map", C.c_void_p), ("density_params", C.c_void_p)]
+                ("max_sample_time", C.c_double), ("density_map", C.c_void_p), ("density_params", C.c_void_p),
+                ("construction", C.c_int32)]
 
 
 def load():

@@ -78,16 +78,29 @@ knn_permute_kernel(const double* __restrict__ verts, const uint32_t* __restrict_
     for (uint32_t c2 = cc + 1; c2 <= (uint32_t)ncell; ++c2) cell_start[c2] = (uint32_t)nv;
 }
 
+// k_of (may be NULL) = the list length of every query by ORIGINAL index (<= k_row, the row length of the outputs), and
+// pred_only restricts a query's candidates to the vertices with a SMALLER original index: together they are the
+// neighbour search of a planner that inserts its vertices one at a time (construction 2, roadmap_connect) --
+// vertex i sees its predecessors only, with the k of the graph size at ITS insertion -- as one batch.
 __global__ void __launch_bounds__(64)
 knn_kernel(const double* __restrict__ verts_sorted, const uint32_t* __restrict__ sorted_id,
-           const uint32_t* __restrict__ cell_start, KnnGrid g, int nv, int k, uint32_t* __restrict__ out_idx,
-           double* __restrict__ out_dist) {
+           const uint32_t* __restrict__ cell_start, KnnGrid g, int nv, int k_row, const int* __restrict__ k_of,
+           int pred_only, uint32_t* __restrict__ out_idx, double* __restrict__ out_dist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* bd = reinterpret_cast<double*>(smem);                      // [k][64]
-  uint32_t* bi = reinterpret_cast<uint32_t*>(bd + (size_t)k * 64);  // [k][64] original indices
+  double* bd = reinterpret_cast<double*>(smem);                          // [k_row][64]
+  uint32_t* bi = reinterpret_cast<uint32_t*>(bd + (size_t)k_row * 64);  // [k_row][64] original indices
   const int lane = threadIdx.x;
   const int p = blockIdx.x * 64 + lane;  // query = sorted position p: neighbouring lanes share cells
   if (p >= nv) return;
+  const uint32_t qi = sorted_id[p];
+  const int k = k_of ? min(k_of[qi], k_row) : k_row;
+  if (k <= 0) {
+    for (int a = 0; a < k_row; ++a) {
+      out_idx[(size_t)qi * k_row + a] = 0xffffffffu;
+      out_dist[(size_t)qi * k_row + a] = INFINITY;
+    }
+    return;
+  }
   double q[7];
 #pragma unroll
   for (int c = 0; c < 7; ++c) q[c] = verts_sorted[(size_t)p * 7 + c];
@@ -115,6 +128,7 @@ knn_kernel(const double* __restrict__ verts_sorted, const uint32_t* __restrict__
         const uint32_t j0 = cell_start[yy * g.gx + xa], j1 = cell_start[yy * g.gx + xb + 1];
         for (uint32_t j = j0; j < j1; ++j) {
           if ((int)j == p) continue;
+          if (pred_only && sorted_id[j] >= qi) continue;
           const double* c = verts_sorted + (size_t)j * 7;
           const double dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
           const double dp = sqrt(dx * dx + dy * dy + dz * dz);
@@ -147,11 +161,11 @@ knn_kernel(const double* __restrict__ verts_sorted, const uint32_t* __restrict__
     }
   }
   // selection sort by (distance, index); unused slots (fewer than k candidates) are marked
-  const size_t i = sorted_id[p];
-  for (int a = 0; a < k; ++a) {
+  const size_t i = qi;
+  for (int a = 0; a < k_row; ++a) {
     if (a >= count) {
-      out_idx[i * k + a] = 0xffffffffu;
-      out_dist[i * k + a] = INFINITY;
+      out_idx[i * k_row + a] = 0xffffffffu;
+      out_dist[i * k_row + a] = INFINITY;
       continue;
     }
     int best = a;
@@ -165,8 +179,8 @@ knn_kernel(const double* __restrict__ verts_sorted, const uint32_t* __restrict__
     bi[best * 64 + lane] = bi[a * 64 + lane];
     bd[a * 64 + lane] = dbest;
     bi[a * 64 + lane] = ibest;
-    out_idx[i * k + a] = ibest;
-    out_dist[i * k + a] = dbest;
+    out_idx[i * k_row + a] = ibest;
+    out_dist[i * k_row + a] = dbest;
   }
 }
 
@@ -323,6 +337,19 @@ chain_motion_cost_kernel(const float* __restrict__ cost3, const uint32_t* __rest
   cost[e] = feasible ? total : INFINITY;
 }
 
+// construction 1: the interior states of the 0.5 m chains of ONE milestone (tasks: a[7], b[7], t per row) -- the states
+// themselves are needed on the host, where the valid ones become graph vertices (prm_motion_cost.cpp:353-366)
+__global__ void __launch_bounds__(64)
+chain_states_kernel(const double* __restrict__ tasks, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const double* t = tasks + (size_t)i * 15;
+  double st[7];
+  se3_interpolate(t, t + 7, t[14], st);
+#pragma unroll
+  for (int c = 0; c < 7; ++c) out[(size_t)i * 7 + c] = st[c];
+}
+
 }  // namespace artp
 
 // -------------------------------------------------------------------------------------------------------
@@ -414,6 +441,11 @@ struct artp_roadmap {
 };
 
 namespace {
+
+// OMPL 1.4.2 KStarStrategy for SE3 (dimension 6): k = ceil(e (1 + 1/6) ln n), n = the number of graph vertices
+inline int roadmap_kstar(size_t n) {
+  return (int)std::ceil(2.718281828459045 * (1.0 + 1.0 / 6.0) * std::log((double)n));
+}
 
 // The roadmap owns a copy of the caller's preprocess parameters; call after every struct assignment / swap.
 void roadmap_fix_params(artp_roadmap* rm) {
@@ -610,8 +642,11 @@ bool roadmap_sssp_dev(artp_roadmap* rm, std::vector<uint32_t>* path, double* cos
 
 // Verdict (0.5 m interpolation rule), interior-state count and chain cost of ne edges whose endpoint states
 // are on the device; results to the host arrays.
+// direct: no interpolation rule -- every edge is one sub-edge of unknown validity (reported valid), the way the
+// reference's planners put the edges of an already dense neighbourhood (n_interp == 0, prm_motion_cost.cpp:345-348)
+// and LazyPRM*'s edges into their graphs.
 int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const double* d_s1, const double* d_s2,
-                           size_t ne, uint8_t* evalid, uint32_t* einterp, double* ecost) {
+                           size_t ne, uint8_t* evalid, uint32_t* einterp, double* ecost, bool direct = false) {
   if (ne == 0) return ARTP_OK;
   hipStream_t st = c->stream;
   double* d_cost = nullptr;
@@ -627,7 +662,12 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cost), ne * sizeof(double)));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_evalid), ne));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_einterp), ne * sizeof(uint32_t)));
-  RM_TRY(artp_check_edges_interp_dev(c, d_s1, d_s2, ne, d_evalid, d_einterp));
+  if (direct) {
+    RM_HIP(hipMemsetAsync(d_evalid, 1, ne, st));
+    RM_HIP(hipMemsetAsync(d_einterp, 0, ne * sizeof(uint32_t), st));
+  } else {
+    RM_TRY(artp_check_edges_interp_dev(c, d_s1, d_s2, ne, d_evalid, d_einterp));
+  }
   if (prm->objective <= 1) {
     artp::PathLengthParams pl{prm->objective == 1, prm->max_lon_vel, prm->max_lat_vel, prm->max_ang_vel};
     hipLaunchKernelGGL(artp::edge_chain_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, pl, d_s1,
@@ -668,7 +708,7 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
 // same for edges (eu[e], ev[e]) of host vertices: gathers the endpoint states on the host first
 int roadmap_eval_edges_host(artp_ctx* c, const artp_roadmap_params* prm, const std::vector<double>& verts,
                             const uint32_t* eu, const uint32_t* ev, size_t ne, uint8_t* evalid, uint32_t* einterp,
-                            double* ecost) {
+                            double* ecost, bool direct = false) {
   if (ne == 0) return ARTP_OK;
   std::vector<double> s(2 * ne * 7);
   for (size_t e = 0; e < ne; ++e) {
@@ -682,7 +722,7 @@ int roadmap_eval_edges_host(artp_ctx* c, const artp_roadmap_params* prm, const s
   RM_HIP(hipSetDevice(c->device));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_s), s.size() * sizeof(double)));
   RM_HIP(hipMemcpy(d_s, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice));
-  RM_TRY(roadmap_eval_edges_dev(c, prm, d_s, d_s + ne * 7, ne, evalid, einterp, ecost));
+  RM_TRY(roadmap_eval_edges_dev(c, prm, d_s, d_s + ne * 7, ne, evalid, einterp, ecost, direct));
   cleanup();
   return ARTP_OK;
 }
@@ -742,10 +782,30 @@ static int roadmap_connect(artp_ctx* c, const artp_roadmap_params* prm, const do
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(uint64_t)));
   // 2. k nearest neighbours
   int k = (int)prm->k_neighbors;
-  if (k <= 0) k = (int)std::ceil(2.718281828459045 * (1.0 + 1.0 / 6.0) * std::log((double)nv));  // KStarStrategy
+  if (k <= 0) k = roadmap_kstar((size_t)nv);
   if (k > (int)nv - 1) k = (int)nv - 1;
   if (k < 1) k = 1;
   if (k > 128) k = 128;
+  // construction 2 (LazyPRMStarMinUpdate::addValidMilestone, lazy_prm_star_min_update.cpp:424-446): vertex i is
+  // connected to the k_i nearest of its PREDECESSORS, k_i = the rule at the graph size of its insertion (i + 1, itself
+  // included; it enters the nearest-neighbour structure last)
+  const bool pred_only = prm->construction == 2;
+  int* d_k_of = nullptr;
+  if (pred_only) {
+    std::vector<int> k_of(nv);
+    for (size_t i = 0; i < nv; ++i) {
+      int ki = prm->k_neighbors ? (int)prm->k_neighbors : roadmap_kstar(i + 1);
+      if (ki > (int)i) ki = (int)i;
+      k_of[i] = ki > k ? k : ki;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&d_k_of), nv * sizeof(int)) != hipSuccess ||
+        hipMemcpy(d_k_of, k_of.data(), nv * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      if (d_k_of) (void)hipFree(d_k_of);
+      c->last_error = "k table upload failed";
+      cleanup();
+      return ARTP_ERR_HIP;
+    }
+  }
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_knn), nv * k * sizeof(uint32_t)));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_knn_dist), nv * k * sizeof(double)));
   {
@@ -797,11 +857,13 @@ static int roadmap_connect(artp_ctx* c, const artp_roadmap_params* prm, const do
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
       if (okk) {
         hipLaunchKernelGGL(artp::knn_kernel, dim3((unsigned)((nv + 63) / 64)), dim3(64), lds, st, (const double*)d_vs,
-                           (const uint32_t*)d_id_s, (const uint32_t*)d_start, g, (int)nv, k, d_knn, d_knn_dist);
+                           (const uint32_t*)d_id_s, (const uint32_t*)d_start, g, (int)nv, k, (const int*)d_k_of,
+                           pred_only ? 1 : 0, d_knn, d_knn_dist);
         okk = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
       }
     }
     cleanup_knn();
+    if (d_k_of) (void)hipFree(d_k_of);
     if (!okk) {
       c->last_error = "k-NN stage failed";
       cleanup();
@@ -872,8 +934,9 @@ static int roadmap_connect(artp_ctx* c, const artp_roadmap_params* prm, const do
     d_s2 = d_s1 + ne * 7;
     hipLaunchKernelGGL(artp::gather_edge_states_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
                        (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2);
+    // construction 2: the lazy planner puts DIRECT edges of unknown validity into its graph (no interpolation rule)
     const int rc = roadmap_eval_edges_dev(c, prm, d_s1, d_s2, ne, rm->evalid.data(), rm->einterp.data(),
-                                          rm->ecost.data());
+                                          rm->ecost.data(), pred_only);
     if (rc != ARTP_OK) return fail(rc);
     std::vector<unsigned long long> keys(ne);
     if (hipMemcpy(keys.data(), d_keys_unique, ne * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(ARTP_ERR_HIP);
@@ -1044,11 +1107,451 @@ static int roadmap_build_impl(artp_ctx* c, const artp_roadmap_params* prm_in, co
   return ARTP_OK;
 }
 
+// ---- construction 1: the reference's own insertion order (PRMMotionCost::addValidMilestone) ---------------------------
+// The graph under construction.  Vertex ids: 0 = start, 1 = goal (their rows are reserved from the beginning, they are
+// INSERTED last, like baseSolve does, prm_motion_cost.cpp:447-470), 2.. = insertion order (milestones and the chain
+// vertices their connection attempts leave behind).
+struct IncrementalGraph {
+  artp_ctx* c = nullptr;
+  artp_roadmap_params prm{};
+  std::vector<double> verts;
+  std::vector<uint8_t> inserted;            // vertex is in the graph (and, but for the milestone in flight, in nn_)
+  std::vector<uint32_t> eu, ev;             // sub-edges, creation order
+  size_t n_graph = 0;                       // boost::num_vertices(g_)
+  std::vector<uint32_t> knn_rows;           // neighbour list of every MILESTONE (id, then its neighbours), for export
+  int k_max = 0;
+  uint64_t states_checked = 0;
+  // nn_: uniform xy grid of vertex ids
+  double x0 = 0, y0 = 0, h = 1, inv_h = 1;
+  int gx = 1, gy = 1;
+  std::vector<std::vector<uint32_t>> cells;
+  // device staging of one milestone's chains
+  double *d_tasks = nullptr, *d_states = nullptr;
+  uint8_t* d_valid = nullptr;
+  size_t cap = 0;
+  std::vector<double> tasks, states;
+  std::vector<uint8_t> valid;
+  ~IncrementalGraph() {
+    for (void* p : {(void*)d_tasks, (void*)d_states, (void*)d_valid})
+      if (p) (void)hipFree(p);
+  }
+  size_t nv() const { return verts.size() / 7; }
+  int cell_of(double v, double v0, int g) const {
+    const int cc = (int)std::floor((v - v0) * inv_h);
+    return cc < 0 ? 0 : (cc >= g ? g - 1 : cc);
+  }
+  void nn_add(uint32_t id) {
+    const double* s = &verts[(size_t)id * 7];
+    cells[(size_t)cell_of(s[1], y0, gy) * gx + cell_of(s[0], x0, gx)].push_back(id);
+  }
+  void setup_grid(size_t expected_vertices) {
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    x0 = c->geom.pos_x - 0.5 * c->geom.len_x;
+    y0 = c->geom.pos_y - 0.5 * c->geom.len_y;
+    h = std::sqrt(c->geom.len_x * c->geom.len_y * 3.0 / (double)std::max<size_t>(expected_vertices, 16));
+    const double hmin = std::max(c->geom.len_x, c->geom.len_y) / 1024.0;
+    if (h < hmin) h = hmin;
+    inv_h = 1.0 / h;
+    gx = std::max(1, (int)std::ceil(c->geom.len_x * inv_h));
+    gy = std::max(1, (int)std::ceil(c->geom.len_y * inv_h));
+    cells.assign((size_t)gx * gy, {});
+  }
+  // nn_->nearestK(q, k) under OMPL's SE3 distance, ascending (distance, id).  The distance is at least the planar one
+  // and every cell of ring r is at least (r - 1) h away in the plane: the ring walk stops -- exactly -- once k
+  // candidates are held and that bound reaches the k-th distance.
+  void nn_nearest(const double* q, int k, std::vector<std::pair<double, uint32_t>>& out) const {
+    out.clear();
+    if (k <= 0) return;
+    const int cx = cell_of(q[0], x0, gx), cy = cell_of(q[1], y0, gy);
+    const int rmax = std::max(std::max(cx, gx - 1 - cx), std::max(cy, gy - 1 - cy));
+    auto visit = [&](int xx, int yy) {
+      for (uint32_t id : cells[(size_t)yy * gx + xx]) {
+        const double* v = &verts[(size_t)id * 7];
+        const double dx = v[0] - q[0], dy = v[1] - q[1], dz = v[2] - q[2];
+        const double dp = std::sqrt(dx * dx + dy * dy + dz * dz);
+        if ((int)out.size() == k && dp > out.front().first) continue;
+        const double dq = std::fabs(v[3] * q[3] + v[4] * q[4] + v[5] * q[5] + v[6] * q[6]);
+        const std::pair<double, uint32_t> cand{dp + (dq > 1.0 - 1e-9 ? 0.0 : std::acos(dq)), id};
+        if ((int)out.size() < k) {
+          out.push_back(cand);
+          std::push_heap(out.begin(), out.end());
+        } else if (cand < out.front()) {
+          std::pop_heap(out.begin(), out.end());
+          out.back() = cand;
+          std::push_heap(out.begin(), out.end());
+        }
+      }
+    };
+    for (int r = 0; r <= rmax; ++r) {
+      if ((int)out.size() == k && (double)(r - 1) * h >= out.front().first) break;
+      for (int yy = cy - r; yy <= cy + r; ++yy) {
+        if (yy < 0 || yy >= gy) continue;
+        if (yy == cy - r || yy == cy + r) {
+          for (int xx = std::max(cx - r, 0); xx <= std::min(cx + r, gx - 1); ++xx) visit(xx, yy);
+        } else {
+          if (cx - r >= 0) visit(cx - r, yy);
+          if (r > 0 && cx + r < gx) visit(cx + r, yy);
+        }
+      }
+    }
+    std::sort_heap(out.begin(), out.end());
+  }
+  int eval_tasks(size_t n) {  // tasks -> states, valid
+    hipStream_t st = c->stream;
+    if (hipSetDevice(c->device) != hipSuccess) return ARTP_ERR_HIP;
+    if (cap < n) {
+      for (void* p : {(void*)d_tasks, (void*)d_states, (void*)d_valid})
+        if (p) (void)hipFree(p);
+      d_tasks = d_states = nullptr;
+      d_valid = nullptr;
+      cap = std::max<size_t>(2 * n, 1024);
+      if (hipMalloc(reinterpret_cast<void**>(&d_tasks), cap * 15 * sizeof(double)) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&d_states), cap * 7 * sizeof(double)) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&d_valid), cap) != hipSuccess) {
+        cap = 0;
+        c->last_error = "chain staging allocation failed";
+        return ARTP_ERR_HIP;
+      }
+    }
+    states.resize(n * 7);
+    valid.resize(n);
+    if (hipMemcpyAsync(d_tasks, tasks.data(), n * 15 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+      return ARTP_ERR_HIP;
+    hipLaunchKernelGGL(artp::chain_states_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                       (const double*)d_tasks, (int)n, d_states);
+    const int rc = artp_validate_states_dev(c, d_states, n, d_valid, nullptr);
+    if (rc != ARTP_OK) return rc;
+    if (hipMemcpyAsync(states.data(), d_states, n * 7 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(valid.data(), d_valid, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return ARTP_ERR_HIP;
+    states_checked += n;
+    return check_error_flag(c);
+  }
+  // PRMMotionCost::addValidMilestone (prm_motion_cost.cpp:325-390) for the vertex whose row is already in verts
+  int add_valid_milestone(uint32_t m) {
+    ++n_graph;  // :326 the milestone is a graph vertex first ...
+    inserted[m] = 1;
+    const int k = prm.k_neighbors ? (int)prm.k_neighbors : roadmap_kstar(n_graph);  // KStarStrategy at insertion time
+    std::vector<std::pair<double, uint32_t>> nbrs;
+    const double q[7] = {verts[(size_t)m * 7 + 0], verts[(size_t)m * 7 + 1], verts[(size_t)m * 7 + 2], verts[(size_t)m * 7 + 3],
+                         verts[(size_t)m * 7 + 4], verts[(size_t)m * 7 + 5], verts[(size_t)m * 7 + 6]};
+    nn_nearest(q, k, nbrs);  // :334 connectionStrategy_(m): m itself is not in nn_ yet
+    if ((int)nbrs.size() > k_max) k_max = (int)nbrs.size();
+    knn_rows.push_back(m);
+    knn_rows.push_back((uint32_t)nbrs.size());
+    for (const auto& nb : nbrs) knn_rows.push_back(nb.second);
+    // :340-344 the interior states of every neighbour's chain, one device batch for the whole milestone
+    std::vector<uint32_t> n_interp(nbrs.size());
+    tasks.clear();
+    for (size_t t = 0; t < nbrs.size(); ++t) {
+      const double* b = &verts[(size_t)nbrs[t].second * 7];
+      const double dx = b[0] - q[0], dy = b[1] - q[1];
+      const double cnt = std::floor(std::sqrt(dx * dx + dy * dy) / 0.5);
+      if (!(cnt >= 0.0) || cnt > 65536.0) {
+        c->last_error = "a connection needs more than 65536 interpolation states (non-finite state?)";
+        return ARTP_ERR_INVALID_ARG;
+      }
+      n_interp[t] = (uint32_t)cnt;
+      const double div = 1.0 / (double)(n_interp[t] + 1);
+      for (uint32_t step = 1; step <= n_interp[t]; ++step) {
+        tasks.insert(tasks.end(), q, q + 7);
+        tasks.insert(tasks.end(), b, b + 7);
+        tasks.push_back((double)step * div);
+      }
+    }
+    const size_t n_tasks = tasks.size() / 15;
+    if (n_tasks) {
+      const int rc = eval_tasks(n_tasks);
+      if (rc != ARTP_OK) return rc;
+    }
+    size_t at = 0;
+    for (size_t t = 0; t < nbrs.size(); ++t) {
+      const uint32_t nb = nbrs[t].second;
+      uint32_t prev = m;
+      bool ok = true;
+      for (uint32_t step = 0; step < n_interp[t]; ++step) {  // :353-371 the valid prefix stays in the graph
+        if (ok && valid[at + step]) {
+          const uint32_t v = (uint32_t)nv();
+          verts.insert(verts.end(), states.begin() + (at + step) * 7, states.begin() + (at + step + 1) * 7);
+          inserted.push_back(1);
+          ++n_graph;
+          eu.push_back(prev);
+          ev.push_back(v);
+          nn_add(v);  // :364 a neighbour target for every later milestone
+          prev = v;
+        } else {
+          ok = false;
+        }
+      }
+      at += n_interp[t];
+      if (ok) {  // :345-348 direct edge, :373-377 last edge of a complete chain
+        eu.push_back(prev);
+        ev.push_back(nb);
+      }
+    }
+    nn_add(m);  // :387 ... and a neighbour target last
+    return ARTP_OK;
+  }
+};
+
+// graph -> artp_roadmap: edges sorted by (u, v), u < v, one batched cost evaluation (updateEdges fills the weights of
+// the reference's graph in one batch as well, prm_motion_cost.cpp:27-73); every sub-edge is direct
+static int incremental_finish(IncrementalGraph& g, artp_roadmap* rm, const std::vector<uint8_t>* vertex_ok) {
+  const size_t ne = g.eu.size(), nv = g.nv();
+  std::vector<std::pair<uint32_t, uint32_t>> e(ne);
+  for (size_t i = 0; i < ne; ++i) e[i] = {std::min(g.eu[i], g.ev[i]), std::max(g.eu[i], g.ev[i])};
+  std::sort(e.begin(), e.end());
+  e.erase(std::unique(e.begin(), e.end()), e.end());
+  rm->ctx = g.c;
+  rm->params = g.prm;
+  roadmap_fix_params(rm);
+  rm->verts = g.verts;
+  rm->k = std::max(g.k_max, 1);
+  rm->knn.assign(nv * (size_t)rm->k, 0xffffffffu);
+  rm->knn_dist.assign(nv * (size_t)rm->k, INFINITY);
+  for (size_t at = 0; at < g.knn_rows.size();) {
+    const uint32_t m = g.knn_rows[at], cnt = g.knn_rows[at + 1];
+    for (uint32_t t = 0; t < cnt; ++t) {
+      const uint32_t nb = g.knn_rows[at + 2 + t];
+      rm->knn[(size_t)m * rm->k + t] = nb;
+      const double *a = &g.verts[(size_t)m * 7], *b = &g.verts[(size_t)nb * 7];
+      const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+      const double dq = std::fabs(a[3] * b[3] + a[4] * b[4] + a[5] * b[5] + a[6] * b[6]);
+      rm->knn_dist[(size_t)m * rm->k + t] = std::sqrt(dx * dx + dy * dy + dz * dz) + (dq > 1.0 - 1e-9 ? 0.0 : std::acos(dq));
+    }
+    at += 2 + cnt;
+  }
+  const size_t n = e.size();
+  rm->eu.resize(n);
+  rm->ev.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    rm->eu[i] = e[i].first;
+    rm->ev[i] = e[i].second;
+  }
+  rm->evalid.assign(n, 0);
+  rm->einterp.assign(n, 0);
+  rm->ecost.assign(n, 0.0);
+  rm->eremoved.assign(n, 0);
+  const int rc = roadmap_eval_edges_host(g.c, &rm->params, rm->verts, rm->eu.data(), rm->ev.data(), n, rm->evalid.data(),
+                                         rm->einterp.data(), rm->ecost.data(), true);
+  if (rc != ARTP_OK) return rc;
+  if (vertex_ok)
+    for (size_t i = 0; i < n; ++i)
+      if (!(*vertex_ok)[rm->eu[i]] || !(*vertex_ok)[rm->ev[i]]) rm->evalid[i] = 0;
+  rm->csr_dirty = true;
+  rm->d_graph_dirty = true;
+  rm->d_graph_ne = 0;
+  rm->d_edge_states_stale = true;
+  return ARTP_OK;
+}
+
+// sampleGraph's loop (prm_motion_cost.cpp:171-194) over the accepted states of the sample stream from index `first` on:
+// milestones are added while the graph has fewer than max_vertices vertices (chain vertices count) and fewer than
+// max_n_edges sub-edges.  The stream position behind the last sample consumed goes to *next_out.
+static int incremental_sample_graph(IncrementalGraph& g, size_t max_vertices, uint64_t first, uint64_t* next_out,
+                                    uint64_t* n_reweights, uint64_t* budget_flags) {
+  artp_ctx* c = g.c;
+  const artp_roadmap_params& prm = g.prm;
+  hipStream_t st = c->stream;
+  const size_t batch = 4096;
+  double *d_batch = nullptr, *d_compact = nullptr, *d_verts = nullptr;
+  uint8_t* d_valid = nullptr;
+  uint32_t* d_idx = nullptr;
+  uint64_t* d_cnt = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_batch, (void*)d_compact, (void*)d_valid, (void*)d_idx, (void*)d_cnt, (void*)d_verts})
+      if (p) (void)hipFree(p);
+  };
+  RM_HIP(hipSetDevice(c->device));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_batch), batch * 7 * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_compact), batch * 7 * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_valid), batch));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), batch * sizeof(uint32_t)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt), 2 * sizeof(uint64_t)));
+  const size_t R = (prm.density_map && prm.density_params && prm.recompute_density_after_n_samples)
+                       ? prm.recompute_density_after_n_samples : 0;
+  std::vector<double> acc(batch * 7);
+  std::vector<uint32_t> idx(batch);
+  size_t q_n = 0, q_at = 0;
+  uint64_t base = first, next = first;
+  size_t n_proc = 0;  // counts from 0 in every sampleGraph call (:169)
+  int empty_rounds = 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  while (g.n_graph < max_vertices && (!prm.max_n_edges || g.eu.size() < prm.max_n_edges)) {
+    if (q_at == q_n) {
+      base = next;
+      RM_TRY(artp_sample_and_validate_dev(c, prm.seed, base, batch, d_batch, d_valid, nullptr));
+      RM_TRY(artp_compact_valid_dev(c, d_batch, d_valid, batch, d_compact, d_cnt));
+      RM_TRY(artp_compact_valid_indices_dev(c, d_valid, batch, d_idx, d_cnt + 1));
+      uint64_t got = 0;
+      RM_HIP(hipMemcpyAsync(&got, d_cnt, sizeof(got), hipMemcpyDeviceToHost, st));
+      RM_HIP(hipStreamSynchronize(st));
+      if (got) {
+        RM_HIP(hipMemcpyAsync(acc.data(), d_compact, (size_t)got * 7 * sizeof(double), hipMemcpyDeviceToHost, st));
+        RM_HIP(hipMemcpyAsync(idx.data(), d_idx, (size_t)got * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RM_HIP(hipStreamSynchronize(st));
+      }
+      q_n = (size_t)got;
+      q_at = 0;
+      next = base + batch;
+      if (!got) {
+        if (++empty_rounds > 64) {
+          c->last_error = "sampler produced too few valid states for the requested roadmap";
+          cleanup();
+          return ARTP_ERR_CAPACITY;
+        }
+        continue;
+      }
+      empty_rounds = 0;
+    }
+    const uint32_t m = (uint32_t)g.nv();
+    g.verts.insert(g.verts.end(), acc.begin() + q_at * 7, acc.begin() + (q_at + 1) * 7);
+    g.inserted.push_back(0);
+    const uint64_t consumed = base + idx[q_at];
+    ++q_at;
+    if (q_at == q_n) next = base + batch; else next = consumed + 1;
+    RM_TRY(g.add_valid_milestone(m));
+    if (R && g.n_graph / R > n_proc) {
+      // :190-193 Map::reApplyPreprocessing(): the distribution follows the inverse density of ALL graph vertices; the
+      // stream continues right behind the sample that gave this milestone
+      const size_t nvx = g.nv() - 2;
+      if (d_verts) (void)hipFree(d_verts);
+      d_verts = nullptr;
+      RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_verts), nvx * 7 * sizeof(double)));
+      RM_HIP(hipMemcpyAsync(d_verts, g.verts.data() + 14, nvx * 7 * sizeof(double), hipMemcpyHostToDevice, st));
+      RM_TRY(artp_preprocessed_reweight_dev(c, prm.density_map, prm.density_params, d_verts, nvx, 1));
+      ++n_proc;
+      ++*n_reweights;
+      next = consumed + 1;
+      q_at = q_n = 0;
+    }
+    if (prm.max_sample_time > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > prm.max_sample_time) {
+      *budget_flags |= 1u;  // "Reached sample timer limit." (:177-185)
+      break;
+    }
+  }
+  if (prm.max_n_edges && g.eu.size() >= prm.max_n_edges) *budget_flags |= 2u;
+  *next_out = next;
+  cleanup();
+  return ARTP_OK;
+}
+
+static int roadmap_build_incremental(artp_ctx* c, const artp_roadmap_params* prm, const double* start7,
+                                     const double* goal7, artp_roadmap** out) {
+  *out = nullptr;
+  auto cleanup = []() {};
+  {
+    double sg[14];
+    std::memcpy(sg, start7, 7 * sizeof(double));
+    std::memcpy(sg + 7, goal7, 7 * sizeof(double));
+    uint8_t ok[2] = {0, 0};
+    RM_TRY(artp_validate_states(c, sg, 2, ok, nullptr));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    if (!ok[0] || !ok[1]) {
+      c->last_error = !ok[0] ? "start state is not valid" : "goal state is not valid";
+      return ARTP_ERR_INVALID_ARG;
+    }
+  }
+  IncrementalGraph g;
+  g.c = c;
+  g.prm = *prm;
+  g.verts.assign(start7, start7 + 7);
+  g.verts.insert(g.verts.end(), goal7, goal7 + 7);
+  g.inserted.assign(2, 0);
+  g.setup_grid(prm->n_milestones);
+  uint64_t next = prm->first_index, n_reweights = 0, budget_flags = 0;
+  RM_TRY(incremental_sample_graph(g, prm->n_milestones, prm->first_index, &next, &n_reweights, &budget_flags));
+  if (g.n_graph < 1) {
+    c->last_error = "the sampling-time budget ended before the first milestone";
+    return ARTP_ERR_CAPACITY;
+  }
+  // baseSolve: start and goal become milestones of the finished roadmap (:447-470)
+  RM_TRY(g.add_valid_milestone(0));
+  RM_TRY(g.add_valid_milestone(1));
+  auto rm = new artp_roadmap();
+  const int rc = incremental_finish(g, rm, nullptr);
+  if (rc != ARTP_OK) {
+    delete rm;
+    return rc;
+  }
+  rm->samples_drawn = next - prm->first_index;
+  rm->n_reweights = n_reweights;
+  rm->budget_flags = budget_flags;
+  *out = rm;
+  return ARTP_OK;
+}
+
+// artp_roadmap_grow for construction 1: sampleGraph called again on the kept graph.  Vertices the current map
+// invalidated stay in the vertex list (ids are stable) but leave the nearest-neighbour structure, and their edges are
+// marked invalid; n_more = how many more graph vertices (chain vertices included) the budget allows.
+static int roadmap_grow_incremental(artp_roadmap* rm, uint64_t n_more, uint64_t out[2]) {
+  artp_ctx* c = rm->ctx;
+  auto cleanup = []() {};
+  const size_t nv = rm->nv();
+  std::vector<uint8_t> vok(nv, 0);
+  RM_TRY(artp_validate_states(c, rm->verts.data(), nv, vok.data(), nullptr));
+  RM_HIP(hipStreamSynchronize(c->stream));
+  if (!vok[0] || !vok[1]) {
+    c->last_error = !vok[0] ? "start state is not valid" : "goal state is not valid";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  IncrementalGraph g;
+  g.c = c;
+  g.prm = rm->params;
+  g.verts = rm->verts;
+  g.inserted.assign(nv, 1);
+  g.eu = rm->eu;
+  g.ev = rm->ev;
+  g.n_graph = nv;
+  g.k_max = rm->k;
+  g.setup_grid(nv + (size_t)n_more);
+  size_t kept = 0;
+  for (uint32_t v = 0; v < nv; ++v)
+    if (vok[v]) {
+      g.nn_add(v);
+      ++kept;
+    }
+  for (uint32_t m = 0; m < nv; ++m) {  // the neighbour lists recorded so far
+    uint32_t cnt = 0;
+    while ((int)cnt < rm->k && rm->knn[(size_t)m * rm->k + cnt] != 0xffffffffu) ++cnt;
+    if (!cnt) continue;
+    g.knn_rows.push_back(m);
+    g.knn_rows.push_back(cnt);
+    for (uint32_t t = 0; t < cnt; ++t) g.knn_rows.push_back(rm->knn[(size_t)m * rm->k + t]);
+  }
+  uint64_t next = rm->params.first_index + rm->samples_drawn, n_reweights = 0, budget_flags = 0;
+  RM_TRY(incremental_sample_graph(g, nv + (size_t)n_more, next, &next, &n_reweights, &budget_flags));
+  vok.resize(g.nv(), 1);
+  auto fresh = new artp_roadmap();
+  const int rc = incremental_finish(g, fresh, &vok);
+  if (rc != ARTP_OK) {
+    delete fresh;
+    return rc;
+  }
+  fresh->samples_drawn = next - rm->params.first_index;
+  fresh->n_reweights = rm->n_reweights + n_reweights;
+  fresh->budget_flags = budget_flags;
+  fresh->params.n_milestones = (uint32_t)std::min<size_t>(nv + (size_t)n_more, 0xffffffffu);
+  std::swap(*rm, *fresh);
+  roadmap_fix_params(rm);
+  roadmap_fix_params(fresh);
+  artp_roadmap_destroy(fresh);
+  if (out) {
+    out[0] = kept;
+    out[1] = nv - kept;
+  }
+  return ARTP_OK;
+}
+
 int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double* start7, const double* goal7,
                        artp_roadmap** out) {
   if (!c || !prm || !start7 || !goal7 || !out || prm->n_milestones < 1 || prm->objective < 0 ||
-      prm->objective > 2 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0))
+      prm->objective > 2 || !(prm->max_lon_vel > 0) || !(prm->max_lat_vel > 0) || !(prm->max_ang_vel > 0) ||
+      prm->construction < 0 || prm->construction > 2)
     return ARTP_ERR_INVALID_ARG;
+  if (prm->construction == 1) return roadmap_build_incremental(c, prm, start7, goal7, out);
   return roadmap_build_impl(c, prm, start7, goal7, nullptr, 0, prm->n_milestones, prm->first_index, out);
 }
 
@@ -1059,6 +1562,7 @@ int artp_roadmap_build(artp_ctx* c, const artp_roadmap_params* prm, const double
 // whole set -- 10^4 vertices / 10^5 edges are one small batch, cheaper than bookkeeping which edges survive.
 int artp_roadmap_grow(artp_roadmap* rm, uint64_t n_more, uint64_t out[2]) {
   if (!rm) return ARTP_ERR_INVALID_ARG;
+  if (rm->params.construction == 1) return roadmap_grow_incremental(rm, n_more, out);
   artp_ctx* c = rm->ctx;
   const size_t nv = rm->nv();
   std::vector<uint8_t> vok(nv, 0);
@@ -1137,8 +1641,9 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
       }
       rm->d_edge_states_stale = false;
     }
+    // constructions 1 and 2 hold direct sub-edges only (validity is the lazy path check's business)
     rc = roadmap_eval_edges_dev(c, &rm->params, rm->d_edge_states, rm->d_edge_states + ne * 7, ne, rm->evalid.data(),
-                                rm->einterp.data(), rm->ecost.data());
+                                rm->einterp.data(), rm->ecost.data(), rm->params.construction != 0);
     if (rc != ARTP_OK) return rc;
   }
   for (size_t v = 0; v < nv; ++v) vbad += vok[v] ? 0 : 1;

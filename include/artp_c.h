@@ -268,6 +268,22 @@ typedef struct artp_roadmap_params {
   double max_sample_time;                      /* seconds, params.h:50 (default 2.0) */
   struct artp_preprocessed* density_map;
   const struct artp_preprocess_params* density_params;
+  /* How the graph is put together from the accepted-state stream (same stream, same predicates in every mode):
+   *   0 = batched (default): all milestones first, k nearest over the FINAL vertex set, symmetrised pairs, one
+   *       interpolation-rule verdict and one chain cost per pair.  Fastest; not the reference's graph.
+   *   1 = PRMMotionCost::addValidMilestone order (prm_motion_cost.cpp:325-390), the reference's OWN graph: milestones
+   *       are inserted one at a time, each is connected to the k = ceil(e (1 + 1/6) ln n) nearest vertices present
+   *       at ITS insertion (n = vertices then, itself included; it becomes a neighbour target last), the VALID
+   *       PREFIX of every 0.5 m chain stays in the graph as vertices that are neighbour targets for later milestones
+   *       (:353-371), start and goal join last (baseSolve, :447-470).  n_milestones is the reference's
+   *       max_n_vertices and counts the chain vertices too, max_n_edges counts the sub-edges (:171-172).  The
+   *       insertion loop is sequential by construction (host); the interior states of a milestone's k chains are
+   *       interpolated and validated as one small device batch.  Vertex ids: 0 start, 1 goal, then insertion order.
+   *   2 = LazyPRMStarMinUpdate::addValidMilestone order (lazy_prm_star_min_update.cpp:424-446), BASELINE config 1's
+   *       planner: start, goal, then the milestones; vertex i gets DIRECT edges of unknown validity to the
+   *       k = ceil(e (1 + 1/6) ln (i + 1)) nearest of its predecessors, validity is established lazily by
+   *       artp_roadmap_solve.  Predecessor-only search with a per-vertex k is one batch on the device. */
+  int32_t construction;
 } artp_roadmap_params;
 void artp_roadmap_params_defaults(artp_roadmap_params* p);
 /* Samples, connects and validates.  ARTP_ERR_INVALID_ARG (artp_last_error says which) when start or goal

@@ -142,8 +142,9 @@ class IncrementalPRM:
             if p is None:
                 return None, math.inf, removed, checked
             s1, s2 = self.verts[p[:-1]], self.verts[p[1:]]
-            # the reference walks the path from the goal and removes the FIRST invalid edge it meets (:640-661)
-            ok, _ = self.om.check_motions(self.rob, s2[::-1], s1[::-1])
+            # the reference walks the path from the goal and removes the FIRST invalid edge it meets (:640-661); every
+            # edge is checked in travel direction: checkMotion(*state, *prevState), state = the vertex nearer the start
+            ok, _ = self.om.check_motions(self.rob, s1[::-1], s2[::-1])
             checked += len(ok)
             bad = np.flatnonzero(ok == 0)
             if len(bad) == 0:

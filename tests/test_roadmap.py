@@ -674,3 +674,130 @@ def test_costs_against_the_reference_planners_own_graph_construction():
     out = os.path.join(common.ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(report, open(os.path.join(out, "roadmap_vs_reference_construction.json"), "w"), indent=1)
+
+
+def _edge_set(ex):
+    return {(int(u), int(v)) for (u, v), ok in zip(ex["edges"], ex["edge_valid"]) if ok}
+
+
+@pytest.mark.gpu
+def test_construction_2_reproduces_the_lazy_prm_star_graph():
+    """artp_roadmap_params::construction = 2 against oracle/prm_incremental.lazy_prm_star_min_update (BASELINE config 1's
+    planner restated literally): the SAME EDGE SET -- start, goal, then the milestones, every vertex connected to the
+    k = ceil(e (1 + 1/6) ln n) nearest of its predecessors with n counted at its own insertion -- the same weights, the
+    same lazy removals and the same answer.  On the flat C1 map that answer is the direct start-goal edge."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    import prm_incremental as PI
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from synthetic import make_map
+    rob = O.robot("yaml")
+    for name, gm, n_ms in (("c1", make_map(100, 0.1, flat=True), 2000), ("perlin", make_map(160, 0.04, seed=1234), 1500)):
+        om = O.OracleMap(gm)
+        ctx = Context(0, "yaml")
+        ctx.upload_map(gm)
+        se3 = ctx.sample_states(42, 0, 1 << (13 if name == "c1" else 15))
+        lab = om.states_valid(rob, se3)
+        assert np.array_equal(ctx.validate_states(se3), lab)
+        acc = se3[lab != 0]
+        assert len(acc) >= n_ms
+        if name == "c1":
+            z0 = float(acc[0, 2])
+            s, g = np.array([-4.0, -4.0, z0, 0, 0, 0, 1.0]), np.array([4.0, 4.0, z0, 0, 0, 0, 1.0])
+        else:
+            near = lambda xy: acc[np.argmin(np.hypot(acc[:, 0] - xy[0], acc[:, 1] - xy[1]))]
+            s, g = near((gm.pos_x - 2.4, gm.pos_y - 2.4)), near((gm.pos_x + 2.4, gm.pos_y + 2.4))
+        ref = PI.lazy_prm_star_min_update(om, rob, acc, s, g, n_ms)
+        rm = Roadmap(ctx, s, g, n_milestones=n_ms, seed=42, construction=2)
+        ex = rm.export()
+        assert np.array_equal(ex["verts"][2:], acc[:n_ms]) and ex["verts"].shape[0] == ref["vertices"]
+        p, c, removed = rm.solve()
+        # the oracle's graph after ITS solve lacks the removed edges: compare against edges + removals on both sides
+        ref_edges = set(ref["graph"].edges.keys())
+        ex2 = rm.export()
+        mine_all = {(int(u), int(v)) for u, v in ex2["edges"]}
+        mine_left = {(int(u), int(v)) for (u, v), r in zip(ex2["edges"], ex2["edge_removed"]) if not r}
+        assert len(mine_all) == ref["edges"], (name, len(mine_all), ref["edges"])
+        assert mine_left == ref_edges, (name, len(mine_left ^ ref_edges))
+        assert (ex["edge_interp"] == 0).all() and ex["edge_valid"].all()
+        w_ref = np.array([ref["graph"].edges[(int(u), int(v))] for (u, v), r in zip(ex2["edges"], ex2["edge_removed"]) if not r])
+        assert np.allclose(ex2["edge_cost"][ex2["edge_removed"] == 0], w_ref, rtol=1e-12, atol=0)
+        assert removed == ref["lazy_removals"], (name, removed, ref["lazy_removals"])
+        assert (p is None) == (ref["path"] is None)
+        if p is not None:
+            assert abs(c - ref["path_cost"]) < 1e-9 * max(1.0, c), (name, c, ref["path_cost"])
+            assert np.allclose(p, ref["path"], atol=1e-12)
+        if name == "c1":
+            assert len(p) == 2 and abs(c - 8.0 * np.sqrt(2.0) / 0.5) < 1e-9
+        rm.close()
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_construction_1_reproduces_the_prm_motion_cost_graph():
+    """artp_roadmap_params::construction = 1 against oracle/prm_incremental.build_and_solve (PRMMotionCost::
+    addValidMilestone / sampleGraph / baseSolve / constructSolution restated literally) on the 160 x 160 Perlin map with
+    the reference's budgets (10 000 vertices, 50 000 edges): the same milestones consumed, the same chain vertices (the
+    valid prefixes of failing chains included), the SAME EDGE SET, the same lazy removals, the same path."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    import prm_incremental as PI
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from synthetic import make_map
+    rob = O.robot("yaml")
+    gm = make_map(160, 0.04, seed=1234)
+    om = O.OracleMap(gm)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    se3 = ctx.sample_states(42, 0, 1 << 15)
+    lab = om.states_valid(rob, se3)
+    assert np.array_equal(ctx.validate_states(se3), lab)
+    acc = se3[lab != 0]
+    near = lambda xy: acc[np.argmin(np.hypot(acc[:, 0] - xy[0], acc[:, 1] - xy[1]))]
+    s, g = near((gm.pos_x - 2.4, gm.pos_y - 2.4)), near((gm.pos_x + 2.4, gm.pos_y + 2.4))
+    for budget_v, budget_e in ((10000, 50000), (1200, 50000)):   # the edge budget ends the first, the vertex budget the second
+        ref = PI.build_and_solve(om, rob, O.interpolate, acc, s, g, max_n_vertices=budget_v, max_n_edges=budget_e)
+        G = ref["graph"]
+        rm = Roadmap(ctx, s, g, n_milestones=budget_v, max_n_edges=budget_e, seed=42, construction=1)
+        ex = rm.export()
+        st = rm.stats()
+        assert st["vertices"] == ref["vertices"], (st["vertices"], ref["vertices"])
+        # oracle ids: insertion order, start and goal inserted last (each followed by its own chain vertices); here start = 0,
+        # goal = 1, the rest in insertion order
+        ms = np.flatnonzero(np.array(G.is_milestone))
+        vs, vg = int(ms[-2]), int(ms[-1])
+        assert np.array_equal(G.verts[vs], s) and np.array_equal(G.verts[vg], g)
+        to_mine = np.empty(G.nv, np.int64)
+        nxt = 2
+        for o in range(G.nv):
+            if o == vs:
+                to_mine[o] = 0
+            elif o == vg:
+                to_mine[o] = 1
+            else:
+                to_mine[o] = nxt
+                nxt += 1
+        assert np.allclose(ex["verts"][to_mine], G.verts[:G.nv], atol=1e-12)
+        chain = ~np.array(G.is_milestone)
+        assert int(chain.sum()) == ref["chain_vertices"] and ref["chain_vertices"] > 100
+        p, c, removed = rm.solve()
+        ex2 = rm.export()
+        mine_all = {(int(u), int(v)) for u, v in ex2["edges"]}
+        mine_left = {(int(u), int(v)) for (u, v), r in zip(ex2["edges"], ex2["edge_removed"]) if not r}
+        ref_left = {tuple(sorted((int(to_mine[a]), int(to_mine[b])))) for (a, b) in G.edges.keys()}
+        assert len(mine_all) == ref["edges"], (len(mine_all), ref["edges"])
+        assert mine_left == ref_left, len(mine_left ^ ref_left)
+        assert removed == ref["lazy_removals"], (removed, ref["lazy_removals"])
+        assert (p is None) == (ref["path"] is None), budget_v
+        if budget_v == 10000:
+            assert p is not None
+        if p is not None:
+            assert abs(c - ref["path_cost"]) < 1e-9 * c, (c, ref["path_cost"])
+            assert np.allclose(p, ref["path"], atol=1e-12)
+        assert st["samples_drawn"] > 0 and (st["edge_budget_hit"] or budget_v != 10000)
+        rm.close()
+    ctx.close()
