@@ -14,9 +14,13 @@
 //   5. host: CSR graph, A* (exact heap search), the final path's edges re-checked with the discrete motion
 //      validator; an invalid one is removed and the search repeated (LazyPRM's loop)
 // The reference inserts milestones one by one (each sees only its predecessors, interpolated states become
-// vertices and neighbours themselves), so graphs differ by construction; what is kept is every predicate
-// (validity, interpolation rule, costs, search).  OMPL is not available here: parity for this row is
-// unpinned, the tests check the stage results against brute force / the oracle / scipy.
+// vertices and neighbours themselves), so the batched graph differs by construction; what is kept is every predicate
+// (validity, interpolation rule, costs, search).  artp_roadmap_params::construction selects the reference's own
+// graphs instead: 1 = PRMMotionCost::addValidMilestone's insertion loop (IncrementalGraph below: sequential on the
+// host, one small device batch of chain states per milestone), 2 = LazyPRMStarMinUpdate's predecessor-only direct
+// edges (one device batch: knn_kernel with pred_only and a per-vertex k).  Both reproduce the edge SET of
+// oracle/prm_incremental.py's literal restatement (tests/test_roadmap.py).  OMPL is not available here: parity for
+// this row is unpinned, the tests check the stage results against brute force / the oracle / scipy.
 #pragma once
 
 #include <algorithm>
@@ -1641,9 +1645,10 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
       }
       rm->d_edge_states_stale = false;
     }
-    // constructions 1 and 2 hold direct sub-edges only (validity is the lazy path check's business)
+    // construction 2 holds direct edges of unknown validity (the lazy path check's business); the sub-edges of
+    // construction 1 are shorter than 0.5 m, so the rule passes them as they are and only applies to query edges
     rc = roadmap_eval_edges_dev(c, &rm->params, rm->d_edge_states, rm->d_edge_states + ne * 7, ne, rm->evalid.data(),
-                                rm->einterp.data(), rm->ecost.data(), rm->params.construction != 0);
+                                rm->einterp.data(), rm->ecost.data(), rm->params.construction == 2);
     if (rc != ARTP_OK) return rc;
   }
   for (size_t v = 0; v < nv; ++v) vbad += vok[v] ? 0 : 1;
@@ -1735,7 +1740,7 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
     pv[e] = pre[e].second;
   }
   const int rc = roadmap_eval_edges_host(c, &rm->params, rm->verts, pu.data(), pv.data(), np, pvalid.data(),
-                                         pinterp.data(), pcost.data());
+                                         pinterp.data(), pcost.data(), rm->params.construction == 2);
   if (rc != ARTP_OK) {
     std::memcpy(&rm->verts[0], old_sg, sizeof(old_sg));
     std::copy(old_knn.begin(), old_knn.end(), rm->knn.begin());

@@ -169,6 +169,18 @@ class Planner {
     prm_->setSeed(seed);
   }
 
+  // Build the roadmap in the reference planners' own insertion order instead of the batched front end:
+  // PRMMotionCost::addValidMilestone's graph for "prm_motion_cost" (prm_motion_cost.cpp:325-390), LazyPRMStarMinUpdate's
+  // for the LazyPRM* names (lazy_prm_star_min_update.cpp:424-446).  Same answers as the reference's graph gives, at
+  // the price of the sequential insertion loop (include/artp_c.h, artp_roadmap_params::construction).  The kept
+  // roadmap is dropped; the next plan() samples a new one.
+  void setReferenceConstruction(bool on) {
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    prm_->setConstruction(!on ? 0 : (params_->planner.name == "prm_motion_cost" ? 1 : 2));
+    prm_->clear();
+    have_roadmap_ = false;
+  }
+
   // planner.cpp:192-262
   PlannerStatus plan(const StateType& start, const StateType& goal) {
     std::lock_guard<std::mutex> lock(map_mutex_);

@@ -29,6 +29,11 @@ class BatchPRM {
   BatchPRM& operator=(const BatchPRM&) = delete;
 
   void setSeed(uint64_t seed) { seed_ = seed; }
+  // artp_roadmap_params::construction (include/artp_c.h): 0 = the batched front end (default), 1 = the graph of
+  // PRMMotionCost::addValidMilestone (chain vertices included), 2 = the graph of LazyPRMStarMinUpdate.  Takes effect at
+  // the next sampleGraph.
+  void setConstruction(int construction) { construction_ = construction; }
+  int construction() const { return construction_; }
   void clear() {
     if (rm_) artp_roadmap_destroy(rm_);
     rm_ = nullptr;
@@ -44,6 +49,7 @@ class BatchPRM {
     artp_roadmap_params p;
     artp_roadmap_params_defaults(&p);
     p.seed = seed_;
+    p.construction = construction_;
     p.n_milestones = params_->planner.prm_motion_cost.max_n_vertices;
     // planner.name selects the objective like Planner::Planner (planner.cpp:108-127): the learned motion
     // cost for "prm_motion_cost", PathLengthObjective otherwise
@@ -188,6 +194,7 @@ class BatchPRM {
   GpuContextPtr gpu_;
   artp_roadmap* rm_{nullptr};
   uint64_t seed_{42};
+  int construction_{0};
   artp_preprocessed* density_map_{nullptr};
   artp_preprocess_params density_params_{};
 };

@@ -123,6 +123,23 @@ int main(int argc, char** argv) {
     CHECK(planner->roadmap()->numVertices() > 4002);  // it grew while planning
   }
 
+  {  // the reference planner's own graph construction (LazyPRM* here: predecessor-only direct edges) behind the same surface
+    planner->setReferenceConstruction(true);
+    const PlannerStatus st = planner->plan(start, goal);
+    CHECK(st == PlannerStatus::SOLVED);
+    if (st == PlannerStatus::SOLVED) {
+      const auto path = planner->getSolutionPath(false);
+      std::vector<double> flat;
+      for (const auto& s : path) flat.insert(flat.end(), s.begin(), s.end());
+      std::vector<uint8_t> mv(path.size() - 1);
+      CHECK(artp_check_motions(planner->gpu()->get(), flat.data(), flat.data() + 7, mv.size(), mv.data()) == ARTP_OK);
+      for (const uint8_t x : mv) CHECK(x != 0);
+      std::printf("reference construction: %zu states, cost %.4f; roadmap %zu vertices %zu edges\n", path.size(),
+                  planner->getSolutionCost(), planner->roadmap()->numVertices(), planner->roadmap()->numEdges());
+    }
+    planner->setReferenceConstruction(false);
+  }
+
   // a start far off the map cannot be repaired by the region search (start.cpp:40-46 -> INVALID_START)
   Planner::StateType off;
   toState(sg, &off);

@@ -292,9 +292,23 @@ def c1_leg(local_rank):
     q, d = rm.simplify(p)
     gpu.update({"path_cost": c, "simplified_path_cost": d})
     rm.close()
+    # C1's own planner on the device: construction 2 = LazyPRMStarMinUpdate's graph (start, goal, milestones; every
+    # vertex to the k nearest of its predecessors, k at its own insertion) as one predecessor-only k-NN batch
+    t0 = time.perf_counter()
+    rm2 = Roadmap(ctx, s, g, n_milestones=2000, seed=42, construction=2)
+    t1 = time.perf_counter()
+    p2, c2, rep2 = rm2.solve()
+    t2 = time.perf_counter()
+    st2 = rm2.stats()
+    gpu_ref = {"construction": 2, "vertices": int(st2["vertices"]), "edges": int(st2["candidate_edges"]), "path_cost": c2,
+               "path_states": None if p2 is None else int(len(p2)), "lazy_removals": int(rep2),
+               "build_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3,
+               "same_edge_count_as_reference_construction": bool(int(st2["candidate_edges"]) == lit["edges"]),
+               "same_cost_as_reference_construction": bool(abs(c2 - lit["path_cost"]) < 1e-9)}
+    rm2.close()
     ctx.close()
     return {"config": "C1: flat 100x100@0.1m, start (-4,-4,yaw 0) -> goal (4,4), PathLengthObjective, 2000 milestones",
-            "cpu_lazy_prm_star": cpu, "gpu_batch_prm": gpu, "analytic_optimum_s": optimum,
+            "cpu_lazy_prm_star": cpu, "gpu_batch_prm": gpu, "gpu_lazy_prm_star_graph": gpu_ref, "analytic_optimum_s": optimum,
             "labels_match": gpu["label_hash"] == cpu["label_hash"],
             # north star "path cost within 1e-4": the batched GPU plan (simplified, as Planner::plan returns it) against
             # the cost of the reference planner's own incremental construction on the same states
@@ -953,6 +967,23 @@ def main():
                 "candidate_edges": int(st["candidate_edges"]), "valid_edges": int(st["valid_edges"]),
                 "path_states": None if path is None else int(len(path)), "path_cost_s": cost, "lazy_removals": rep,
                 "straight_line_cost_s": float(np.linalg.norm(g_state[:3] - s_state[:3]) / 0.5)}
+        # the reference planners' own insertion orders on the same map and query (include/artp_c.h, construction):
+        # 1 = PRMMotionCost::addValidMilestone with the reference's budgets (10 000 vertices -- chain vertices count --
+        # / 50 000 edges; sequential host loop, one small device batch per milestone), 2 = LazyPRMStarMinUpdate's
+        # predecessor-only graph (one device batch)
+        for name, kw in (("prm_motion_cost_order", dict(n_milestones=10_000, max_n_edges=50_000, construction=1)),
+                         ("lazy_prm_star_order_10000", dict(n_milestones=10_000, construction=2))):
+            t0 = time.perf_counter()
+            rm = Roadmap(ctx, s_state, g_state, seed=seed, **kw)
+            t1 = time.perf_counter()
+            path, cost, rep = rm.solve()
+            t2 = time.perf_counter()
+            st = rm.stats()
+            rm.close()
+            roadmap[name] = {"build_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "vertices": int(st["vertices"]),
+                             "edges": int(st["candidate_edges"]), "samples_drawn": int(st["samples_drawn"]),
+                             "path_states": None if path is None else int(len(path)), "path_cost_s": cost,
+                             "lazy_removals": rep}
     except Exception as ex:  # pragma: no cover
         roadmap = {"error": repr(ex)}
 

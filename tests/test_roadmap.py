@@ -801,3 +801,65 @@ def test_construction_1_reproduces_the_prm_motion_cost_graph():
         assert st["samples_drawn"] > 0 and (st["edge_budget_hit"] or budget_v != 10000)
         rm.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_reference_order_roadmaps_upkeep():
+    """grow / revalidate / set_query on roadmaps built in the reference planners' insertion orders.
+    construction 2: growing by n milestones gives the graph a fresh build over n more milestones gives (the insertion
+    order is the stream order either way).  construction 1: sampleGraph continued on the kept graph -- vertex ids and
+    coordinates of the old graph are a prefix of the new one, every old edge is still there, the new milestones connect
+    into the old graph; nothing is invalid after a revalidate on the unchanged map; a new query solves."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from synthetic import make_map
+    gm = make_map(160, 0.04, seed=1234)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    se3 = ctx.sample_states(42, 0, 1 << 15)
+    acc = se3[ctx.validate_states(se3) != 0]
+    near = lambda xy: acc[np.argmin(np.hypot(acc[:, 0] - xy[0], acc[:, 1] - xy[1]))]
+    s, g = near((gm.pos_x - 2.4, gm.pos_y - 2.4)), near((gm.pos_x + 2.4, gm.pos_y + 2.4))
+    # ---- construction 2 ----
+    a = Roadmap(ctx, s, g, n_milestones=600, seed=42, construction=2)
+    assert a.grow(300) == {"kept": 600, "dropped": 0}
+    b = Roadmap(ctx, s, g, n_milestones=900, seed=42, construction=2)
+    ea, eb = a.export(), b.export()
+    assert np.array_equal(ea["verts"], eb["verts"]) and np.array_equal(ea["edges"], eb["edges"])
+    assert np.allclose(ea["edge_cost"], eb["edge_cost"], rtol=1e-15)
+    rv = a.revalidate()
+    assert rv["invalid_vertices"] == 0 and rv["valid_edges_after"] == len(ea["edges"]) and rv["start_valid"] and rv["goal_valid"]
+    pa, ca, _ = a.solve()
+    pb, cb, _ = b.solve()
+    assert (pa is None) == (pb is None) and (pa is None or abs(ca - cb) < 1e-12)
+    a.close()
+    b.close()
+    # ---- construction 1 ----
+    r = Roadmap(ctx, s, g, n_milestones=2000, seed=42, construction=1)
+    e0, st0 = r.export(), r.stats()
+    assert 2000 <= st0["vertices"] < 2000 + 2 + 200        # the last milestone's chains and the query vertices overshoot
+    out = r.grow(2000)
+    e1, st1 = r.export(), r.stats()
+    assert out == {"kept": st0["vertices"], "dropped": 0}
+    assert st0["vertices"] + 2000 <= st1["vertices"] < st0["vertices"] + 2000 + 200 and st1["samples_drawn"] > st0["samples_drawn"]
+    assert np.array_equal(e1["verts"][:st0["vertices"]], e0["verts"])
+    old = {(int(u), int(v)) for u, v in e0["edges"]}
+    new = {(int(u), int(v)) for u, v in e1["edges"]}
+    assert old <= new and len(new) > len(old)
+    assert any(u < st0["vertices"] <= v for u, v in new - old)      # new vertices are wired into the old graph
+    assert (e1["edge_interp"] == 0).all() and e1["edge_valid"].all()
+    # sub-edges are at most 0.5 m long in the plane (or direct edges of dense neighbourhoods: n_interp = 0)
+    d = np.hypot(*(e1["verts"][e1["edges"][:, 0], :2] - e1["verts"][e1["edges"][:, 1], :2]).T)
+    assert d.max() < 0.5 + 1e-9
+    rv = r.revalidate()
+    assert rv["invalid_vertices"] == 0 and rv["valid_edges_after"] == len(new)
+    p, c, _ = r.solve()
+    assert p is not None and np.array_equal(p[0], s) and np.array_equal(p[-1], g)
+    assert ctx.validate_states(p).all() and ctx.check_motions(p[:-1], p[1:]).all()
+    s2, g2 = g, near(p[len(p) // 2, :2] + 0.2)     # a query inside the component the first one crossed
+    r.set_query(s2, g2)
+    p2, c2, _ = r.solve()
+    assert p2 is not None and np.array_equal(p2[0], s2) and np.array_equal(p2[-1], g2)
+    assert ctx.check_motions(p2[:-1], p2[1:]).all()
+    r.close()
+    ctx.close()
