@@ -614,7 +614,13 @@ def main():
             st_h = se3.cpu().numpy()
             pos = np.flatnonzero(valid.cpu().numpy())
             ii, jj = pair_edges(st_h[pos], args.edges)
-            E = len(ii)
+            # the blocks of the all-gather have ONE size: the smallest edge count any rank found (normally --edges)
+            e_t = torch.tensor([len(ii)], device=dev, dtype=torch.int64)
+            dist.all_reduce(e_t, op=dist.ReduceOp.MIN)
+            E = int(e_t.item())
+            if E == 0:
+                raise RuntimeError("no edge pairs on some rank")
+            ii, jj = ii[:E], jj[:E]
             s1 = torch.from_numpy(np.ascontiguousarray(st_h[pos[ii]])).to(dev)
             s2 = torch.from_numpy(np.ascontiguousarray(st_h[pos[jj]])).to(dev)
             ei = torch.from_numpy(pos[ii].astype(np.int32)).to(dev)
