@@ -236,14 +236,19 @@ __device__ __forceinline__ unsigned stride_level_offset(const TablesDev& t, int 
 // Tier 1: ONE block that contains the window.  A block of B samples anchored at the multiple of s = B / 4 below
 // the window's corner reaches at least B - s + 1 samples past it: windows up to 7 / 13 / 25 samples use the
 // 8 / 16 / 32 blocks.
-__device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
+// cover_finite (both tiers): set when the blocks looked at prove that the WINDOW holds no non-finite sample (no block
+// carries the flag bit and none has max' = +inf, which is what a NaN block or a block with a +inf sample stores): the
+// tail then needs neither the flag gathers of the exact statistics nor the per-vertex flags of the probe.
+__device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b, bool& cover_finite) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int wmax = wX > wZ ? wX : wZ;
   if (wmax > 25) return -1;
   const int l = wmax <= 7 ? 0 : (wmax <= 13 ? 1 : 2), sh = l + 1;
   const int nxs = (f.nW + (1 << sh) - 1) >> sh;
   const unsigned e = gather32(t.st, stride_level_offset(t, l) + (unsigned)((b.minX >> sh) + (b.minZ >> sh) * nxs));
-  return conservative_exits(b, stride_max(e), stride_min(e), e & 1u);
+  const float mx = stride_max(e);
+  cover_finite = !(e & 1u) && mx < INFINITY;
+  return conservative_exits(b, mx, stride_min(e), e & 1u);
 }
 
 // Tier 2: a tight cover.  Blocks of B <= min(wX, wZ) (8 at least) per axis: one at the anchor below the window's low
@@ -254,7 +259,7 @@ __device__ __forceinline__ int coarse_block_exit(const FieldDev& f, const Tables
 // needs them or not: a foot window takes 2 x 2 of the 8-sample blocks, a torso window up to 3 x 3 of the 16s); a
 // window that needs more stays undecided here.
 template <int N>
-__device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b) {
+__device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesDev& t, const BoxHF& b, bool& cover_finite) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int m = wX < wZ ? wX : wZ, wl = wX > wZ ? wX : wZ;
   // block size by the short side, but large enough that N blocks span the long side (N B - s samples at least): a
@@ -298,13 +303,14 @@ __device__ __forceinline__ int tight_cover_exit(const FieldDev& f, const TablesD
     vmax = (mx > vmax) ? mx : vmax;
     vmin = (mn < vmin) ? mn : vmin;
   }
+  cover_finite = cover_finite || (!(nf & 1u) && vmax < INFINITY);
   return conservative_exits(b, vmax, vmin, nf & 1u);
 }
 
 // Exact window statistics from the tables.  Returns false when the tables cannot answer (window
 // thinner than the smallest block, or a NaN in the window -> the running-dMAX quirk needs the scan).
 __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const TablesDev& t, const BoxHF& b,
-                                                   WindowStats& w) {
+                                                   WindowStats& w, bool window_known_finite) {
   const int wX = b.maxX - b.minX + 1, wZ = b.maxZ - b.minZ + 1;
   const int m = wX < wZ ? wX : wZ;
   if (m < 4) return false;
@@ -332,7 +338,8 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
           const int xx = b.minX + i * B, zz = b.minZ + j * B;
           const unsigned at = lo + (unsigned)((xx < lastX ? xx : lastX) + (zz < lastZ ? zz : lastZ) * f.nW);
           v[u] = gather32(t.mm, at);
-          if (t.has_nonfinite) fb[u] = gather32(t.fl, at);  // uniform: a fully finite layer skips the lookup
+          // a fully finite layer (uniform) and a window the stride tables proved finite skip the flag lookup
+          if (t.has_nonfinite && !window_known_finite) fb[u] = gather32(t.fl, at);
         }
       }
 #pragma unroll
@@ -494,8 +501,9 @@ __device__ __forceinline__ bool probe_vertices_inside(const FieldDev& f, const T
 #define ARTP_CODE_OPEN 4
 __device__ __forceinline__ int classify_head(const FieldDev& f, const TablesDev& tab, const MapGeom& g,
                                              const RobotDev& rb, const float t[3], const float R[9],
-                                             const float bR[9], int k, BoxHF& b) {
+                                             const float bR[9], int k, BoxHF& b, bool& cover_finite) {
   const bool body = (k == 0);
+  cover_finite = false;
   float pose[16];
   state_box_pose(rb, t, R, k, pose);
   if (!map_is_inside(g, (double)pose[0], (double)pose[1])) {
@@ -507,8 +515,8 @@ __device__ __forceinline__ int classify_head(const FieldDev& f, const TablesDev&
                     body ? rb.torso[2] : rb.foot[2], b);
   if (!b.on_field) return body ? 0 : 1;  // AABB off the field: no contact (heightfield.cpp:1868-1877)
   if (tab.valid) {
-    int coarse = coarse_block_exit(f, tab, b);
-    if (coarse < 0) coarse = body ? tight_cover_exit<3>(f, tab, b) : tight_cover_exit<2>(f, tab, b);
+    int coarse = coarse_block_exit(f, tab, b, cover_finite);
+    if (coarse < 0) coarse = body ? tight_cover_exit<3>(f, tab, b, cover_finite) : tight_cover_exit<2>(f, tab, b, cover_finite);
     if (coarse >= 0) return (body ? coarse : !coarse) ? 1 : 0;
   }
   return ARTP_CODE_OPEN;
@@ -518,10 +526,10 @@ __device__ __forceinline__ int classify_head(const FieldDev& f, const TablesDev&
 // the vertex probe.  0 = decided ok, 1 = decided failing, 2 = undecided (exits known not to fire), 3 = undecided
 // (tables could not answer).
 __device__ __forceinline__ int classify_tail(const FieldDev& f, const TablesDev& tab, const BoxHF& b, bool body,
-                                             bool& all_finite, long long* t_stats = nullptr) {
+                                             bool window_known_finite, bool& all_finite, long long* t_stats = nullptr) {
   WindowStats w;
   int hit = 0, ec;
-  const bool have_stats = tab.valid && table_window_stats(f, tab, b, w);
+  const bool have_stats = tab.valid && table_window_stats(f, tab, b, w, window_known_finite);
   all_finite = have_stats && w.allFinite;
 #ifdef ARTP_STAGE_TIMING
   if (t_stats) *t_stats = (w.maxY > 1e30f) ? 0 : clock64();  // depends on the statistics: taken after they arrive
@@ -537,7 +545,8 @@ __device__ __forceinline__ int classify_tail(const FieldDev& f, const TablesDev&
 
 // Queue record of a box into the LDS slot dst[0..5].  dst[5].z carries the classify stage's own bookkeeping (the
 // lane the box came from); consumers ignore it.
-__device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned state, unsigned origin, float4* dst) {
+__device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned state, unsigned origin, float4* dst,
+                                             bool cover_finite = false) {
   dst[0] = make_float4(b.pos[0], b.pos[1], b.pos[2], b.R[0]);
   dst[1] = make_float4(b.R[1], b.R[2], b.R[3], b.R[4]);
   dst[2] = make_float4(b.R[5], b.R[6], b.R[7], b.R[8]);
@@ -545,7 +554,8 @@ __device__ __forceinline__ void stage_record(const BoxHF& b, bool body, unsigned
   const unsigned wx = ((unsigned)(unsigned short)b.minX) | ((unsigned)(unsigned short)b.maxX << 16);
   const unsigned wz = ((unsigned)(unsigned short)b.minZ) | ((unsigned)(unsigned short)b.maxZ << 16);
   dst[4] = make_float4(b.aabb[4], b.aabb[5], __uint_as_float(wx), __uint_as_float(wz));
-  dst[5] = make_float4(__uint_as_float(state), __uint_as_float(body ? 0u : 1u), __uint_as_float(origin), 0.0f);
+  dst[5] = make_float4(__uint_as_float(state), __uint_as_float(body ? 0u : 1u), __uint_as_float(origin),
+                       __uint_as_float(cover_finite ? 1u : 0u));
 }
 
 __device__ __forceinline__ unsigned record_kind(bool body, bool exits_negative, bool all_finite) {
@@ -631,7 +641,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   ARTP_C_MARK(0);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int rank = 0;
-  bool open;
+  bool open, cover_finite;
   BoxHF b;
   {
     const float4* rp = &prec[(sub * 64 + lane) * 5];
@@ -642,9 +652,9 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
     rot_from_quat(r0.w, r1.x, r1.y, r1.z, R);
     int code;
     if (body)
-      code = classify_head(fb, tb, g, rb, t, R, bR, 0, b);
+      code = classify_head(fb, tb, g, rb, t, R, bR, 0, b, cover_finite);
     else
-      code = classify_head(ff, tf, g, rb, t, R, bR, k, b);
+      code = classify_head(ff, tf, g, rb, t, R, bR, k, b, cover_finite);
     if (!live) code = 0;
     codes[sub][k][lane] = (uint8_t)code;
     ARTP_C_MARK(1);
@@ -668,7 +678,7 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
   if (open) {
     const int cap = body ? CAP_T : CAP_F;
     if (rank < cap) {
-      stage_record(b, body, (unsigned)i, threadIdx.x, open_recs + 6 * ((body ? 0 : CAP_T) + rank));
+      stage_record(b, body, (unsigned)i, threadIdx.x, open_recs + 6 * ((body ? 0 : CAP_T) + rank), cover_finite);
     } else {
       // more open boxes than the list holds (it takes a map the stride tables cannot decide much on): the box goes
       // to the queue as it is, marked "tables could not answer", and the scan stages evaluate its exits.  One
@@ -725,16 +735,16 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 #ifdef ARTP_STAGE_TIMING
     long long t_stats = 0;
     if (list_t)
-      code2 = classify_tail(fb, tb, bb, true, all_finite, &t_stats);
+      code2 = classify_tail(fb, tb, bb, true, rec.pad[1] != 0u, all_finite, &t_stats);
     else
-      code2 = classify_tail(ff, tf, bb, false, all_finite, &t_stats);
+      code2 = classify_tail(ff, tf, bb, false, rec.pad[1] != 0u, all_finite, &t_stats);
     t_stats = __shfl(t_stats, 0);
     if (t_stats) { c_acc[4] += (unsigned long long)(t_stats - c_prev); c_prev = t_stats; }
 #else
     if (list_t)
-      code2 = classify_tail(fb, tb, bb, true, all_finite);
+      code2 = classify_tail(fb, tb, bb, true, rec.pad[1] != 0u, all_finite);
     else
-      code2 = classify_tail(ff, tf, bb, false, all_finite);
+      code2 = classify_tail(ff, tf, bb, false, rec.pad[1] != 0u, all_finite);
 #endif
     codes[(origin >> 6) % SUB][(origin >> 6) / SUB][origin & 63] = (uint8_t)code2;
   }
