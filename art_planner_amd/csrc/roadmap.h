@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <queue>
+#include <tuple>
 #include <vector>
 
 namespace artp {
@@ -201,10 +202,12 @@ knn_edge_keys_kernel(const uint32_t* __restrict__ knn, int nv, int k, unsigned l
 
 __global__ void __launch_bounds__(256)
 gather_edge_states_kernel(const double* __restrict__ verts, const unsigned long long* __restrict__ keys, size_t ne,
-                          double* __restrict__ s1, double* __restrict__ s2) {
+                          double* __restrict__ s1, double* __restrict__ s2, int flip) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
-  const uint32_t u = (uint32_t)(keys[e] >> 32), v = (uint32_t)(keys[e] & 0xffffffffu);
+  // flip: the edge's cost direction is larger id -> smaller id (construction 2: new vertex -> predecessor)
+  const uint32_t a = (uint32_t)(keys[e] >> 32), b = (uint32_t)(keys[e] & 0xffffffffu);
+  const uint32_t u = flip ? b : a, v = flip ? a : b;
 #pragma unroll
   for (int c = 0; c < 7; ++c) {
     s1[e * 7 + c] = verts[(size_t)u * 7 + c];
@@ -433,6 +436,11 @@ struct artp_roadmap {
   std::vector<uint32_t> einterp;   // interior states of the chain
   std::vector<double> ecost;
   std::vector<uint8_t> eremoved;   // removed by the lazy path check
+  // The reference computes an edge's weight ONCE, in the direction it was added to the undirected graph
+  // (opt_->motionCost(m, n) new -> old in lazy_prm_star_min_update.cpp:436; source -> target of boost::add_edge(prev, new) /
+  // (m, n) in PRMMotionCostMaintainer::updateEdges, prm_motion_cost.cpp:33-44) -- it matters for the directional and the
+  // learned objective.  eflip[e] = 1: that direction is ev -> eu.  Empty = all 0 (construction 0: eu -> ev).
+  std::vector<uint8_t> eflip;
   // CSR over the valid, not removed edges
   std::vector<uint32_t> row, adj, adj_edge;
   bool csr_dirty = true;
@@ -712,12 +720,13 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
 // same for edges (eu[e], ev[e]) of host vertices: gathers the endpoint states on the host first
 int roadmap_eval_edges_host(artp_ctx* c, const artp_roadmap_params* prm, const std::vector<double>& verts,
                             const uint32_t* eu, const uint32_t* ev, size_t ne, uint8_t* evalid, uint32_t* einterp,
-                            double* ecost, bool direct = false) {
+                            double* ecost, bool direct = false, const uint8_t* flip = nullptr) {
   if (ne == 0) return ARTP_OK;
   std::vector<double> s(2 * ne * 7);
   for (size_t e = 0; e < ne; ++e) {
-    std::memcpy(&s[e * 7], &verts[(size_t)eu[e] * 7], 7 * sizeof(double));
-    std::memcpy(&s[(ne + e) * 7], &verts[(size_t)ev[e] * 7], 7 * sizeof(double));
+    const bool fl = flip && flip[e];
+    std::memcpy(&s[e * 7], &verts[(size_t)(fl ? ev[e] : eu[e]) * 7], 7 * sizeof(double));
+    std::memcpy(&s[(ne + e) * 7], &verts[(size_t)(fl ? eu[e] : ev[e]) * 7], 7 * sizeof(double));
   }
   double* d_s = nullptr;
   auto cleanup = [&]() {
@@ -937,7 +946,8 @@ static int roadmap_connect(artp_ctx* c, const artp_roadmap_params* prm, const do
     if (hipMalloc(reinterpret_cast<void**>(&d_s1), 2 * ne * 7 * sizeof(double)) != hipSuccess) return fail(ARTP_ERR_HIP);
     d_s2 = d_s1 + ne * 7;
     hipLaunchKernelGGL(artp::gather_edge_states_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
-                       (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2);
+                       (const double*)d_verts, (const unsigned long long*)d_keys_unique, ne, d_s1, d_s2, pred_only ? 1 : 0);
+    if (pred_only) rm->eflip.assign(ne, 1);
     // construction 2: the lazy planner puts DIRECT edges of unknown validity into its graph (no interpolation rule)
     const int rc = roadmap_eval_edges_dev(c, prm, d_s1, d_s2, ne, rm->evalid.data(), rm->einterp.data(),
                                           rm->ecost.data(), pred_only);
@@ -1303,10 +1313,14 @@ struct IncrementalGraph {
 // the reference's graph in one batch as well, prm_motion_cost.cpp:27-73); every sub-edge is direct
 static int incremental_finish(IncrementalGraph& g, artp_roadmap* rm, const std::vector<uint8_t>* vertex_ok) {
   const size_t ne = g.eu.size(), nv = g.nv();
-  std::vector<std::pair<uint32_t, uint32_t>> e(ne);
-  for (size_t i = 0; i < ne; ++i) e[i] = {std::min(g.eu[i], g.ev[i]), std::max(g.eu[i], g.ev[i])};
+  // (min, max, creation direction is max -> min): an edge is created once, so (min, max) is unique
+  std::vector<std::tuple<uint32_t, uint32_t, uint8_t>> e(ne);
+  for (size_t i = 0; i < ne; ++i)
+    e[i] = std::make_tuple(std::min(g.eu[i], g.ev[i]), std::max(g.eu[i], g.ev[i]), (uint8_t)(g.eu[i] > g.ev[i] ? 1 : 0));
   std::sort(e.begin(), e.end());
-  e.erase(std::unique(e.begin(), e.end()), e.end());
+  e.erase(std::unique(e.begin(), e.end(), [](const auto& a, const auto& b) {
+            return std::get<0>(a) == std::get<0>(b) && std::get<1>(a) == std::get<1>(b);
+          }), e.end());
   rm->ctx = g.c;
   rm->params = g.prm;
   roadmap_fix_params(rm);
@@ -1329,16 +1343,18 @@ static int incremental_finish(IncrementalGraph& g, artp_roadmap* rm, const std::
   const size_t n = e.size();
   rm->eu.resize(n);
   rm->ev.resize(n);
+  rm->eflip.resize(n);
   for (size_t i = 0; i < n; ++i) {
-    rm->eu[i] = e[i].first;
-    rm->ev[i] = e[i].second;
+    rm->eu[i] = std::get<0>(e[i]);
+    rm->ev[i] = std::get<1>(e[i]);
+    rm->eflip[i] = std::get<2>(e[i]);
   }
   rm->evalid.assign(n, 0);
   rm->einterp.assign(n, 0);
   rm->ecost.assign(n, 0.0);
   rm->eremoved.assign(n, 0);
   const int rc = roadmap_eval_edges_host(g.c, &rm->params, rm->verts, rm->eu.data(), rm->ev.data(), n, rm->evalid.data(),
-                                         rm->einterp.data(), rm->ecost.data(), true);
+                                         rm->einterp.data(), rm->ecost.data(), true, rm->eflip.data());
   if (rc != ARTP_OK) return rc;
   if (vertex_ok)
     for (size_t i = 0; i < n; ++i)
@@ -1508,6 +1524,8 @@ static int roadmap_grow_incremental(artp_roadmap* rm, uint64_t n_more, uint64_t 
   g.inserted.assign(nv, 1);
   g.eu = rm->eu;
   g.ev = rm->ev;
+  for (size_t e = 0; e < g.eu.size() && e < rm->eflip.size(); ++e)
+    if (rm->eflip[e]) std::swap(g.eu[e], g.ev[e]);  // creation direction (incremental_finish sorts it out again)
   g.n_graph = nv;
   g.k_max = rm->k;
   g.setup_grid(nv + (size_t)n_more);
@@ -1631,6 +1649,15 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
             hipMemcpyAsync(d_v, rm->verts.data(), nv * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
             hipMemcpyAsync(d_uv, rm->eu.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
             hipMemcpyAsync(d_uv + ne, rm->ev.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+      std::vector<uint32_t> src, dst;  // end points in cost direction (eflip)
+      if (okk && !rm->eflip.empty()) {
+        src = rm->eu;
+        dst = rm->ev;
+        for (size_t e = 0; e < ne; ++e)
+          if (rm->eflip[e]) std::swap(src[e], dst[e]);
+        okk = hipMemcpyAsync(d_uv, src.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+              hipMemcpyAsync(d_uv + ne, dst.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+      }
       if (okk) {
         hipLaunchKernelGGL(artp::gather_edge_states_uv_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream,
                            (const double*)d_v, (const uint32_t*)d_uv, (const uint32_t*)(d_uv + ne), ne, rm->d_edge_states,
@@ -1758,6 +1785,7 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
   splice(rm->ecost, pcost);
   std::vector<uint8_t> zeros(np, 0);
   splice(rm->eremoved, zeros);
+  if (!rm->eflip.empty()) splice(rm->eflip, zeros);  // query vertex (the smaller id) -> neighbour: the order it is added in
   rm->csr_dirty = true;
   rm->d_edge_states_stale = true;
   rm->d_graph_ne = 0;  // the edge list changed: the device copy is rebuilt at the next search

@@ -282,7 +282,10 @@ typedef struct artp_roadmap_params {
    *   2 = LazyPRMStarMinUpdate::addValidMilestone order (lazy_prm_star_min_update.cpp:424-446), BASELINE config 1's
    *       planner: start, goal, then the milestones; vertex i gets DIRECT edges of unknown validity to the
    *       k = ceil(e (1 + 1/6) ln (i + 1)) nearest of its predecessors, validity is established lazily by
-   *       artp_roadmap_solve.  Predecessor-only search with a per-vertex k is one batch on the device. */
+   *       artp_roadmap_solve.  Predecessor-only search with a per-vertex k is one batch on the device.
+   * In modes 1 and 2 an edge's cost is evaluated ONCE in the direction the reference adds it to its undirected graph
+   * (new vertex -> neighbour, along the chain from the milestone: opt_->motionCost(m, n), updateEdges' source ->
+   * target) -- visible with the directional and the learned objective; mode 0 evaluates smaller id -> larger id. */
   int32_t construction;
 } artp_roadmap_params;
 void artp_roadmap_params_defaults(artp_roadmap_params* p);

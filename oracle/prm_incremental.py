@@ -47,9 +47,14 @@ class IncrementalPRM:
     """The graph of PRMMotionCost: vertices = states, undirected edges with a weight, nn_ = the vertices that
     already went through nn_->add."""
 
-    def __init__(self, om, rob, interpolate, max_lon_vel=0.5):
+    def __init__(self, om, rob, interpolate, max_lon_vel=0.5, cost_fn=None):
+        """cost_fn(state_a, state_b): the objective's motionCost in the direction the edge is ADDED (the reference
+        computes a weight once per edge: opt_->motionCost(m, n), lazy_prm_star_min_update.cpp:436; source -> target in
+        updateEdges, prm_motion_cost.cpp:33-44).  None = PathLengthObjective without use_directional_cost (symmetric,
+        Euclidean / max_lon_vel, also the A* heuristic); with a cost_fn the search runs without a heuristic."""
         self.om, self.rob, self.interpolate = om, rob, interpolate
         self.max_lon_vel = max_lon_vel
+        self.cost_fn = cost_fn
         self.verts = np.empty((1024, 7), np.float64)
         self.nv = 0
         self.in_nn = np.zeros(1024, bool)
@@ -69,7 +74,10 @@ class IncrementalPRM:
         return self.nv - 1
 
     def _add_edge(self, a, b):
-        w = float(np.linalg.norm(self.verts[a, :3] - self.verts[b, :3]) / self.max_lon_vel)
+        if self.cost_fn is not None:
+            w = float(self.cost_fn(self.verts[a], self.verts[b]))
+        else:
+            w = float(np.linalg.norm(self.verts[a, :3] - self.verts[b, :3]) / self.max_lon_vel)
         self.edges[(min(a, b), max(a, b))] = w
         self.adj[a].append(b)
         self.adj[b].append(a)
@@ -106,7 +114,10 @@ class IncrementalPRM:
 
     # ---- constructSolution (:536-673) ------------------------------------------------------------------------
     def _astar(self, start, goal):
-        h = lambda v: float(np.linalg.norm(self.verts[v, :3] - self.verts[goal, :3]) / self.max_lon_vel)
+        if self.cost_fn is None:
+            h = lambda v: float(np.linalg.norm(self.verts[v, :3] - self.verts[goal, :3]) / self.max_lon_vel)
+        else:
+            h = lambda v: 0.0
         g = {start: 0.0}
         prev = {}
         closed = set()
@@ -157,10 +168,10 @@ class IncrementalPRM:
 
 
 def build_and_solve(om, rob, interpolate, accepted, start, goal, max_n_vertices=10000, max_n_edges=50000,
-                    max_lon_vel=0.5):
+                    max_lon_vel=0.5, cost_fn=None):
     """sampleGraph over the accepted-state stream, then baseSolve: start and goal join as milestones, A* + lazy edge
     check.  Returns a dict of counts, the path and its cost."""
-    g = IncrementalPRM(om, rob, interpolate, max_lon_vel)
+    g = IncrementalPRM(om, rob, interpolate, max_lon_vel, cost_fn)
     used = 0
     for s in accepted:
         if not (g.nv < max_n_vertices and len(g.edges) < max_n_edges):   # :171-172
@@ -175,7 +186,7 @@ def build_and_solve(om, rob, interpolate, accepted, start, goal, max_n_vertices=
             "lazy_edges_checked": checked, "path_cost": c, "path": None if p is None else g.verts[p].copy(), "graph": g}
 
 
-def lazy_prm_star_min_update(om, rob, accepted, start, goal, n_milestones, max_lon_vel=0.5):
+def lazy_prm_star_min_update(om, rob, accepted, start, goal, n_milestones, max_lon_vel=0.5, cost_fn=None):
     """BASELINE config 1's planner, literally: LazyPRMStarMinUpdate (lazy_prm_star_min_update.cpp).
       baseSolve (:496-615): start and goal become milestones FIRST (:507-535), then one accepted sample at a time
       (`do sampleUniform while !isValid`, :552-555) through addValidMilestone (:424-446): the k = ceil(e (1 + 1/6) ln n)
@@ -185,7 +196,7 @@ def lazy_prm_star_min_update(om, rob, accepted, start, goal, n_milestones, max_l
     The termination condition is a planning time in the reference; here it is a milestone budget, and the solution is
     constructed once on the final graph (the graph only grows, so no intermediate solution can be cheaper than the
     final search's, lazy removals aside).  Returns a dict like build_and_solve."""
-    g = IncrementalPRM(om, rob, None, max_lon_vel)
+    g = IncrementalPRM(om, rob, None, max_lon_vel, cost_fn)
 
     def add(s):
         m = g._add_vertex(np.asarray(s, np.float64), True)

@@ -863,3 +863,118 @@ def test_reference_order_roadmaps_upkeep():
     assert ctx.check_motions(p2[:-1], p2[1:]).all()
     r.close()
     ctx.close()
+
+
+def _directional_cost(a, b, v_lon=0.5, v_lat=0.1, v_ang=0.5):
+    """PathLengthObjective::motionCost with use_directional_cost (path_length_objective.cpp:26-56), a -> b."""
+    def yaw(q):
+        return float(np.float32(np.arctan2(2 * (q[3] * q[2] + q[0] * q[1]), 1 - 2 * (q[1] ** 2 + q[2] ** 2))))
+    dx, dy = b[0] - a[0], b[1] - a[1]
+    y1, y2 = yaw(a[3:]), yaw(b[3:])
+    dd = abs(y1 - y2)
+    dyaw = 2 * np.pi - dd if dd > np.pi else dd
+    lon = np.cos(y1) * dx + np.sin(y1) * dy
+    lat = -np.sin(y1) * dx + np.cos(y1) * dy
+    return max(abs(lon) / v_lon, abs(lat) / v_lat, abs(dyaw) / v_ang)
+
+
+@pytest.mark.gpu
+def test_reference_order_constructions_weigh_edges_in_the_direction_they_were_added():
+    """The reference computes an edge's weight once, in the direction the edge was ADDED to its undirected graph
+    (opt_->motionCost(m, n): new vertex -> neighbour, lazy_prm_star_min_update.cpp:436; source -> target in updateEdges,
+    prm_motion_cost.cpp:33-44: m -> first chain vertex -> ... -> neighbour).  With the directional objective that is
+    visible: weights and path cost of construction 1 and 2 equal the oracle's, whose _add_edge(a, b) is called in the
+    reference's order."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    import prm_incremental as PI
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from synthetic import make_map
+    rob = O.robot("yaml")
+    gm = make_map(160, 0.04, seed=1234)
+    om = O.OracleMap(gm)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    se3 = ctx.sample_states(42, 0, 1 << 15)
+    lab = om.states_valid(rob, se3)
+    acc = se3[lab != 0]
+    near = lambda xy: acc[np.argmin(np.hypot(acc[:, 0] - xy[0], acc[:, 1] - xy[1]))]
+    s, g = near((gm.pos_x - 2.4, gm.pos_y - 2.4)), near((gm.pos_x + 2.4, gm.pos_y + 2.4))
+    # construction 2: every edge is (new -> predecessor) = (larger id -> smaller id)
+    ref = PI.lazy_prm_star_min_update(om, rob, acc, s, g, 800, cost_fn=_directional_cost)
+    rm = Roadmap(ctx, s, g, n_milestones=800, seed=42, construction=2, objective=1)
+    ex = rm.export()
+    w_ref = np.array([ref["graph"].edges.get((int(u), int(v)), np.nan) for u, v in ex["edges"]])
+    p, c, removed = rm.solve()
+    left = rm.export()["edge_removed"] == 0
+    assert np.isfinite(w_ref[left]).all() and np.allclose(ex["edge_cost"][left], w_ref[left], rtol=1e-9, atol=1e-12)
+    V = ex["verts"]
+    asym = [abs(_directional_cost(V[v], V[u]) - _directional_cost(V[u], V[v])) for u, v in ex["edges"][:2000]]
+    assert max(asym) > 0.1                                          # the direction matters for this objective
+    assert removed == ref["lazy_removals"] and (p is None) == (ref["path"] is None)
+    if p is not None:
+        assert abs(c - ref["path_cost"]) < 1e-9 * c and np.allclose(p, ref["path"], atol=1e-12)
+    rm.close()
+    # construction 1
+    ref = PI.build_and_solve(om, rob, O.interpolate, acc, s, g, max_n_vertices=2500, max_n_edges=50000,
+                             cost_fn=_directional_cost)
+    G = ref["graph"]
+    rm = Roadmap(ctx, s, g, n_milestones=2500, max_n_edges=50000, seed=42, construction=1, objective=1)
+    ex = rm.export()
+    ms = np.flatnonzero(np.array(G.is_milestone))
+    vs, vg = int(ms[-2]), int(ms[-1])
+    to_mine = np.empty(G.nv, np.int64)
+    nxt = 2
+    for o in range(G.nv):
+        if o == vs:
+            to_mine[o] = 0
+        elif o == vg:
+            to_mine[o] = 1
+        else:
+            to_mine[o] = nxt
+            nxt += 1
+    p, c, removed = rm.solve()
+    ex2 = rm.export()
+    ref_w = {tuple(sorted((int(to_mine[a]), int(to_mine[b])))): w for (a, b), w in G.edges.items()}
+    left = ex2["edge_removed"] == 0
+    assert {(int(u), int(v)) for u, v in ex2["edges"][left]} == set(ref_w.keys())
+    w_ref = np.array([ref_w[(int(u), int(v))] for u, v in ex2["edges"][left]])
+    assert np.allclose(ex2["edge_cost"][left], w_ref, rtol=1e-9, atol=1e-12)
+    assert removed == ref["lazy_removals"] and (p is None) == (ref["path"] is None)
+    if p is not None:
+        assert abs(c - ref["path_cost"]) < 1e-9 * c
+    rm.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_construction_1_reweights_like_sample_graph():
+    """sampleGraph's in-build re-weighting (prm_motion_cost.cpp:190-193) in the reference's insertion order: the check
+    `num_vertices / R > n_proc` counts GRAPH vertices (chain vertices included) after every milestone, and the sample
+    stream continues right behind the sample that gave the milestone.  Until the first re-weighting the graph is the
+    fixed-distribution graph, vertex for vertex; afterwards the milestones differ."""
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, pm, s, g = _preprocessed_ctx()
+    R, budget = 300, 1500
+    fixed = Roadmap(ctx, s, g, n_milestones=budget, seed=3, construction=1)
+    ef, sf_ = fixed.export(), fixed.stats()
+    fixed.close()
+    rw = Roadmap(ctx, s, g, n_milestones=budget, seed=3, construction=1, recompute_density_after_n_samples=R,
+                 density_map=pm)
+    er, sr = rw.export(), rw.stats()
+    # one re-weighting per milestone at most, every time the vertex count passed another multiple of R
+    assert 1 <= sr["reweightings"] <= (sr["vertices"] - 2) // R and sf_["reweightings"] == 0
+    # vertices 2 .. are in insertion order: identical until the milestone that triggered the first re-weighting
+    n_same = 0
+    while n_same < min(len(ef["verts"]), len(er["verts"])) - 2 and np.array_equal(ef["verts"][2 + n_same], er["verts"][2 + n_same]):
+        n_same += 1
+    assert R <= n_same < R + 200 and n_same < sr["vertices"] - 2, n_same
+    assert sr["samples_drawn"] != sf_["samples_drawn"]
+    p, c, _ = rw.solve()
+    assert p is None or (ctx.validate_states(p).all() and ctx.check_motions(p[:-1], p[1:]).all())
+    rw.close()
+    pm.reweight_dev(None)
+    pm.close()
+    ctx.close()
