@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "pipeline.h"
@@ -55,6 +56,7 @@ struct artp_ctx {
   unsigned char* flag_buf[2] = {nullptr, nullptr};  // per-level non-finite / NaN block flags
   unsigned* stride_buf[2] = {nullptr, nullptr};      // stride tables (TablesDev::st)
   unsigned char* partner_buf[2] = {nullptr, nullptr};
+  unsigned* partner_cnt[2] = {nullptr, nullptr};  // partner counts per cell (pipeline.h partner_count_kernel)
   int partner_R_built[2] = {-1, -1};
   int layer_has_nonfinite[2] = {1, 1};
   float4* tri_raw_buf[2] = {nullptr, nullptr};
@@ -318,39 +320,48 @@ unsigned grid_sub(const artp_ctx* c, int per_cu) {
   return (g + ARTP_NSUB - 1) / ARTP_NSUB * ARTP_NSUB;
 }
 
-// Range tables of one layer (pipeline.h).  Levels 0..5 (block 1..32); the kernels use levels 2..5.
-// Partner table of the foot layer (FieldDev::partner_flags).  Radius = the largest index window a foot box
-// can have: box diagonal / sample spacing, + the window's rounding and dCollideHeightfield's +1 border.
-// dirty = {x0, z0, x1, z1} (inclusive sample range that changed) or nullptr for the whole layer.
-int build_partner_table(artp_ctx* c, int slot, const int* dirty) {
-  FieldDev& f = c->field[slot];
-  f.partner_flags = nullptr;
-  f.partner_R = 0;
+// Partner table of a layer (FieldDev::partner_flags).  Radius = the largest index window a box of that layer can have:
+// box diagonal / sample spacing, + the window's rounding and dCollideHeightfield's +1 border; -1 = no table (windows
+// larger than the stages hold anyway).
+int partner_radius(const artp_ctx* c, int slot) {
+  const FieldDev& f = c->field[slot];
   const float* side = slot == 1 ? c->robot.foot : c->robot.torso;
   const double diag = std::sqrt((double)side[0] * side[0] + (double)side[1] * side[1] + (double)side[2] * side[2]);
   const int R = (int)std::ceil(diag / std::fmin((double)f.sample_w, (double)f.sample_d)) + 3;
-  if (R > 63) return ARTP_OK;  // larger windows than the stages hold anyway
-  int cx0 = 0, cz0 = 0, cx1 = f.nW - 1, cz1 = f.nD - 1;
-  if (dirty && c->partner_R_built[slot] == R) {
-    cx0 = std::max(dirty[0] - R - 1, 0);
-    cz0 = std::max(dirty[1] - R - 1, 0);
-    cx1 = std::min(dirty[2] + R + 1, f.nW - 1);
-    cz1 = std::min(dirty[3] + R + 1, f.nD - 1);
+  return R > 63 ? -1 : R;
+}
+
+// launch geometry over a rectangle set: the largest rectangle (widened by `margin`) decides grid.x, the tallest grid.y
+static void partner_rect_extent(const FieldDev& f, const PartnerRects& pr, int margin, int* max_cells, int* max_rows) {
+  *max_cells = *max_rows = 1;
+  for (int k = 0; k < pr.n; ++k) {
+    const int nx = std::min(pr.x1[k] + margin, f.nW - 1) - std::max(pr.x0[k] - margin, 0) + 1;
+    const int nz = std::min(pr.z1[k] + margin, f.nD - 1) - std::max(pr.z0[k] - margin, 0) + 1;
+    *max_cells = std::max(*max_cells, nx * nz);
+    *max_rows = std::max(*max_rows, pr.z1[k] - pr.z0[k] + 1);
   }
-  const int ncx = cx1 - cx0 + 1, ncz = cz1 - cz0 + 1, ncell = ncx * ncz;
-  hipLaunchKernelGGL(partner_flags_clear_kernel, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, f.nW, cx0, cz0,
-                     ncx, ncz, c->partner_buf[slot]);
-  {
-    // raw cross products of every cell the pass below reads: the rectangle widened by R
-    const int rx0 = std::max(cx0 - R, 0), rz0 = std::max(cz0 - R, 0);
-    const int rx1 = std::min(cx1 + R, f.nW - 1), rz1 = std::min(cz1 + R, f.nD - 1);
-    const int rnx = rx1 - rx0 + 1, rnz = rz1 - rz0 + 1;
-    hipLaunchKernelGGL(tri_raw_kernel, dim3((rnx * rnz + 255) / 256), dim3(256), 0, c->stream, f, rx0, rz0, rnx, rnz,
-                       c->tri_raw_buf[slot]);
-  }
-  hipLaunchKernelGGL(partner_flags_kernel, dim3((ncell + 255) / 256, 2 * R + 1), dim3(256), 0, c->stream, f, R, cx0,
-                     cz0, ncx, ncz, (const float4*)c->tri_raw_buf[slot],
-                     reinterpret_cast<unsigned*>(c->partner_buf[slot]));
+}
+
+// Whole layer: raw cross products, counts over every full neighbourhood, flags.
+int build_partner_table_full(artp_ctx* c, int slot) {
+  FieldDev& f = c->field[slot];
+  f.partner_flags = nullptr;
+  f.partner_R = 0;
+  c->partner_R_built[slot] = -1;
+  const int R = partner_radius(c, slot);
+  if (R < 0) return ARTP_OK;
+  PartnerRects all{};
+  all.n = 1;
+  all.x0[0] = all.z0[0] = 0;
+  all.x1[0] = f.nW - 1;   // the last column / row hold no cell: tri_raw writes +inf there, the counts stay 0
+  all.z1[0] = f.nD - 1;
+  const int ncell = f.nW * f.nD;
+  hipLaunchKernelGGL(tri_raw_rects_kernel, dim3((ncell + 255) / 256, 1), dim3(256), 0, c->stream, f, all,
+                     c->tri_raw_buf[slot], c->partner_cnt[slot]);
+  hipLaunchKernelGGL(partner_count_kernel<false>, dim3((ncell + 255) / 256, 2 * R + 1, 1), dim3(256), 0, c->stream, f, R,
+                     (const float4*)c->tri_raw_buf[slot], c->partner_cnt[slot], all, 1);
+  hipLaunchKernelGGL(partner_flags_from_counts_kernel, dim3((ncell + 255) / 256, 1), dim3(256), 0, c->stream, f.nW, f.nD, all,
+                     0, (const unsigned*)c->partner_cnt[slot], c->partner_buf[slot]);
   HIP_TRY(c, hipGetLastError());
   c->partner_R_built[slot] = R;
   f.partner_flags = c->partner_buf[slot];
@@ -358,7 +369,76 @@ int build_partner_table(artp_ctx* c, int slot, const int* dirty) {
   return ARTP_OK;
 }
 
-int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr, int n_dirty = 1) {
+// Rectangle updates, step 1 of 2 -- BEFORE the samples are overwritten.  dirty: n x {x0, z0, x1, z1} inclusive sample
+// ranges.  The cells whose triangles change are the rectangles widened by one cell towards the origin; rectangles that
+// touch are merged into their bounding box (a cell treated as changed although it is not costs work, not
+// correctness: its old and new contributions cancel).  Returns the rectangle set in *pr (n = 0: the caller rebuilds
+// the whole table in step 2) after taking the OLD triangles' contributions off the counts of the cells around them.
+int partner_update_begin(artp_ctx* c, int slot, const int* dirty, int n_dirty, PartnerRects* pr) {
+  const FieldDev& f = c->field[slot];
+  *pr = PartnerRects{};
+  const int R = partner_radius(c, slot);
+  if (R < 0 || c->partner_R_built[slot] != R || n_dirty <= 0) return ARTP_OK;
+  std::vector<std::array<int, 4>> rects;
+  for (int k = 0; k < n_dirty; ++k)
+    rects.push_back({std::max(dirty[4 * k] - 1, 0), std::max(dirty[4 * k + 1] - 1, 0), std::min(dirty[4 * k + 2], f.nW - 2),
+                     std::min(dirty[4 * k + 3], f.nD - 2)});
+  for (bool merged = true; merged;) {
+    merged = false;
+    for (size_t a = 0; a < rects.size() && !merged; ++a)
+      for (size_t b = a + 1; b < rects.size() && !merged; ++b)
+        if (rects[a][0] <= rects[b][2] && rects[b][0] <= rects[a][2] && rects[a][1] <= rects[b][3] && rects[b][1] <= rects[a][3]) {
+          rects[a] = {std::min(rects[a][0], rects[b][0]), std::min(rects[a][1], rects[b][1]),
+                      std::max(rects[a][2], rects[b][2]), std::max(rects[a][3], rects[b][3])};
+          rects.erase(rects.begin() + b);
+          merged = true;
+        }
+  }
+  if (rects.size() > 8) return ARTP_OK;
+  // a changed region that is most of the layer: the full build is cheaper than two restricted passes
+  size_t changed = 0;
+  for (const auto& r : rects) changed += (size_t)(r[2] - r[0] + 1) * (r[3] - r[1] + 1);
+  if (changed * 4 > (size_t)f.nW * f.nD) return ARTP_OK;
+  for (size_t k = 0; k < rects.size(); ++k) {
+    if (rects[k][2] < rects[k][0] || rects[k][3] < rects[k][1]) continue;
+    const int j = pr->n++;
+    pr->x0[j] = rects[k][0]; pr->z0[j] = rects[k][1]; pr->x1[j] = rects[k][2]; pr->z1[j] = rects[k][3];
+  }
+  if (pr->n == 0) return ARTP_OK;
+  int cells, rows;
+  partner_rect_extent(f, *pr, R, &cells, &rows);
+  hipLaunchKernelGGL(partner_count_kernel<true>, dim3((cells + 255) / 256, rows, pr->n), dim3(256), 0, c->stream, f, R,
+                     (const float4*)c->tri_raw_buf[slot], c->partner_cnt[slot], *pr, -1);
+  HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+// Step 2 of 2 -- after the samples changed: the new raw cross products of the changed cells, the NEW triangles'
+// contributions onto the cells around them, a full recount of the changed cells themselves, flags of everything touched.
+int partner_update_end(artp_ctx* c, int slot, const PartnerRects& pr) {
+  if (pr.n == 0) return build_partner_table_full(c, slot);
+  FieldDev& f = c->field[slot];
+  const int R = c->partner_R_built[slot];
+  int cells0, cellsR, rows;
+  partner_rect_extent(f, pr, 0, &cells0, &rows);
+  partner_rect_extent(f, pr, R, &cellsR, &rows);
+  hipLaunchKernelGGL(tri_raw_rects_kernel, dim3((cells0 + 255) / 256, pr.n), dim3(256), 0, c->stream, f, pr,
+                     c->tri_raw_buf[slot], c->partner_cnt[slot]);
+  hipLaunchKernelGGL(partner_count_kernel<true>, dim3((cellsR + 255) / 256, rows, pr.n), dim3(256), 0, c->stream, f, R,
+                     (const float4*)c->tri_raw_buf[slot], c->partner_cnt[slot], pr, 1);
+  hipLaunchKernelGGL(partner_count_kernel<false>, dim3((cells0 + 255) / 256, 2 * R + 1, pr.n), dim3(256), 0, c->stream, f, R,
+                     (const float4*)c->tri_raw_buf[slot], c->partner_cnt[slot], pr, 1);
+  hipLaunchKernelGGL(partner_flags_from_counts_kernel, dim3((cellsR + 255) / 256, pr.n), dim3(256), 0, c->stream, f.nW, f.nD,
+                     pr, R, (const unsigned*)c->partner_cnt[slot], c->partner_buf[slot]);
+  HIP_TRY(c, hipGetLastError());
+  f.partner_flags = c->partner_buf[slot];
+  f.partner_R = R;
+  return ARTP_OK;
+}
+
+// Range tables of one layer (pipeline.h).  Levels 0..5 (block 1..32); the kernels use levels 2..5.  pr = the changed
+// rectangles of a rectangle update whose step 1 (partner_update_begin) has run, nullptr = new layer.
+int build_tables(artp_ctx* c, int slot, const PartnerRects* pr = nullptr) {
   const FieldDev& f = c->field[slot];
   const size_t elems = (size_t)f.nW * f.nD;
   if (c->table_elems[slot] < elems) {
@@ -367,6 +447,9 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr, int n_dirty 
     if (c->stride_buf[slot]) HIP_TRY(c, hipFree(c->stride_buf[slot]));
     c->stride_buf[slot] = nullptr;
     if (c->partner_buf[slot]) HIP_TRY(c, hipFree(c->partner_buf[slot]));
+    if (c->partner_cnt[slot]) HIP_TRY(c, hipFree(c->partner_cnt[slot]));
+    c->partner_cnt[slot] = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->partner_cnt[slot]), elems * sizeof(unsigned)));
     if (c->tri_raw_buf[slot]) HIP_TRY(c, hipFree(c->tri_raw_buf[slot]));
     c->tri_raw_buf[slot] = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->tri_raw_buf[slot]), elems * sizeof(float4)));
@@ -413,12 +496,10 @@ int build_tables(artp_ctx* c, int slot, const int* dirty = nullptr, int n_dirty 
                        f.nW, f.nD, off[1], off[2], off[3], c->stride_buf[slot]);
     HIP_TRY(c, hipGetLastError());
   }
-  // dirty: n_dirty x {x0, z0, x1, z1}; a rectangle update that meets a table not built for this R falls back to the
-  // whole layer once
-  for (int k = 0; k < (dirty ? n_dirty : 1); ++k) {
-    const int rc_partner = build_partner_table(c, slot, dirty ? dirty + 4 * k : nullptr);
-    if (rc_partner != ARTP_OK) return rc_partner;
-  }
+  // a rectangle update that met a table not built for this R (or too many / too large rectangles) has pr->n = 0 and
+  // rebuilds the whole table
+  const int rc_partner = pr ? partner_update_end(c, slot, *pr) : build_partner_table_full(c, slot);
+  if (rc_partner != ARTP_OK) return rc_partner;
   t.valid = 1;
   return ARTP_OK;
 }
@@ -625,6 +706,7 @@ void artp_destroy(artp_ctx* c) {
     if (c->flag_buf[s]) (void)hipFree(c->flag_buf[s]);
     if (c->stride_buf[s]) (void)hipFree(c->stride_buf[s]);
     if (c->partner_buf[s]) (void)hipFree(c->partner_buf[s]);
+    if (c->partner_cnt[s]) (void)hipFree(c->partner_cnt[s]);
     if (c->tri_raw_buf[s]) (void)hipFree(c->tri_raw_buf[s]);
   }
   for (int l = 0; l < 5; ++l) {
@@ -934,16 +1016,8 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
   }
   c->field[slot].has_nan = has_nan;
   c->layer_has_nonfinite[slot] = has_nonfinite;
-  HIP_TRY(c, hipMemcpyAsync(c->rect_stage_dev, c->rect_stage_host, need, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(scatter_rects_kernel, dim3((unsigned)((max_cells + 255) / 256), (unsigned)n_rects), dim3(256), 0, c->stream,
-                     reinterpret_cast<const float*>(static_cast<const char*>(c->rect_stage_dev) + rec_bytes),
-                     static_cast<const RectDev*>(c->rect_stage_dev), n_rects, rows, cols, c->field_data[slot]);
-  HIP_TRY(c, hipGetLastError());
-  // both staging buffers are free again once the scatter has run: the next update (whatever stream the context is on
-  // by then) waits for this event before it touches them
-  HIP_TRY(c, hipEventRecord(c->rect_stage_done, c->stream));
-  // range / stride tables once (the whole map is ~1 MB: rebuilding beats tracking dirty blocks); the partner table
-  // only recomputes each dirty rectangle plus its margin
+  // partner table, step 1: what the OLD triangles of the rectangles contribute to the cells around them comes off the
+  // counts while the old samples are still there (stream order: in front of the scatter)
   std::vector<int> dirty((size_t)4 * n_rects);
   for (int k = 0; k < n_rects; ++k) {
     const int row0 = rects[4 * k], col0 = rects[4 * k + 1], nrows = rects[4 * k + 2], ncols = rects[4 * k + 3];
@@ -952,7 +1026,22 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
     dirty[4 * k + 2] = row0 + nrows - 1;
     dirty[4 * k + 3] = cols - 1 - col0;
   }
-  return build_tables(c, slot, dirty.data(), n_rects);
+  PartnerRects pr;
+  {
+    const int rcp = partner_update_begin(c, slot, dirty.data(), n_rects, &pr);
+    if (rcp != ARTP_OK) return rcp;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->rect_stage_dev, c->rect_stage_host, need, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(scatter_rects_kernel, dim3((unsigned)((max_cells + 255) / 256), (unsigned)n_rects), dim3(256), 0, c->stream,
+                     reinterpret_cast<const float*>(static_cast<const char*>(c->rect_stage_dev) + rec_bytes),
+                     static_cast<const RectDev*>(c->rect_stage_dev), n_rects, rows, cols, c->field_data[slot]);
+  HIP_TRY(c, hipGetLastError());
+  // both staging buffers are free again once the scatter has run: the next update (whatever stream the context is on
+  // by then) waits for this event before it touches them
+  HIP_TRY(c, hipEventRecord(c->rect_stage_done, c->stream));
+  // range / stride tables once (the whole map is ~1 MB: rebuilding beats tracking dirty blocks); the partner table,
+  // step 2: the new triangles' contributions and a recount of the changed cells
+  return build_tables(c, slot, &pr);
 }
 
 int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, int col0, int nrows, int ncols) {

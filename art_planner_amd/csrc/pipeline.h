@@ -122,13 +122,11 @@ stride_tables_kernel(const float2* __restrict__ mm, const unsigned char* __restr
 // Partner table (FieldDev::partner_flags): both triangles of a cell against every triangle of the
 // (2R+1)^2 cell neighbourhood, with the very arithmetic of the plane stage (triangle_plane on absolute
 // sample coordinates, the raw-cross pre-filter, the four epsilon compares).
-// Pass 1 (tri_raw_kernel): per cell {raw0, raw2} of the ABC and the DBC triangle (+inf for a triangle
+// Pass 1 (tri_raw_rects_kernel): per cell {raw0, raw2} of the ABC and the DBC triangle (+inf for a triangle
 // with a non-finite vertex: it can never be kept, and +inf fails the pre-filter).
-// Pass 2: one lane per (cell of the rectangle [cx0, cx0+ncx) x [cz0, cz0+ncz), neighbourhood row
-// dz = blockIdx.y - R); the inner loop is one 16-byte load and four pre-filter compares per neighbour cell,
-// the exact planes are only formed on a pre-filter hit.  Hits are OR-ed into the byte table (the caller
-// zeroes the rectangle first).  A changed sample can alter the flags of cells up to R+1 cells away only,
-// so rectangle updates recompute a margin instead of the map.
+// Pass 2 (partner_count_kernel): one lane per (own cell, neighbour row); the inner loop is one 16-byte load and four
+// pre-filter compares per neighbour cell, the exact planes are only formed on a pre-filter hit.  Partners are COUNTED
+// per own triangle; the byte table the box stages read is derived from the counts (see below).
 __device__ __forceinline__ void cell_triangle(const FieldDev& f, int cx, int cz, bool up, bool& finite,
                                               float pl[4], float raw[3]) {
   const int i = cx + cz * f.nW;
@@ -142,31 +140,49 @@ __device__ __forceinline__ void cell_triangle(const FieldDev& f, int cx, int cz,
     triangle_plane(xB, hD, zC, xB, hB, zA, xA, hC, zC, false, pl, raw);
 }
 
-__global__ void __launch_bounds__(256)
-tri_raw_kernel(FieldDev f, int cx0, int cz0, int ncx, int ncz, float4* __restrict__ raw4) {
-  const int li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= ncx * ncz) return;
-  const int cx = cx0 + li % ncx, cz = cz0 + li / ncx;
-  float4 o = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-  if (cx < f.nW - 1 && cz < f.nD - 1) {
-    float pl[4], raw[3];
-    bool fin;
-    cell_triangle(f, cx, cz, true, fin, pl, raw);
-    if (fin) { o.x = raw[0]; o.y = raw[2]; }
-    cell_triangle(f, cx, cz, false, fin, pl, raw);
-    if (fin) { o.z = raw[0]; o.w = raw[2]; }
-  }
-  raw4[cx + cz * f.nW] = o;
-}
+// The table is kept as COUNTS (cnt32[cell]: low half = partner triangles of the cell's ABC, high half = of its DBC;
+// at most 2 (2R+1)^2 < 2^16) and the byte flags the box stages read are derived from them.  Counts are what makes a
+// rectangle update local: a pair (own cell c, neighbour cell e) can only change when one of its ends changed, so
+//   c inside a changed rectangle:   recount over the full neighbourhood (RESTRICT = false)
+//   c outside, within R of one:     count -= its partners among the rectangle's OLD triangles (before the samples are
+//                                   overwritten), count += its partners among the NEW ones (RESTRICT = true, sign -+1)
+// -- (53 + 2 R)^2 cells x 53^2 neighbours twice + 53^2 cells x (2R+1)^2 instead of (53 + 2 R + 2)^2 x (2R+1)^2 pairs
+// for a 52 x 52 sample patch and the torso's R = 41: 2.8 x fewer of the ~30-instruction pair tests this kernel is
+// bound by.  A pair is always evaluated from the own cell's side with the own cell's tolerance, exactly as the full
+// build evaluates it, so the counts of an updated table equal those of a fresh build.
+struct PartnerRects {  // changed-cell rectangles (inclusive cell ranges), pairwise disjoint
+  int n;
+  int x0[8], z0[8], x1[8], z1[8];
+};
 
+// One launch for all rectangles (blockIdx.z = rectangle k).  RESTRICT: own cells = rectangle k widened by R, neighbours =
+// rectangle k, grid.y = its rows.  Otherwise: own cells = rectangle k, neighbours = everything within R, grid.y = 2 R + 1
+// (the whole layer is one rectangle).
+template <bool RESTRICT>
 __global__ void __launch_bounds__(256)
-partner_flags_kernel(FieldDev f, int R, int cx0, int cz0, int ncx, int ncz, const float4* __restrict__ raw4,
-                     unsigned* __restrict__ flags32) {
+partner_count_kernel(FieldDev f, int R, const float4* __restrict__ raw4, unsigned* __restrict__ cnt32, PartnerRects pr,
+                     int sign) {
+  const int k = blockIdx.z;
+  const int cx0 = RESTRICT ? max(pr.x0[k] - R, 0) : pr.x0[k], cz0 = RESTRICT ? max(pr.z0[k] - R, 0) : pr.z0[k];
+  const int cx1 = RESTRICT ? min(pr.x1[k] + R, f.nW - 2) : pr.x1[k], cz1 = RESTRICT ? min(pr.z1[k] + R, f.nD - 2) : pr.z1[k];
+  const int ncx = cx1 - cx0 + 1, ncz = cz1 - cz0 + 1;
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= ncx * ncz) return;
   const int cx = cx0 + li % ncx, cz = cz0 + li / ncx;
   if (cx >= f.nW - 1 || cz >= f.nD - 1) return;
-  const int z = cz + (int)blockIdx.y - R;
+  int z, xa = cx - R, xb = cx + R;
+  if (RESTRICT) {
+    // own cells inside ANY changed rectangle are recounted in full elsewhere
+    for (int j = 0; j < pr.n; ++j)
+      if (cx >= pr.x0[j] && cx <= pr.x1[j] && cz >= pr.z0[j] && cz <= pr.z1[j]) return;
+    z = pr.z0[k] + (int)blockIdx.y;
+    if (z > pr.z1[k] || z < cz - R || z > cz + R) return;
+    xa = max(xa, pr.x0[k]);
+    xb = min(xb, pr.x1[k]);
+  } else {
+    if ((int)blockIdx.y > 2 * R) return;
+    z = cz + (int)blockIdx.y - R;
+  }
   if (z < 0 || z > f.nD - 2) return;
   const int i = cx + cz * f.nW;
   float pl[2][4], raw[2][3], tol[2];
@@ -179,8 +195,8 @@ partner_flags_kernel(FieldDev f, int R, int cx0, int cz0, int ncx, int ncz, cons
     const float len = sqrtf(raw[o][0] * raw[o][0] + raw[o][1] * raw[o][1] + raw[o][2] * raw[o][2]);
     tol[o] = !own[o] ? -1.0f : ((fabsf(pl[o][1]) >= 0.05f) ? f.partner_tol * len : INFINITY);
   }
-  unsigned out = 0;
-  const int x0 = max(cx - R, 0), x1 = min(cx + R, f.nW - 2);
+  unsigned n0 = 0, n1 = 0;
+  const int x0 = max(xa, 0), x1 = min(xb, f.nW - 2);
   for (int x = x0; x <= x1; ++x) {
     const int e = x + z * f.nW;
     const float4 r = raw4[e];
@@ -199,18 +215,51 @@ partner_flags_kernel(FieldDev f, int R, int cx0, int cz0, int ncx, int ncz, cons
       bool fin;
       cell_triangle(f, x, z, p == 0, fin, p2, r2);
       if (!fin) continue;
-#pragma unroll
-      for (int o = 0; o < 2; ++o)
-        if (own[o] && !(same && o == p) && planes_eps_equal(pl[o], p2)) out |= 1u << o;
+      if (own[0] && !(same && p == 0) && planes_eps_equal(pl[0], p2)) ++n0;
+      if (own[1] && !(same && p == 1) && planes_eps_equal(pl[1], p2)) ++n1;
     }
   }
-  if (out) atomicOr(&flags32[i >> 2], out << (8 * (i & 3)));
+  const unsigned delta = n0 | (n1 << 16);
+  if (delta) {
+    if (sign > 0) atomicAdd(&cnt32[i], delta); else atomicSub(&cnt32[i], delta);
+  }
 }
 
+// raw cross products of the rectangles' cells (the changed cells of an update), their counts to zero for the recount
 __global__ void __launch_bounds__(256)
-partner_flags_clear_kernel(int nW, int cx0, int cz0, int ncx, int ncz, unsigned char* __restrict__ flags) {
+tri_raw_rects_kernel(FieldDev f, PartnerRects pr, float4* __restrict__ raw4, unsigned* __restrict__ cnt32) {
+  const int k = blockIdx.y;
+  const int ncx = pr.x1[k] - pr.x0[k] + 1, ncz = pr.z1[k] - pr.z0[k] + 1;
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li < ncx * ncz) flags[(cx0 + li % ncx) + (size_t)(cz0 + li / ncx) * nW] = 0;
+  if (li >= ncx * ncz) return;
+  const int cx = pr.x0[k] + li % ncx, cz = pr.z0[k] + li / ncx;
+  float4 o = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+  if (cx < f.nW - 1 && cz < f.nD - 1) {
+    float pl[4], raw[3];
+    bool fin;
+    cell_triangle(f, cx, cz, true, fin, pl, raw);
+    if (fin) { o.x = raw[0]; o.y = raw[2]; }
+    cell_triangle(f, cx, cz, false, fin, pl, raw);
+    if (fin) { o.z = raw[0]; o.w = raw[2]; }
+  }
+  raw4[cx + cz * f.nW] = o;
+  cnt32[cx + (size_t)cz * f.nW] = 0u;
+}
+
+// byte flags from the counts (bit 0: the ABC triangle has a partner, bit 1: the DBC triangle) for the rectangles
+// widened by `margin` cells
+__global__ void __launch_bounds__(256)
+partner_flags_from_counts_kernel(int nW, int nD, PartnerRects pr, int margin, const unsigned* __restrict__ cnt32,
+                                 unsigned char* __restrict__ flags) {
+  const int k = blockIdx.y;
+  const int cx0 = max(pr.x0[k] - margin, 0), cz0 = max(pr.z0[k] - margin, 0);
+  const int cx1 = min(pr.x1[k] + margin, nW - 1), cz1 = min(pr.z1[k] + margin, nD - 1);
+  const int ncx = cx1 - cx0 + 1, ncz = cz1 - cz0 + 1;
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= ncx * ncz) return;
+  const size_t i = (cx0 + li % ncx) + (size_t)(cz0 + li / ncx) * nW;
+  const unsigned c = cnt32[i];
+  flags[i] = (unsigned char)(((c & 0xffffu) ? 1u : 0u) | ((c >> 16) ? 2u : 0u));
 }
 
 // Conservative exits from the stride tables.  A set of blocks whose union CONTAINS the window bounds the window's
