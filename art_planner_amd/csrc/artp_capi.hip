@@ -949,8 +949,14 @@ scatter_rects_kernel(const float* __restrict__ staged, const RectDev* __restrict
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= r.nrows * r.ncols) return;
   const int i = t % r.nrows, jj = t / r.nrows;
-  const int z = cols - 1 - (r.col0 + jj);
-  data[(size_t)(r.row0 + i) + (size_t)z * rows] = staged[r.offset + t];
+  const int row = r.row0 + i, col = r.col0 + jj;
+  // the rectangles of a call apply IN ORDER: a cell that a later rectangle also covers is that rectangle's to write
+  for (int k = (int)blockIdx.y + 1; k < n_rects; ++k) {
+    const RectDev q = rects[k];
+    if (row >= q.row0 && row < q.row0 + q.nrows && col >= q.col0 && col < q.col0 + q.ncols) return;
+  }
+  const int z = cols - 1 - col;
+  data[(size_t)row + (size_t)z * rows] = staged[r.offset + t];
 }
 }  // namespace
 

@@ -98,8 +98,9 @@ int artp_upload_layer(artp_ctx* ctx, int slot, const float* layer_colmajor, int 
 int artp_update_layer_rect(artp_ctx* ctx, int slot, const float* patch, int row0, int col0,
                            int nrows, int ncols);
 /* Several rectangles of one slot in one call (what computeChange, change.cpp:9-51, yields per map update):
- * patches[k] is column-major nrows x ncols, rects = n_rects x {row0, col0, nrows, ncols}.  One staged copy, the range
- * tables rebuilt once, the partner table per rectangle.  Both forms are ASYNCHRONOUS on the context's stream: the
+ * patches[k] is column-major nrows x ncols, rects = n_rects x {row0, col0, nrows, ncols}, applied IN ORDER (where
+ * rectangles overlap the later one wins).  One staged copy, the range tables rebuilt once, the partner table (kept as
+ * counts) re-evaluated for the pairs with an end in a changed rectangle only.  Both forms are ASYNCHRONOUS on the context's stream: the
  * patches are copied to a pinned staging buffer before the call returns (the caller's buffers are free again), the
  * device work is ordered in front of whatever the stream runs next. */
 int artp_update_layer_rects(artp_ctx* ctx, int slot, int n_rects, const float* const* patches, const int* rects);

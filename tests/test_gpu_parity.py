@@ -312,6 +312,58 @@ def test_partner_table_incremental_equals_full(big_map):
     ctx2.close()
 
 
+def test_partner_counts_survive_overlapping_many_and_huge_rectangles(big_map):
+    """artp_update_layer_rects keeps the partner table as counts and re-evaluates only the pairs with an end in a changed
+    rectangle.  The cases its bookkeeping has to get right, each against a fresh upload of the final layers (both slots:
+    the torso's R = 41 neighbourhood and the feet's R = 12): rectangles that overlap and rectangles that only touch (merged
+    into bounding boxes), a rectangle on the map border, more rectangles than one launch takes (whole-table rebuild), a
+    rectangle that is most of the map (whole-table rebuild), and a second call on top of the first."""
+    gm = _terraced(common.crop_map(big_map, 60, 80, 200), step=0.02)
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm, sampler=False)
+    rng = np.random.default_rng(11)
+    layers = {0: gm["elevation"].copy(), 1: gm["elevation_masked"].copy()}
+
+    def apply(origins_sizes):
+        for slot in (0, 1):
+            patches, origins = [], []
+            for (r0, c0, nr, nc) in origins_sizes:
+                cur = layers[slot][r0:r0 + nr, c0:c0 + nc]
+                patch = cur + np.float32(0.013) * rng.integers(0, 3, (nr, nc)).astype(np.float32)
+                layers[slot][r0:r0 + nr, c0:c0 + nc] = patch      # later rectangles of a call see the earlier ones
+                patches.append(patch.copy())
+                origins.append((r0, c0))
+            ctx.update_layer_rects(slot, patches, origins)
+
+    def check(tag):
+        gm2 = common.crop_map(gm, 0, 0, gm.rows)
+        gm2.pos_x, gm2.pos_y = gm.pos_x, gm.pos_y
+        gm2.layers["elevation"] = np.asfortranarray(layers[0])
+        gm2.layers["elevation_masked"] = np.asfortranarray(layers[1])
+        ctx2 = _ctx("yaml")
+        ctx2.upload_map(gm2, sampler=False)
+        for slot in (0, 1):
+            inc, r1 = ctx.partner_table(slot, (gm.rows, gm.cols))
+            full, r2 = ctx2.partner_table(slot, (gm.rows, gm.cols))
+            assert r1 == r2 > 0 and np.array_equal(inc, full), (tag, slot, int((inc != full).sum()))
+        se3 = common.random_states(gm2, 30000, rng, z_off=(0.0, 0.03), tilt=0.15, spread=0.5)
+        vo = O.OracleMap(gm2).states_valid(O.robot("yaml"), se3)
+        assert np.array_equal(ctx.validate_states(se3), vo), tag
+        ctx2.close()
+
+    apply([(20, 30, 40, 40), (50, 60, 30, 30), (90, 90, 10, 10), (100, 90, 12, 10)])   # overlap; touch
+    check("overlap + touch")
+    apply([(0, 0, 15, 25), (185, 170, 15, 30), (60, 0, 20, 8)])                            # borders
+    check("borders")
+    apply([(10 + 20 * k, 150, 6, 6) for k in range(9)])                                    # nine rectangles
+    check("nine")
+    apply([(5, 5, 150, 160)])                                                              # most of the map
+    check("huge")
+    apply([(70, 70, 52, 52), (20, 120, 52, 52), (130, 10, 52, 52)])                        # the config-5 shape, on top
+    check("c5 shape")
+    ctx.close()
+
+
 def test_empty_ragged_and_error_inputs(big_map):
     """Edge cases of the batch interfaces: empty batches, batches that are not a multiple of any tile size,
     states far outside the map, calls before a map was uploaded, and a robot too large for the window tile."""
