@@ -1399,8 +1399,8 @@ int artp_sample_and_validate_dev(artp_ctx* c, uint64_t seed, uint64_t first_inde
   }
   if (n_valid) {
     HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
-    size_t blocks = (n + 255) / 256;
-    if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+    size_t blocks = (n / 16 + 255) / 256 + 1;
+    if (blocks > (size_t)c->n_cus * 4) blocks = (size_t)c->n_cus * 4;
     hipLaunchKernelGGL(count_valid_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream,
                        (const uint8_t*)valid_out, n, c->d_count);
     HIP_TRY(c, hipGetLastError());
@@ -1474,7 +1474,7 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   HIP_TRY(c, hipMemsetAsync(counts + n, 0, sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(d_total, 0, 16, c->stream));
   size_t blocks = (n + 255) / 256;
-  if (blocks > (size_t)c->n_cus * 32) blocks = (size_t)c->n_cus * 32;
+  if (blocks > (size_t)c->n_cus * 4) blocks = (size_t)c->n_cus * 4;  // grid-stride; one atomic per workgroup on the total
   hipLaunchKernelGGL(motion_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->geom,
                      c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total);
   HIP_TRY(c, hipGetLastError());

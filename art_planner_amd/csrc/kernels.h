@@ -886,7 +886,15 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) my_total += __shfl_xor(my_total, m, 64);
-  if ((threadIdx.x & 63) == 0 && my_total) atomicAdd(total64, my_total);
+  // one atomic per workgroup (a returning atomic per wavefront on one word: 4096 of them for 2^18 edges were most of
+  // this kernel's 55 us)
+  __shared__ unsigned long long wave_total[4];
+  if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = my_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long tot = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    if (tot) atomicAdd(total64, tot);
+  }
   if (my_overflow) atomicExch(overflow, 1);
 }
 
@@ -999,15 +1007,37 @@ last_valid_kernel(const double* __restrict__ s1, const double* __restrict__ s2, 
   }
 }
 
+// Labels != 0 of a batch.  Sixteen labels per load, one atomic per WORKGROUP of a grid of a few workgroups per CU: with
+// an atomic per wavefront of a wavefront-per-256-labels grid (32 768 atomics on one word for 2^22 labels) the counter's
+// L2 atomic unit was the whole 0.4 ms of the kernel.
 __global__ void __launch_bounds__(256)
 count_valid_kernel(const uint8_t* __restrict__ valid, size_t n, unsigned long long* __restrict__ out) {
-  unsigned long long c = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x)
-    c += valid[i] ? 1 : 0;
+  __shared__ unsigned wave_sum[4];
+  unsigned c = 0;
+  const size_t n16 = (reinterpret_cast<uintptr_t>(valid) & 15u) ? 0 : n / 16;  // aligned 16-byte chunks
+  const uint4* v16 = reinterpret_cast<const uint4*>(valid);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 q = v16[i];
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // a byte is non-zero iff any of its bits is set: fold each byte onto its lowest bit
+      unsigned t = w[k] | (w[k] >> 4);
+      t |= t >> 2;
+      t |= t >> 1;
+      c += (unsigned)__popc(t & 0x01010101u);
+    }
+  }
+  for (size_t i = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    c += valid[i] ? 1u : 0u;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long tot = (unsigned long long)wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    if (tot) atomicAdd(out, tot);
+  }
 }
 
 
