@@ -803,16 +803,30 @@ __device__ __forceinline__ int float_order_key(float v) {
 }
 __global__ void __launch_bounds__(256)
 finite_min_max_kernel(const float* __restrict__ layer, int n, int* __restrict__ keys) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride, one pair of atomics per WORKGROUP (a pair per wavefront of a wavefront-per-256-samples grid kept the
+  // two words' atomic unit busy for the kernel's whole 0.08 ms)
+  __shared__ int wlo[4], whi[4];
   int lo = 0x7fffffff, hi = (int)0x80000000;
-  if (t < n && artp::is_finite(layer[t])) lo = hi = float_order_key(layer[t]);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const float v = layer[t];
+    if (artp::is_finite(v)) {
+      const int k = float_order_key(v);
+      lo = min(lo, k);
+      hi = max(hi, k);
+    }
+  }
   for (int off = 32; off > 0; off >>= 1) {
     lo = min(lo, __shfl_xor(lo, off, 64));
     hi = max(hi, __shfl_xor(hi, off, 64));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&keys[0], lo);
-    atomicMax(&keys[1], hi);
+    wlo[threadIdx.x >> 6] = lo;
+    whi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&keys[0], min(min(wlo[0], wlo[1]), min(wlo[2], wlo[3])));
+    atomicMax(&keys[1], max(max(whi[0], whi[1]), max(whi[2], whi[3])));
   }
 }
 
@@ -1308,8 +1322,8 @@ static int finite_min_max_dev(artp_ctx* c, const float* d_layer, size_t n, float
   int init[2] = {0x7fffffff, (int)0x80000000};
   int* d_keys = reinterpret_cast<int*>(c->d_count);
   HIP_TRY(c, hipMemcpyAsync(d_keys, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(finite_min_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_layer, (int)n,
-                     d_keys);
+  hipLaunchKernelGGL(finite_min_max_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->n_cus)), dim3(256), 0,
+                     c->stream, d_layer, (int)n, d_keys);
   HIP_TRY(c, hipGetLastError());
   int keys[2];
   HIP_TRY(c, hipMemcpyAsync(keys, d_keys, sizeof(keys), hipMemcpyDeviceToHost, c->stream));

@@ -167,23 +167,51 @@ cdf_rows_kernel(const float* __restrict__ prob, int rows, int cols, float* __res
                 float* __restrict__ row_sum) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
+  // the additions stay in column order (the reference's float rounding); only the LOADS are taken eight at a time, in
+  // front of the dependent chain -- a load per addition made every step wait for memory (0.15 ms for 400 columns)
+  constexpr int U = 8;
   float s = 0.f;
-  for (int j = 0; j < cols; ++j) s += prob[i + (size_t)j * rows];
+  for (int j0 = 0; j0 < cols; j0 += U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (j0 + u < cols) ? prob[i + (size_t)(j0 + u) * rows] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j0 + u < cols) s += v[u];
+  }
   row_sum[i] = s;
   float c = 0.f;
-  for (int j = 0; j < cols; ++j) {
-    c += prob[i + (size_t)j * rows] / s;
-    cum_prob[i + (size_t)j * rows] = c;
+  for (int j0 = 0; j0 < cols; j0 += U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (j0 + u < cols) ? prob[i + (size_t)(j0 + u) * rows] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j0 + u < cols) {
+        c += v[u] / s;
+        cum_prob[i + (size_t)(j0 + u) * rows] = c;
+      }
   }
 }
-__global__ void cdf_rowwise_kernel(const float* __restrict__ row_sum, int rows, float* __restrict__ cum_rowwise,
-                                   float* __restrict__ any_prob) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// one workgroup: the row sums go through LDS, thread 0 adds them in row order
+#define ARTP_CDF_ROWS_LDS 4096
+__global__ void __launch_bounds__(256)
+cdf_rowwise_kernel(const float* __restrict__ row_sum, int rows, float* __restrict__ cum_rowwise,
+                   float* __restrict__ any_prob) {
+  __shared__ float rs[ARTP_CDF_ROWS_LDS];
+  if (blockIdx.x != 0) return;
+  const bool in_lds = rows <= ARTP_CDF_ROWS_LDS;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) rs[i] = row_sum[i];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float* src = in_lds ? rs : row_sum;
   float total = 0.f;
-  for (int i = 0; i < rows; ++i) total += row_sum[i];
+  for (int i = 0; i < rows; ++i) total += src[i];
   float c = 0.f;
   for (int i = 0; i < rows; ++i) {
-    c += row_sum[i] / total;
+    c += src[i] / total;
     cum_rowwise[i] = c;
   }
   *any_prob = total;
@@ -254,22 +282,35 @@ base_distribution_kernel(const float* __restrict__ blurred, const unsigned* __re
 }
 // applyMaxUnknownProbability (probability_distribution.cpp:50-90): probability mass of the observed and of
 // the unobserved cells ...
-__global__ void __launch_bounds__(256)
+// Two stages in a FIXED order (one workgroup, grid-stride, then a shuffle tree): floating-point atomics from 2 500
+// wavefronts added the same numbers in a different order every run -- the cap's scale factor, and through it the CDF,
+// could differ in the last bit between two runs on the same map.
+__global__ void __launch_bounds__(1024)
 known_unknown_mass_kernel(const float* __restrict__ prob, const float* __restrict__ observed, int n,
                           double* __restrict__ mass) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double part[2][16];
   double known = 0.0, unknown = 0.0;
-  if (t < n) {
-    if (observed[t] > 0.0f) known = (double)prob[t];
-    else unknown = (double)prob[t];
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    if (observed[t] > 0.0f) known += (double)prob[t];
+    else unknown += (double)prob[t];
   }
   for (int off = 32; off > 0; off >>= 1) {
     known += __shfl_xor(known, off, 64);
     unknown += __shfl_xor(unknown, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (known != 0.0) atomicAdd(&mass[0], known);
-    if (unknown != 0.0) atomicAdd(&mass[1], unknown);
+    part[0][threadIdx.x >> 6] = known;
+    part[1][threadIdx.x >> 6] = unknown;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double k = 0.0, u = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      k += part[0][w];
+      u += part[1][w];
+    }
+    mass[0] = k;
+    mass[1] = u;
   }
 }
 // ... and the rescaling that caps the unobserved share at max_prob
@@ -515,7 +556,7 @@ bool pre_sampling_distribution(artp_ctx* c, artp_preprocessed* pp, const artp_pr
                      density ? (const float*)L(PRE_NSAMPLES) : (const float*)nullptr, (const unsigned*)max_bits,
                      (const float*)L(PRE_SAMPLE_FILTER), n, L(PRE_SAMPLE_PROB));
   if (prm->use_max_prob_unknown_samples) {
-    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, grid, blk, 0, st, (const float*)L(PRE_SAMPLE_PROB),
+    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, dim3(1), dim3(1024), 0, st, (const float*)L(PRE_SAMPLE_PROB),
                        (const float*)L(PRE_OBSERVED), n, mass);
     hipLaunchKernelGGL(artp::cap_unknown_kernel, grid, blk, 0, st, (const float*)L(PRE_OBSERVED), (const double*)mass,
                        prm->max_prob_unknown_samples, n, L(PRE_SAMPLE_PROB));
@@ -525,7 +566,7 @@ bool pre_sampling_distribution(artp_ctx* c, artp_preprocessed* pp, const artp_pr
   float* total = pp->scalars();
   hipLaunchKernelGGL(artp::cdf_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st,
                      (const float*)L(PRE_SAMPLE_PROB), rows, cols, L(PRE_CUM_PROB), row_sum);
-  hipLaunchKernelGGL(artp::cdf_rowwise_kernel, dim3(1), dim3(1), 0, st, (const float*)row_sum, rows, pp->rowwise(),
+  hipLaunchKernelGGL(artp::cdf_rowwise_kernel, dim3(1), dim3(256), 0, st, (const float*)row_sum, rows, pp->rowwise(),
                      total);
   ok = ok && hipGetLastError() == hipSuccess;
   if (d_taps) {
