@@ -333,23 +333,35 @@ change_kernel(const float* __restrict__ elev_new, const float* __restrict__ trav
               const float* __restrict__ elev_old, const float* __restrict__ trav_old, int rows, int cols, int si,
               int sj, float thres, float* __restrict__ updated, int* __restrict__ rect, unsigned long long* __restrict__ count) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * cols) return;
-  const int i = t % rows, j = t / rows;
+  const bool in = t < rows * cols;
+  const int i = in ? t % rows : 0, j = in ? t / rows : 0;
   const int io = i - si, jo = j - sj;
-  float u = 1.0f;
-  if (io >= 0 && jo >= 0 && io < rows && jo < cols) {
+  float u = in ? 1.0f : 0.0f;
+  if (in && io >= 0 && jo >= 0 && io < rows && jo < cols) {
     const size_t o = (size_t)io + (size_t)jo * rows;
     const bool height_changed = fabsf(elev_new[t] - elev_old[o]) > thres;
     const bool trav_changed = trav_old[o] - trav_new[t] > 0.5f;
     if (!height_changed && !trav_changed) u = 0.0f;
   }
-  updated[t] = u;
-  if (u != 0.0f) {
-    atomicMin(&rect[0], i);
-    atomicMin(&rect[1], j);
-    atomicMax(&rect[2], i);
-    atomicMax(&rect[3], j);
-    atomicAdd(count, 1ull);
+  if (in) updated[t] = u;
+  // bounding rectangle and count of the changed cells: reduced across the wavefront first (an atomic per changed cell
+  // on five words: 8 000 cells of a 5 % update queued up behind each other)
+  const bool ch = u != 0.0f;
+  const unsigned long long bal = __ballot(ch);
+  if (bal == 0ull) return;
+  int i0 = ch ? i : 0x7fffffff, j0 = ch ? j : 0x7fffffff, i1 = ch ? i : -1, j1 = ch ? j : -1;
+  for (int off = 32; off > 0; off >>= 1) {
+    i0 = min(i0, __shfl_xor(i0, off, 64));
+    j0 = min(j0, __shfl_xor(j0, off, 64));
+    i1 = max(i1, __shfl_xor(i1, off, 64));
+    j1 = max(j1, __shfl_xor(j1, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&rect[0], i0);
+    atomicMin(&rect[1], j0);
+    atomicMax(&rect[2], i1);
+    atomicMax(&rect[3], j1);
+    atomicAdd(count, (unsigned long long)__popcll(bal));
   }
 }
 
