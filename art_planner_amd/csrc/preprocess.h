@@ -205,16 +205,53 @@ cdf_rowwise_kernel(const float* __restrict__ row_sum, int rows, float* __restric
     for (int i = threadIdx.x; i < rows; i += blockDim.x) rs[i] = row_sum[i];
     __syncthreads();
   }
-  if (threadIdx.x != 0) return;
-  const float* src = in_lds ? rs : row_sum;
-  float total = 0.f;
-  for (int i = 0; i < rows; ++i) total += src[i];
-  float c = 0.f;
-  for (int i = 0; i < rows; ++i) {
-    c += src[i] / total;
-    cum_rowwise[i] = c;
+  if (!in_lds) {  // maps with more rows than the LDS buffer holds: the plain serial form
+    if (threadIdx.x != 0) return;
+    float total = 0.f;
+    for (int i = 0; i < rows; ++i) total += row_sum[i];
+    float c = 0.f;
+    for (int i = 0; i < rows; ++i) {
+      c += row_sum[i] / total;
+      cum_rowwise[i] = c;
+    }
+    *any_prob = total;
+    return;
   }
-  *any_prob = total;
+  // the ORDERED parts (total, running sum) stay with thread 0, reads taken eight at a time in front of the additions;
+  // the quotients, which do not depend on each other, are formed by everybody in between
+  __shared__ float s_total;
+  constexpr int U = 8;
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int i0 = 0; i0 < rows; i0 += U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (i0 + u < rows) ? rs[i0 + u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + u < rows) total += v[u];
+    }
+    s_total = total;
+    *any_prob = total;
+  }
+  __syncthreads();
+  const float total = s_total;
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) rs[i] = rs[i] / total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float c = 0.f;
+    for (int i0 = 0; i0 < rows; i0 += U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (i0 + u < rows) ? rs[i0 + u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + u < rows) {
+          c += v[u];
+          cum_rowwise[i0 + u] = c;
+        }
+    }
+  }
 }
 __global__ void __launch_bounds__(256)
 pre_fill_kernel(float* __restrict__ out, int n, float v) {
@@ -282,15 +319,16 @@ base_distribution_kernel(const float* __restrict__ blurred, const unsigned* __re
 }
 // applyMaxUnknownProbability (probability_distribution.cpp:50-90): probability mass of the observed and of
 // the unobserved cells ...
-// Two stages in a FIXED order (one workgroup, grid-stride, then a shuffle tree): floating-point atomics from 2 500
-// wavefronts added the same numbers in a different order every run -- the cap's scale factor, and through it the CDF,
-// could differ in the last bit between two runs on the same map.
-__global__ void __launch_bounds__(1024)
+// Summed in a FIXED order -- every workgroup its grid-stride share (thread order, then a shuffle tree, then the four
+// wavefronts in order) into partial[2 b], partial[2 b + 1]; a second launch adds the partial sums in workgroup order:
+// floating-point atomics from 2 500 wavefronts added the same numbers in a different order every run, and the cap's
+// scale factor -- through it the CDF -- could differ in the last bit between two runs on the same map.
+__global__ void __launch_bounds__(256)
 known_unknown_mass_kernel(const float* __restrict__ prob, const float* __restrict__ observed, int n,
-                          double* __restrict__ mass) {
-  __shared__ double part[2][16];
+                          double* __restrict__ partial) {
+  __shared__ double part[2][4];
   double known = 0.0, unknown = 0.0;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     if (observed[t] > 0.0f) known += (double)prob[t];
     else unknown += (double)prob[t];
   }
@@ -304,14 +342,19 @@ known_unknown_mass_kernel(const float* __restrict__ prob, const float* __restric
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double k = 0.0, u = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-      k += part[0][w];
-      u += part[1][w];
-    }
-    mass[0] = k;
-    mass[1] = u;
+    partial[2 * blockIdx.x] = ((part[0][0] + part[0][1]) + part[0][2]) + part[0][3];
+    partial[2 * blockIdx.x + 1] = ((part[1][0] + part[1][1]) + part[1][2]) + part[1][3];
   }
+}
+__global__ void known_unknown_mass_final_kernel(const double* __restrict__ partial, int n_part, double* __restrict__ mass) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double k = 0.0, u = 0.0;
+  for (int b = 0; b < n_part; ++b) {
+    k += partial[2 * b];
+    u += partial[2 * b + 1];
+  }
+  mass[0] = k;
+  mass[1] = u;
 }
 // ... and the rescaling that caps the unobserved share at max_prob
 __global__ void __launch_bounds__(256)
@@ -568,8 +611,14 @@ bool pre_sampling_distribution(artp_ctx* c, artp_preprocessed* pp, const artp_pr
                      density ? (const float*)L(PRE_NSAMPLES) : (const float*)nullptr, (const unsigned*)max_bits,
                      (const float*)L(PRE_SAMPLE_FILTER), n, L(PRE_SAMPLE_PROB));
   if (prm->use_max_prob_unknown_samples) {
-    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, dim3(1), dim3(1024), 0, st, (const float*)L(PRE_SAMPLE_PROB),
-                       (const float*)L(PRE_OBSERVED), n, mass);
+    // the partial sums live in the scratch layer the row sums use further down (8-byte aligned inside it); a map too
+    // small to hold them is summed by one workgroup straight into `mass`
+    const int n_part = n >= 8192 ? 64 : 1;
+    double* partial = n_part > 1 ? reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(L(PRE_T0)) + 7) & ~(uintptr_t)7) : mass;
+    hipLaunchKernelGGL(artp::known_unknown_mass_kernel, dim3(n_part), dim3(256), 0, st, (const float*)L(PRE_SAMPLE_PROB),
+                       (const float*)L(PRE_OBSERVED), n, partial);
+    if (n_part > 1)
+      hipLaunchKernelGGL(artp::known_unknown_mass_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, n_part, mass);
     hipLaunchKernelGGL(artp::cap_unknown_kernel, grid, blk, 0, st, (const float*)L(PRE_OBSERVED), (const double*)mass,
                        prm->max_prob_unknown_samples, n, L(PRE_SAMPLE_PROB));
   }
