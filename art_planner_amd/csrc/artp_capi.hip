@@ -38,7 +38,6 @@ struct artp_ctx {
   float* field_data[2] = {nullptr, nullptr};
   size_t field_elems[2] = {0, 0};
   bool have_field[2] = {false, false};
-  std::vector<float> field_host[2];  // ODE-layout host mirror (for rect updates / has_nan)
   void* rect_stage_host = nullptr;   // artp_update_layer_rects: pinned staging (rectangle records + patches) ...
   void* rect_stage_dev = nullptr;    // ... and its device twin
   size_t rect_stage_cap = 0;
@@ -57,6 +56,7 @@ struct artp_ctx {
   unsigned* stride_buf[2] = {nullptr, nullptr};      // stride tables (TablesDev::st)
   unsigned char* partner_buf[2] = {nullptr, nullptr};
   unsigned* partner_cnt[2] = {nullptr, nullptr};  // partner counts per cell (pipeline.h partner_count_kernel)
+  int* d_diff = nullptr;                          // result of layer_diff_kernel (six ints)
   int partner_R_built[2] = {-1, -1};
   int layer_has_nonfinite[2] = {1, 1};
   float4* tri_raw_buf[2] = {nullptr, nullptr};
@@ -652,6 +652,7 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc(&c->d_error, sizeof(int)) != hipSuccess ||
       hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_diff), 8 * sizeof(int)) != hipSuccess ||
       hipMemset(c->d_error, 0, sizeof(int)) != hipSuccess) {
     artp_destroy(c);
     return ARTP_ERR_HIP;
@@ -721,6 +722,7 @@ void artp_destroy(artp_ctx* c) {
     if (c->d_act[l]) (void)hipFree(c->d_act[l]);
   if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->d_map_f32) (void)hipFree(c->d_map_f32);
+  if (c->d_diff) (void)hipFree(c->d_diff);
   if (c->pin_states) (void)hipHostFree(c->pin_states);
   if (c->pin_labels) (void)hipHostFree(const_cast<uint8_t*>(c->pin_labels));
   delete c;  // d_error / d_count of every lane went with the lanes above
@@ -831,7 +833,7 @@ finite_min_max_kernel(const float* __restrict__ layer, int n, int* __restrict__ 
 }
 
 // Everything of artp_upload_layer that follows the sample data being in c->field_data[slot] (ODE layout) and
-// mirrored in c->field_host[slot]: dxHeightfieldData::SetData, the checker's frame, scratch sizing, tables.
+// dxHeightfieldData::SetData, the checker's frame, scratch sizing, tables.
 int finish_layer(artp_ctx* c, int slot, int rows, int cols, double len_x, double len_y, double pos_x, double pos_y,
                  int has_nan, int has_nonfinite) {
   c->layer_has_nonfinite[slot] = has_nonfinite;
@@ -906,8 +908,7 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
   const size_t elems = (size_t)rows * cols;
   // field_.mat = layer.rowwise().reverse() (height_map_box_checker.cpp:44): ODE sample (x, z) =
   // layer(x, cols-1-z), stored x-fastest.
-  std::vector<float>& host = c->field_host[slot];
-  host.resize(elems);
+  std::vector<float> host(elems);
   int has_nan = 0, has_nonfinite = 0;
   for (int j = 0; j < cols; ++j)
     for (int i = 0; i < rows; ++i) {
@@ -924,13 +925,84 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
   return finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, has_nan, has_nonfinite);
 }
 
-// Same from a layer that already lives in HBM (column-major, this context's device): the layout flip runs
-// on the device; only the 640 kB host mirror that rectangle updates patch comes back.
+// Difference between a device layer (column-major rows x cols) and the installed samples of a slot (ODE layout), bit for
+// bit: out[0..3] = bounding rectangle {x0, z0, x1, z1} of the samples that differ (x0 > x1: none), out[4] / out[5] = the
+// NEW layer holds a non-finite sample / a NaN.
+__global__ void __launch_bounds__(256)
+layer_diff_kernel(const float* __restrict__ layer, int rows, int cols, const float* __restrict__ data, int* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = t < rows * cols;
+  const int x = in ? t % rows : 0, z = in ? t / rows : 0;
+  const float v = in ? layer[(size_t)x + (size_t)(cols - 1 - z) * rows] : 0.0f;
+  const bool differs = in && __float_as_uint(v) != __float_as_uint(data[t]);
+  if (__any(in && !artp::is_finite(v)) && (threadIdx.x & 63) == 0) atomicOr(&out[4], 1);
+  if (__any(in && v != v) && (threadIdx.x & 63) == 0) atomicOr(&out[5], 1);
+  if (!__any(differs)) return;
+  int x0 = differs ? x : 0x7fffffff, z0 = differs ? z : 0x7fffffff, x1 = differs ? x : -1, z1 = differs ? z : -1;
+  for (int off = 32; off > 0; off >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, off, 64));
+    z0 = min(z0, __shfl_xor(z0, off, 64));
+    x1 = max(x1, __shfl_xor(x1, off, 64));
+    z1 = max(z1, __shfl_xor(z1, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&out[0], x0);
+    atomicMin(&out[1], z0);
+    atomicMax(&out[2], x1);
+    atomicMax(&out[3], z1);
+  }
+}
+
+// the samples [x0, x1] x [z0, z1] (ODE coordinates) of a device layer into the installed samples
+__global__ void __launch_bounds__(256)
+copy_rect_to_ode_layout_kernel(const float* __restrict__ layer, int rows, int cols, int x0, int z0, int nx, int nz,
+                               float* __restrict__ data) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nx * nz) return;
+  const int x = x0 + t % nx, z = z0 + t / nx;
+  data[(size_t)x + (size_t)z * rows] = layer[(size_t)x + (size_t)(cols - 1 - z) * rows];
+}
+
+// Same from a layer that already lives in HBM (column-major, this context's device): the layout flip runs on the
+// device.  When the slot already holds a layer of the same geometry, the new one is compared with it bit for bit
+// first: no difference -> nothing to do; a difference confined to a quarter of the samples or less -> only that
+// rectangle is rewritten and the tables take the rectangle-update path (what a 10 Hz map stream looks like: the
+// partner table of the torso layer alone is 0.76 ms when rebuilt, a tenth of that for a small rectangle); the result is
+// the same tables either way.
 static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer, int rows, int cols, double len_x,
                              double len_y, double pos_x, double pos_y) {
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t elems = (size_t)rows * cols;
+  const FieldDev& f0 = c->field[slot];
+  const bool same_geometry = c->have_field[slot] && c->have_geom && f0.nW == rows && f0.nD == cols &&
+                             c->geom.len_x == len_x && c->geom.len_y == len_y && c->geom.pos_x == pos_x &&
+                             c->geom.pos_y == pos_y && c->tables[slot].valid && c->field_elems[slot] >= elems;
+  if (same_geometry) {
+    int init[6] = {0x7fffffff, 0x7fffffff, -1, -1, 0, 0}, got[6];
+    int* d_out = reinterpret_cast<int*>(c->d_diff);
+    HIP_TRY(c, hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(layer_diff_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream, d_layer, rows, cols,
+                       (const float*)c->field_data[slot], d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(got, d_out, sizeof(got), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (got[0] > got[2]) return ARTP_OK;  // bit-identical: the installed layer and its tables stand
+    const int nx = got[2] - got[0] + 1, nz = got[3] - got[1] + 1;
+    if ((size_t)nx * nz * 4 <= elems) {
+      c->map_version.fetch_add(1, std::memory_order_release);
+      const int dirty[4] = {got[0], got[1], got[2], got[3]};
+      PartnerRects pr;
+      int rc = partner_update_begin(c, slot, dirty, 1, &pr);  // the old triangles' contributions: before the copy
+      if (rc != ARTP_OK) return rc;
+      hipLaunchKernelGGL(copy_rect_to_ode_layout_kernel, dim3((unsigned)((nx * nz + 255) / 256)), dim3(256), 0, c->stream,
+                         d_layer, rows, cols, got[0], got[1], nx, nz, c->field_data[slot]);
+      HIP_TRY(c, hipGetLastError());
+      c->field[slot].has_nan = got[5];          // exact: the flags are those of the whole new layer
+      c->layer_has_nonfinite[slot] = got[4];
+      return build_tables(c, slot, &pr);
+    }
+  }
   int rc = ensure_field_storage(c, slot, elems);
   if (rc != ARTP_OK) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
@@ -938,10 +1010,7 @@ static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer,
   hipLaunchKernelGGL(flip_to_ode_layout_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream, d_layer,
                      rows, cols, c->field_data[slot], d_flags);
   HIP_TRY(c, hipGetLastError());
-  std::vector<float>& host = c->field_host[slot];
-  host.resize(elems);
   int flags[2] = {0, 0};
-  HIP_TRY(c, hipMemcpyAsync(host.data(), c->field_data[slot], elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, flags[1], flags[0]);
@@ -1014,7 +1083,6 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
   }
   RectDev* h_rec = static_cast<RectDev*>(c->rect_stage_host);
   float* h_pat = reinterpret_cast<float*>(static_cast<char*>(c->rect_stage_host) + rec_bytes);
-  std::vector<float>& host = c->field_host[slot];
   int has_nan = c->field[slot].has_nan, has_nonfinite = c->layer_has_nonfinite[slot];
   size_t off = 0;
   for (int k = 0; k < n_rects; ++k) {
@@ -1029,9 +1097,6 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
       has_nan |= (v != v);
       has_nonfinite |= !std::isfinite(v);
     }
-    for (int jj = 0; jj < ncols; ++jj)  // host mirror (ODE layout), kept for diagnostics
-      std::memcpy(host.data() + (size_t)row0 + (size_t)(cols - 1 - (col0 + jj)) * rows, patches[k] + (size_t)jj * nrows,
-                  sizeof(float) * nrows);
     off += cells;
   }
   c->field[slot].has_nan = has_nan;

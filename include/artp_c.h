@@ -404,7 +404,10 @@ int artp_inpaint_layer(artp_ctx* ctx, const float* layer, int rows, int cols, in
  * vertex density), traversability_sample_filter, updated (rows x cols floats each) or cum_prob_rowwise (rows). */
 int artp_preprocessed_get_layer(artp_ctx* ctx, const artp_preprocessed* pp, const char* name, float* out);
 /* Planner::setMap (planner.cpp:135-163): make the result the context's map -- both height fields with
- * their tables, the sampler layers and the z bounds. */
+ * their tables, the sampler layers and the z bounds.  When the context already holds a map of the same geometry, each
+ * height field is compared with the installed one bit for bit first: an identical layer keeps its tables, a layer that
+ * differs inside a rectangle of at most a quarter of the map is rewritten there only and its tables take the
+ * rectangle-update path (artp_update_layer_rects) -- the same tables as a fresh install, at the cost of the change. */
 int artp_preprocessed_install(artp_ctx* ctx, const artp_preprocessed* pp);
 /* Map::reApplyPreprocessing (art_planner/src/map/map.cpp:94-96), the part that can change on an unchanged map:
  * the sampling distribution re-weighted by the inverse density of the given roadmap vertices (DEVICE pointer,

@@ -61,6 +61,62 @@ def test_install_equals_host_upload():
     b.close()
 
 
+@pytest.mark.gpu
+def test_reinstall_takes_the_rectangle_path_and_equals_a_fresh_install():
+    """artp_preprocessed_install on a context that already holds a map of the same geometry compares the new height
+    fields with the installed ones bit for bit and rewrites only the rectangle that differs (tables through the
+    rectangle-update path).  After a small change, a no-op re-install and a large change the context must be
+    indistinguishable from a fresh one that installed the final map: partner tables of both slots, labels, edges,
+    the sampler's states; the map version moves with every install that changed something."""
+    from art_planner_amd.context import Context
+    from synthetic import make_map
+    gm = make_map(200, 0.04, seed=5)
+    elev = gm["elevation"].copy()
+    a = Context(0, "yaml")
+
+    def install(ctx, e):
+        pp = ctx.preprocess_map(e, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y, traversability=gm["traversability"])
+        pp.install()
+        return pp
+
+    def same_as_fresh(e, tag):
+        b = Context(0, "yaml")
+        ppb = install(b, e)
+        for slot in (0, 1):
+            ta, ra = a.partner_table(slot, (gm.rows, gm.cols))
+            tb, rb = b.partner_table(slot, (gm.rows, gm.cols))
+            assert ra == rb > 0 and np.array_equal(ta, tb), (tag, slot, int((ta != tb).sum()))
+        se3 = b.sample_states(3, 0, 1 << 16)
+        assert np.array_equal(a.sample_states(3, 0, 1 << 16), se3, equal_nan=True), tag   # a NaN cell gives a NaN z
+        assert np.array_equal(a.validate_states(se3), b.validate_states(se3)), tag
+        fin = se3[np.isfinite(se3).all(axis=1)]                   # the edge entry points refuse non-finite states
+        va, na = a.check_edges_interp(fin[:3000], fin[1:3001])
+        vb, nb = b.check_edges_interp(fin[:3000], fin[1:3001])
+        assert np.array_equal(va, vb) and np.array_equal(na, nb), tag
+        assert np.array_equal(a.check_motions(fin[:500], fin[1:501]), b.check_motions(fin[:500], fin[1:501])), tag
+        ppb.close()
+        b.close()
+
+    pps = [install(a, elev)]
+    v0 = a.map_version()
+    elev[60:85, 90:130] += np.float32(0.07)                       # a small patch: the rectangle path
+    elev[70, 100] = np.nan                                        # ... that brings the layer's first NaN
+    pps.append(install(a, elev))
+    v1 = a.map_version()
+    assert v1 > v0
+    same_as_fresh(elev, "small change")
+    pps.append(install(a, elev))                                  # nothing changed
+    same_as_fresh(elev, "no change")
+    elev[70, 100] = elev[70, 101]                                 # the NaN goes again: the flags must follow
+    elev[10:190, 5:195] -= np.float32(0.02)                       # most of the map: the whole-layer path
+    pps.append(install(a, elev))
+    assert a.map_version() > v1
+    same_as_fresh(elev, "large change")
+    for pp in pps:
+        pp.close()
+    a.close()
+
+
 def _gauss_taps(k, sigma):
     """cv::getGaussianKernel: float taps exp(-x^2 / (2 sigma^2)), normalised by their (double) sum."""
     x = np.arange(k) - (k - 1) * 0.5
