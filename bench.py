@@ -998,20 +998,38 @@ def main():
     try:
         if args.skip_extras:
             raise RuntimeError("skipped (--skip-extras)")
-        pre_ms, inst_ms = [], []
-        for _ in range(5):
+        # three kinds of install: a map the context has not seen (all tables built: alternating between two different
+        # maps), the same map with a 40 x 40 patch changed (the install diffs the height fields on the device and takes
+        # the rectangle path), the identical map again (nothing to do but the sampler layers and the diff itself)
+        pre_ms, inst_new, inst_patch, inst_same = [], [], [], []
+        other = raw_map(args.map, args.res, seed=4321)
+        e_a, e_b = gm["elevation"], other["elevation"]
+        e_p = e_a.copy()
+        e_p[180:220, 150:190] += np.float32(0.05)
+
+        def one(elev, trav, sink):
             t0 = time.perf_counter()
-            pp = ctx.preprocess_map(gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y,
-                                    traversability=gm["traversability"])
+            pp = ctx.preprocess_map(elev, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y, traversability=trav)
             t1 = time.perf_counter()
             pp.install()
             ctx.synchronize()
             t2 = time.perf_counter()
             pp.close()
             pre_ms.append((t1 - t0) * 1e3)
-            inst_ms.append((t2 - t1) * 1e3)
+            sink.append((t2 - t1) * 1e3)
+
+        for r_ in range(5):
+            one(e_b if r_ % 2 == 0 else e_a, other["traversability"] if r_ % 2 == 0 else gm["traversability"], inst_new)
+        one(e_a, gm["traversability"], [])
+        for r_ in range(5):
+            one(e_p if r_ % 2 == 0 else e_a, gm["traversability"], inst_patch)
+        one(e_a, gm["traversability"], [])
+        for r_ in range(5):
+            one(e_a, gm["traversability"], inst_same)
         preprocess = {"preprocess_ms_incl_h2d": float(np.median(pre_ms)),
-                      "install_ms_incl_tables": float(np.median(inst_ms)), "map": f"{gm.rows}x{gm.cols}"}
+                      "install_ms_incl_tables": float(np.median(inst_new)),
+                      "reinstall_ms_40x40_patch_changed": float(np.median(inst_patch)),
+                      "reinstall_ms_identical_map": float(np.median(inst_same)), "map": f"{gm.rows}x{gm.cols}"}
     except Exception as ex:  # pragma: no cover
         preprocess = {"error": repr(ex)}
 
