@@ -1875,15 +1875,19 @@ int artp_materialise_from_bits_dev(artp_ctx* c, uint64_t seed, const uint64_t* b
                      reinterpret_cast<unsigned long long*>(counts_dev));
   RankBases bases{};
   for (int r = 0; r < n_ranks; ++r) bases.base[r] = base_index[r];
-  const dim3 grid((unsigned)((words + 7) / 8), (unsigned)n_ranks);  // a wavefront per pair of words, four per workgroup
+  // a lane per output state: at most min(cap, prefix) of them per rank (the kernel reads the rank's count)
+  const size_t max_out = cap < prefix_bits ? cap : prefix_bits;
+  const dim3 grid((unsigned)((max_out + 255) / 256), (unsigned)n_ranks);
   if (c->sampler.from_distribution)
     hipLaunchKernelGGL(materialise_from_bits_kernel<true>, grid, dim3(256), 0, c->stream, c->sampler, c->geom, c->robot, seed,
                        bases, reinterpret_cast<const unsigned long long*>(bits), words_per_rank, words, prefix_bits,
-                       (const unsigned*)offsets, (const unsigned*)tile_tot, (int)n_tiles, cap, se3_out);
+                       (const unsigned*)offsets, (const unsigned*)tile_tot, (int)n_tiles, cap,
+                       reinterpret_cast<const unsigned long long*>(counts_dev), se3_out);
   else
     hipLaunchKernelGGL(materialise_from_bits_kernel<false>, grid, dim3(256), 0, c->stream, c->sampler, c->geom, c->robot, seed,
                        bases, reinterpret_cast<const unsigned long long*>(bits), words_per_rank, words, prefix_bits,
-                       (const unsigned*)offsets, (const unsigned*)tile_tot, (int)n_tiles, cap, se3_out);
+                       (const unsigned*)offsets, (const unsigned*)tile_tot, (int)n_tiles, cap,
+                       reinterpret_cast<const unsigned long long*>(counts_dev), se3_out);
   HIP_TRY(c, hipGetLastError());
   return ARTP_OK;
 }

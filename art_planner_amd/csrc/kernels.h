@@ -727,16 +727,9 @@ bits_word_offsets_kernel(const unsigned long long* __restrict__ bits, size_t wor
 
 struct RankBases { unsigned long long base[16]; };  // first global sample index of every rank's batch
 
-// position of the k-th (0-based) set bit of the 128-bit mask (lo, hi); k < popcount
-__device__ __forceinline__ int select_bit128(unsigned long long lo, unsigned long long hi, int k) {
-  const int c = __popcll(lo);
-  unsigned long long v = lo;
+// position of the k-th (0-based) set bit of a 64-bit word; k < popcount
+__device__ __forceinline__ int select_bit64(unsigned long long v, int k) {
   int pos = 0;
-  if (k >= c) {
-    k -= c;
-    v = hi;
-    pos = 64;
-  }
 #pragma unroll
   for (int w = 32; w >= 1; w >>= 1) {
     const int cnt = __popcll(v & ((1ull << w) - 1ull));
@@ -749,42 +742,47 @@ __device__ __forceinline__ int select_bit128(unsigned long long lo, unsigned lon
   return pos;
 }
 
-// One wavefront per PAIR of bitmap words: lane k of round j re-samples the pair's (64 j + k)-th accepted state -- at
-// the usual 40 % acceptance one round with ~54 of 64 lanes busy, where a lane per bit kept 27 busy.
+// One lane per OUTPUT state: lane j of rank r finds the bitmap word that holds the rank's j-th accepted candidate -- the
+// tile by walking the (<= 64) tile totals, the word by a binary search over the tile's 1024 exclusive offsets, the bit by
+// select -- and re-samples that candidate.  Every lane has a state to make and consecutive lanes write consecutive
+// rows (the earlier form, a wavefront per pair of bitmap words, kept ~47 of 64 lanes busy on the words it needed and
+// launched two thirds of its wavefronts only to find them beyond the requested prefix: 60 us for 65 536 states).
 template <bool FROM_DIST>
 __global__ void __launch_bounds__(256)
 materialise_from_bits_kernel(SamplerDev sm, MapGeom g, RobotDev rb, uint64_t seed, RankBases bases,
                              const unsigned long long* __restrict__ bits, size_t words_per_rank, size_t words,
                              size_t prefix_bits, const unsigned* __restrict__ offsets,
                              const unsigned* __restrict__ tile_tot, int n_tiles, size_t cap,
-                             double* __restrict__ out /*[ranks][cap][7]*/) {
+                             const unsigned long long* __restrict__ counts, double* __restrict__ out /*[ranks][cap][7]*/) {
   __shared__ float row_cdf_lds[ARTP_ROW_CDF_LDS];
   const float* row_cdf = stage_row_cdf(sm, g, row_cdf_lds);
-  const int r = blockIdx.y, lane = threadIdx.x & 63;
-  const size_t w = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;  // first word of the wavefront's pair
-  if (w >= words) return;
-  // accepted states in front of the pair = the tiles in front of its tile (<= 64 of them at 2^22 candidates: a lane
-  // each, summed across the wavefront) + the word's offset within the tile
-  const int tile = (int)(w / ARTP_BITS_TILE);
-  unsigned tsum = 0;
-  for (int k = lane; k < tile; k += 64) tsum += tile_tot[(size_t)r * n_tiles + k];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
-  const unsigned first = tsum + offsets[(size_t)r * words + w];
-  if (first >= cap) return;  // wave-uniform: everything from here on lies beyond the requested prefix
-  const unsigned long long* b = bits + (size_t)r * words_per_rank;
-  const unsigned long long lo = masked_word(b, w, words, prefix_bits), hi = masked_word(b, w + 1, words, prefix_bits);
-  const int total = __popcll(lo) + __popcll(hi);
-  for (int k = lane; k < total; k += 64) {
-    const unsigned rank = first + (unsigned)k;
-    if (rank >= cap) break;
-    const int bit = select_bit128(lo, hi, k);
-    double st[7];
-    sample_one<FROM_DIST>(sm, g, rb, seed, bases.base[r] + w * 64 + (unsigned)bit, st, row_cdf);
-    double* o = out + ((size_t)r * cap + rank) * 7;
-#pragma unroll
-    for (int q = 0; q < 7; ++q) o[q] = st[q];
+  const int r = blockIdx.y;
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t have = counts[r] < cap ? (size_t)counts[r] : cap;
+  if (j >= have) return;
+  unsigned rest = (unsigned)j;
+  int tile = 0;
+  for (; tile < n_tiles - 1; ++tile) {
+    const unsigned tt = tile_tot[(size_t)r * n_tiles + tile];
+    if (rest < tt) break;
+    rest -= tt;
   }
+  // the last word of the tile whose exclusive offset is <= rest (it holds the bit: the next offset is larger)
+  const size_t w_first = (size_t)tile * ARTP_BITS_TILE;
+  const size_t w_end = w_first + ARTP_BITS_TILE < words ? w_first + ARTP_BITS_TILE : words;
+  const unsigned* off = offsets + (size_t)r * words;
+  size_t lo = w_first, hi = w_end;  // invariant: off[lo] <= rest, answer in [lo, hi)
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) >> 1;
+    if (off[mid] <= rest) lo = mid; else hi = mid;
+  }
+  const unsigned long long word = masked_word(bits + (size_t)r * words_per_rank, lo, words, prefix_bits);
+  const int bit = select_bit64(word, (int)(rest - off[lo]));
+  double st[7];
+  sample_one<FROM_DIST>(sm, g, rb, seed, bases.base[r] + lo * 64 + (unsigned)bit, st, row_cdf);
+  double* o = out + ((size_t)r * cap + j) * 7;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) o[q] = st[q];
 }
 
 // ---- R7 ------------------------------------------------------------------------------------------
