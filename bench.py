@@ -396,6 +396,9 @@ def main():
     ap.add_argument("--materialise", type=int, default=1 << 16,
                     help="N>1: accepted states of EVERY rank re-materialised on every rank per step, per rank block "
                          "(-1 = all of them, 0 = none; the gathered index lists are always complete)")
+    ap.add_argument("--materialise-on", choices=["main", "comm"], default="comm",
+                    help="stream the re-materialisation runs on: lane 0's (between two batches) or the exchange's side "
+                         "stream, right behind the all-gather (beside the next batch)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-gather path even with one rank (self-test)")
     args = ap.parse_args()
@@ -501,6 +504,11 @@ def main():
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
         for e in done_ev:
             e.record()
+        if args.materialise_on == "comm":
+            ctx.set_lane(3)                      # a lane of its own (stream, scratch) for the side stream's launches
+            with torch.cuda.stream(comm):
+                ctx.use_torch_stream()
+            ctx.set_lane(0)
         try:  # trial exchange outside the timed region; a failing collective must not lose the whole run
             ctx.pack_valid_bits_dev(valid, bits_buf[0])
             gatherers[0].gather(bits_buf[0])
@@ -512,9 +520,10 @@ def main():
     if do_gather:
         setup_gather()
 
-    def materialise(j):
+    def materialise(j, wait=True):
         gb = gatherers[j & 1]
-        torch.cuda.current_stream().wait_event(done_ev[j & 1])
+        if wait:
+            torch.cuda.current_stream().wait_event(done_ev[j & 1])
         prefix = S if mat_cap >= cap else min(S, 8 * mat_cap)
         # every rank's accepted states in ONE call (two launches whatever N is): rank r's first mat_cap accepted states
         # among its first `prefix` candidates, re-sampled from (seed, global index)
@@ -541,12 +550,17 @@ def main():
                 comm.wait_event(ev)
             with torch.cuda.stream(comm):
                 gatherers[b].gather(bits_buf[b])               # one bit per candidate state over xGMI
+                if args.materialise_on == "comm" and mat_cap > 0:
+                    ctx.set_lane(3)
+                    materialise(i, wait=False)                 # same stream, right behind the all-gather
+                    ctx.set_lane(0)
                 done_ev[b].record()
-            # materialise the accepted states of every rank for the PREVIOUS step (its gather has had a
-            # whole step to complete).  On lane 0's stream: the validity kernels are persistent grids with static
-            # striding, and a kernel that shares their CUs from a side stream costs them more than it hides
-            # (measured: +0.36 ms for 0.15 ms of work).
-            if i > 0 and mat_cap > 0:
+            # --materialise-on main: the accepted states of every rank for the PREVIOUS step (its gather has had a whole
+            # step to complete) on lane 0's stream, between two batches.  That was the better place while the
+            # re-materialisation was a 0.15 ms kernel (beside the persistent validity grids it cost them +0.36 ms); the
+            # lane-per-output-state kernel is short enough to ride behind the all-gather on the side stream (default:
+            # +1.2 % per step against `main`).
+            if i > 0 and mat_cap > 0 and args.materialise_on == "main":
                 materialise(i - 1)
 
     def timed_region(n_steps):
@@ -557,7 +571,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i)
-        if do_gather and mat_cap > 0:
+        if do_gather and mat_cap > 0 and args.materialise_on == "main":
             materialise(n_steps - 1)
         torch.cuda.synchronize()
         if dist is not None:
