@@ -450,6 +450,8 @@ def main():
     # end of one part's pipeline overlap another part's long kernels.  Default 1 = everything on one stream (what the
     # per-kernel profiles and `roofline.kernel_ms` use): on the final kernels a second lane no longer pays.
     lanes = max(1, min(4, args.lanes))
+    if lanes == 4 and args.materialise_on == "comm":
+        args.materialise_on = "main"  # lane 3 is taken by the fourth batch part
     if S % (128 * lanes):
         raise SystemExit("--batch must be a multiple of 128 * lanes")
     part = S // lanes
