@@ -1540,8 +1540,8 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
     return ARTP_ERR_CAPACITY;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n) | first_bad (n) | total64, overflow flag
-  int rc = ensure_tmp(c, 2, (4 * n + 2) * sizeof(uint32_t) + 32);
+  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n) | first_bad (n) | total64, overflow flag | slerp constants (n x 24 B)
+  int rc = ensure_tmp(c, 2, (4 * n + 2) * sizeof(uint32_t) + 48 + n * sizeof(SlerpEdge));
   if (rc) return rc;
   uint32_t* counts = static_cast<uint32_t*>(c->tmp[2]);
   uint32_t* offsets = counts + (n + 1);
@@ -1550,12 +1550,13 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   unsigned long long* d_total = reinterpret_cast<unsigned long long*>(
       (reinterpret_cast<uintptr_t>(first_bad + n) + 7) & ~(uintptr_t)7);
   int* d_overflow = reinterpret_cast<int*>(d_total + 1);
+  SlerpEdge* d_slerp = reinterpret_cast<SlerpEdge*>(d_total + 2);  // 8-byte aligned like d_total
   HIP_TRY(c, hipMemsetAsync(counts + n, 0, sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(d_total, 0, 16, c->stream));
   size_t blocks = (n + 255) / 256;
   if (blocks > (size_t)c->n_cus * 4) blocks = (size_t)c->n_cus * 4;  // grid-stride; one atomic per workgroup on the total
   hipLaunchKernelGGL(motion_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->geom,
-                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total);
+                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total, d_slerp);
   HIP_TRY(c, hipGetLastError());
   size_t need = 0;
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(n + 1), c->stream));
@@ -1594,7 +1595,8 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
     uint32_t* edge_of = static_cast<uint32_t*>(c->tmp[3]);
     uint8_t* ex_valid = reinterpret_cast<uint8_t*>(edge_of + total);
     hipLaunchKernelGGL(expand_edges_recs_kernel, dim3((unsigned)eb), dim3(256), 0, c->stream, c->field[0], mode, s1, s2, n,
-                       (const uint32_t*)offsets, (const uint32_t*)aux, static_cast<PoseRec*>(c->tmp[7]), edge_of);
+                       (const uint32_t*)offsets, (const uint32_t*)aux, (const SlerpEdge*)d_slerp,
+                       static_cast<PoseRec*>(c->tmp[7]), edge_of);
     HIP_TRY(c, hipGetLastError());
     rc = launch_validate_pipeline(c, nullptr, total, ex_valid, true);
     if (rc) return rc;

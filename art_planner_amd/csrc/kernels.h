@@ -794,20 +794,34 @@ __device__ __forceinline__ double so3_arc_length(const double* q1, const double*
   return acos(dq);
 }
 
-// OMPL SE3StateSpace::interpolate: R^3 lerp + SO3 slerp.
-__device__ __forceinline__ void se3_interpolate(const double* a, const double* b, double t,
-                                                double* out) {
+// OMPL SE3StateSpace::interpolate: R^3 lerp + SO3 slerp.  The part of the slerp that depends on the two end states only
+// (arc length: an acos; 1 / sin(theta); the sign of the quaternion dot product) is its own function: an edge has ~50
+// interior states, and the expansion kernel takes these three numbers per edge from the planning kernel instead of
+// forming them per state (the same operations on the same inputs: the same bits).
+struct SlerpEdge { double theta, inv_sin, sgn; };  // inv_sin / sgn only meaningful when theta > DBL_EPSILON
+__device__ __forceinline__ SlerpEdge slerp_edge(const double* q1, const double* q2) {
+  SlerpEdge e;
+  e.theta = so3_arc_length(q1, q2);
+  e.inv_sin = 0.0;
+  e.sgn = 1.0;
+  if (e.theta > 2.220446049250313e-16) {
+    e.inv_sin = 1.0 / sin(e.theta);
+    const double dq = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+    if (dq < 0) e.sgn = -1.0;
+  }
+  return e;
+}
+__device__ __forceinline__ void se3_interpolate_pre(const double* a, const double* b, double t, const SlerpEdge& e,
+                                                    double* out) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) out[i] = a[i] + (b[i] - a[i]) * t;
   const double* q1 = a + 3;
   const double* q2 = b + 3;
-  const double theta = so3_arc_length(q1, q2);
-  if (theta > 2.220446049250313e-16) {
-    const double d = 1.0 / sin(theta);
-    const double s0 = sin((1.0 - t) * theta);
-    double s1 = sin(t * theta);
-    const double dq = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
-    if (dq < 0) s1 = -s1;
+  if (e.theta > 2.220446049250313e-16) {
+    const double d = e.inv_sin;
+    const double s0 = sin((1.0 - t) * e.theta);
+    double s1 = sin(t * e.theta);
+    if (e.sgn < 0) s1 = -s1;
     out[3] = (q1[0] * s0 + q2[0] * s1) * d;
     out[4] = (q1[1] * s0 + q2[1] * s1) * d;
     out[5] = (q1[2] * s0 + q2[2] * s1) * d;
@@ -818,6 +832,10 @@ __device__ __forceinline__ void se3_interpolate(const double* a, const double* b
     out[5] = q1[2];
     out[6] = q1[3];
   }
+}
+__device__ __forceinline__ void se3_interpolate(const double* a, const double* b, double t,
+                                                double* out) {
+  se3_interpolate_pre(a, b, t, slerp_edge(a + 3, b + 3), out);
 }
 
 // mode 0: DiscreteMotionValidator::checkMotion -> tasks = 1 (s2) + max(nd-1, 0), nd = validSegmentCount
@@ -839,7 +857,7 @@ __global__ void __launch_bounds__(256)
 motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restrict__ s1,
                    const double* __restrict__ s2, size_t n, uint32_t* __restrict__ counts,
                    uint32_t* __restrict__ aux, uint8_t* __restrict__ valid, int* __restrict__ overflow,
-                   unsigned long long* __restrict__ total64) {
+                   unsigned long long* __restrict__ total64, SlerpEdge* __restrict__ slerp) {
   unsigned long long my_total = 0;
   int my_overflow = 0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
@@ -880,6 +898,7 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
     counts[e] = cnt;
     aux[e] = ax;
     valid[e] = 1;
+    if (slerp) slerp[e] = slerp_edge(a + 3, b + 3);
     my_total += cnt;
   }
 #pragma unroll
@@ -905,7 +924,7 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
 __global__ void __launch_bounds__(256)
 expand_edges_recs_kernel(FieldDev f, int mode, const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
-                         PoseRec* __restrict__ recs, uint32_t* __restrict__ edge_of) {
+                         const SlerpEdge* __restrict__ slerp, PoseRec* __restrict__ recs, uint32_t* __restrict__ edge_of) {
   __shared__ float4 stage[4][64 * 4];
   const int lane = threadIdx.x & 63;
   float4* rw = stage[threadIdx.x >> 6];
@@ -930,12 +949,12 @@ expand_edges_recs_kernel(FieldDev f, int mode, const double* __restrict__ s1, co
           for (int i = 0; i < 7; ++i) st[i] = b[i];
         } else {
           const uint32_t nd = aux[e];
-          se3_interpolate(a, b, (double)k / (double)nd, st);
+          se3_interpolate_pre(a, b, (double)k / (double)nd, slerp[e], st);
         }
       } else {
         const uint32_t n_interp = aux[e];
         const double n_interp_div = 1.0 / (n_interp + 1);
-        se3_interpolate(a, b, (k + 1) * n_interp_div, st);
+        se3_interpolate_pre(a, b, (k + 1) * n_interp_div, slerp[e], st);
       }
       float4 r[4];
       make_pose_rec(f, st, r);
