@@ -168,7 +168,7 @@ class IncrementalPRM:
 
 
 def build_and_solve(om, rob, interpolate, accepted, start, goal, max_n_vertices=10000, max_n_edges=50000,
-                    max_lon_vel=0.5, cost_fn=None):
+                    max_lon_vel=0.5, cost_fn=None, max_replans=1000):
     """sampleGraph over the accepted-state stream, then baseSolve: start and goal join as milestones, A* + lazy edge
     check.  Returns a dict of counts, the path and its cost."""
     g = IncrementalPRM(om, rob, interpolate, max_lon_vel, cost_fn)
@@ -180,13 +180,14 @@ def build_and_solve(om, rob, interpolate, accepted, start, goal, max_n_vertices=
         used += 1
     vs = g.add_valid_milestone(np.asarray(start, np.float64))
     vg = g.add_valid_milestone(np.asarray(goal, np.float64))
-    p, c, removed, checked = g.solve(vs, vg)
+    p, c, removed, checked = g.solve(vs, vg, max_replans)
     return {"milestones_used": used, "vertices": g.nv, "chain_vertices": int(g.nv - sum(g.is_milestone)),
             "edges": len(g.edges) + removed, "interior_states_checked": g.states_checked, "lazy_removals": removed,
             "lazy_edges_checked": checked, "path_cost": c, "path": None if p is None else g.verts[p].copy(), "graph": g}
 
 
-def lazy_prm_star_min_update(om, rob, accepted, start, goal, n_milestones, max_lon_vel=0.5, cost_fn=None):
+def lazy_prm_star_min_update(om, rob, accepted, start, goal, n_milestones, max_lon_vel=0.5, cost_fn=None,
+                             max_replans=1000):
     """BASELINE config 1's planner, literally: LazyPRMStarMinUpdate (lazy_prm_star_min_update.cpp).
       baseSolve (:496-615): start and goal become milestones FIRST (:507-535), then one accepted sample at a time
       (`do sampleUniform while !isValid`, :552-555) through addValidMilestone (:424-446): the k = ceil(e (1 + 1/6) ln n)
@@ -214,6 +215,6 @@ def lazy_prm_star_min_update(om, rob, accepted, start, goal, n_milestones, max_l
     for s in accepted[:n_milestones]:
         add(s)
         used += 1
-    p, c, removed, checked = g.solve(vs, vg)
+    p, c, removed, checked = g.solve(vs, vg, max_replans)
     return {"milestones_used": used, "vertices": g.nv, "edges": len(g.edges) + removed, "lazy_removals": removed,
             "lazy_edges_checked": checked, "path_cost": c, "path": None if p is None else g.verts[p].copy(), "graph": g}
