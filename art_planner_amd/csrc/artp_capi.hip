@@ -2242,7 +2242,14 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
     return ARTP_ERR_INVALID_ARG;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, c->stream, edges, b, (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
+  // up to 2^16 edges (a roadmap update's query): four lanes per edge; above that a lane per edge fills the GPU.  Both
+  // kernels accumulate every unit in the same order: the same bits
+  if (b <= (1u << 16))
+    hipLaunchKernelGGL(fc_cost_split_kernel, dim3((unsigned)((b + FC_SPLIT_EDGES - 1) / FC_SPLIT_EDGES)), dim3(256), 0, c->stream,
+                       edges, b, (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
+  else
+    hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, c->stream, edges, b,
+                       (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
   HIP_TRY(c, hipGetLastError());
   return ARTP_OK;
 }

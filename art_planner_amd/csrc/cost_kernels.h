@@ -699,4 +699,136 @@ fc_cost_kernel(const float* __restrict__ edges, size_t B, const half_t* __restri
   cost[3 * e + 2] = 1.0f - prob;  // cost_query.py:65-69 returns cost[3] = 1 - prob
 }
 
+// Small batches (a roadmap update of the reference queries ~50 000 edges): one lane per edge leaves most of the GPU idle
+// behind ~7 300 dependent FMAs per lane (76 us for 50 000 edges).  Here FOUR lanes share an edge: every lane forms the
+// edge's 64 inputs itself (the loads hit the L1, tar0 is 160 FMAs), then computes a quarter of the 48 hidden units, and
+// -- after the hidden layer went through LDS -- a quarter of the 84 head units; one lane adds the heads up in the same
+// order as fc_cost_kernel.  Every unit is still accumulated by one lane over k ascending: the results are bit-identical
+// to fc_cost_kernel's.  The weights are lane-varying operands now (the part index), so they come from LDS (16-byte
+// reads, four distinct addresses per wavefront).  A wavefront = 16 edges x 4 parts, part = lane / 16.
+#define FC_SPLIT_EDGES 64
+#define FC_SPLIT_HSTRIDE 84
+__global__ void __launch_bounds__(256)
+fc_cost_split_kernel(const float* __restrict__ edges, size_t B, const half_t* __restrict__ feat, CostMapGeom g,
+                     const float* __restrict__ wts, float* __restrict__ cost) {
+  __shared__ __attribute__((aligned(16))) float w[(FcWeights::TOTAL + 3) & ~3];
+  // per edge: the 48 hidden units, then -- once the four lanes hold them in registers -- the 84 head units over them
+  __shared__ __attribute__((aligned(16))) float hs[FC_SPLIT_EDGES][FC_SPLIT_HSTRIDE];
+  float (*as_)[FC_SPLIT_HSTRIDE] = hs;
+  {
+    // the blob is 16-byte aligned (hipMalloc) and the LDS copy padded to a multiple of four floats
+    const float4* src = reinterpret_cast<const float4*>(wts);
+    float4* dst = reinterpret_cast<float4*>(w);
+    for (int i = threadIdx.x; i < FcWeights::TOTAL / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = (FcWeights::TOTAL / 4) * 4 + threadIdx.x; i < FcWeights::TOTAL; i += blockDim.x) w[i] = wts[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane >> 4, el = wave * 16 + (lane & 15);
+  const size_t e_raw = (size_t)blockIdx.x * FC_SPLIT_EDGES + el;
+  const bool live = e_raw < B;
+  const size_t e = live ? e_raw : B - 1;
+  const float* ed = edges + 6 * e;
+  const double tx = ed[0], ty = ed[1], tyaw = ed[2], sx = ed[3], sy = ed[4], syaw = ed[5];
+  double pr = (sx - g.cx) / g.feat_res + (double)g.row_bias;
+  double pc = (sy - g.cy) / g.feat_res + (double)g.col_bias;
+  pr = pr < 1.0 ? 1.0 : (pr > (double)(g.F - 2) ? (double)(g.F - 2) : pr);
+  pc = pc < 1.0 ? 1.0 : (pc > (double)(g.F - 2) ? (double)(g.F - 2) : pc);
+  const int row = (int)pr, col = (int)pc;
+  const half_t* fp = feat + ((size_t)row * g.F + col) * 48;
+  float x[64];
+#pragma unroll
+  for (int v = 0; v < 6; ++v) {
+    const half8 t8 = reinterpret_cast<const half8*>(fp)[v];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[v * 8 + j] = (float)t8[j];
+  }
+  const float dx = (float)(tx - sx), dy = (float)(ty - sy);
+  float dyaw = (float)(tyaw - syaw);
+  const float PI = 3.14159265358979323846f;
+  if (dyaw > PI) dyaw -= 2.0f * PI;
+  if (dyaw < -PI) dyaw += 2.0f * PI;
+  const float sya = (float)syaw;
+  float t[10];
+  t[0] = dx;
+  t[1] = dy;
+  t[2] = sqrtf(dx * dx + dy * dy);
+  t[3] = atan2f(dy, dx);
+  t[4] = dyaw;
+  t[5] = cosf(dyaw);
+  t[6] = sinf(dyaw);
+  t[7] = sya;
+  t[8] = cosf(sya);
+  t[9] = sinf(sya);
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float a = w[FcWeights::TAR0_B + o];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) a = fmaf(t[k], w[FcWeights::TAR0_W + o * 10 + k], a);
+    x[48 + o] = a;
+  }
+  // hidden units 12 part .. 12 part + 11
+  for (int oo = 0; oo < 12; ++oo) {
+    const int o = part * 12 + oo;
+    const float4* wr = reinterpret_cast<const float4*>(&w[FcWeights::OUT0_W + o * 64]);
+    float a = w[FcWeights::OUT0_B + o];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const float4 q = wr[k4];
+      a = fmaf(x[4 * k4 + 0], q.x, a);
+      a = fmaf(x[4 * k4 + 1], q.y, a);
+      a = fmaf(x[4 * k4 + 2], q.z, a);
+      a = fmaf(x[4 * k4 + 3], q.w, a);
+    }
+    hs[el][o] = a > 0.f ? a : 0.3f * a;
+  }
+  wave_lds_sync();
+  float h[48];
+#pragma unroll
+  for (int k4 = 0; k4 < 12; ++k4) {
+    const float4 q = reinterpret_cast<const float4*>(&hs[el][0])[k4];
+    h[4 * k4 + 0] = q.x;
+    h[4 * k4 + 1] = q.y;
+    h[4 * k4 + 2] = q.z;
+    h[4 * k4 + 3] = q.w;
+  }
+  wave_lds_sync();  // every lane of the wavefront has its edge's hidden units: the buffer is free for the head units
+  // head units: part p takes 6 of h1, 6 of h2, 9 of h3
+  for (int u = 0; u < 21; ++u) {
+    int wo, bo, slot;
+    if (u < 6) {
+      wo = FcWeights::H1_W + (part * 6 + u) * 48; bo = FcWeights::H1_B + part * 6 + u; slot = part * 6 + u;
+    } else if (u < 12) {
+      wo = FcWeights::H2_W + (part * 6 + u - 6) * 48; bo = FcWeights::H2_B + part * 6 + u - 6; slot = 24 + part * 6 + u - 6;
+    } else {
+      wo = FcWeights::H3_W + (part * 9 + u - 12) * 48; bo = FcWeights::H3_B + part * 9 + u - 12; slot = 48 + part * 9 + u - 12;
+    }
+    const float4* wr = reinterpret_cast<const float4*>(&w[wo]);
+    float a = w[bo];
+#pragma unroll
+    for (int k4 = 0; k4 < 12; ++k4) {
+      const float4 q = wr[k4];
+      a = fmaf(h[4 * k4 + 0], q.x, a);
+      a = fmaf(h[4 * k4 + 1], q.y, a);
+      a = fmaf(h[4 * k4 + 2], q.z, a);
+      a = fmaf(h[4 * k4 + 3], q.w, a);
+    }
+    as_[el][slot] = a > 0.f ? a : 0.3f * a;
+  }
+  wave_lds_sync();
+  if (part != 0 || !live) return;
+  float power = w[FcWeights::O1_B], tim = w[FcWeights::O2_B], prob = w[FcWeights::O3_B];
+  for (int o = 0; o < 24; ++o) {
+    power = fmaf(as_[el][o], w[FcWeights::O1_W + o], power);
+    tim = fmaf(as_[el][24 + o], w[FcWeights::O2_W + o], tim);
+  }
+  for (int o = 0; o < 36; ++o) prob = fmaf(as_[el][48 + o], w[FcWeights::O3_W + o], prob);
+  power = power > 0.f ? power : 0.f;
+  tim = tim > 0.f ? tim : 0.f;
+  prob = 1.0f / (1.0f + expf(-prob));
+  cost[3 * e + 0] = power;
+  cost[3 * e + 1] = tim;
+  cost[3 * e + 2] = 1.0f - prob;
+}
+
 }  // namespace artp

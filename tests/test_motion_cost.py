@@ -215,6 +215,13 @@ def test_gpu_cost_full_map_properties(big_map):
     # against the numpy oracle fed with the GPU's own feature map (isolates the per-edge MLP, fp32)
     co = mo.fc_costs(p, np.transpose(f, (2, 0, 1)), e[:4096], big_map.res, big_map.len_x, big_map.len_y)
     assert np.abs(c1[:4096] - co).max() < 1e-3
+    # batches up to 2^16 edges run four lanes per edge, larger ones a lane per edge: every unit is accumulated in the same
+    # order by both, so the same edge gets the same bits whichever batch it arrives in (ragged sizes included)
+    big = np.tile(e, (2, 1))[:70001]                       # > 2^16: the lane-per-edge kernel
+    cb = ctx.cost_query(big)
+    assert np.array_equal(cb[:B], c1) and np.array_equal(cb[B:], c1[:70001 - B])
+    for n_small in (1, 63, 64, 65, 4097):
+        assert np.array_equal(ctx.cost_query(e[:n_small]), c1[:n_small])
     ctx.close()
 
 
