@@ -23,6 +23,11 @@ SYMBOLS = [
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_pack_edge_results_dev", "artp_cost_update_map_dev", "artp_pack_valid_bits_dev", "artp_indices_from_bits_dev",
     "artp_materialise_from_bits_dev",
+    "artp_shard_first_index", "artp_group_create", "artp_group_unique_id", "artp_group_create_rank",
+    "artp_group_destroy", "artp_group_last_error", "artp_group_world_size", "artp_group_local_count",
+    "artp_group_rank", "artp_group_ctx", "artp_group_ranks_seen", "artp_group_configure",
+    "artp_group_sample_and_validate_step", "artp_group_step_buffers", "artp_group_exchange_edges",
+    "artp_group_edge_buffers", "artp_group_synchronize", "artp_group_abort",
     "artp_algorithmic_vertices_dev",
     "artp_debug_pipeline_counters", "artp_debug_partner_table", "artp_roadmap_params_defaults",
     "artp_roadmap_build", "artp_roadmap_stats", "artp_roadmap_export", "artp_roadmap_solve", "artp_roadmap_destroy",
@@ -65,6 +70,11 @@ class PreprocessInputs(C.Structure):  # artp_preprocess_inputs
     _fields_ = [("elevation", C.c_void_p), ("traversability", C.c_void_p), ("observed", C.c_void_p),
                 ("vertex_se3", C.c_void_p), ("n_vertices", C.c_size_t), ("rows", C.c_int), ("cols", C.c_int),
                 ("len_x", C.c_double), ("len_y", C.c_double), ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class GroupEdges(C.Structure):  # artp_group_edges
+    _fields_ = [("valid", C.c_void_p), ("edge_i", C.c_void_p), ("edge_j", C.c_void_p), ("cost", C.c_void_p),
+                ("n", C.c_size_t)]
 
 
 class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
@@ -139,6 +149,28 @@ def load():
     L.artp_pack_edge_results_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
     L.artp_pack_valid_bits_dev.argtypes = [vp, vp, sz, vp]
     L.artp_indices_from_bits_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.artp_shard_first_index.argtypes = [u64, i32, i32, u64]
+    L.artp_shard_first_index.restype = u64
+    L.artp_group_create.argtypes = [C.POINTER(i32), i32, C.POINTER(Params), i32, C.POINTER(vp)]
+    L.artp_group_unique_id.argtypes = [vp]
+    L.artp_group_create_rank.argtypes = [i32, i32, i32, vp, C.POINTER(Params), C.POINTER(vp)]
+    L.artp_group_destroy.argtypes = [vp]
+    L.artp_group_destroy.restype = None
+    L.artp_group_last_error.argtypes = [vp]
+    L.artp_group_last_error.restype = C.c_char_p
+    L.artp_group_world_size.argtypes = [vp]
+    L.artp_group_local_count.argtypes = [vp]
+    L.artp_group_rank.argtypes = [vp, i32]
+    L.artp_group_ctx.argtypes = [vp, i32]
+    L.artp_group_ctx.restype = vp
+    L.artp_group_ranks_seen.argtypes = [vp, C.POINTER(i32)]
+    L.artp_group_configure.argtypes = [vp, u64, sz, sz, sz]
+    L.artp_group_sample_and_validate_step.argtypes = [vp, u64]
+    L.artp_group_step_buffers.argtypes = [vp, i32, u64] + [C.POINTER(vp)] * 5
+    L.artp_group_exchange_edges.argtypes = [vp, C.POINTER(GroupEdges), sz]
+    L.artp_group_edge_buffers.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.artp_group_synchronize.argtypes = [vp, i32]
+    L.artp_group_abort.argtypes = [vp]
     L.artp_algorithmic_vertices_dev.argtypes = [vp, vp, sz, C.POINTER(u64)]
     L.artp_debug_pipeline_counters.argtypes = [vp, C.POINTER(u64 * 8)]
     L.artp_debug_partner_table.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int)]
@@ -183,7 +215,8 @@ def load():
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("artp_destroy", "artp_cost_blob_bytes", "artp_roadmap_destroy",
                                                   "artp_roadmap_params_defaults", "artp_preprocess_params_defaults",
-                                                  "artp_preprocess_params_yaml", "artp_preprocessed_destroy"):
+                                                  "artp_preprocess_params_yaml", "artp_preprocessed_destroy",
+                                                  "artp_group_destroy"):
             fn.restype = C.c_int
     _lib = L
     return L

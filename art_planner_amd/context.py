@@ -36,9 +36,21 @@ class Context:
         self.h = h
         self.device = device
 
+    @classmethod
+    def borrowed(cls, handle, device: int, params) -> "Context":
+        """View of an artp_ctx somebody else owns (a device group's member): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = _capi.load()
+        self.params = params
+        self.h = C.c_void_p(handle)
+        self.device = device
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.artp_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.L.artp_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -622,6 +622,8 @@ const char* artp_status_string(int s) {
     case ARTP_ERR_NO_MAP: return "required layer not uploaded";
     case ARTP_ERR_CAPACITY: return "box window exceeds the LDS tile capacity";
     case ARTP_ERR_NO_WEIGHTS: return "motion-cost weights not loaded";
+    case ARTP_ERR_TIMEOUT: return "timed out waiting for a device group";
+    case ARTP_ERR_COMM: return "RCCL unavailable or a communicator call failed";
     default: return "unknown status";
   }
 }
@@ -2295,6 +2297,7 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 
 #include "roadmap.h"
 #include "preprocess.h"
+#include "group.h"
 
 #ifdef ARTP_STAGE_TIMING
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {

@@ -17,8 +17,129 @@ import torch
 
 
 def shard_first_index(step: int, rank: int, world: int, batch: int) -> int:
-    """First global sample index of (step, rank)."""
+    """First global sample index of (step, rank) -- the same numbers as artp_shard_first_index of the C ABI."""
     return (step * world + rank) * batch
+
+
+class DeviceGroup:
+    """Python view of an artp_group (include/artp_c.h "multi-GPU"): the exchange steps behind the C ABI, over RCCL
+    bound directly by libartp.so -- no torch.distributed in the data path.  Two ways in, like the C entry points:
+    DeviceGroup.single_process(devices) and DeviceGroup.from_rank(device, rank, world, unique_id)."""
+
+    def __init__(self, handle, params):
+        import ctypes as C
+        from . import _capi
+        from .context import Context
+        self.L, self.h, self.params = _capi.load(), handle, params
+        self.world = self.L.artp_group_world_size(self.h)
+        self.n_local = self.L.artp_group_local_count(self.h)
+        self.ranks = [self.L.artp_group_rank(self.h, l) for l in range(self.n_local)]
+        self.contexts = []
+        for l in range(self.n_local):
+            ctx_h = self.L.artp_group_ctx(self.h, l)
+            self.contexts.append(Context.borrowed(ctx_h, -1, params))
+        self.batch = 0
+
+    @staticmethod
+    def _params(params):
+        from . import _capi
+        from .context import make_params
+        return params if isinstance(params, _capi.Params) else make_params(params)
+
+    @classmethod
+    def single_process(cls, devices, params="yaml", transport: int = 0) -> "DeviceGroup":
+        import ctypes as C
+        from . import _capi
+        L, p = _capi.load(), cls._params(params)
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = L.artp_group_create(arr, len(devices), C.byref(p), transport, C.byref(h))
+        if rc != 0:
+            raise _capi.ArtpError(f"artp_group_create failed: {L.artp_status_string(rc).decode()} ({rc})")
+        g = cls(h, p)
+        for l, d in enumerate(devices):
+            g.contexts[l].device = d
+        return g
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _capi
+        L = _capi.load()
+        buf = (C.c_uint8 * 128)()
+        rc = L.artp_group_unique_id(buf)
+        if rc != 0:
+            raise _capi.ArtpError(f"artp_group_unique_id failed: {L.artp_status_string(rc).decode()} ({rc})")
+        return bytes(buf)
+
+    @classmethod
+    def from_rank(cls, device: int, rank: int, world: int, unique_id: bytes, params="yaml") -> "DeviceGroup":
+        import ctypes as C
+        from . import _capi
+        L, p = _capi.load(), cls._params(params)
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        rc = L.artp_group_create_rank(device, rank, world, buf, C.byref(p), C.byref(h))
+        if rc != 0:
+            raise _capi.ArtpError(f"artp_group_create_rank failed: {L.artp_status_string(rc).decode()} ({rc})")
+        g = cls(h, p)
+        g.contexts[0].device = device
+        return g
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            from . import _capi
+            raise _capi.ArtpError(f"{what} failed: {self.L.artp_status_string(rc).decode()} ({rc}) "
+                                  f"{self.L.artp_group_last_error(self.h).decode()}")
+
+    def ranks_seen(self) -> int:
+        import ctypes as C
+        n = C.c_int(0)
+        self._chk(self.L.artp_group_ranks_seen(self.h, C.byref(n)), "artp_group_ranks_seen")
+        return n.value
+
+    def configure(self, seed: int, batch: int, materialise_cap: int = 0, prefix: int = 0):
+        self._chk(self.L.artp_group_configure(self.h, seed, batch, materialise_cap, prefix), "artp_group_configure")
+        self.batch, self.mat_cap = batch, min(materialise_cap, prefix or batch)
+
+    def step(self, step: int):
+        self._chk(self.L.artp_group_sample_and_validate_step(self.h, step), "artp_group_sample_and_validate_step")
+
+    def synchronize(self, timeout_ms: int = -1):
+        self._chk(self.L.artp_group_synchronize(self.h, timeout_ms), "artp_group_synchronize")
+
+    def abort(self):
+        self.L.artp_group_abort(self.h)
+
+    def step_pointers(self, local: int, step: int):
+        """(se3, valid, bits, states, counts) device addresses of member `local` for `step`."""
+        import ctypes as C
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self._chk(self.L.artp_group_step_buffers(self.h, local, step, *[C.byref(p) for p in ptrs]),
+                  "artp_group_step_buffers")
+        return tuple(p.value for p in ptrs)
+
+    def exchange_edges(self, per_local, cap: int):
+        """per_local: one (valid, edge_i, edge_j, cost, n) tuple of device addresses per local member."""
+        from . import _capi
+        arr = (_capi.GroupEdges * self.n_local)()
+        for l, (v, i, j, c, n) in enumerate(per_local):
+            arr[l].valid, arr[l].edge_i, arr[l].edge_j, arr[l].cost, arr[l].n = v, i, j, c, n
+        self._chk(self.L.artp_group_exchange_edges(self.h, arr, cap), "artp_group_exchange_edges")
+
+    def edge_pointers(self, local: int):
+        import ctypes as C
+        rec, cnt = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.artp_group_edge_buffers(self.h, local, C.byref(rec), C.byref(cnt)), "artp_group_edge_buffers")
+        return rec.value, cnt.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.contexts:
+                c.close()
+            self.L.artp_group_destroy(self.h)
+            self.h = None
 
 
 class ValidStateGatherer:

@@ -38,7 +38,9 @@ typedef enum {
   ARTP_ERR_HIP = -3,         /* a HIP runtime call failed; artp_last_error() has the text */
   ARTP_ERR_NO_MAP = -4,      /* a required layer was not uploaded (reference: hasMap() == false) */
   ARTP_ERR_CAPACITY = -5,    /* box too large for the LDS window tile of this context */
-  ARTP_ERR_NO_WEIGHTS = -6
+  ARTP_ERR_NO_WEIGHTS = -6,
+  ARTP_ERR_TIMEOUT = -7,     /* artp_group_synchronize: a member's stream did not finish in time */
+  ARTP_ERR_COMM = -8         /* RCCL missing, or a communicator call failed (artp_group_last_error) */
 } artp_status;
 
 /* Numeric fields of art_planner::Params the hot path reads
@@ -221,6 +223,73 @@ int artp_indices_from_bits_dev(artp_ctx* ctx, const uint64_t* bits, size_t n, ui
  * valid[e] != 0 in input order, *n_out_dev their number; the block is then all-gathered (RCCL). */
 int artp_pack_edge_results_dev(artp_ctx* ctx, const uint8_t* valid, const uint32_t* edge_i, const uint32_t* edge_j,
                                const float* cost, size_t n, uint32_t* records_out, uint64_t* n_out_dev);
+/* ---- multi-GPU: device groups --------------------------------------------------------------
+ * The path shards over independent sample batches: the map is replicated, rank r of W owns the states
+ * [ (step W + r) S, (step W + r + 1) S ) of the (seed, index) sample stream (artp_shard_first_index: gap-free for
+ * any W, so labels do not depend on W), and the exchange steps are all-gathers of fixed-size blocks over xGMI.
+ * A group owns, for every LOCAL device, one artp_ctx, one RCCL communicator (librccl is bound at run time with
+ * dlopen: libartp.so itself does not depend on it), a side stream for the collectives and the double-buffered
+ * exchange buffers.  This is what lets a C++ host -- the reference's PlannerRos keeps ONE planner object and calls
+ * it from its planning thread, art_planner_ros/src/planner_ros.cpp:250-319 -- use every GPU of the node without an
+ * interpreter in the process.  Two ways to build one:
+ *   artp_group_create       one process, n devices (ncclCommInitAll); every device gets a host worker thread, so the
+ *                           launches of a step are issued in parallel.
+ *   artp_group_create_rank  one process per GPU (torchrun / mpirun style): rank 0 makes the id
+ *                           (artp_group_unique_id), the launcher distributes its 128 bytes, every rank joins
+ *                           (ncclCommInitRank).
+ * transport: ARTP_GROUP_RCCL (default) or ARTP_GROUP_PEER_COPY -- single-process groups only: the all-gather as
+ * hipMemcpyPeerAsync pushes between the members; it also accepts the SAME device several times, which is how the
+ * W > 1 sharding / exchange logic is tested on a one-GPU box.
+ * The map: upload / install it on every member's context (artp_group_ctx) -- maps are replicated.  A group call
+ * returns the first failing member's status; artp_group_last_error has the text. */
+typedef struct artp_group artp_group;
+enum { ARTP_GROUP_RCCL = 0, ARTP_GROUP_PEER_COPY = 1 };
+#define ARTP_GROUP_ID_BYTES 128
+uint64_t artp_shard_first_index(uint64_t step, int rank, int world, uint64_t batch);
+int artp_group_create(const int* devices, int n, const artp_params* params, int transport, artp_group** out);
+int artp_group_unique_id(uint8_t id[ARTP_GROUP_ID_BYTES]);
+int artp_group_create_rank(int device, int rank, int world, const uint8_t id[ARTP_GROUP_ID_BYTES],
+                           const artp_params* params, artp_group** out);
+void artp_group_destroy(artp_group* g);
+const char* artp_group_last_error(const artp_group* g);
+int artp_group_world_size(const artp_group* g);
+int artp_group_local_count(const artp_group* g);
+int artp_group_rank(const artp_group* g, int local);           /* global rank of local member `local` */
+artp_ctx* artp_group_ctx(artp_group* g, int local);            /* owned by the group */
+/* The number of ranks the transport itself sees: an all-reduce (sum) of ones. */
+int artp_group_ranks_seen(artp_group* g, int* ranks_seen);
+/* Sizes of the state exchange: batch = S candidates per rank and step; every rank's first
+ * min(accepted, materialise_cap) accepted states among its first prefix candidates (0 = all S) are re-materialised
+ * on every member after the all-gather (0 = bitmaps only).  (Re)allocates the buffers; drains the group first. */
+int artp_group_configure(artp_group* g, uint64_t seed, size_t batch, size_t materialise_cap, size_t prefix);
+/* One step of the sharded rejection-sampling loop (prm_motion_cost.cpp:174-186 / lazy_prm_star_min_update.cpp:552-554
+ * across the node), ASYNCHRONOUS: for every local member -- artp_sample_and_validate_dev on its shard
+ * [artp_shard_first_index(step, rank, W, S), + S), one validity bit per candidate (artp_pack_valid_bits_dev), the
+ * all-gather of the W bitmaps on the side stream, artp_materialise_from_bits_dev behind it.  Buffers are
+ * double-buffered by step parity: step k + 2 waits for step k's exchange on the device, the host never blocks. */
+int artp_group_sample_and_validate_step(artp_group* g, uint64_t step);
+/* What a step left on member `local` (device pointers, valid once the step's work is done: artp_group_synchronize):
+ * se3 / valid = its own S candidates and labels (single-buffered: the next step overwrites them), bits = the W
+ * gathered bitmaps (W x ceil(S / 64) words), states = W x materialise_cap x 7 doubles, counts = W accepted counts
+ * among the prefix.  Any out pointer may be NULL. */
+int artp_group_step_buffers(artp_group* g, int local, uint64_t step, const double** se3, const uint8_t** valid,
+                            const uint64_t** bits, const double** states, const uint64_t** counts);
+/* The second exchange: per local member the n edges it owns -- valid / edge_i / edge_j / cost as for
+ * artp_pack_edge_results_dev (device pointers, on that member's GPU) -- packed into 20-byte records and all-gathered
+ * in blocks of `cap` records (n <= cap on every rank; the same cap on every rank).  ASYNCHRONOUS.  Result on every
+ * member (artp_group_edge_buffers): records = W x cap x 5 u32, counts = W record counts.  i / j stay in the owner's
+ * numbering; add artp_shard_first_index(step, r, W, S) for block r on arrival. */
+typedef struct artp_group_edges {
+  const uint8_t* valid; const uint32_t* edge_i; const uint32_t* edge_j; const float* cost; size_t n;
+} artp_group_edges;
+int artp_group_exchange_edges(artp_group* g, const artp_group_edges* per_local, size_t cap);
+int artp_group_edge_buffers(artp_group* g, int local, const uint32_t** records, const uint64_t** counts);
+/* Waits until every stream of every local member is idle, at most timeout_ms (< 0: no limit).  ARTP_ERR_TIMEOUT
+ * names the member and the stream that did not finish (a collective whose peer never arrived) and leaves the group
+ * as it is: artp_group_abort tears the communicators down (ncclCommAbort) so that the process can report and exit. */
+int artp_group_synchronize(artp_group* g, int timeout_ms);
+int artp_group_abort(artp_group* g);
+
 /* Measurement helper: the ALGORITHMIC window size of a batch = sum over states of
  * the heightfield vertices (nMaxX-nMinX+1)*(nMaxZ-nMinZ+1) of all five boxes, no credit for
  * early-outs or short-circuiting, 0 for a box whose centre is outside the map or whose AABB is off

@@ -12,11 +12,12 @@ import golden_io
 HOST = os.path.join(common.ROOT, "art_planner_amd", "host")
 BIN = os.path.join(HOST, "test_host")
 BIN_PLANNER = os.path.join(HOST, "test_planner")
+BIN_GROUP = os.path.join(HOST, "test_group")
 
 
 def _build():
     subprocess.check_call(["make", "-s", "-C", HOST])
-    assert os.path.exists(BIN) and os.path.exists(BIN_PLANNER)
+    assert os.path.exists(BIN) and os.path.exists(BIN_PLANNER) and os.path.exists(BIN_GROUP)
 
 
 def test_host_mirror_builds_and_refuses_without_gpu():
@@ -28,6 +29,54 @@ def test_host_mirror_builds_and_refuses_without_gpu():
     assert r.returncode == 3, r.stdout + r.stderr   # context creation throws: no CPU fallback
     r = subprocess.run([BIN_PLANNER], capture_output=True, text=True)
     assert r.returncode == 3, r.stdout + r.stderr
+    r = subprocess.run([BIN_GROUP], capture_output=True, text=True)   # artp_group_create refuses too
+    assert r.returncode == 3, r.stdout + r.stderr
+
+
+def test_shard_first_index_is_the_same_function_on_both_sides_of_the_abi():
+    from art_planner_amd import _capi
+    from art_planner_amd.distributed import shard_first_index
+    L = _capi.load()
+    for step, rank, world, batch in ((0, 0, 1, 1), (3, 2, 8, 1 << 22), (1000003, 7, 8, 4194304), (5, 15, 16, 12345)):
+        assert L.artp_shard_first_index(step, rank, world, batch) == shard_first_index(step, rank, world, batch)
+
+
+def _write_map_part(f, gm, zb):
+    hack = np.zeros((gm.rows, gm.cols), np.float32, order="F")
+    hack[:, 0] = gm["cum_prob_rowwise"]
+    f.write(struct.pack("<ii", gm.rows, gm.cols))
+    f.write(struct.pack("<dddd", gm.len_x, gm.len_y, gm.pos_x, gm.pos_y))
+    for layer in (gm["elevation"], gm["elevation_masked"], gm["cum_prob"], hack, gm["normal_x"], gm["normal_y"],
+                  gm["normal_z"], gm["plane_fit_std_dev"]):
+        f.write(np.asfortranarray(layer, np.float32).tobytes(order="F"))
+    f.write(struct.pack("<dd", *zb))
+
+
+@pytest.mark.gpu
+def test_device_group_through_the_c_abi(tmp_path):
+    """test_group.cpp: artp_group_* (include/artp_c.h "multi-GPU") from a C++ host, no interpreter and no torch in the
+    process: an RCCL group over every visible GPU and a three-rank peer-copy group on device 0 -- gathered bitmaps,
+    accepted counts, re-materialised states and edge records of EVERY rank bit-identical to what one plain context
+    computes for that rank's shard; steps in flight without host waits; the group's throughput as a C++ host sees it
+    (gpurun_out/group_test.json)."""
+    _build()
+    import oracle_py as O
+    from synthetic import make_map
+    gm = make_map(160, 0.04, seed=7)
+    rob = O.robot("yaml")
+    elev = gm["elevation"]
+    fin = elev[np.isfinite(elev)]
+    zb = (float(fin.min()) - rob.reach_z / 2, float(fin.max()) + rob.reach_z / 2)
+    path = tmp_path / "map.bin"
+    with open(path, "wb") as f:
+        _write_map_part(f, gm, zb)
+    out_dir = os.path.join(common.ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    r = subprocess.run([BIN_GROUP, str(path), os.path.join(out_dir, "group_test.json")], capture_output=True,
+                       text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "test_group ok" in r.stdout
 
 
 def test_real_library_branches_compile():
