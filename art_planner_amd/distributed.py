@@ -21,6 +21,17 @@ def shard_first_index(step: int, rank: int, world: int, batch: int) -> int:
     return (step * world + rank) * batch
 
 
+class _DeviceArray:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr: int, shape, typestr: str, device) -> torch.Tensor:
+    """A torch tensor over device memory somebody else owns (a device group's exchange buffers): no copy.
+    typestr as in numpy ("<f8", "<i8", "<u1", "<i4")."""
+    return torch.as_tensor(_DeviceArray(ptr, shape, typestr), device=device)
+
+
 class DeviceGroup:
     """Python view of an artp_group (include/artp_c.h "multi-GPU"): the exchange steps behind the C ABI, over RCCL
     bound directly by libartp.so -- no torch.distributed in the data path.  Two ways in, like the C entry points:

@@ -358,6 +358,59 @@ def pair_edges(acc, want, max_gap=3):
     return np.concatenate(ii)[:want], np.concatenate(jj)[:want]
 
 
+class Watchdog:
+    """A multi-GPU run must not end without its JSON line.  Every rank runs one: the main thread names the stage it
+    enters and how long it may take; when a stage overruns (a collective whose peer never arrived, a rank that died)
+    rank 0 prints the line from what has been measured so far -- `value` = the no-exchange aggregate when the exchange
+    is what hung, `gather_error` = the stage that hung -- and every rank leaves with os._exit (a stuck RCCL kernel cannot
+    be unwound).  ctypes calls and torch.cuda.synchronize release the GIL, so the timer thread runs while the main thread
+    is stuck inside them."""
+
+    def __init__(self, rank, enabled=True):
+        self.rank, self.enabled = rank, enabled
+        self.partial = {}          # rank 0: the fields of the line known so far
+        self.stage_name, self.deadline = "start", None
+        self.lock = threading.Lock()
+        self.fired = False
+        self.line_printed = False  # rank 0 has printed the real line: a late stage (final barrier) only ends the process
+        if enabled:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def stage(self, name, timeout_s):
+        with self.lock:
+            self.stage_name, self.deadline = name, time.monotonic() + timeout_s
+
+    def done(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                name = self.stage_name
+            if late:
+                self.fired = True
+                if self.rank == 0 and self.line_printed:
+                    os._exit(0)
+                if self.rank == 0:
+                    out = dict(self.partial)
+                    out["gather_error"] = f"watchdog: stage '{name}' did not finish in time"
+                    out.setdefault("value", None)
+                    try:
+                        import ctypes
+                        ctypes.CDLL(None).fflush(None)
+                    except Exception:
+                        pass
+                    print(json.dumps(out))
+                    sys.stdout.flush()
+                else:
+                    sys.stderr.write(f"[bench rank {self.rank}] watchdog: stage '{name}' did not finish in time\n")
+                    sys.stderr.flush()
+                os._exit(0 if self.rank == 0 else 3)
+
+
 def self_launch(n_gpus, argv):
     """`python bench.py --gpus N` with no launcher around it: re-exec under torch.distributed.run, one rank per GPU
     of this node over RCCL (what the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
@@ -399,6 +452,12 @@ def main():
     ap.add_argument("--materialise-on", choices=["main", "comm"], default="comm",
                     help="stream the re-materialisation runs on: lane 0's (between two batches) or the exchange's side "
                          "stream, right behind the all-gather (beside the next batch)")
+    ap.add_argument("--exchange", choices=["group", "torch"], default="group",
+                    help="N>1: who runs the exchange steps -- `group` = artp_group_* of the C ABI (librccl bound by "
+                         "libartp.so, one C call per step: what a C++ host uses), `torch` = torch.distributed "
+                         "all_gather_into_tensor driven from Python (round 1-3's path)")
+    ap.add_argument("--watchdog", type=float, default=120.0,
+                    help="N>1: seconds a multi-GPU stage may take before rank 0 prints the line with what it has")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-gather path even with one rank (self-test)")
     args = ap.parse_args()
@@ -432,12 +491,39 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from art_planner_amd.context import Context
-    from art_planner_amd.distributed import shard_first_index
+    from art_planner_amd.distributed import DeviceGroup, shard_first_index
     from synthetic import map_from_device, raw_map
+
+    multi = N > 1 or args.force_dist
+    wd = Watchdog(rank, enabled=multi)
+    if N > 1:  # rank 0's extras would keep the other ranks waiting at the last barrier for minutes
+        args.skip_extras, args.no_cpu_baseline, args.no_pmc = True, True, True
+    gather_error = None
+    grp = None
+    if multi and args.exchange == "group" and not args.no_gather and args.lanes == 1:
+        # the device group of the C ABI, one process per GPU: rank 0 makes the RCCL id, torch.distributed (already up
+        # for the barrier and the max-over-ranks clock) carries its 128 bytes to the others
+        wd.stage("artp_group_create_rank (RCCL communicator)", args.watchdog)
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(DeviceGroup.unique_id()), dtype=torch.uint8).to(dev)
+            dist.broadcast(uid, src=0)
+            grp = DeviceGroup.from_rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), "yaml")
+        except Exception as ex:  # pragma: no cover
+            gather_error = "group: " + repr(ex)
+            grp = None
+        # every rank must take the same path: fall back to the torch exchange everywhere if any rank failed
+        ok_t = torch.tensor([1 if grp is not None else 0], device=dev, dtype=torch.int64)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if int(ok_t.item()) == 0 and grp is not None:
+            grp.close()
+            grp = None
+        wd.done()
 
     # synthetic inputs: raw terrain + traversability; every derived layer (masked elevation, normals, CDF) comes
     # from the product's device preprocessing, installed as the context's map
-    ctx = Context(local_rank, "yaml")
+    ctx = grp.contexts[0] if grp is not None else Context(local_rank, "yaml")
     gm = map_from_device(ctx, raw_map(args.map, args.res, seed=1234))
     # one explicit stream carries the kernels AND the HIP events that time them
     main_stream = torch.cuda.Stream(device=dev)
@@ -472,7 +558,6 @@ def main():
     # ---- warmup (also sizes the fixed-capacity all-gather blocks) -----------------------------
     cap = 0
     counts = [None, None]
-    gather_error = None
     for i in range(max(W, 1)):
         c = ctx.sample_and_validate_dev(seed, first_index(1000000 + i), S, se3, valid, count=True)
         cap = max(cap, c)
@@ -481,10 +566,39 @@ def main():
     bits_buf = gatherers = all_states = mat_states = mat_counts = idx_tmp = cnt_tmp = done_ev = None
     rccl_ranks_seen = None
 
+    use_grp = grp          # the device group that runs the exchange (None: torch.distributed does)
+    grp_mat_cap = [None]
+
+    def configure_group(mc):
+        """Sizes of the group's state exchange: mc accepted states per rank re-materialised on every rank, looked for
+        among the first 8 * mc candidates of a rank's block (everything when mc covers the block's accepted states)."""
+        if grp_mat_cap[0] == mc:
+            return
+        prefix = S if mc >= cap else min(S, 8 * max(mc, 1))
+        use_grp.configure(seed, S, mc, prefix)
+        grp_mat_cap[0] = mc
+
     def setup_gather():
         """Buffers of the exchange step + one trial all-gather (outside any timed region)."""
         nonlocal cap, bits_buf, gatherers, all_states, mat_states, mat_counts, idx_tmp, cnt_tmp, done_ev, do_gather, gather_error, rccl_ranks_seen
         from art_planner_amd.distributed import ValidBitmapGatherer, agree_capacity
+        if use_grp is not None:
+            # the C-ABI group owns the exchange buffers, the side stream and the communicator
+            wd.stage("artp_group_ranks_seen + trial exchange", args.watchdog)
+            try:
+                rccl_ranks_seen = use_grp.ranks_seen()                # an all-reduce of ones on the group's communicator
+                if dist is not None:
+                    cap = agree_capacity(cap, S, dev)
+                else:
+                    cap = min(int(cap * 1.1) + 1024, S)
+                configure_group(min(cap, max(args.materialise, 1)) if args.materialise >= 0 else cap)
+                use_grp.step(0)
+                use_grp.synchronize(int(args.watchdog * 1000))
+            except Exception as ex:  # pragma: no cover
+                gather_error = repr(ex)
+                do_gather = False
+            wd.done()
+            return
         ones = torch.ones(1, device=dev, dtype=torch.int64)
         dist.all_reduce(ones)                                     # the rank count RCCL itself sees
         rccl_ranks_seen = int(ones.item())
@@ -533,6 +647,11 @@ def main():
                                       mat_cap, all_states[:, :mat_cap] if mat_cap == cap else mat_states, mat_counts)
 
     def step(i):
+        if do_gather and use_grp is not None:
+            # ONE call into the C ABI per step: sample + validate the rank's shard, pack the bitmap, all-gather on the
+            # group's side stream, re-materialise behind it (group.h); the host only enqueues
+            use_grp.step(i)
+            return
         b = i & 1
         ready = []
         for l in range(lanes):
@@ -565,17 +684,23 @@ def main():
             if i > 0 and mat_cap > 0 and args.materialise_on == "main":
                 materialise(i - 1)
 
-    def timed_region(n_steps):
-        """Exactly n_steps steps, barrier + synchronize on both sides, MAX over ranks."""
+    per_rank_ms = {}
+
+    def timed_region(n_steps, tag="headline"):
+        """Exactly n_steps steps, barrier + synchronize on both sides, MAX over ranks (per-rank times kept)."""
+        if do_gather and use_grp is not None:
+            configure_group(mat_cap)     # (re)allocation outside the clock
+        wd.stage(f"timed region '{tag}' ({n_steps} steps)", args.watchdog)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i)
-        if do_gather and mat_cap > 0 and args.materialise_on == "main":
+        if do_gather and use_grp is None and mat_cap > 0 and args.materialise_on == "main":
             materialise(n_steps - 1)
         torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
         dt_ = time.perf_counter() - t0
@@ -583,12 +708,45 @@ def main():
             t = torch.tensor([dt_], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ = float(t.item())
+            tl = torch.tensor([t_local], device=dev, dtype=torch.float64)
+            allt = torch.empty(world, device=dev, dtype=torch.float64)
+            dist.all_gather_into_tensor(allt, tl)
+            per_rank_ms[tag] = [float(x) / n_steps * 1e3 for x in allt.tolist()]
+        else:
+            per_rank_ms[tag] = [t_local / n_steps * 1e3]
+        wd.done()
         return dt_
 
     # ---- the headline region -----------------------------------------------------------------------
+    base_line = {"metric": "validated states/sec on 400x400@0.04m map (sample + validity check)", "unit": "states/s",
+                 "n_gpus": N, "steps": K, "warmup": W, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                 "dtype": "f32", "data": "synthetic",
+                 "config": {"workload": "C2: lazy_prm_star_min_update front end, 400x400@0.04m Perlin terrain (seed "
+                                        "1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
+                            "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}"}}
+    no_exchange = None
+    if multi and do_gather:
+        # first the same K steps WITHOUT any exchange (only the barrier and the clock cross ranks): if the exchange hangs
+        # on this node, the watchdog's line still carries a measured aggregate -- flagged as such
+        do_gather, keep = False, True
+        k0 = max(3, min(K, 20))
+        dt0 = timed_region(k0, "no_exchange")
+        do_gather = keep
+        no_exchange = {"states_per_s": N * S * k0 / dt0, "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
+                       "per_rank_ms_per_step": per_rank_ms.get("no_exchange")}
+        wd.partial = dict(base_line, value=no_exchange["states_per_s"], ms_per_step=no_exchange["ms_per_step"],
+                          steps=k0, headline_includes_exchange=False,
+                          distributed={"world_size": world, "rccl_ranks_seen": rccl_ranks_seen,
+                                       "no_exchange": no_exchange, "exchange": args.exchange if use_grp else "torch"})
     mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise)) if do_gather else 0
     dt = timed_region(K)
     value = N * S * K / dt
+    if multi:
+        wd.partial = dict(base_line, value=value, ms_per_step=dt / K * 1e3, headline_includes_exchange=bool(do_gather),
+                          distributed={"world_size": world, "rccl_ranks_seen": rccl_ranks_seen, "no_exchange": no_exchange,
+                                       "per_rank_ms_per_step": per_rank_ms.get("headline"),
+                                       "exchange": ("artp_group (C ABI, librccl bound by libartp.so)" if use_grp
+                                                    else "torch.distributed") if do_gather else None})
 
     # ---- the exchange step under the other materialisation settings and the edge exchange, all ranks; at N = 1
     # without --force-dist a one-rank RCCL group is brought up AFTER the headline so that every N reports the block ----
@@ -596,11 +754,18 @@ def main():
     dist_extras = None
     if N == 1 and dist is None and not args.no_gather and not args.skip_extras:
         try:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            comm = torch.cuda.Stream(device=dev)
+            if args.exchange == "group":
+                # a one-member RCCL group of the C ABI (its own context: the map is replicated per member)
+                use_grp = DeviceGroup.single_process([local_rank], "yaml")
+                map_from_device(use_grp.contexts[0], raw_map(args.map, args.res, seed=1234))
+                with torch.cuda.stream(main_stream):
+                    use_grp.contexts[0].use_torch_stream()
+            else:
+                import torch.distributed as dist
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                comm = torch.cuda.Stream(device=dev)
             do_gather = True
             setup_gather()
         except Exception as ex:  # pragma: no cover
@@ -610,13 +775,16 @@ def main():
     if do_gather:
         k2 = max(3, min(K, 20))
         mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise))
-        dist_extras = {"world_size": world, "rccl_ranks_seen": rccl_ranks_seen, "backend": dist.get_backend(),
+        dist_extras = {"world_size": world, "rccl_ranks_seen": rccl_ranks_seen,
+                       "exchange": ("artp_group_* of the C ABI (librccl bound by libartp.so; one call per step)"
+                                    if use_grp is not None else "torch.distributed " + dist.get_backend()),
                        "headline_includes_exchange": bool(headline_gathers),
-                       "materialise_default": args.materialise,
-                       "states_per_s_default": value if headline_gathers else N * S * k2 / timed_region(k2)}
+                       "materialise_default": args.materialise, "no_exchange": no_exchange,
+                       "per_rank_ms_per_step": per_rank_ms,
+                       "states_per_s_default": value if headline_gathers else N * S * k2 / timed_region(k2, "default")}
         for name, mc in (("states_per_s_materialise_all", cap), ("states_per_s_materialise_none", 0)):
             mat_cap = mc
-            dist_extras[name] = N * S * k2 / timed_region(k2)
+            dist_extras[name] = N * S * k2 / timed_region(k2, name[13:])
         mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise))
         dist_extras["per_gpu_states_per_s"] = {k_: v_ / N for k_, v_ in dist_extras.items()
                                                  if k_.startswith("states_per_s_")}
@@ -631,8 +799,10 @@ def main():
             pos = np.flatnonzero(valid.cpu().numpy())
             ii, jj = pair_edges(st_h[pos], args.edges)
             # the blocks of the all-gather have ONE size: the smallest edge count any rank found (normally --edges)
+            wd.stage("edge exchange", args.watchdog)
             e_t = torch.tensor([len(ii)], device=dev, dtype=torch.int64)
-            dist.all_reduce(e_t, op=dist.ReduceOp.MIN)
+            if dist is not None:
+                dist.all_reduce(e_t, op=dist.ReduceOp.MIN)
             E = int(e_t.item())
             if E == 0:
                 raise RuntimeError("no edge pairs on some rank")
@@ -651,11 +821,16 @@ def main():
             cost3 = torch.empty((E, 3), dtype=torch.float32, device=dev)
             rec = torch.zeros((E, 5), dtype=torch.int32, device=dev)
             ecount = torch.zeros(1, dtype=torch.int64, device=dev)
-            eg = EdgeResultGatherer(N, E, dev)
+            eg = EdgeResultGatherer(N, E, dev) if use_grp is None else None
 
             def edge_step():
                 ctx.check_edges_interp_dev(s1, s2, ev)
                 ctx.cost_query_dev(rows, cost3)
+                if use_grp is not None:
+                    # pack + all-gather of the 20-byte records inside the C ABI; the next exchange waits for this one
+                    # on the device, the host does not
+                    use_grp.exchange_edges([(ev.data_ptr(), ei.data_ptr(), ej.data_ptr(), cost3.data_ptr(), E)], E)
+                    return
                 ctx.pack_edge_results_dev(ev, ei, ej, cost3, rec, ecount)
                 ready = torch.cuda.Event()
                 ready.record()
@@ -666,18 +841,30 @@ def main():
 
             edge_step()
             torch.cuda.synchronize()
-            dist.barrier()
+            if dist is not None:
+                dist.barrier()
             t0 = time.perf_counter()
             for _ in range(k2):
                 edge_step()
             torch.cuda.synchronize()
-            dist.barrier()
+            if dist is not None:
+                dist.barrier()
             t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ij, cst, ok = eg.global_records(0, S)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if use_grp is not None:
+                from art_planner_amd.distributed import device_view
+                rec_p, cnt_p = use_grp.edge_pointers(0)
+                torch.cuda.synchronize()
+                cnts = device_view(cnt_p, (N,), "<i8", dev).cpu().numpy()   # the W record counts, as gathered on this rank
+                n_gathered, ok = int(cnts.sum()), bool((cnts <= E).all())
+            else:
+                ij, cst, ok = eg.global_records(0, S)
+                n_gathered = int(ij.shape[0])
+            wd.done()
             dist_extras["edges"] = {"edges_per_gpu_per_step": E, "steps": k2,
                                     "edges_per_s": N * E * k2 / float(t.item()),
-                                    "valid_edges_gathered": int(ij.shape[0]), "blocks_ok": bool(ok),
+                                    "valid_edges_gathered": n_gathered, "blocks_ok": bool(ok),
                                     "what": "0.5 m interpolation rule + learned cost (seeded weights) + "
                                             "{u32 i, u32 j, f32 cost[3]} all-gather (RCCL, side stream)"}
         except Exception as ex:  # pragma: no cover
@@ -685,9 +872,16 @@ def main():
 
     if rank != 0:
         if dist is not None:
+            wd.stage("waiting for rank 0's report", max(args.watchdog, 600.0))
             dist.barrier()
+            wd.done()
+            if use_grp is not None:
+                use_grp.close()
             dist.destroy_process_group()
         return
+    if multi:
+        wd.stage("rank 0: roofline timing and report", max(args.watchdog, 600.0))
+        wd.partial["distributed"] = dist_extras
 
     # ---- everything below: rank 0, outside the timed region ------------------------------------
     # batch 0 again (deterministic) for the roofline, label hash, edges and CPU baseline
@@ -1149,6 +1343,8 @@ def main():
                    "lanes": f"{lanes} (the step's batch as {lanes} contiguous part(s) on {lanes} HIP stream(s) of one "
                             "context; roofline.kernel_ms is one part-free batch on one stream)",
                    "sharding": f"sample-index ranges over {N} GPU(s)" +
+                               ((" [exchange: artp_group_* of the C ABI]" if use_grp is not None else " [exchange: torch.distributed]")
+                                if do_gather else "") +
                                (", validity bitmaps (1 bit per candidate) all-gathered over RCCL + the first "
                                 f"{'all' if args.materialise < 0 else args.materialise} accepted states of every rank per step "
                                 "re-materialised on every rank" if do_gather else "")},
@@ -1169,11 +1365,23 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if wd.fired:   # the watchdog is printing its own line: never two
+        time.sleep(5)
+        return
+    wd.done()
     print(json.dumps(out))
     sys.stdout.flush()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        wd.line_printed = True
+        wd.stage("final barrier", args.watchdog)
+        try:
+            dist.barrier()
+            if use_grp is not None:
+                use_grp.close()
+            dist.destroy_process_group()
+        except Exception:  # pragma: no cover
+            pass
+        wd.done()
 
 
 if __name__ == "__main__":

@@ -78,3 +78,26 @@ def test_bench_multi_gpu_launch_fails_with_a_clear_message_not_an_assertion():
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "torch.distributed.run" in r.stderr
     assert "Traceback" not in r.stderr
+
+
+def test_watchdog_prints_the_partial_line_when_a_multi_gpu_stage_hangs():
+    """A multi-GPU run must not end without its JSON line: when a stage overruns -- a collective
+    whose peer never arrived -- rank 0 prints the line from what was measured so far with `gather_error` naming the
+    stage and exits 0; the other ranks leave without printing; a stage that finishes in time prints nothing."""
+    import subprocess
+    import sys
+    prog = ("import sys, time; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench\n"
+            "wd = bench.Watchdog(int(sys.argv[1]))\n"
+            "wd.stage('quick', 5.0); wd.done()\n"
+            "wd.partial = {'metric': 'm', 'value': 123.0, 'headline_includes_exchange': False}\n"
+            "wd.stage('bitmap all-gather', 0.6)\n"
+            "time.sleep(30)\n" % (common.ROOT, os.path.join(common.ROOT, "tests")))
+    r0 = subprocess.run([sys.executable, "-c", prog, "0"], capture_output=True, text=True, timeout=60)
+    assert r0.returncode == 0, r0.stderr
+    lines = [l for l in r0.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 123.0 and "bitmap all-gather" in d["gather_error"] and d["headline_includes_exchange"] is False
+    r1 = subprocess.run([sys.executable, "-c", prog, "1"], capture_output=True, text=True, timeout=60)
+    assert r1.returncode == 3 and not [l for l in r1.stdout.splitlines() if l.startswith("{")]
+    assert "bitmap all-gather" in r1.stderr
