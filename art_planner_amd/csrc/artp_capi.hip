@@ -42,6 +42,14 @@ struct artp_ctx {
   void* rect_stage_dev = nullptr;    // ... and its device twin
   size_t rect_stage_cap = 0;
   hipEvent_t rect_stage_done = nullptr;  // the last update's host-to-device copy
+  // Ordering of map writes against the lanes: a map write is issued on the current lane's stream.  In
+  // front of it that stream waits for the work every other lane has been given so far (they may still read the old
+  // samples / tables: lane_mark); behind it `map_written` is recorded, and a lane whose map_seen is behind
+  // map_write_seq waits for that event before its next launch (artp_set_lane / the write itself for the current lane).
+  hipEvent_t map_written = nullptr;
+  hipEvent_t lane_mark[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t map_write_seq = 0;
+  uint64_t map_seen[4] = {0, 0, 0, 0};
   SamplerDev sampler{};
   float* sampler_buf = nullptr;
   float* sampler_pack = nullptr;  // derived tables: packed cells, row-major CDF, pivots
@@ -169,6 +177,34 @@ void unpark_lane(artp_ctx* c, int lane) {
     c->tmp_cap[k] = l.tmp_cap[k];
   }
   c->cur_lane = lane;
+}
+
+// In front of a map write: the current stream waits for everything the other lanes were given so far.
+int order_after_other_lanes(artp_ctx* c) {
+  for (int l = 0; l < ARTP_MAX_LANES; ++l) {
+    if (l == c->cur_lane || !c->lanes[l].init) continue;
+    if (!c->lane_mark[l]) HIP_TRY(c, hipEventCreateWithFlags(&c->lane_mark[l], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->lane_mark[l], c->lanes[l].stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lane_mark[l], 0));
+  }
+  return ARTP_OK;
+}
+
+// Behind a map write that returns before the device is done (rectangle updates, same-geometry re-install): the other
+// lanes' next launches wait for it.  The host-synchronous writers (full upload, sampler layers) call it too: free.
+int publish_map_write(artp_ctx* c) {
+  if (!c->map_written) HIP_TRY(c, hipEventCreateWithFlags(&c->map_written, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->map_written, c->stream));
+  c->map_seen[c->cur_lane] = ++c->map_write_seq;
+  return ARTP_OK;
+}
+
+int lane_sees_map(artp_ctx* c) {  // after unpark_lane: the now-current lane catches up with the last map write
+  if (c->map_seen[c->cur_lane] != c->map_write_seq && c->map_written) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->map_written, 0));
+    c->map_seen[c->cur_lane] = c->map_write_seq;
+  }
+  return ARTP_OK;
 }
 
 void fill_robot(artp_ctx* c) {
@@ -410,6 +446,13 @@ int partner_update_begin(artp_ctx* c, int slot, const int* dirty, int n_dirty, P
   hipLaunchKernelGGL(partner_count_kernel<true>, dim3((cells + 255) / 256, rows, pr->n), dim3(256), 0, c->stream, f, R,
                      (const float4*)c->tri_raw_buf[slot], c->partner_cnt[slot], *pr, -1);
   HIP_TRY(c, hipGetLastError());
+  // From here to the end of step 2 the counts are half-updated: until partner_update_end has queued its passes the
+  // table counts as NOT built, so a failure in between (the copy, the scatter, the range tables) makes the next update
+  // rebuild it from scratch instead of working incrementally on broken counts.
+  c->partner_R_built[slot] = -1;
+  c->tables[slot].valid = 0;
+  c->field[slot].partner_flags = nullptr;  // a validation that ran on a half-updated map would take the list path
+  c->field[slot].partner_R = 0;
   return ARTP_OK;
 }
 
@@ -418,7 +461,7 @@ int partner_update_begin(artp_ctx* c, int slot, const int* dirty, int n_dirty, P
 int partner_update_end(artp_ctx* c, int slot, const PartnerRects& pr) {
   if (pr.n == 0) return build_partner_table_full(c, slot);
   FieldDev& f = c->field[slot];
-  const int R = c->partner_R_built[slot];
+  const int R = partner_radius(c, slot);  // what step 1 checked the table against (it then marked it "not built")
   int cells0, cellsR, rows;
   partner_rect_extent(f, pr, 0, &cells0, &rows);
   partner_rect_extent(f, pr, R, &cellsR, &rows);
@@ -431,6 +474,7 @@ int partner_update_end(artp_ctx* c, int slot, const PartnerRects& pr) {
   hipLaunchKernelGGL(partner_flags_from_counts_kernel, dim3((cellsR + 255) / 256, pr.n), dim3(256), 0, c->stream, f.nW, f.nD,
                      pr, R, (const unsigned*)c->partner_cnt[slot], c->partner_buf[slot]);
   HIP_TRY(c, hipGetLastError());
+  c->partner_R_built[slot] = R;
   f.partner_flags = c->partner_buf[slot];
   f.partner_R = R;
   return ARTP_OK;
@@ -695,6 +739,9 @@ void artp_destroy(artp_ctx* c) {
   if (c->rect_stage_host) (void)hipHostFree(c->rect_stage_host);
   if (c->rect_stage_dev) (void)hipFree(c->rect_stage_dev);
   if (c->rect_stage_done) (void)hipEventDestroy(c->rect_stage_done);
+  if (c->map_written) (void)hipEventDestroy(c->map_written);
+  for (auto& e : c->lane_mark)
+    if (e) (void)hipEventDestroy(e);
   for (auto& l : c->lanes) {
     if (!l.init) continue;
     for (int s = 0; s < 8; ++s)
@@ -734,6 +781,10 @@ int artp_set_stream(artp_ctx* c, void* hip_stream) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   c->stream = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream
+  if (c->map_written) {  // a stream this context has not used before: order it behind the last map write
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->map_written, 0));
+  }
   return ARTP_OK;
 }
 
@@ -741,6 +792,10 @@ int artp_use_own_stream(artp_ctx* c) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   c->stream = c->own_stream;
+  if (c->map_written) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->map_written, 0));
+  }
   return ARTP_OK;
 }
 
@@ -776,7 +831,7 @@ int artp_set_lane(artp_ctx* c, int lane) {
   }
   park_lane(c);
   unpark_lane(c, lane);
-  return ARTP_OK;
+  return lane_sees_map(c);
 }
 
 int artp_get_lane(artp_ctx* c) { return c ? c->cur_lane : -1; }
@@ -919,12 +974,16 @@ int artp_upload_layer(artp_ctx* c, int slot, const float* layer, int rows, int c
       has_nan |= (v != v);
       has_nonfinite |= !std::isfinite(v);
     }
-  int rc = ensure_field_storage(c, slot, elems);
+  int rc = order_after_other_lanes(c);  // lanes that still validate on the old samples
+  if (rc != ARTP_OK) return rc;
+  rc = ensure_field_storage(c, slot, elems);
   if (rc != ARTP_OK) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->field_data[slot], host.data(), elems * sizeof(float),
                             hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, has_nan, has_nonfinite);
+  rc = finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, has_nan, has_nonfinite);
+  if (rc != ARTP_OK) return rc;
+  return publish_map_write(c);
 }
 
 // Difference between a device layer (column-major rows x cols) and the installed samples of a slot (ODE layout), bit for
@@ -980,6 +1039,10 @@ static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer,
   const bool same_geometry = c->have_field[slot] && c->have_geom && f0.nW == rows && f0.nD == cols &&
                              c->geom.len_x == len_x && c->geom.len_y == len_y && c->geom.pos_x == pos_x &&
                              c->geom.pos_y == pos_y && c->tables[slot].valid && c->field_elems[slot] >= elems;
+  {
+    const int rco = order_after_other_lanes(c);
+    if (rco != ARTP_OK) return rco;
+  }
   if (same_geometry) {
     int init[6] = {0x7fffffff, 0x7fffffff, -1, -1, 0, 0}, got[6];
     int* d_out = reinterpret_cast<int*>(c->d_diff);
@@ -1002,7 +1065,9 @@ static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer,
       HIP_TRY(c, hipGetLastError());
       c->field[slot].has_nan = got[5];          // exact: the flags are those of the whole new layer
       c->layer_has_nonfinite[slot] = got[4];
-      return build_tables(c, slot, &pr);
+      rc = build_tables(c, slot, &pr);
+      if (rc != ARTP_OK) return rc;
+      return publish_map_write(c);  // asynchronous like the rectangle updates: the other lanes wait on the device
     }
   }
   int rc = ensure_field_storage(c, slot, elems);
@@ -1015,7 +1080,9 @@ static int upload_layer_from_device(artp_ctx* c, int slot, const float* d_layer,
   int flags[2] = {0, 0};
   HIP_TRY(c, hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, flags[1], flags[0]);
+  rc = finish_layer(c, slot, rows, cols, len_x, len_y, pos_x, pos_y, flags[1], flags[0]);
+  if (rc != ARTP_OK) return rc;
+  return publish_map_write(c);
 }
 
 // Rectangle updates (config 5).  One call takes any number of rectangles of one slot: the patches go through ONE
@@ -1061,6 +1128,10 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
     max_cells = std::max(max_cells, nrows * ncols);
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  {
+    const int rco = order_after_other_lanes(c);
+    if (rco != ARTP_OK) return rco;
+  }
   c->map_version.fetch_add(1, std::memory_order_release);
   // staging: pinned host buffer (patches + rectangle records), reused once the previous update's copy is done
   const size_t rec_bytes = ((size_t)n_rects * sizeof(RectDev) + 15) & ~(size_t)15;
@@ -1128,7 +1199,13 @@ int artp_update_layer_rects(artp_ctx* c, int slot, int n_rects, const float* con
   HIP_TRY(c, hipEventRecord(c->rect_stage_done, c->stream));
   // range / stride tables once (the whole map is ~1 MB: rebuilding beats tracking dirty blocks); the partner table,
   // step 2: the new triangles' contributions and a recount of the changed cells
-  return build_tables(c, slot, &pr);
+  {
+    const int rct = build_tables(c, slot, &pr);
+    if (rct != ARTP_OK) return rct;
+  }
+  // the call returns with the device work queued: launches on the context's OTHER lanes are ordered behind it on the
+  // device (map_written), this lane's by stream order
+  return publish_map_write(c);
 }
 
 int artp_update_layer_rect(artp_ctx* c, int slot, const float* patch, int row0, int col0, int nrows, int ncols) {

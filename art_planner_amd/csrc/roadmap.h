@@ -436,6 +436,9 @@ struct artp_roadmap {
   std::vector<uint32_t> einterp;   // interior states of the chain
   std::vector<double> ecost;
   std::vector<uint8_t> eremoved;   // removed by the lazy path check
+  // vertices the CURRENT map invalidated but that stay in `verts` (artp_roadmap_revalidate, growing a construction-1
+  // graph): not neighbour targets for a new query (the reference's invalid vertices are not in nn_).  Empty = none.
+  std::vector<uint8_t> vinvalid;
   // The reference computes an edge's weight ONCE, in the direction it was added to the undirected graph
   // (opt_->motionCost(m, n) new -> old in lazy_prm_star_min_update.cpp:436; source -> target of boost::add_edge(prev, new) /
   // (m, n) in PRMMotionCostMaintainer::updateEdges, prm_motion_cost.cpp:33-44) -- it matters for the directional and the
@@ -1552,6 +1555,18 @@ static int roadmap_grow_incremental(artp_roadmap* rm, uint64_t n_more, uint64_t 
     delete fresh;
     return rc;
   }
+  // The reference removes an edge the lazy path check rejected from g_ for good (prm_motion_cost.cpp:652-660): the
+  // removals of the graph so far carry over.  Edge identity is stable -- (min, max) vertex ids, both lists sorted.
+  {
+    size_t o = 0;
+    const size_t no = rm->eu.size();
+    for (size_t e = 0; e < fresh->eu.size(); ++e) {
+      while (o < no && (rm->eu[o] < fresh->eu[e] || (rm->eu[o] == fresh->eu[e] && rm->ev[o] < fresh->ev[e]))) ++o;
+      if (o < no && rm->eu[o] == fresh->eu[e] && rm->ev[o] == fresh->ev[e] && rm->eremoved[o]) fresh->eremoved[e] = 1;
+    }
+  }
+  fresh->vinvalid.assign(g.nv(), 0);
+  for (size_t v = 0; v < g.nv(); ++v) fresh->vinvalid[v] = vok[v] ? 0 : 1;
   fresh->samples_drawn = next - rm->params.first_index;
   fresh->n_reweights = rm->n_reweights + n_reweights;
   fresh->budget_flags = budget_flags;
@@ -1684,6 +1699,8 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
     after += rm->evalid[e] ? 1 : 0;
   }
   std::fill(rm->eremoved.begin(), rm->eremoved.end(), 0);
+  rm->vinvalid.assign(nv, 0);
+  for (size_t v = 0; v < nv; ++v) rm->vinvalid[v] = vok[v] ? 0 : 1;
   rm->csr_dirty = true;
   rm->d_graph_dirty = true;
   if (out) {
@@ -1735,6 +1752,7 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
     cand.reserve(nv);
     for (uint32_t j = 0; j < nv; ++j) {
       if (j == q) continue;
+      if (j >= 2 && j < rm->vinvalid.size() && rm->vinvalid[j]) continue;  // invalidated by the current map
       const double* b = &rm->verts[(size_t)j * 7];
       const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
       cand.push_back({std::sqrt(dx * dx + dy * dy + dz * dz) + arc(a + 3, b + 3), j});

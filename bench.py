@@ -200,18 +200,35 @@ def summarise_pmc(per_kernel, extra_kernels=()):
             "lds_busy_time_weighted": w_lds / tot_us if tot_us else None, "csrc_hash": csrc_hash()}
 
 
+def binding_fractions(pmc, hbm_traffic_frac):
+    """The occupancy fractions a bound is chosen from (the largest binds): VALU issue and LDS issue, time-weighted over
+    the pipeline's kernels, and HBM traffic / time / peak -- all from PMC counters.  {} without counters."""
+    if not pmc:
+        return {}
+    out = {"valu_issue": float(pmc["valu_busy_time_weighted"]), "lds": float(pmc["lds_busy_time_weighted"])}
+    if hbm_traffic_frac is not None:
+        out["hbm"] = float(hbm_traffic_frac)
+    return out
+
+
 def load_committed_pmc():
-    """profiles/pmc_r03.json, only if it was measured on THIS checkout's kernel sources."""
-    path = os.path.join(ROOT, "profiles", "pmc_r03.json")
-    if not os.path.exists(path):
+    """The newest profiles/pmc_rNN.json, only if it was measured on THIS checkout's kernel sources."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r[0-9][0-9].json")), reverse=True)
+    if not paths:
         return None, "no committed PMC profile"
-    try:
-        d = json.load(open(path))
-    except Exception as ex:  # pragma: no cover
-        return None, f"unreadable committed PMC profile: {ex!r}"
-    if d.get("csrc_hash") != csrc_hash():
-        return None, f"committed PMC profile is STALE (measured on csrc {d.get('csrc_hash')}, checkout is {csrc_hash()})"
-    return d, "committed profiles/pmc_r03.json (same kernel sources)"
+    note = None
+    for path in paths:
+        name = os.path.basename(path)
+        try:
+            d = json.load(open(path))
+        except Exception as ex:  # pragma: no cover
+            note = note or f"unreadable committed PMC profile {name}: {ex!r}"
+            continue
+        if d.get("csrc_hash") != csrc_hash():
+            note = note or f"committed PMC profile {name} is STALE (measured on csrc {d.get('csrc_hash')}, checkout is {csrc_hash()})"
+            continue
+        return d, f"committed profiles/{name} (same kernel sources)"
+    return None, note
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -312,7 +329,11 @@ def c1_leg(local_rank):
             "labels_match": gpu["label_hash"] == cpu["label_hash"],
             # north star "path cost within 1e-4": the batched GPU plan (simplified, as Planner::plan returns it) against
             # the cost of the reference planner's own incremental construction on the same states
-            "path_cost_within_1e-4": bool(abs(d - lit["path_cost"]) < 1e-4 and abs(lit["path_cost"] - optimum) < 1e-4)}
+            "path_cost_within_1e-4": bool(abs(d - lit["path_cost"]) < 1e-4 and abs(lit["path_cost"] - optimum) < 1e-4),
+            # the two comparisons on their own (rounds 1-2 reported the first under the combined key)
+            "path_cost_vs_analytic_optimum_within_1e-4": bool(abs(d - optimum) < 1e-4),
+            "path_cost_vs_reference_construction_within_1e-4": bool(abs(d - lit["path_cost"]) < 1e-4),
+            "reference_order_graph_cost_vs_reference_construction_within_1e-4": bool(abs(c2 - lit["path_cost"]) < 1e-4)}
 
 
 def cnn_flops(n):
@@ -931,10 +952,26 @@ def main():
     elif N > 1:
         pmc_note = "N > 1: PMC passes only run at N = 1"
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    if pmc is None and N > 1:
+        pmc, pmc_note = load_committed_pmc()    # hash-guarded: only a profile of these very kernel sources
+        pmc_note = f"{pmc_note} (N > 1: the live PMC passes only run at N = 1)"
     traffic = pmc["validity_hbm_bytes_per_launch"] if pmc else None
+    hbm_traffic_frac = None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    # The bound that BINDS, derived from this run's counters: the largest of the three occupancy fractions.  The
+    # algorithmic-byte figure of the bench contract (what the reference's window scans read / kernel time) is kept under
+    # its own key: the exact range / stride / partner tables answer the scans without reading those bytes, so it exceeds
+    # the HBM peak and is a statement about the ALGORITHM, not a fraction of any roofline.
+    fracs = binding_fractions(pmc, hbm_traffic_frac)
+    bound = max(fracs, key=fracs.get) if fracs else None
     roofline = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "bound": bound, "achieved": None if bound is None else fracs[bound], "peak": 1.0 if bound else None,
+        "unit": {"valu_issue": "fraction of VALU issue cycles (SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel cycles)), "
+                               "time-weighted over the pipeline's kernels",
+                 "lds": "fraction of LDS issue cycles", "hbm": "fraction of the 8 TB/s HBM peak (PMC traffic / time)",
+                 None: None}[bound],
+        "frac": None if bound is None else min(1.0, fracs[bound]),
+        "occupancy_fractions": fracs,
+        "traffic": traffic, "hbm_traffic_frac": hbm_traffic_frac,
         "kernel": "validity pipeline (artp_validate_states_dev)", "kernel_ms": k_ms,
         "fused_sample_validate_ms": step_ms,
         # the timed region's own rate: `lanes` parts side by side, sampler included (the figures above are ONE batch
@@ -943,20 +980,24 @@ def main():
                          "algorithmic_GBps": alg_bytes / (dt / K) / 1e9},
         "kernel_launches": "classify_states_kernel + feet_stream_kernel<4> + resolve_boxes_kernel<2,64,0> + 5 "
                            "near-empty fallback launches (profiles/README.md)",
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes_per_state": alg_bytes / S,
         "validate_only_states_per_s": S / (k_ms * 1e-3),
-        "note": "SECONDARY yardstick by the bench contract: achieved = ALGORITHMIC bytes (what the reference's window "
-                "scans read, SURVEY.md 8d) / kernel time; frac > 1 because exact range / partner tables avoid reading "
-                "them.  What binds is VALU issue: see `binding`.",
-        # the bound that binds: instruction issue, from this run's PMC passes
+        "algorithmic_hbm": {
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "ratio_to_peak": achieved / HBM_PEAK_GBS,
+            "bytes_per_launch": alg_bytes, "bytes_per_state": alg_bytes / S,
+            "note": "SURVEY.md 8d's yardstick: ALGORITHMIC bytes = 4 B x the heightfield vertices of all five index windows "
+                    "of a state + 29 B, no credit for early-outs, / kernel time.  Above the HBM peak because the exact "
+                    "tables make the scans unnecessary (labels identical): credit as throughput, not as a roofline "
+                    "fraction"},
+        "note": "bound / frac = the largest occupancy fraction of the pipeline measured by this run's PMC passes "
+                "(`binding.per_kernel` has every kernel; classify_states_kernel itself is bound by its L2 requests x "
+                "latency / L1 miss concurrency, DESIGN.md 4.1)",
         "binding": None if not pmc else {
-            "bound": "valu_issue", "valu_busy_time_weighted": pmc["valu_busy_time_weighted"],
+            "bound": bound, "valu_busy_time_weighted": pmc["valu_busy_time_weighted"],
             "valu_busy_note": "SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * GRBM_GUI_ACTIVE / 8).  A value of 1.0 - 1.1 "
                               "means saturated: instructions that issue with an empty EXEC mask (16-lane groups of a "
                               "wavefront on different branches) retire in fewer than the four cycles the formula charges",
             "lds_busy_time_weighted": pmc["lds_busy_time_weighted"],
-            "hbm_traffic_frac_of_peak": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "hbm_traffic_frac_of_peak": hbm_traffic_frac,
             "per_kernel": pmc["kernels"],
             "pmc_kernel_us_sum_vs_hip_events_ms": [pmc["validity_kernel_us_sum"], k_ms]},
         "pmc_source": pmc_note, "csrc_hash": csrc_hash()}
@@ -1001,8 +1042,11 @@ def main():
             pmc_e, note_e = collect_pmc_live(args, "check_motion")
             if pmc_e is not None:
                 ms_cm = edges["check_motion"]["ms"]
+                hbm_e = pmc_e["validity_hbm_bytes_per_launch"] / (ms_cm * 1e-3) / 1e9 / HBM_PEAK_GBS
+                fr_e = binding_fractions(pmc_e, hbm_e)
                 edges["check_motion"]["binding"] = {
-                    "bound": "valu_issue", "valu_busy_time_weighted": pmc_e["valu_busy_time_weighted"],
+                    "bound": max(fr_e, key=fr_e.get), "occupancy_fractions": fr_e,
+                    "valu_busy_time_weighted": pmc_e["valu_busy_time_weighted"],
                     "lds_busy_time_weighted": pmc_e["lds_busy_time_weighted"],
                     "hbm_bytes_per_batch": pmc_e["validity_hbm_bytes_per_launch"],
                     "hbm_traffic_frac_of_peak": pmc_e["validity_hbm_bytes_per_launch"] / (ms_cm * 1e-3) / 1e9 / HBM_PEAK_GBS,

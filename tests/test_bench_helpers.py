@@ -101,3 +101,15 @@ def test_watchdog_prints_the_partial_line_when_a_multi_gpu_stage_hangs():
     r1 = subprocess.run([sys.executable, "-c", prog, "1"], capture_output=True, text=True, timeout=60)
     assert r1.returncode == 3 and not [l for l in r1.stdout.splitlines() if l.startswith("{")]
     assert "bitmap all-gather" in r1.stderr
+
+
+def test_the_reported_bound_is_derived_from_the_counters():
+    """`roofline.bound` / `frac` name the LARGEST occupancy fraction the PMC passes measured (no literal),
+    never the algorithmic-byte figure; without counters there is nothing to choose from."""
+    assert bench.binding_fractions(None, None) == {}
+    pmc = {"valu_busy_time_weighted": 0.86, "lds_busy_time_weighted": 0.04}
+    fr = bench.binding_fractions(pmc, 0.10)
+    assert max(fr, key=fr.get) == "valu_issue" and fr["hbm"] == 0.10
+    fr = bench.binding_fractions({"valu_busy_time_weighted": 0.2, "lds_busy_time_weighted": 0.1}, 0.7)
+    assert max(fr, key=fr.get) == "hbm"
+    assert set(bench.binding_fractions(pmc, None)) == {"valu_issue", "lds"}

@@ -736,6 +736,68 @@ def test_lanes_overlap_and_agree_with_one_stream(big_map, ctx_yaml):
     assert ctx_yaml.lane == 0
 
 
+def test_map_writes_are_ordered_against_the_other_lanes(big_map):
+    """artp_update_layer_rects and the same-geometry re-install return with their device work
+    queued on the CURRENT lane's stream; a validation issued right afterwards on ANOTHER lane (no host sync in between)
+    must see the new samples and tables -- and a map write issued while another lane still validates on the old map
+    must not overtake it.  Labels of both orders against the oracle on the respective map."""
+    import copy
+    import torch
+    rob = O.robot("yaml")
+    gm = big_map
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm)
+    dev = "cuda:0"
+    n = 1 << 17
+    se3 = torch.empty((n, 7), dtype=torch.float64, device=dev)
+    ctx.use_torch_stream()
+    ctx.sample_states_dev(5, 0, n, se3)
+    torch.cuda.synchronize()
+    states = se3.cpu().numpy()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    ctx.set_lane(1)
+    with torch.cuda.stream(streams[0]):
+        ctx.use_torch_stream()
+    ctx.set_lane(0)
+    with torch.cuda.stream(streams[1]):
+        ctx.use_torch_stream()
+    maps = [gm]
+    r0, c0, nr, nc = 60, 90, 200, 180
+    rng = np.random.default_rng(3)
+    labels_old = torch.empty(n, dtype=torch.uint8, device=dev)
+    labels_new = torch.empty(n, dtype=torch.uint8, device=dev)
+    for rep in range(4):
+        cur = maps[-1]
+        nxt = copy.copy(cur)
+        nxt.layers = dict(cur.layers)
+        for name in ("elevation", "elevation_masked"):
+            a = cur[name].copy(order="F")
+            a[r0:r0 + nr, c0:c0 + nc] += np.float32(0.35 if rep % 2 == 0 else -0.35)
+            nxt.layers[name] = a
+        maps.append(nxt)
+        # lane 1 validates on the CURRENT map (a long batch) ...
+        ctx.set_lane(1)
+        with torch.cuda.stream(streams[0]):
+            ctx.validate_states_dev(se3, labels_old)
+        # ... lane 0 writes the NEXT map right away (no sync): must not overtake lane 1's reads
+        ctx.set_lane(0)
+        with torch.cuda.stream(streams[1]):
+            ctx.update_layer_rects(0, [nxt["elevation"][r0:r0 + nr, c0:c0 + nc]], [(r0, c0)])
+            ctx.update_layer_rects(1, [nxt["elevation_masked"][r0:r0 + nr, c0:c0 + nc]], [(r0, c0)])
+        # ... and lane 1 validates again at once: must see the new samples and tables
+        ctx.set_lane(1)
+        with torch.cuda.stream(streams[0]):
+            ctx.validate_states_dev(se3, labels_new)
+        ctx.set_lane(0)
+        ctx.synchronize()
+        ref_old = O.OracleMap(cur).states_valid(rob, states[:20000])
+        ref_new = O.OracleMap(nxt).states_valid(rob, states[:20000])
+        assert (ref_old != ref_new).sum() > 50
+        assert np.array_equal(labels_old.cpu().numpy()[:20000], ref_old), rep
+        assert np.array_equal(labels_new.cpu().numpy()[:20000], ref_new), rep
+    ctx.close()
+
+
 def test_huge_robot_uses_the_largest_table_levels(big_map):
     """A robot twice the size of ANYmal: torso windows of ~55 samples (32-sample blocks, three per axis), foot
     windows of ~20 (the feet's 2 x 2 tight cover of 16-sample blocks, or none) -- labels equal the oracle's."""

@@ -978,3 +978,63 @@ def test_construction_1_reweights_like_sample_graph():
     pm.reweight_dev(None)
     pm.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_lazy_removals_survive_a_grow_and_invalid_vertices_are_no_query_neighbours():
+    """ADVICE r3.  (1) construction 1: the reference removes an edge its lazy path check rejected from g_ for good
+    (prm_motion_cost.cpp:652-660) -- after solve -> grow -> solve the edges removed by the first solve are still marked
+    removed and the second solve does not pay for them again.  (2) after a map update invalidated vertices, a new query
+    is connected to valid vertices only (the reference's invalid vertices are not in nn_)."""
+    from art_planner_amd.context import Context
+    from art_planner_amd.roadmap import Roadmap
+    from synthetic import make_map
+    gm = make_map(160, 0.04, seed=1234)
+    ctx = Context(0, "yaml")
+    ctx.upload_map(gm)
+    se3 = ctx.sample_states(42, 0, 1 << 15)
+    acc = se3[ctx.validate_states(se3) != 0]
+    near = lambda xy: acc[np.argmin(np.hypot(acc[:, 0] - xy[0], acc[:, 1] - xy[1]))]
+    s, g = near((gm.pos_x - 2.4, gm.pos_y - 2.4)), near((gm.pos_x + 2.4, gm.pos_y + 2.4))
+    r = Roadmap(ctx, s, g, n_milestones=10000, max_n_edges=50000, seed=42, construction=1)
+    p0, c0, rep0 = r.solve()
+    e0 = r.export()
+    rem0 = {(int(u), int(v)) for (u, v), x in zip(e0["edges"], e0["edge_removed"]) if x}
+    assert p0 is not None and rep0 >= 1 and len(rem0) == rep0
+    r.grow(300)
+    e1 = r.export()
+    rem1 = {(int(u), int(v)) for (u, v), x in zip(e1["edges"], e1["edge_removed"]) if x}
+    assert rem0 <= rem1, "lazy removals must carry over a grow"
+    p1, c1, rep1 = r.solve()
+    assert p1 is not None and ctx.check_motions(p1[:-1], p1[1:]).all()
+    e2 = r.export()
+    rem2 = {(int(u), int(v)) for (u, v), x in zip(e2["edges"], e2["edge_removed"]) if x}
+    assert rem0 <= rem2 and rep1 == len(rem2) - len(rem1)      # only NEW removals were paid for
+    # (2) raise a block of terrain under part of the roadmap, revalidate, re-query next to it
+    verts = e2["verts"]
+    mid = verts[len(verts) // 2, :2]
+    # grid_map index of a position: rows run against x, columns against y
+    i0 = int((gm.pos_x + gm.len_x / 2 - mid[0]) / gm.res)
+    j0 = int((gm.pos_y + gm.len_y / 2 - mid[1]) / gm.res)
+    r0, c0_ = min(max(0, i0 - 20), gm.rows - 40), min(max(0, j0 - 20), gm.cols - 40)
+    for slot, name in ((0, "elevation"), (1, "elevation_masked")):
+        a = gm[name].copy(order="F")
+        patch = a[r0:r0 + 40, c0_:c0_ + 40].copy()
+        patch[::2, :] += np.float32(0.6)           # a washboard: nothing stands there any more
+        ctx.update_layer_rect(slot, patch, r0, c0_)
+    rv = r.revalidate()
+    assert rv["invalid_vertices"] > 0
+    vok = ctx.validate_states(r.export()["verts"])
+    assert (vok == 0).sum() == rv["invalid_vertices"]
+    good = r.export()["verts"][vok != 0]
+    block_xy = verts[np.flatnonzero(vok == 0)[0], :2]
+    cand = good[np.argsort(np.hypot(good[:, 0] - block_xy[0], good[:, 1] - block_xy[1]))]
+    s2, g2 = cand[0], cand[5]                       # valid states right next to the invalidated region
+    r.set_query(s2, g2)
+    ex = r.export()
+    for q in (0, 1):
+        nb = ex["knn"][q]
+        nb = nb[nb != 0xffffffff]
+        assert len(nb) > 0 and (vok[nb[nb >= 2]] != 0).all(), "a query vertex was connected to an invalid vertex"
+    r.close()
+    ctx.close()
