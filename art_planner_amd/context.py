@@ -320,6 +320,14 @@ class Context:
         self._chk(self.L.artp_cost_query(self.h, e.ctypes.data, e.shape[0], out.ctypes.data), "artp_cost_query")
         return out
 
+    def cost_query_cells(self, edges):
+        """(rows, cols) of the feature-map cells the cost query gathers (artp_cost_debug_query_cells)."""
+        e = np.ascontiguousarray(edges, np.float32).reshape(-1, 6)
+        rows, cols = np.empty(e.shape[0], np.int32), np.empty(e.shape[0], np.int32)
+        self._chk(self.L.artp_cost_debug_query_cells(self.h, e.ctypes.data, e.shape[0], rows.ctypes.data,
+                                                     cols.ctypes.data), "artp_cost_debug_query_cells")
+        return rows, cols
+
     def cost_query_dev(self, edges_t, cost_t):
         self._chk(self.L.artp_cost_query_dev(self.h, edges_t.data_ptr(), edges_t.shape[0], cost_t.data_ptr()),
                   "artp_cost_query_dev")

@@ -2263,7 +2263,8 @@ static int cost_update_map_impl(artp_ctx* c, const float* elev_xy, bool on_devic
   if (rc) return rc;
   // CostQuery.setMapParams (cost_query.py:26-35): featureResFactor = 2, mapClip = 24
   CostMapGeom& g = c->cost_geom;
-  g.F = c->feat_h;  // square maps in the reference; the column extent is feat_w (see fc kernel clamp)
+  g.Fh = c->feat_h;  // predictor.features.shape[2] / shape[3] (cost_query.py:54-55): maps need not be square
+  g.Fw = c->feat_w;
   g.feat_res = res * 2;
   g.row_bias = (int)((len_x / res - 2 * 24) / 2 * 0.5);
   g.col_bias = (int)((len_y / res - 2 * 24) / 2 * 0.5);
@@ -2316,10 +2317,6 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
   if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
   if (!c->have_features) return ARTP_ERR_NO_MAP;
   if (b == 0) return ARTP_OK;
-  if (c->feat_h != c->feat_w) {
-    c->last_error = "cost query supports square feature maps";
-    return ARTP_ERR_INVALID_ARG;
-  }
   HIP_TRY(c, hipSetDevice(c->device));
   // up to 2^16 edges (a roadmap update's query): four lanes per edge; above that a lane per edge fills the GPU.  Both
   // kernels accumulate every unit in the same order: the same bits
@@ -2330,6 +2327,29 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
     hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, c->stream, edges, b,
                        (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
   HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+// diagnostics: the feature-map cell CostQuery.__call__ gathers for every edge's start (cost_query.py:54-55), from the
+// very device function the cost kernels use
+int artp_cost_debug_query_cells(artp_ctx* c, const float* edges, size_t b, int32_t* rows_out, int32_t* cols_out) {
+  if (!c || (b && (!edges || !rows_out || !cols_out))) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (!c->have_features) return ARTP_ERR_NO_MAP;
+  if (b == 0) return ARTP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_tmp(c, 0, b * 6 * sizeof(float));
+  if (rc) return rc;
+  rc = ensure_tmp(c, 1, 2 * b * sizeof(int));
+  if (rc) return rc;
+  int* d_rc = static_cast<int*>(c->tmp[1]);
+  HIP_TRY(c, hipMemcpyAsync(c->tmp[0], edges, b * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(cost_query_cells_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, c->stream,
+                     static_cast<const float*>(c->tmp[0]), b, c->cost_geom, d_rc, d_rc + b);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(rows_out, d_rc, b * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(cols_out, d_rc + b, b * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ARTP_OK;
 }
 

@@ -603,11 +603,33 @@ struct FcWeights {  // BN folded; fp32; offsets into one LDS/global array
 };
 
 struct CostMapGeom {
-  int F;              // feature map is F x F
+  int Fh, Fw;         // feature map is Fh x Fw = predictor.features.shape[2], shape[3] (cost_query.py:54-55)
   double feat_res;    // res * featureResDownsampleFactor (cost_query.py:33)
   int row_bias, col_bias;  // cost_query.py:34-35
   double cx, cy;      // map centre subtracted by the server (cost_query_server.py:134-135,160-161)
 };
+
+// CostQuery.__call__'s gather index (cost_query.py:54-55) for a start position: float64 arithmetic (the server hands
+// float64 numpy to torch), clamp to [1, shape - 2], .long() truncation.  The ONE place the product computes it (both
+// fc kernels and artp_cost_debug_query_cells, which the tests compare with the reference's own CostQuery).
+__device__ __forceinline__ void cost_query_cell(const CostMapGeom& g, double sx, double sy, int* row, int* col) {
+  double pr = (sx - g.cx) / g.feat_res + (double)g.row_bias;
+  double pc = (sy - g.cy) / g.feat_res + (double)g.col_bias;
+  pr = pr < 1.0 ? 1.0 : (pr > (double)(g.Fh - 2) ? (double)(g.Fh - 2) : pr);
+  pc = pc < 1.0 ? 1.0 : (pc > (double)(g.Fw - 2) ? (double)(g.Fw - 2) : pc);
+  *row = (int)pr;
+  *col = (int)pc;
+}
+
+__global__ void __launch_bounds__(256)
+cost_query_cells_kernel(const float* __restrict__ edges, size_t B, CostMapGeom g, int* __restrict__ rows, int* __restrict__ cols) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B) return;
+  int r, c;
+  cost_query_cell(g, (double)edges[6 * e + 3], (double)edges[6 * e + 4], &r, &c);
+  rows[e] = r;
+  cols[e] = c;
+}
 
 // edges: [B][6] = tx ty tyaw sx sy syaw (motion_cost_objective.h:22, prm_motion_cost.cpp:41-52)
 // feat : NHWC fp16 [F][F][48], index [row][col] with row growing along world x (cost_query_server.py:74)
@@ -621,13 +643,9 @@ fc_cost_kernel(const float* __restrict__ edges, size_t B, const half_t* __restri
   if (e >= B) return;
   const float* ed = edges + 6 * e;
   const double tx = ed[0], ty = ed[1], tyaw = ed[2], sx = ed[3], sy = ed[4], syaw = ed[5];
-  // cost_query.py:51-55 (double arithmetic: the server hands float64 numpy to torch)
-  double pr = (sx - g.cx) / g.feat_res + (double)g.row_bias;
-  double pc = (sy - g.cy) / g.feat_res + (double)g.col_bias;
-  pr = pr < 1.0 ? 1.0 : (pr > (double)(g.F - 2) ? (double)(g.F - 2) : pr);
-  pc = pc < 1.0 ? 1.0 : (pc > (double)(g.F - 2) ? (double)(g.F - 2) : pc);
-  const int row = (int)pr, col = (int)pc;
-  const half_t* fp = feat + ((size_t)row * g.F + col) * 48;
+  int row, col;
+  cost_query_cell(g, sx, sy, &row, &col);  // cost_query.py:51-55
+  const half_t* fp = feat + ((size_t)row * g.Fw + col) * 48;
   float x[64];
 #pragma unroll
   for (int v = 0; v < 6; ++v) {
@@ -730,12 +748,9 @@ fc_cost_split_kernel(const float* __restrict__ edges, size_t B, const half_t* __
   const size_t e = live ? e_raw : B - 1;
   const float* ed = edges + 6 * e;
   const double tx = ed[0], ty = ed[1], tyaw = ed[2], sx = ed[3], sy = ed[4], syaw = ed[5];
-  double pr = (sx - g.cx) / g.feat_res + (double)g.row_bias;
-  double pc = (sy - g.cy) / g.feat_res + (double)g.col_bias;
-  pr = pr < 1.0 ? 1.0 : (pr > (double)(g.F - 2) ? (double)(g.F - 2) : pr);
-  pc = pc < 1.0 ? 1.0 : (pc > (double)(g.F - 2) ? (double)(g.F - 2) : pc);
-  const int row = (int)pr, col = (int)pc;
-  const half_t* fp = feat + ((size_t)row * g.F + col) * 48;
+  int row, col;
+  cost_query_cell(g, sx, sy, &row, &col);
+  const half_t* fp = feat + ((size_t)row * g.Fw + col) * 48;
   float x[64];
 #pragma unroll
   for (int v = 0; v < 6; ++v) {

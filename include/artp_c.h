@@ -517,6 +517,10 @@ int artp_cost_set_hole_filling(artp_ctx* ctx, int enabled);
  * cost [B][3] = energy, time, risk (= 1 - prob; cost_query.py:65-69). */
 int artp_cost_query(artp_ctx* ctx, const float* edges, size_t b, float* cost);
 int artp_cost_query_dev(artp_ctx* ctx, const float* edges, size_t b, float* cost);
+/* diagnostics: the feature-map cell (row, col) CostQuery.__call__ gathers for each edge's start position
+ * (cost_query.py:54-55: float64 arithmetic, clamp to [1, shape - 2], .long()) -- computed by the device function the
+ * cost kernels use; the tests compare it with the reference's own CostQuery.  Host buffers. */
+int artp_cost_debug_query_cells(artp_ctx* ctx, const float* edges, size_t b, int32_t* rows_out, int32_t* cols_out);
 /* diagnostics: feature map as float [fh][fw][48]; out may be NULL to query the size */
 int artp_cost_get_features(artp_ctx* ctx, float* out, int* fh, int* fw);
 

@@ -62,20 +62,23 @@ def cnn_features(p, elev):
 
 
 def query_cells(edges, res, len_x, len_y, F, cx=0.0, cy=0.0):
-    """CostQuery.setMapParams + the index arithmetic of __call__ (cost_query.py:26-35,54-55)."""
+    """CostQuery.setMapParams + the index arithmetic of __call__ (cost_query.py:26-35,54-55): float64 arithmetic (the
+    server hands float64 numpy to torch, cost_query_server.py:131-136), clamp to [1, shape - 2], .long() truncation.
+    F = features.shape[2] for a square feature map, or (shape[2], shape[3]).  Pinned on the reference's own CostQuery
+    by tests/golden/cost_query_ref.npz (make_golden_cost.py imports cost_query.py where it lies)."""
+    Fh, Fw = (F, F) if np.isscalar(F) else F
     feat_res = res * 2
     row_bias = int((len_x / res - 2 * 24) / 2 * 0.5)
     col_bias = int((len_y / res - 2 * 24) / 2 * 0.5)
     e = np.asarray(edges, np.float64)
-    row = np.clip((e[:, 3] - cx) / feat_res + row_bias, 1, F - 2).astype(np.int64)
-    col = np.clip((e[:, 4] - cy) / feat_res + col_bias, 1, F - 2).astype(np.int64)
+    row = np.clip((e[:, 3] - cx) / feat_res + row_bias, 1, Fh - 2).astype(np.int64)
+    col = np.clip((e[:, 4] - cy) / feat_res + col_bias, 1, Fw - 2).astype(np.int64)
     return row, col
 
 
 def fc_costs(p, feats, edges, res, len_x, len_y, cx=0.0, cy=0.0):
     """CostQuery.__call__ + network.FCpart: edges [B,6] -> [B,3] = energy, time, 1 - prob."""
-    F = feats.shape[1]
-    row, col = query_cells(edges, res, len_x, len_y, F, cx, cy)
+    row, col = query_cells(edges, res, len_x, len_y, (feats.shape[1], feats.shape[2]), cx, cy)
     f = feats[:, row, col].T.astype(np.float32)  # [B,48]
     e = np.asarray(edges, np.float32)
     d = e[:, :3] - e[:, 3:]

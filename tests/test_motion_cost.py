@@ -19,9 +19,12 @@ GOLD = np.load(os.path.join(common.GOLDEN_DIR, "motion_cost.npz"))
 # The HIP path (fp16 activations, fp32 accumulation) must stay within ANCHOR_FACTOR x these figures of the float32
 # result: the survey's 2e-3 rel / 1e-3 abs (8c) is tighter than the reference's own half evaluation achieves
 # (C3: cost errors up to 8e-3, 2.5e-3 beyond the relative part for 1 % of the edges), so it cannot be the bar.
+# Factor 1.0 since round 4 (1.5 before): the HIP path may not lose more than the reference's own half evaluation does;
+# measured it loses 0.3 - 0.55 x that (gpurun_out/motion_cost_err_*.json).
 import json  # noqa: E402
 ANCHOR = json.load(open(os.path.join(common.GOLDEN_DIR, "motion_cost_fp16_anchor.json")))["cases"]
-ANCHOR_FACTOR = 1.5
+ANCHOR_FACTOR = 1.0
+CQ_REF = np.load(os.path.join(common.GOLDEN_DIR, "cost_query_ref.npz"))
 
 
 def _assert_within_reference_half_error(f_hwc, ref_chw, c, c_ref, case, report=None):
@@ -51,6 +54,26 @@ def test_oracle_matches_reference_network_golden():
     assert np.abs(f - GOLD["features"]).max() < 1e-3
     c = mo.fc_costs(p, GOLD["features"], GOLD["edges"], res, L, L)
     assert np.abs(c - GOLD["costs"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["sq", "rect"])
+def test_oracle_gather_and_costs_equal_the_reference_cost_query(tag):
+    """R9 pinned on the reference's OWN CostQuery (cost_query.py:26-35,39-69, imported where it lies by
+    tests/golden/make_golden_cost.py): rows / cols of the gather -- starts far outside the map (both clamps), starts
+    exactly on feature-cell borders +- one float32 ulp (the .long() truncation decides), a non-square map -- are
+    IDENTICAL; the costs equal the reference FCpart's on the gathered features."""
+    g = CQ_REF
+    crop = g[f"{tag}_crop"].astype(np.float32)
+    res = float(g["res"])
+    Lx, Ly = crop.shape[0] * res, crop.shape[1] * res
+    p = mo.random_params(0)
+    f = mo.cnn_features(p, crop)
+    assert (tag == "rect") == (f.shape[1] != f.shape[2])
+    rows, cols = mo.query_cells(g[f"{tag}_edges"], res, Lx, Ly, (f.shape[1], f.shape[2]))
+    assert np.array_equal(rows, g[f"{tag}_rows"]) and np.array_equal(cols, g[f"{tag}_cols"])
+    assert rows.min() == 1 and rows.max() == f.shape[1] - 2 and cols.min() == 1 and cols.max() == f.shape[2] - 2
+    c = mo.fc_costs(p, f, g[f"{tag}_edges"], res, Lx, Ly)
+    assert np.abs(c - g[f"{tag}_costs"]).max() < 1e-4
 
 
 def test_blob_layout():
@@ -188,6 +211,36 @@ def test_gpu_features_and_costs_match_reference_golden():
     c = ctx.cost_query(GOLD["edges"])
     # vs the REFERENCE network's float32 outputs, within 1.5x of the reference's own half-vs-float32 error
     _assert_within_reference_half_error(f, GOLD["features"], c, GOLD["costs"], "golden_112")
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["sq", "rect"])
+def test_gpu_gather_and_costs_equal_the_reference_cost_query(tag):
+    """The HIP cost query against the reference's own CostQuery (tests/golden/cost_query_ref.npz): the gathered cell of
+    every edge -- computed by the device function both cost kernels use -- is IDENTICAL to the reference's (clamps,
+    cell borders +- 1 ulp, non-square feature map 36 x 32), the costs within the reference's own half-vs-float32 error."""
+    from art_planner_amd.context import Context
+    g = CQ_REF
+    crop = g[f"{tag}_crop"].astype(np.float32)
+    res = float(g["res"])
+    Lx, Ly = crop.shape[0] * res, crop.shape[1] * res
+    ctx = Context(0, "yaml")
+    ctx.cost_load_weights(convert_weights.to_blob(mo.random_params(0)))
+    ctx.cost_update_map(crop, res, Lx, Ly)
+    f = ctx.cost_features()
+    assert f.shape[:2] == ((36, 32) if tag == "rect" else (32, 32))
+    e = g[f"{tag}_edges"]
+    rows, cols = ctx.cost_query_cells(e)
+    assert np.array_equal(rows, g[f"{tag}_rows"]) and np.array_equal(cols, g[f"{tag}_cols"])
+    c = ctx.cost_query(e)                                   # <= 2^16 edges: four lanes per edge
+    big = np.tile(e, (24, 1))                               # > 2^16 edges: the lane-per-edge kernel
+    assert np.array_equal(ctx.cost_query(big)[:len(e)], c)
+    ce = np.abs(c - g[f"{tag}_costs"])
+    a = ANCHOR["golden_112"]
+    assert ce.max() <= ANCHOR_FACTOR * a["cost_err_max"] and ce.mean() <= ANCHOR_FACTOR * a["cost_err_mean"], (ce.max(), ce.mean())
+    # and the features the costs were computed on, against the float32 oracle (== the reference to 2e-5)
+    _assert_features_close(f, mo.cnn_features(mo.random_params(0), crop), tag)
     ctx.close()
 
 
