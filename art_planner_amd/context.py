@@ -214,6 +214,12 @@ class Context:
         self._chk(self.L.artp_check_motions_dev(self.h, s1_t.data_ptr(), s2_t.data_ptr(), s1_t.shape[0],
                                                 valid_t.data_ptr()), "artp_check_motions_dev")
 
+    def check_motions_last_valid_dev(self, s1_t, s2_t, valid_t, last_t_t, last_state_t=None):
+        self._chk(self.L.artp_check_motions_last_valid_dev(self.h, s1_t.data_ptr(), s2_t.data_ptr(), s1_t.shape[0],
+                                                           valid_t.data_ptr(), last_t_t.data_ptr(),
+                                                           last_state_t.data_ptr() if last_state_t is not None else None),
+                  "artp_check_motions_last_valid_dev")
+
     def check_edges_interp_dev(self, s1_t, s2_t, valid_t, nint_t=None):
         self._chk(self.L.artp_check_edges_interp_dev(self.h, s1_t.data_ptr(), s2_t.data_ptr(), s1_t.shape[0],
                                                      valid_t.data_ptr(),
