@@ -2197,8 +2197,14 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
                          (const float*)c->d_convb[2], (const half8*)c->d_convw_chunk[2], (const float*)c->d_convb[3], Bf);
       return ARTP_OK;
     };
-    const int rcb = rounds_cost(18) < rounds_cost(16) ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
-                                                      : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16);
+    // (round 4: 12 added -- 400 x 400 is 256 tiles of 12 = ONE round on all 256 CUs against 144 tiles of 16 on 144 CUs)
+    int t_best = 16;
+    for (int t : {12, 18})
+      if (rounds_cost(t) < rounds_cost(t_best)) t_best = t;
+    if (const char* ev = std::getenv("ARTP_C345_T")) t_best = std::atoi(ev);  // tuning
+    const int rcb = t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
+                    : t_best == 12 ? launch_b(conv345_kernel<12>, C345Cfg<12>::LDS_BYTES, 12)
+                                   : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16);
     if (rcb != ARTP_OK) return rcb;
     HIP_TRY(c, hipGetLastError());
     A = Bf;  // the 15 x 15 layer below reads conv5's output
@@ -2219,15 +2225,21 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
         best = tr;
       }
     }
-    auto launch = [&](auto kfn, int lds, int tr) -> int {
+    auto launch = [&](auto kfn, int lds, int tr, int threads = 256) -> int {
       HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       const unsigned blocks = (unsigned)(((wf + 15) / 16) * ((hf + tr - 1) / tr));
-      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw[4],
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(threads), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw[4],
                          (const float*)c->d_convb[4], c->d_feat);
       return ARTP_OK;
     };
     int rcl;
-    if (best == 9)
+    // no more 8-row tiles than CUs (C3: 242): one 8-wavefront workgroup per CU, two wavefronts per SIMD
+    const long tiles8 = (long)((wf + 15) / 16) * ((hf + 7) / 8);
+    const char* ev8 = std::getenv("ARTP_KSPLIT_NWV");
+    const bool wide = ev8 ? std::atoi(ev8) == 8 : tiles8 <= c->n_cus;
+    if (wide)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
+    else if (best == 9)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9>::LDS_BYTES, 9);
     else if (best == 10)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 10>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 10>::LDS_BYTES, 10);

@@ -54,23 +54,30 @@ struct ConvLdsCfg {
 //  * TR is chosen per launch (cost_run_cnn): the launch's last, partly filled round of workgroups costs a full
 //    round's time, so at 800 x 800 (376 x 376 outputs) 9-row tiles -- 1008 workgroups = 2 rounds of 512 -- beat
 //    8-row tiles -- 1128 = 2.2 rounds -- by a tenth although each tile is an eighth bigger.
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR = 8>
+//  * NWV = wavefronts per workgroup (round 4).  4: two workgroups share a CU (the C4 launch: 1008 tiles).  8: ONE
+//    workgroup per CU whose eight wavefronts split the k-steps eight ways -- for launches with no more tiles than CUs
+//    (C3: 242 tiles on 256 CUs, where a 4-wavefront workgroup left every SIMD with a single wavefront and nothing to
+//    issue MFMAs while it waits for its B fragments or its LDS row: MFMA busy 0.40).  Same tile, same B traffic, two
+//    wavefronts per SIMD; the reduction takes eight partial tiles instead of four.
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR = 8, int NWV = 4>
 struct ConvKsplitCfg {
   using P = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
-  static constexpr int RED_BYTES = 4 * 4 * NT * 1024;           // four wavefronts' partial rows, four rows at a time
+  static constexpr int RED_BYTES = NWV * 4 * NT * 1024;         // the wavefronts' partial rows, four rows at a time
   static constexpr int STAGE_BYTES = TR * P::TP * COUT * 2;     // finished NHWC tile
   static constexpr int STAGE_OFF = RED_BYTES;
   static constexpr int LDS_BYTES = P::A_BYTES > RED_BYTES + STAGE_BYTES ? P::A_BYTES : RED_BYTES + STAGE_BYTES;
-  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  static_assert(NWV == 4 || NWV == 8, "k-steps are dealt out modulo a power of two");
+  static_assert(LDS_BYTES <= (NWV == 4 ? 80 : 160) * 1024, "two workgroups per CU (NWV = 4), one (NWV = 8)");
   static_assert((COUT * 2) % 16 == 0, "a pixel is a whole number of 16-byte chunks");
 };
 
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR>
-__global__ void __launch_bounds__(256, 2)
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1)
 conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
                    const float* __restrict__ bias, half_t* __restrict__ out) {
   using Cfg = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
   constexpr int KSTEPS = Cfg::KSTEPS;
+  constexpr int NTH = 64 * NWV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;
   const int Hout = Hin - KH + 1, Wout = Win - KW + 1;
@@ -84,12 +91,12 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   // All of a thread's loads are in flight before the first LDS store (one memory round trip, not 16).
   {
     constexpr int CPR = Cfg::ROW_B / 16;  // 16-byte chunks per patch row
-    constexpr int NIT = (Cfg::PR * CPR + 255) / 256;
+    constexpr int NIT = (Cfg::PR * CPR + NTH - 1) / NTH;
     const long row_bytes = (long)Win * Cfg::PIX_B;
     half8 v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int c = tid + it * 256;
+      const int c = tid + it * NTH;
       const int r = c / CPR, cc = c - r * CPR;
       const long off = (long)ox0 * Cfg::PIX_B + (long)cc * 16;
 #pragma unroll
@@ -99,7 +106,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int c = tid + it * 256;
+      const int c = tid + it * NTH;
       const int r = c / CPR, cc = c - r * CPR;
       if (c < Cfg::PR * CPR) *reinterpret_cast<half8*>(As + r * Cfg::ROW_B + cc * 16) = v[it];
     }
@@ -115,13 +122,14 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   const char* a_lane = As + li * Cfg::PIX_B + kg * 16;
   // which k-steps a wavefront takes, and in which order, rotates with the workgroup index (the workgroups of a launch
   // stream the same 1 MB of B fragments; no two neighbours in the same order)
-  const int ks_first = (wave + (int)(blockIdx.x & 3u)) & 3;
-  const int nj = (KSTEPS - ks_first + 3) / 4;
+  const int ks_first = (wave + (int)(blockIdx.x & (unsigned)(NWV - 1))) & (NWV - 1);
+  const int nj = (KSTEPS - ks_first + NWV - 1) / NWV;
   const int j0 = (int)((blockIdx.x >> 2) % (unsigned)nj);
   static_assert(KH % 3 == 0 || KH == 1, "the B ring (3 slots) runs on across k-steps: slot = (step index) % 3");
+  static_assert(KSTEPS >= NWV, "every wavefront takes at least one k-step");
   auto ks_of = [&](int jj) {
     const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
-    return ks_first + 4 * j;
+    return ks_first + NWV * j;
   };
   half8 b[3][NT];  // ring over (k-step, kernel row), two ahead -- it never drains: the last two kernel rows of a k-step
                    // prefetch the first two of the wavefront's next k-step
@@ -164,7 +172,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   // The four partial tiles meet in LDS four rows at a time (the patch is dead); wavefront w finishes row 4 h + w.
   // The finished halfs are staged as the NHWC tile [TR][16][COUT] behind the partial rows, then leave as whole
   // 16-byte lanes (a tile row is one contiguous 16*COUT*2-byte run of the output image).
-  using KCfg = ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
+  using KCfg = ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU, TR, NWV>;
   typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
   floatx4* red = reinterpret_cast<floatx4*>(smem);
   char* stage = smem + KCfg::STAGE_OFF;
@@ -180,12 +188,12 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
       }
     __syncthreads();
     const int m = 4 * h + wave;
-    if (m < TR) {
+    if (wave < 4 && m < TR) {  // wavefront w < 4 finishes row 4 h + w (the others only contribute their partials)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         floatx4 v = red[((0 * 4 + wave) * NT + n) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NWV; ++w) {
           const floatx4 p = red[((w * 4 + wave) * NT + n) * 64 + lane];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += p[r];
@@ -207,7 +215,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   __syncthreads();
   {
     constexpr int CPR = 16 * COUT * 2 / 16;  // 16-byte chunks per tile row
-    for (int c = tid; c < TR * CPR; c += 256) {
+    for (int c = tid; c < TR * CPR; c += NTH) {
       const int m = c / CPR, cc = c - m * CPR;
       const int px = (cc * 16) / (COUT * 2);
       if (oy0 + m < Hout && ox0 + px < Wout)
