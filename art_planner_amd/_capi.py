@@ -85,7 +85,7 @@ class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
                 ("risk_threshold", C.c_float),
                 ("max_n_edges", C.c_uint32), ("recompute_density_after_n_samples", C.c_uint32),
                 ("max_sample_time", C.c_double), ("density_map", C.c_void_p), ("density_params", C.c_void_p),
-                ("construction", C.c_int32)]
+                ("construction", C.c_int32), ("max_query_edge_length", C.c_double)]
 
 
 def load():

@@ -318,6 +318,18 @@ chain_edge_matrix_kernel(const double* __restrict__ s1, const double* __restrict
   }
 }
 
+// MotionCostObjective::motionCost's own split of a motion (motion_cost_objective.cpp:41-42):
+// n_interp = (unsigned)(lateralDistance / max_query_edge_length)
+__global__ void __launch_bounds__(256)
+motion_cost_interp_kernel(const double* __restrict__ s1, const double* __restrict__ s2, size_t ne, double step,
+                          uint32_t* __restrict__ n_interp) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const double dx = s2[e * 7] - s1[e * 7], dy = s2[e * 7 + 1] - s1[e * 7 + 1];
+  const double q = sqrt(dx * dx + dy * dy) / step;
+  n_interp[e] = q >= 0.0 && q < 4194304.0 ? (uint32_t)q : 0u;
+}
+
 __global__ void __launch_bounds__(256)
 chain_rows_kernel(const uint32_t* __restrict__ n_interp, size_t ne, uint32_t* __restrict__ rows) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,18 +672,21 @@ bool roadmap_sssp_dev(artp_roadmap* rm, std::vector<uint32_t>* path, double* cos
 // direct: no interpolation rule -- every edge is one sub-edge of unknown validity (reported valid), the way the
 // reference's planners put the edges of an already dense neighbourhood (n_interp == 0, prm_motion_cost.cpp:345-348)
 // and LazyPRM*'s edges into their graphs.
+// segment_cost_step > 0 (learned objective only): the edges are path SEGMENTS priced the way
+// MotionCostObjective::motionCost prices a motion -- split by max_query_edge_length, not along the validity chain.
 int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const double* d_s1, const double* d_s2,
-                           size_t ne, uint8_t* evalid, uint32_t* einterp, double* ecost, bool direct = false) {
+                           size_t ne, uint8_t* evalid, uint32_t* einterp, double* ecost, bool direct = false,
+                           double segment_cost_step = 0.0) {
   if (ne == 0) return ARTP_OK;
   hipStream_t st = c->stream;
   double* d_cost = nullptr;
   uint8_t* d_evalid = nullptr;
-  uint32_t *d_einterp = nullptr, *d_rows = nullptr, *d_off = nullptr;
+  uint32_t *d_einterp = nullptr, *d_rows = nullptr, *d_off = nullptr, *d_ncost = nullptr;
   float *d_em = nullptr, *d_c3 = nullptr;
   void* d_cub2 = nullptr;
   auto cleanup = [&]() {
     for (void* p : {(void*)d_cost, (void*)d_evalid, (void*)d_einterp, (void*)d_rows, (void*)d_off, (void*)d_em,
-                    (void*)d_c3, d_cub2})
+                    (void*)d_c3, d_cub2, (void*)d_ncost})
       if (p) (void)hipFree(p);
   };
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cost), ne * sizeof(double)));
@@ -689,12 +704,18 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
                        d_s2, (const uint32_t*)d_einterp, ne, d_cost);
   } else {
     // learned cost: one EdgeMatrix row per sub-edge, one batched query, per-chain reduction
+    const uint32_t* d_chain = d_einterp;  // sub-edges of the validity chain (what the reference's graph holds) ...
+    if (segment_cost_step > 0.0) {        // ... or motionCost's own split of a path segment
+      RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_ncost), ne * sizeof(uint32_t)));
+      hipLaunchKernelGGL(artp::motion_cost_interp_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, d_s1, d_s2, ne,
+                         segment_cost_step, d_ncost);
+      d_chain = d_ncost;
+    }
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_rows), (ne + 1) * 4));
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_off), (ne + 1) * 4));
     size_t need = 0;
     uint32_t total = 0;
-    hipLaunchKernelGGL(artp::chain_rows_kernel, dim3((unsigned)((ne + 256) / 256)), dim3(256), 0, st,
-                       (const uint32_t*)d_einterp, ne, d_rows);
+    hipLaunchKernelGGL(artp::chain_rows_kernel, dim3((unsigned)((ne + 256) / 256)), dim3(256), 0, st, d_chain, ne, d_rows);
     RM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_rows, d_off, (int)(ne + 1), st));
     RM_HIP(hipMalloc(&d_cub2, need + 256));
     size_t cap2 = need + 256;
@@ -704,10 +725,10 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_em), (size_t)total * 6 * 4));
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_c3), (size_t)total * 3 * 4));
     hipLaunchKernelGGL(artp::chain_edge_matrix_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, d_s1, d_s2,
-                       (const uint32_t*)d_einterp, (const uint32_t*)d_off, ne, d_em);
+                       d_chain, (const uint32_t*)d_off, ne, d_em);
     RM_TRY(artp_cost_query_dev(c, d_em, total, d_c3));
     hipLaunchKernelGGL(artp::chain_motion_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
-                       (const float*)d_c3, (const uint32_t*)d_off, (const uint32_t*)d_einterp, ne, prm->w_energy,
+                       (const float*)d_c3, (const uint32_t*)d_off, d_chain, ne, prm->w_energy,
                        prm->w_time, prm->w_risk, prm->risk_threshold, d_cost);
   }
   RM_HIP(hipGetLastError());
@@ -723,7 +744,8 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
 // same for edges (eu[e], ev[e]) of host vertices: gathers the endpoint states on the host first
 int roadmap_eval_edges_host(artp_ctx* c, const artp_roadmap_params* prm, const std::vector<double>& verts,
                             const uint32_t* eu, const uint32_t* ev, size_t ne, uint8_t* evalid, uint32_t* einterp,
-                            double* ecost, bool direct = false, const uint8_t* flip = nullptr) {
+                            double* ecost, bool direct = false, const uint8_t* flip = nullptr,
+                            double segment_cost_step = 0.0) {
   if (ne == 0) return ARTP_OK;
   std::vector<double> s(2 * ne * 7);
   for (size_t e = 0; e < ne; ++e) {
@@ -738,7 +760,7 @@ int roadmap_eval_edges_host(artp_ctx* c, const artp_roadmap_params* prm, const s
   RM_HIP(hipSetDevice(c->device));
   RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_s), s.size() * sizeof(double)));
   RM_HIP(hipMemcpy(d_s, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice));
-  RM_TRY(roadmap_eval_edges_dev(c, prm, d_s, d_s + ne * 7, ne, evalid, einterp, ecost, direct));
+  RM_TRY(roadmap_eval_edges_dev(c, prm, d_s, d_s + ne * 7, ne, evalid, einterp, ecost, direct, segment_cost_step));
   cleanup();
   return ARTP_OK;
 }
@@ -768,6 +790,7 @@ void artp_roadmap_params_defaults(artp_roadmap_params* p) {
   p->max_sample_time = 0.0;
   p->density_map = nullptr;
   p->density_params = nullptr;
+  p->max_query_edge_length = 0.5;  // params.h:54
 }
 
 void artp_roadmap_destroy(artp_roadmap* rm) {
@@ -1835,7 +1858,11 @@ int artp_roadmap_simplify_path(artp_roadmap* rm, const double* path_se3, size_t 
   std::vector<uint32_t> ni(ne, 0);
   std::vector<double> ec(ne, 0.0);
   if (ne) {
-    int rc = roadmap_eval_edges_host(c, &rm->params, verts, eu.data(), ev.data(), ne, ok1.data(), ni.data(), ec.data());
+    // shortcut candidates are path segments: the learned objective prices them the way motionCost does
+    // (max_query_edge_length, motion_cost_objective.cpp:41-42); the 0.5 m rule still decides their validity
+    const double mq = rm->params.max_query_edge_length > 0.0 ? rm->params.max_query_edge_length : 0.5;
+    int rc = roadmap_eval_edges_host(c, &rm->params, verts, eu.data(), ev.data(), ne, ok1.data(), ni.data(), ec.data(), false,
+                                     nullptr, rm->params.objective == 2 ? mq : 0.0);
     if (rc != ARTP_OK) return rc;
     std::vector<double> s1(ne * 7), s2(ne * 7);
     for (size_t e = 0; e < ne; ++e) {

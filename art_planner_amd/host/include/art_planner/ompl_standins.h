@@ -5,6 +5,7 @@
 #pragma once
 
 #include <cmath>
+#include <functional>
 #include <memory>
 #include <random>
 #include <utility>
@@ -69,6 +70,11 @@ class RealVectorBounds {
   std::vector<double> high;
 };
 
+class StateSampler;
+class StateSpace;
+using StateSamplerPtr = std::shared_ptr<StateSampler>;
+using StateSamplerAllocator = std::function<StateSamplerPtr(const StateSpace*)>;
+
 class StateSpace {
  public:
   virtual ~StateSpace() = default;
@@ -76,7 +82,17 @@ class StateSpace {
   const T* as() const { return static_cast<const T*>(this); }
   template <class T>
   T* as() { return static_cast<T*>(this); }
+  // ompl/base/StateSpace.h: pure virtual there too
+  virtual State* allocState() const = 0;
+  virtual void freeState(State* state) const = 0;
+  virtual void copyState(State* destination, const State* source) const = 0;
+  void setStateSamplerAllocator(const StateSamplerAllocator& ssa) { ssa_ = ssa; }
+  StateSamplerPtr allocStateSampler() const { return ssa_ ? ssa_(this) : StateSamplerPtr(); }
+
+ private:
+  StateSamplerAllocator ssa_;
 };
+using StateSpacePtr = std::shared_ptr<StateSpace>;
 
 class SO3StateSpace : public StateSpace {
  public:
@@ -87,6 +103,13 @@ class SO3StateSpace : public StateSpace {
     void setIdentity() { x = y = z = 0; w = 1; }
     double x{0}, y{0}, z{0}, w{1};
   };
+  State* allocState() const override { return new StateType(); }
+  void freeState(State* state) const override { delete state->as<StateType>(); }
+  void copyState(State* destination, const State* source) const override {
+    auto* d = destination->as<StateType>();
+    const auto* q = source->as<StateType>();
+    d->x = q->x; d->y = q->y; d->z = q->z; d->w = q->w;
+  }
 };
 
 class SE3StateSpace : public StateSpace {
@@ -111,16 +134,45 @@ class SE3StateSpace : public StateSpace {
   };
   void setBounds(const RealVectorBounds& bounds) { bounds_ = bounds; }
   const RealVectorBounds& getBounds() const { return bounds_; }
-  State* allocState() const { return new StateType(); }
-  void freeState(State* state) const { delete state->as<StateType>(); }
+  State* allocState() const override { return new StateType(); }
+  void freeState(State* state) const override { delete state->as<StateType>(); }
+  void copyState(State* destination, const State* source) const override {
+    auto* d = destination->as<StateType>();
+    const auto* q = source->as<StateType>();
+    d->setXYZ(q->getX(), q->getY(), q->getZ());
+    d->rotation().x = q->rotation().x; d->rotation().y = q->rotation().y;
+    d->rotation().z = q->rotation().z; d->rotation().w = q->rotation().w;
+  }
 
  private:
   RealVectorBounds bounds_{3};
 };
 
+class StateValidityChecker;
+class MotionValidator;
+using StateValidityCheckerPtr = std::shared_ptr<StateValidityChecker>;
+using MotionValidatorPtr = std::shared_ptr<MotionValidator>;
+
+// ompl/base/SpaceInformation.h: the members the mirror's real-library branch touches (the real class has no default
+// constructor; the stand-in keeps one for tests that only need a handle to pass around)
 class SpaceInformation {
  public:
+  SpaceInformation() = default;
+  explicit SpaceInformation(StateSpacePtr space) : space_(std::move(space)) {}
   virtual ~SpaceInformation() = default;
+  const StateSpacePtr& getStateSpace() const { return space_; }
+  State* allocState() const { return space_->allocState(); }
+  void freeState(State* state) const { space_->freeState(state); }
+  void copyState(State* destination, const State* source) const { space_->copyState(destination, source); }
+  void setStateValidityChecker(const StateValidityCheckerPtr& svc) { svc_ = svc; }
+  const StateValidityCheckerPtr& getStateValidityChecker() const { return svc_; }
+  void setMotionValidator(const MotionValidatorPtr& mv) { mv_ = mv; }
+  const MotionValidatorPtr& getMotionValidator() const { return mv_; }
+
+ private:
+  StateSpacePtr space_;
+  StateValidityCheckerPtr svc_;
+  MotionValidatorPtr mv_;
 };
 using SpaceInformationPtr = std::shared_ptr<SpaceInformation>;
 

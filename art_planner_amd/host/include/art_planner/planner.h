@@ -29,6 +29,24 @@
 #include "art_planner/planner_status.h"
 #include "art_planner/planners/batch_prm.h"
 
+// With BOTH real libraries available the class also carries the reference's EXACT public signatures and the protected
+// members a subclass like PlannerRos reaches into (planner.h:41-70, planner_ros.h:24):
+//   setMap(std::unique_ptr<grid_map::GridMap>&&), plan(const ob::ScopedState<>&, const ob::ScopedState<>&),
+//   og::PathGeometric getSolutionPath(const bool&) const; ss_, space_, checker_, sampler_allocator_ (+ params_, map_,
+//   map_mutex_, solved_, which exist in every build).  tests/test_host_mirror.py compiles a PlannerRos-shaped subclass
+//   against tests/fake_include (neither library is installed in this image).
+#if defined(ARTP_HAVE_OMPL) && defined(ARTP_HAVE_GRID_MAP)
+#define ARTP_PLANNER_REFERENCE_SURFACE 1
+#include <functional>
+#include <grid_map_core/GridMap.hpp>
+#include <ompl/base/ScopedState.h>
+#include <ompl/geometric/PathGeometric.h>
+#include <ompl/geometric/SimpleSetup.h>
+#include "art_planner/sampler.h"
+#include "art_planner/validity_checker/validity_checker.h"
+namespace og = ompl::geometric;
+#endif
+
 namespace ob = ompl::base;
 
 namespace art_planner {
@@ -58,9 +76,27 @@ class Planner {
   using StateArray = BatchPRM::StateArray;
   using Path = std::vector<StateArray>;
 
+#ifdef ARTP_PLANNER_REFERENCE_SURFACE
+  // planner.cpp:75-131: the OMPL objects around the same GpuContext -- SimpleSetup on the SE3 space, the validity
+  // checker, the batched motion validator (in place of OMPL's DiscreteMotionValidator) and the sampler allocator
+  explicit Planner(const ParamsConstPtr& params = std::make_shared<const Params>(), int device = 0)
+      : params_(params), gpu_(std::make_shared<GpuContext>(params, device)),
+        prm_(std::make_shared<BatchPRM>(params, gpu_)), sampler_allocator_(params, gpu_) {
+    space_ = std::make_shared<StateSpace>();
+    ss_ = std::make_shared<og::SimpleSetup>(space_);
+    const ob::SpaceInformationPtr si = ss_->getSpaceInformation();
+    checker_ = std::make_shared<StateValidityChecker>(si, params_, gpu_);
+    ss_->setStateValidityChecker(checker_);
+    motion_validator_ = std::make_shared<BatchMotionValidator>(si, gpu_);
+    si->setMotionValidator(motion_validator_);
+    space_->setStateSamplerAllocator(
+        std::bind(&SE3FromSE2SamplerAllocator::getSampler, &sampler_allocator_, std::placeholders::_1));
+  }
+#else
   explicit Planner(const ParamsConstPtr& params = std::make_shared<const Params>(), int device = 0)
       : params_(params), gpu_(std::make_shared<GpuContext>(params, device)),
         prm_(std::make_shared<BatchPRM>(params, gpu_)) {}
+#endif
   ~Planner() {
     if (pre_) artp_preprocessed_destroy(pre_);
   }
@@ -157,7 +193,50 @@ class Planner {
       }
     }
     solved_ = false;
+#ifdef ARTP_PLANNER_REFERENCE_SURFACE
+    {  // planner.cpp:146-163: the state space's bounds, the checker's and the sampler's map
+      ob::RealVectorBounds bounds(3);
+      for (int a = 0; a < 3; ++a) {
+        bounds.setLow(a, low_[a]);
+        bounds.setHigh(a, high_[a]);
+      }
+      space_->setBounds(bounds);
+      checker_->setMap(map_);
+      checker_->heightFieldInstalled();   // both layers went to the device with artp_preprocessed_install above
+      motion_validator_->setZBounds(low_[2], high_[2]);
+      sampler_allocator_.setMap(map_);
+    }
+#endif
   }
+
+#ifdef ARTP_PLANNER_REFERENCE_SURFACE
+  // planner.h:65.  The grid map stays alive inside map_ (map_->getMap(), planner_ros.cpp:339).
+  void setMap(std::unique_ptr<grid_map::GridMap>&& map) {
+    if (!map) return;
+    setMap(std::make_unique<Map>(std::move(map)));
+  }
+
+  // planner.h:67-68
+  PlannerStatus plan(const ob::ScopedState<>& start, const ob::ScopedState<>& goal) {
+    return plan(*start.get()->as<StateType>(), *goal.get()->as<StateType>());
+  }
+
+  // planner.h:70
+  og::PathGeometric getSolutionPath(const bool& simplify = false) const {
+    const Path flat = getSolutionPathFlat(simplify);
+    const ob::SpaceInformationPtr si = ss_->getSpaceInformation();
+    og::PathGeometric path(si);
+    ob::State* st = si->allocState();
+    for (const StateArray& s : flat) {
+      unflattenSE3(s.data(), st);
+      path.append(st);   // copies the state
+    }
+    si->freeState(st);
+    return path;
+  }
+#else
+  Path getSolutionPath(const bool& simplify = false) const { return getSolutionPathFlat(simplify); }
+#endif
 
   bool hasMap() const {
     std::lock_guard<std::mutex> lock(map_mutex_);
@@ -227,7 +306,8 @@ class Planner {
 
   // planner.cpp:266-330: throws when the last plan() did not solve; with simplify, the simplified path
   // only when it is valid and not more expensive than the original.
-  Path getSolutionPath(const bool& simplify = false) const {
+  // (the flattened form; getSolutionPath returns it as it is without OMPL, as an og::PathGeometric with it)
+  Path getSolutionPathFlat(const bool& simplify = false) const {
     std::lock_guard<std::mutex> lock(map_mutex_);
     if (!solved_) throw std::runtime_error("Requested failed solution path.");
     if (!simplify) return path_;
@@ -261,6 +341,14 @@ class Planner {
   std::shared_ptr<Map> map_;
   mutable std::mutex map_mutex_;
   bool solved_{false};
+#ifdef ARTP_PLANNER_REFERENCE_SURFACE
+  // planner.h:41-52 -- what PlannerRos reaches into (planner_ros.cpp:242,254,313,359,373)
+  std::shared_ptr<og::SimpleSetup> ss_;
+  std::shared_ptr<StateSpace> space_;
+  std::shared_ptr<StateValidityChecker> checker_;
+  std::shared_ptr<BatchMotionValidator> motion_validator_;
+  SE3FromSE2SamplerAllocator sampler_allocator_;
+#endif
 
  private:
   double clamp(double v, int axis) const { return v < low_[axis] ? low_[axis] : (v > high_[axis] ? high_[axis] : v); }

@@ -60,6 +60,7 @@ class BatchPRM {
     p.w_time = params_->planner.prm_motion_cost.cost_weights.time;
     p.w_risk = params_->planner.prm_motion_cost.cost_weights.risk;
     p.risk_threshold = params_->planner.prm_motion_cost.risk_threshold;
+    p.max_query_edge_length = params_->planner.prm_motion_cost.max_query_edge_length;  // motion_cost_objective.cpp:42
     p.max_lon_vel = params_->objectives.custom_path_length.max_lon_vel;
     p.max_lat_vel = params_->objectives.custom_path_length.max_lat_vel;
     p.max_ang_vel = params_->objectives.custom_path_length.max_ang_vel;

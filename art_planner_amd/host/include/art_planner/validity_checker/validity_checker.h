@@ -62,6 +62,10 @@ class StateValidityChecker : public ob::StateValidityChecker {
     has_field_ = true;
   }
 
+  // the height fields reached the device another way (art_planner::Planner installs the result of the device
+  // preprocessing, artp_preprocessed_install): hasMap() is true from here on
+  void heightFieldInstalled() { has_field_ = true; }
+
   bool hasMap() const { return static_cast<bool>(map_) && has_field_; }
 
   // validity_checker.cpp:39-45

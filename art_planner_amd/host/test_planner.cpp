@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
   CHECK(planner->plan(start, goal) == PlannerStatus::NO_MAP);
   bool threw = false;
   try {
-    planner->getSolutionPath();
+    planner->getSolutionPathFlat();
   } catch (const std::exception&) {
     threw = true;
   }
@@ -100,9 +100,9 @@ int main(int argc, char** argv) {
     const PlannerStatus st = planner->plan(start, goal);
     CHECK(st == PlannerStatus::SOLVED);
     if (st != PlannerStatus::SOLVED) continue;
-    const auto path = planner->getSolutionPath(false);
+    const auto path = planner->getSolutionPathFlat(false);
     const double cost = planner->getSolutionCost();
-    const auto simple = planner->getSolutionPath(true);
+    const auto simple = planner->getSolutionPathFlat(true);
     CHECK(path.size() >= 2 && simple.size() >= 2 && simple.size() <= path.size());
     for (const auto* p : {&path, &simple}) {
       // endpoints: the start as given (it is valid), the goal within the goal region
@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
     const PlannerStatus st = planner->plan(start, goal);
     CHECK(st == PlannerStatus::SOLVED);
     if (st == PlannerStatus::SOLVED) {
-      const auto path = planner->getSolutionPath(false);
+      const auto path = planner->getSolutionPathFlat(false);
       std::vector<double> flat;
       for (const auto& s : path) flat.insert(flat.end(), s.begin(), s.end());
       std::vector<uint8_t> mv(path.size() - 1);
@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
   CHECK(planner->plan(off, goal) == PlannerStatus::INVALID_START);
   threw = false;
   try {
-    planner->getSolutionPath();
+    planner->getSolutionPathFlat();
   } catch (const std::exception&) {
     threw = true;
   }

@@ -1,0 +1,146 @@
+// A PlannerRos-SHAPED subclass of the host mirror's art_planner::Planner, built with -DARTP_HAVE_OMPL
+// -DARTP_HAVE_EIGEN -DARTP_HAVE_GRID_MAP: the reference's exact signatures -- setMap(std::unique_ptr<grid_map::GridMap>&&),
+// plan(const ob::ScopedState<>&, const ob::ScopedState<>&), og::PathGeometric getSolutionPath(const bool&) const
+// (art_planner/include/art_planner/planner.h:65-70) -- and the protected members art_planner_ros's PlannerRos reaches
+// into (`class PlannerRos : protected Planner`, planner_ros.h:24; planner_ros.cpp:46,131,242,254,313,339,359,373-374:
+// params_, ss_, space_, map_->getMap(), getSolutionPath).  Neither OMPL nor grid_map is installed in this image:
+// tests/test_host_mirror.py compiles this file against the scaffold under tests/fake_include (real include names) and
+// runs it on the GPU with test_planner's fixture, so the branch a maintainer builds is compiled AND executed.
+//   test_planner_ros_shape <fixture.bin>     exit 0 = every check holds, 3 = no GPU
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <vector>
+
+#include "art_planner/planner.h"
+
+#ifndef ARTP_PLANNER_REFERENCE_SURFACE
+#error "build with -DARTP_HAVE_OMPL -DARTP_HAVE_GRID_MAP (and the include paths of the two libraries)"
+#endif
+
+using namespace art_planner;
+
+static int fails = 0;
+#define CHECK(cond)                                                 \
+  do {                                                              \
+    if (!(cond)) {                                                  \
+      std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++fails;                                                      \
+    }                                                               \
+  } while (0)
+
+// what PlannerRos does with its base class, minus ROS
+class PlannerRosShape : protected Planner {
+ public:
+  explicit PlannerRosShape(const ParamsConstPtr& params) : Planner(params, 0) {
+    // planner_ros.cpp:254: converter_(space_); :242 / :313: ss_->getSpaceInformation()
+    CHECK(static_cast<bool>(space_) && static_cast<bool>(ss_) && static_cast<bool>(checker_));
+    CHECK(ss_->getSpaceInformation()->getStateSpace().get() == space_.get());
+    CHECK(static_cast<bool>(ss_->getSpaceInformation()->getMotionValidator()));
+  }
+
+  // planner_ros.cpp:327-343 (mapCallback -> setMap) with the grid map the node receives
+  void mapCallback(std::unique_ptr<grid_map::GridMap>&& map) {
+    setMap(std::move(map));
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    if (map_) {
+      // planner_ros.cpp:339: grid_map::GridMapRosConverter::toMessage(map_->getMap(), out_msg)
+      const grid_map::GridMap& gm = map_->getMap();
+      CHECK(gm.exists(params_->planner.elevation_layer));
+      CHECK(checker_->hasMap());
+    }
+  }
+
+  // planner_ros.cpp:99-135 (getAndPublishPathFromTo): ScopedStates from poses, plan, path to a message
+  PlannerStatus planFromTo(const double* s7, const double* g7, std::vector<std::vector<double>>* out) {
+    ob::ScopedState<> start(space_), goal(space_);
+    unflattenSE3(s7, start.get());
+    unflattenSE3(g7, goal.get());
+    const PlannerStatus status = plan(start, goal);
+    if (status == PlannerStatus::SOLVED) {
+      og::PathGeometric path = getSolutionPath(params_->planner.simplify_solution);   // :131
+      for (ob::State* st : path.getStates()) {   // converter_.pathOmplToRos walks the states
+        double s[7];
+        flattenSE3(st, s);
+        out->emplace_back(s, s + 7);
+      }
+    }
+    return status;
+  }
+
+  bool stateValid(const double* s7) {  // through the OMPL objects: si -> checker_ -> GPU
+    ob::ScopedState<> st(ss_->getSpaceInformation());
+    unflattenSE3(s7, st.get());
+    return ss_->getSpaceInformation()->getStateValidityChecker()->isValid(st.get());
+  }
+  bool motionValid(const double* a7, const double* b7) {
+    ob::ScopedState<> a(space_), b(space_);
+    unflattenSE3(a7, a.get());
+    unflattenSE3(b7, b.get());
+    return ss_->getSpaceInformation()->getMotionValidator()->checkMotion(a.get(), b.get());
+  }
+  void clearPlanner() {  // planner_ros.cpp:359,373-374
+    ss_->clear();
+    ss_->setup();
+  }
+};
+
+int main(int argc, char** argv) {
+  auto params = std::make_shared<Params>();
+  params->robot.torso.length = 1.31; params->robot.torso.width = 0.65; params->robot.torso.height = 0.3;
+  params->robot.torso.offset.z = 0.04;
+  params->robot.feet.offset.x = 0.51; params->robot.feet.offset.y = 0.2; params->robot.feet.offset.z = -0.475;
+  params->robot.feet.reach.x = 0.2; params->robot.feet.reach.y = 0.2; params->robot.feet.reach.z = 0.2;
+  params->planner.start_goal_search.start_radius = 0.3;
+  params->planner.start_goal_search.goal_radius = 0.3;
+  params->planner.start_goal_search.n_iter = 64;
+  params->planner.prm_motion_cost.max_n_vertices = 4000;
+  params->planner.plan_time = 0.05;
+  std::unique_ptr<PlannerRosShape> node;
+  try {
+    node.reset(new PlannerRosShape(params));
+  } catch (const std::exception& e) {
+    std::printf("no GPU context: %s\n", e.what());
+    return 3;
+  }
+  if (argc < 2) return 2;
+  std::ifstream f(argv[1], std::ios::binary);
+  int32_t rows, cols;
+  double geo[4], sg[14];
+  f.read(reinterpret_cast<char*>(&rows), 4);
+  f.read(reinterpret_cast<char*>(&cols), 4);
+  f.read(reinterpret_cast<char*>(geo), 32);
+  const size_t cells = static_cast<size_t>(rows) * cols;
+  std::vector<float> elev(cells), trav(cells);
+  f.read(reinterpret_cast<char*>(elev.data()), cells * 4);
+  f.read(reinterpret_cast<char*>(trav.data()), cells * 4);
+  f.read(reinterpret_cast<char*>(sg), sizeof(sg));
+  if (!f) return 2;
+
+  // the grid map as the node would receive it (column-major layers)
+  auto gm = std::make_unique<grid_map::GridMap>();
+  gm->setGeometry(grid_map::Length(geo[0], geo[1]), geo[0] / rows, grid_map::Position(geo[2], geo[3]));
+  CHECK(gm->getSize()(0) == rows && gm->getSize()(1) == cols);
+  grid_map::Matrix m(rows, cols);
+  std::copy(elev.begin(), elev.end(), m.data());
+  gm->add(params->planner.elevation_layer, m);
+  std::copy(trav.begin(), trav.end(), m.data());
+  gm->add(params->planner.traversability_layer, m);
+  node->mapCallback(std::move(gm));
+
+  CHECK(node->stateValid(sg) && node->stateValid(sg + 7));
+  std::vector<std::vector<double>> path;
+  const PlannerStatus status = node->planFromTo(sg, sg + 7, &path);
+  CHECK(status == PlannerStatus::SOLVED);
+  CHECK(path.size() >= 2);
+  if (path.size() >= 2) {
+    for (int k = 0; k < 2; ++k) CHECK(std::fabs(path.front()[k] - sg[k]) < 0.31 && std::fabs(path.back()[k] - sg[7 + k]) < 0.31);
+    for (size_t i = 0; i < path.size(); ++i) CHECK(node->stateValid(path[i].data()));
+    for (size_t i = 0; i + 1 < path.size(); ++i) CHECK(node->motionValid(path[i].data(), path[i + 1].data()));
+  }
+  node->clearPlanner();
+  std::printf("PlannerRos-shaped subclass: status %d, %zu path states, %d failed checks\n", static_cast<int>(status),
+              path.size(), fails);
+  return fails ? 1 : 0;
+}

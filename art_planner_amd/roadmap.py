@@ -15,7 +15,7 @@ class Roadmap:
     def __init__(self, ctx, start, goal, n_milestones=10000, seed=42, first_index=0, k_neighbors=0,
                  objective=0, max_lon_vel=0.5, max_lat_vel=0.1, max_ang_vel=0.5, max_replans=1000,
                  cost_weights=None, risk_threshold=None, max_n_edges=0, recompute_density_after_n_samples=0,
-                 max_sample_time=0.0, density_map=None, construction=0):
+                 max_sample_time=0.0, density_map=None, construction=0, max_query_edge_length=0.5):
         """construction: 0 = batched, 1 = PRMMotionCost::addValidMilestone order (the reference's own graph, chain
         vertices included), 2 = LazyPRMStarMinUpdate order (predecessor-only direct edges); include/artp_c.h.
         density_map: the PreprocessedMap of the installed map (Context.preprocess_map) -- needed for the in-build
@@ -34,6 +34,7 @@ class Roadmap:
         p.max_n_edges, p.recompute_density_after_n_samples = max_n_edges, recompute_density_after_n_samples
         p.max_sample_time = max_sample_time
         p.construction = construction
+        p.max_query_edge_length = max_query_edge_length
         self._density = density_map  # keeps the map (and its params) alive
         if density_map is not None:
             p.density_map = density_map.h

@@ -357,6 +357,13 @@ typedef struct artp_roadmap_params {
    * (new vertex -> neighbour, along the chain from the milestone: opt_->motionCost(m, n), updateEdges' source ->
    * target) -- visible with the directional and the learned objective; mode 0 evaluates smaller id -> larger id. */
   int32_t construction;
+  /* Params::planner.prm_motion_cost.max_query_edge_length (params.h:54, default 0.5): MotionCostObjective::motionCost
+   * (motion_cost_objective.cpp:41-42) splits a motion into n_interp = (unsigned)(lateral distance / this) + 1 cost
+   * queries -- what prices a path SEGMENT with the learned objective: the shortcut candidates of
+   * artp_roadmap_simplify_path and the path costs it compares.  (The GRAPH's sub-edges are priced one query each by
+   * PRMMotionCostMaintainer::updateEdges, and the 0.5 m of addValidMilestone's validity chain is a constant of its
+   * own, prm_motion_cost.cpp:343: neither depends on this.)  0 = 0.5. */
+  double max_query_edge_length;
 } artp_roadmap_params;
 void artp_roadmap_params_defaults(artp_roadmap_params* p);
 /* Samples, connects and validates.  ARTP_ERR_INVALID_ARG (artp_last_error says which) when start or goal

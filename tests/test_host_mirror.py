@@ -90,6 +90,18 @@ def test_real_library_branches_compile():
                             "-I" + fake, "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(common.ROOT, "include"),
                             os.path.join(HOST, src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+    # with grid_map too, Planner carries the reference's exact signatures and protected members (planner.h:41-70): a
+    # PlannerRos-shaped subclass (`class ... : protected Planner`, planner_ros.h:24) must build against them -- and the
+    # plain mirror programs must keep building in that configuration
+    for src in ("test_planner_ros_shape.cpp", "test_planner.cpp", "test_host.cpp"):
+        r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only", "-DARTP_HAVE_OMPL", "-DARTP_HAVE_EIGEN",
+                            "-DARTP_HAVE_GRID_MAP", "-I" + fake, "-I" + os.path.join(HOST, "include"),
+                            "-I" + os.path.join(common.ROOT, "include"), os.path.join(HOST, src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-DARTP_HAVE_OMPL", "-DARTP_HAVE_EIGEN", "-I" + fake,
+                        "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(common.ROOT, "include"),
+                        os.path.join(HOST, "test_planner_ros_shape.cpp")], capture_output=True, text=True)
+    assert r.returncode != 0 and "ARTP_HAVE_GRID_MAP" in r.stderr     # the exact surface needs both libraries
     # and the branch really is taken: without the fake tree the same flags must fail on the missing headers
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-DARTP_HAVE_OMPL", "-DARTP_HAVE_EIGEN",
                         "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(common.ROOT, "include"),
@@ -211,3 +223,11 @@ def test_planner_mirror_plans_on_a_perlin_map(tmp_path):
         f.write(np.ascontiguousarray(np.stack([acc[i], acc[j]]), np.float64).tobytes())
     r = subprocess.run([BIN_PLANNER, str(path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the same query through the reference's EXACT signatures: a PlannerRos-shaped subclass -- protected
+    # ss_ / space_ / checker_ / map_->getMap(), setMap(std::unique_ptr<grid_map::GridMap>&&), plan(ScopedState, ScopedState),
+    # og::PathGeometric getSolutionPath -- compiled with -DARTP_HAVE_OMPL -DARTP_HAVE_EIGEN -DARTP_HAVE_GRID_MAP against the
+    # scaffold tests/fake_include and RUN on the GPU: SOLVED, every path state and motion valid through the OMPL objects
+    subprocess.check_call(["make", "-s", "-C", HOST, "test_planner_ros_shape"])
+    r = subprocess.run([os.path.join(HOST, "test_planner_ros_shape"), str(path)], capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0 and "0 failed checks" in r.stdout, r.stdout + r.stderr

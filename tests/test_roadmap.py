@@ -1042,3 +1042,56 @@ def test_lazy_removals_survive_a_grow_and_invalid_vertices_are_no_query_neighbou
         assert len(nb) > 0 and (vok[nb[nb >= 2]] != 0).all(), "a query vertex was connected to an invalid vertex"
     r.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_path_segments_are_priced_with_max_query_edge_length(planning_setup):
+    """Params::planner.prm_motion_cost.max_query_edge_length (params.h:54): MotionCostObjective::motionCost splits a motion
+    into (unsigned)(lateral distance / it) + 1 cost queries (motion_cost_objective.cpp:41-77) -- the price of a path
+    SEGMENT (shortcut candidates of the simplification), not of the graph's sub-edges.  With 0.25 instead of the default
+    0.5 the simplified path's cost equals a DP over segments priced with rows rebuilt in numpy at 0.25; the graph's
+    edge costs do not change."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import motion_cost_oracle as mo
+    import convert_weights
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    ctx.cost_load_weights(convert_weights.to_blob(mo.random_params(0)))
+    elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)
+    ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+    w, thr = (0.25, 1.0, 5.0), 2.0   # threshold above every risk: all segments feasible, the DP is about the sums
+
+    def yaw(q):
+        return np.float32(np.arctan2(2 * (q[3] * q[2] + q[0] * q[1]), 1 - 2 * (q[1] ** 2 + q[2] ** 2)))
+
+    def segment_cost(a, b, step):
+        ni = int(np.hypot(b[0] - a[0], b[1] - a[1]) / step)
+        pts = [a] + [O.interpolate(a, b, s / (ni + 1)) for s in range(1, ni + 1)] + [b]
+        rows = [[s1[0], s1[1], yaw(s1[3:]), s0[0], s0[1], yaw(s0[3:])] for s0, s1 in zip(pts[:-1], pts[1:])]
+        r = ctx.cost_query(np.array(rows, np.float32)).astype(np.float64)
+        return float((r[:, 0] * np.float32(w[0]) + r[:, 1] * np.float32(w[1]) + r[:, 2] * np.float32(w[2])).sum())
+
+    costs = {}
+    for mq in (0.5, 0.25):
+        rm = Roadmap(ctx, start, goal, n_milestones=1500, seed=5, objective=2, cost_weights=w, risk_threshold=thr,
+                     max_query_edge_length=mq)
+        path, cost, _ = rm.solve()
+        assert path is not None and len(path) >= 4
+        costs[mq] = (cost, rm.export()["edge_cost"].copy())
+        p = path[:6]
+        simp, scost = rm.simplify(p)
+        n = len(p)
+        ii, jj = np.triu_indices(n, 1)
+        ok = (ctx.check_edges_interp(p[ii], p[jj])[0] != 0) & (ctx.check_motions(p[ii], p[jj]) != 0)
+        best = np.full(n, np.inf)
+        best[0] = 0.0
+        for a, b, o in zip(ii, jj, ok):
+            if o and np.isfinite(best[a]):
+                best[b] = min(best[b], best[a] + segment_cost(p[a], p[b], mq))
+        assert np.isfinite(best[-1]) and abs(best[-1] - scost) <= 1e-5 * max(1.0, scost), (mq, best[-1], scost)
+        rm.close()
+    # the graph (and the plan found on it) is priced per sub-edge of the 0.5 m chain whatever max_query_edge_length is
+    assert costs[0.5][0] == costs[0.25][0] and np.array_equal(costs[0.5][1], costs[0.25][1])
