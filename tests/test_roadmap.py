@@ -1076,7 +1076,7 @@ def test_path_segments_are_priced_with_max_query_edge_length(planning_setup):
 
     costs = {}
     for mq in (0.5, 0.25):
-        rm = Roadmap(ctx, start, goal, n_milestones=1500, seed=5, objective=2, cost_weights=w, risk_threshold=thr,
+        rm = Roadmap(ctx, start, goal, n_milestones=4000, seed=11, objective=2, cost_weights=w, risk_threshold=thr,
                      max_query_edge_length=mq)
         path, cost, _ = rm.solve()
         assert path is not None and len(path) >= 4
