@@ -458,7 +458,14 @@ struct artp_roadmap {
   std::vector<uint8_t> eflip;
   // CSR over the valid, not removed edges
   std::vector<uint32_t> row, adj, adj_edge;
+  std::vector<double> adjw;   // weight per adjacency slot, +inf = not usable (removed / infeasible): what the tree search reads
   bool csr_dirty = true;
+  // Verdicts of the discrete motion validator per edge AND direction ([2 e] = eu -> ev, [2 e + 1] = ev -> eu: the
+  // validator interpolates from its first argument): 0 = not checked, 1 = valid, 2 = invalid.  The reference's lazy
+  // planners keep the same knowledge in edgeValidityProperty_.  Valid for one map version and one edge list.
+  std::vector<uint8_t> emotion;
+  uint64_t emotion_map_version = ~0ull;
+  bool emotion_dirty = true;
   // resident in HBM for artp_roadmap_revalidate: the endpoint states of all edges (s1 rows, then s2 rows), and
   // what they are gathered from after a re-query replaced the first edges (vertex states, edge end points)
   double* d_edge_states = nullptr;
@@ -492,13 +499,17 @@ void roadmap_build_csr(artp_roadmap* rm) {
   for (size_t v = 0; v < nv; ++v) rm->row[v + 1] += rm->row[v];
   rm->adj.assign(rm->row[nv], 0);
   rm->adj_edge.assign(rm->row[nv], 0);
+  rm->adjw.assign(rm->row[nv], INFINITY);
   std::vector<uint32_t> fill(rm->row.begin(), rm->row.end() - 1);
   for (size_t e = 0; e < ne; ++e)
     if (rm->evalid[e] && !rm->eremoved[e]) {
       const uint32_t u = rm->eu[e], v = rm->ev[e];
+      const double w = (std::isfinite(rm->ecost[e]) && rm->ecost[e] >= 0.0) ? rm->ecost[e] : INFINITY;
       rm->adj[fill[u]] = v;
+      rm->adjw[fill[u]] = w;
       rm->adj_edge[fill[u]++] = (uint32_t)e;
       rm->adj[fill[v]] = u;
+      rm->adjw[fill[v]] = w;
       rm->adj_edge[fill[v]++] = (uint32_t)e;
     }
   rm->csr_dirty = false;
@@ -1386,6 +1397,7 @@ static int incremental_finish(IncrementalGraph& g, artp_roadmap* rm, const std::
     for (size_t i = 0; i < n; ++i)
       if (!(*vertex_ok)[rm->eu[i]] || !(*vertex_ok)[rm->ev[i]]) rm->evalid[i] = 0;
   rm->csr_dirty = true;
+  rm->emotion_dirty = true;
   rm->d_graph_dirty = true;
   rm->d_graph_ne = 0;
   rm->d_edge_states_stale = true;
@@ -1725,6 +1737,7 @@ int artp_roadmap_revalidate(artp_roadmap* rm, uint64_t out[4]) {
   rm->vinvalid.assign(nv, 0);
   for (size_t v = 0; v < nv; ++v) rm->vinvalid[v] = vok[v] ? 0 : 1;
   rm->csr_dirty = true;
+  rm->emotion_dirty = true;
   rm->d_graph_dirty = true;
   if (out) {
     out[0] = vbad;
@@ -1828,6 +1841,7 @@ int artp_roadmap_set_query(artp_roadmap* rm, const double* start7, const double*
   splice(rm->eremoved, zeros);
   if (!rm->eflip.empty()) splice(rm->eflip, zeros);  // query vertex (the smaller id) -> neighbour: the order it is added in
   rm->csr_dirty = true;
+  rm->emotion_dirty = true;
   rm->d_edge_states_stale = true;
   rm->d_graph_ne = 0;  // the edge list changed: the device copy is rebuilt at the next search
   return ARTP_OK;
@@ -1941,12 +1955,368 @@ int artp_roadmap_export(const artp_roadmap* rm, double* verts, uint32_t* knn, do
 // from this vertex count on the search runs on the device (host A*: 1.3 ms at 10^4 vertices, 41 ms at 10^5)
 #define ARTP_SSSP_MIN_VERTICES 30000
 
+namespace {
+
+// ---- the lazy path check of the reference planners, replayed from cached verdicts ----------------------------------
+// constructSolution (prm_motion_cost.cpp:536-673, lazy_prm_star_min_update.cpp:619-747): search, walk the path from the
+// goal backwards, checkMotion every edge not known to be valid, remove the FIRST invalid one, search again.  On the
+// reference-order LazyPRM* graph (10^4 milestones, 265 000 direct edges of unknown validity) that is 216 rounds of a
+// search and a validity batch: 181 ms when every round is a host A* and a device call.  Two things make it 10x faster
+// with the SAME removals in the SAME order and the same path:
+//  * the search is a shortest-path TREE from the start that is repaired, not recomputed, when a path edge goes: only
+//    the subtree behind the removed edge is re-settled (Ramalingam-Reps deletion; the removed edge lies on the path to
+//    the goal, usually close to it: the reference removes the invalid edge nearest the goal);
+//  * a verdict is a property of (edge, direction, map): once a few rounds have shown that the graph needs its lazy
+//    checks, EVERY usable edge is checked in both directions in ONE batch (2 x 265 000 motions = 26 M states: 6 ms on
+//    this GPU) and the rounds after that read the table.  The removal rule itself is untouched: only the first invalid
+//    edge of the CURRENT path is removed, whatever else the table knows.
+struct LazyTree {
+  artp_roadmap* rm;
+  std::vector<double> dist;
+  std::vector<uint32_t> pred, pred_edge;
+  std::vector<uint8_t> in_s;
+  std::vector<uint32_t> first_child, next_sib, prev_sib;  // the tree's child lists (0xffffffff = none)
+  std::vector<uint32_t> sub;
+  using Item = std::pair<double, uint32_t>;
+  // everything the searches touch per adjacency slot is contiguous (adj, adjw); dist / pred of 10^4 vertices stay in
+  // the host's L1 / L2 (three random reads per slot into the per-edge arrays made a repair 10x slower)
+  bool usable(uint32_t e) const {
+    const double w = rm->ecost[e];
+    return rm->evalid[e] && !rm->eremoved[e] && std::isfinite(w) && w >= 0.0;
+  }
+  void drop_edge(uint32_t e) {  // the slots of a removed edge stop being usable
+    for (const uint32_t v : {rm->eu[e], rm->ev[e]})
+      for (uint32_t a = rm->row[v]; a < rm->row[v + 1]; ++a)
+        if (rm->adj_edge[a] == e) rm->adjw[a] = INFINITY;
+  }
+  void full() {
+    const size_t nv = rm->nv();
+    dist.assign(nv, INFINITY);
+    pred.assign(nv, 0xffffffffu);
+    pred_edge.assign(nv, 0xffffffffu);
+    in_s.assign(nv, 0);
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> open;
+    dist[0] = 0.0;
+    open.push({0.0, 0u});
+    const uint32_t* adj = rm->adj.data();
+    const double* adjw = rm->adjw.data();
+    while (!open.empty()) {
+      const Item it = open.top();
+      open.pop();
+      const uint32_t u = it.second;
+      if (it.first > dist[u]) continue;
+      const double du = dist[u];
+      for (uint32_t a = rm->row[u], a1 = rm->row[u + 1]; a < a1; ++a) {
+        const uint32_t v = adj[a];
+        const double nd = du + adjw[a];  // +inf for an unusable slot: never an improvement
+        if (nd < dist[v]) {
+          dist[v] = nd;
+          pred[v] = u;
+          pred_edge[v] = rm->adj_edge[a];
+          open.push({nd, v});
+        }
+      }
+    }
+    first_child.assign(nv, 0xffffffffu);
+    next_sib.assign(nv, 0xffffffffu);
+    prev_sib.assign(nv, 0xffffffffu);
+    for (uint32_t v = 0; v < (uint32_t)nv; ++v)
+      if (pred[v] != 0xffffffffu) link(v);
+  }
+  void link(uint32_t v) {  // v becomes the first child of pred[v]
+    const uint32_t p = pred[v], f = first_child[p];
+    next_sib[v] = f;
+    prev_sib[v] = 0xffffffffu;
+    if (f != 0xffffffffu) prev_sib[f] = v;
+    first_child[p] = v;
+  }
+  void unlink(uint32_t v) {
+    const uint32_t p = pred[v], n = next_sib[v], q = prev_sib[v];
+    if (q != 0xffffffffu) next_sib[q] = n; else first_child[p] = n;
+    if (n != 0xffffffffu) prev_sib[n] = q;
+    next_sib[v] = prev_sib[v] = 0xffffffffu;
+  }
+  // the tree edge into `child` is gone (its slots already dropped): re-settle child's subtree
+  void repair(uint32_t child) {
+    const uint32_t* adj = rm->adj.data();
+    const uint32_t* adje = rm->adj_edge.data();
+    const double* adjw = rm->adjw.data();
+    sub.clear();
+    if (pred[child] != 0xffffffffu) unlink(child);
+    sub.push_back(child);
+    in_s[child] = 1;
+    for (size_t i = 0; i < sub.size(); ++i)  // the subtree, by the child lists
+      for (uint32_t x = first_child[sub[i]]; x != 0xffffffffu; x = next_sib[x]) {
+        in_s[x] = 1;
+        sub.push_back(x);
+      }
+    for (const uint32_t x : sub) first_child[x] = next_sib[x] = prev_sib[x] = 0xffffffffu;  // all relinked below
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> open;
+    for (const uint32_t x : sub) {
+      dist[x] = INFINITY;
+      pred[x] = pred_edge[x] = 0xffffffffu;
+    }
+    for (size_t i = 0; i < sub.size(); ++i) {  // the best way in from outside the subtree (inside: dist = +inf for now)
+      const uint32_t x = sub[i];
+      if (i + 2 < sub.size()) {  // the rows are ~850-byte chunks scattered over 8 MB: start the row after next now
+        const uint32_t r = rm->row[sub[i + 2]];
+        __builtin_prefetch(adj + r);
+        __builtin_prefetch(adjw + r);
+        __builtin_prefetch(adjw + r + 8);
+        __builtin_prefetch(adjw + r + 16);
+        __builtin_prefetch(adjw + r + 24);
+      }
+      double best = INFINITY;
+      uint32_t ba = 0xffffffffu;
+      for (uint32_t a = rm->row[x], a1 = rm->row[x + 1]; a < a1; ++a) {
+        const double nd = dist[adj[a]] + adjw[a];
+        if (nd < best) {
+          best = nd;
+          ba = a;
+        }
+      }
+      if (ba != 0xffffffffu) {
+        dist[x] = best;
+        pred[x] = adj[ba];
+        pred_edge[x] = adje[ba];
+        open.push({best, x});
+      }
+    }
+    while (!open.empty()) {
+      const Item it = open.top();
+      open.pop();
+      const uint32_t u = it.second;
+      if (it.first > dist[u]) continue;
+      const double du = dist[u];
+      for (uint32_t a = rm->row[u], a1 = rm->row[u + 1]; a < a1; ++a) {
+        const uint32_t v = adj[a];
+        const double nd = du + adjw[a];
+        if (nd < dist[v]) {  // only subtree vertices can improve: everything else holds its final distance
+          dist[v] = nd;
+          pred[v] = u;
+          pred_edge[v] = adje[a];
+          open.push({nd, v});
+        }
+      }
+    }
+    for (const uint32_t x : sub) {
+      in_s[x] = 0;
+      if (pred[x] != 0xffffffffu) link(x);
+    }
+  }
+};
+
+// checkMotion of (edge, direction) items in one device batch: vertex states and the two index lists go up, the
+// endpoint states are gathered on the device (56 bytes per state never cross PCIe), one verdict byte per item comes back.
+int roadmap_check_motion_items(artp_roadmap* rm, const std::vector<uint32_t>& src, const std::vector<uint32_t>& dst,
+                               std::vector<uint8_t>* ok) {
+  artp_ctx* c = rm->ctx;
+  const size_t n = src.size(), nv = rm->nv();
+  ok->assign(n, 0);
+  if (n == 0) return ARTP_OK;
+  if (n <= 64) {  // a path's worth: the host entry point (one call, no allocations)
+    std::vector<double> s1(n * 7), s2(n * 7);
+    for (size_t i = 0; i < n; ++i) {
+      std::memcpy(&s1[i * 7], &rm->verts[(size_t)src[i] * 7], 7 * sizeof(double));
+      std::memcpy(&s2[i * 7], &rm->verts[(size_t)dst[i] * 7], 7 * sizeof(double));
+    }
+    const int rc = artp_check_motions(c, s1.data(), s2.data(), n, ok->data());
+    if (rc != ARTP_OK) return rc;
+    return hipStreamSynchronize(c->stream) == hipSuccess ? ARTP_OK : ARTP_ERR_HIP;
+  }
+  double *d_v = nullptr, *d_s = nullptr;
+  uint32_t* d_uv = nullptr;
+  uint8_t* d_ok = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_v, (void*)d_s, (void*)d_uv, (void*)d_ok})
+      if (p) (void)hipFree(p);
+  };
+  RM_HIP(hipSetDevice(c->device));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_v), nv * 7 * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_uv), 2 * n * sizeof(uint32_t)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_s), 2 * n * 7 * sizeof(double)));
+  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_ok), n));
+  RM_HIP(hipMemcpyAsync(d_v, rm->verts.data(), nv * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RM_HIP(hipMemcpyAsync(d_uv, src.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  RM_HIP(hipMemcpyAsync(d_uv + n, dst.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(artp::gather_edge_states_uv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double*)d_v, (const uint32_t*)d_uv, (const uint32_t*)(d_uv + n), n, d_s, d_s + n * 7);
+  RM_HIP(hipGetLastError());
+  // in chunks of 2^18 motions (~13 M interior states): the pipeline's scratch (PoseRecs, queues) is sized by the largest
+  // batch a context has seen, and a 10^6-motion batch would make it allocate tens of GB once
+  for (size_t at = 0; at < n; at += (size_t)1 << 18) {
+    const size_t m = std::min(n - at, (size_t)1 << 18);
+    RM_TRY(artp_check_motions_dev(c, d_s + at * 7, d_s + (n + at) * 7, m, d_ok + at));
+  }
+  RM_HIP(hipMemcpyAsync(ok->data(), d_ok, n, hipMemcpyDeviceToHost, c->stream));
+  RM_HIP(hipStreamSynchronize(c->stream));
+  cleanup();
+  return ARTP_OK;
+}
+
+#define ARTP_LAZY_PRECHECK_AFTER 3          // lazy removals before the whole graph is checked in one batch
+#define ARTP_LAZY_PRECHECK_MAX (1u << 22)   // ... unless that is more motions than this
+
+int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
+                       int* n_replans) {
+  artp_ctx* c = rm->ctx;
+  const size_t ne = rm->eu.size();
+  const bool timing = std::getenv("ARTP_SOLVE_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_csr = now(), t_full = 0, t_check = 0, t_repair = 0, t_pre = 0;
+  size_t n_check_calls = 0, n_checked = 0, sub_total = 0, n_pre = 0;
+  if (rm->csr_dirty) roadmap_build_csr(rm);
+  t_csr = now() - t_csr;
+  const uint64_t mv = artp_map_version(c);
+  if (rm->emotion_dirty || rm->emotion.size() != 2 * ne || rm->emotion_map_version != mv) {
+    rm->emotion.assign(2 * ne, 0);
+    rm->emotion_map_version = mv;
+    rm->emotion_dirty = false;
+  }
+  LazyTree t;
+  t.rm = rm;
+  // the first search is goal-directed (A*): a roadmap whose first path passes -- the batched default's usual case --
+  // never pays for the whole tree; the tree is built when the first edge has to go
+  bool have_tree = false;
+  int replans = 0;
+  auto report = [&]() {
+    if (timing)
+      std::fprintf(stderr, "[solve] nv %zu ne %zu: csr %.2f ms, full tree %.2f ms, %zu check calls (%zu motions) %.2f ms of which "
+                   "precheck %zu motions %.2f ms, %d repairs %.2f ms (subtree vertices %zu)\n", rm->nv(), ne, t_csr, t_full,
+                   n_check_calls, n_checked, t_check, n_pre, t_pre, replans, t_repair, sub_total);
+  };
+  bool prechecked = false;
+  std::vector<uint32_t> path, pedge, src, dst, item;
+  std::vector<uint8_t> ok;
+  for (;;) {
+    double path_cost = INFINITY;
+    pedge.clear();
+    if (!have_tree) {
+      if (!roadmap_astar(rm, &path, &path_cost)) {
+        if (n_replans) *n_replans = replans;
+        return ARTP_OK;  // *n_path == 0: start and goal are not connected
+      }
+      for (size_t i = 0; i + 1 < path.size(); ++i) {  // the (unique) edge between two path vertices
+        uint32_t e = 0xffffffffu;
+        for (uint32_t a = rm->row[path[i]]; a < rm->row[path[i] + 1]; ++a)
+          if (rm->adj[a] == path[i + 1] && std::isfinite(rm->adjw[a])) e = rm->adj_edge[a];
+        pedge.push_back(e);
+      }
+    } else {
+      if (!std::isfinite(t.dist[1])) {
+        if (n_replans) *n_replans = replans;
+        report();
+        return ARTP_OK;
+      }
+      path.clear();
+      for (uint32_t v = 1; v != 0u; v = t.pred[v]) {
+        path.push_back(v);
+        pedge.push_back(t.pred_edge[v]);
+      }
+      path.push_back(0u);
+      std::reverse(path.begin(), path.end());
+      std::reverse(pedge.begin(), pedge.end());  // pedge[i] = edge path[i] -> path[i + 1]
+      path_cost = t.dist[1];
+    }
+    const size_t np = path.size();
+    auto slot = [&](size_t i) { return 2 * (size_t)pedge[i] + (path[i] == rm->eu[pedge[i]] ? 0u : 1u); };
+    // verdicts the table does not hold yet: this path's, or -- once the graph has shown that it needs its lazy checks
+    // -- every usable edge's, both directions, in one batch
+    src.clear();
+    dst.clear();
+    item.clear();
+    if (!prechecked && replans >= ARTP_LAZY_PRECHECK_AFTER) {
+      size_t unknown = 0;
+      for (size_t e = 0; e < ne; ++e)
+        if (t.usable((uint32_t)e)) unknown += (rm->emotion[2 * e] == 0) + (rm->emotion[2 * e + 1] == 0);
+      if (unknown <= ARTP_LAZY_PRECHECK_MAX) {
+        for (size_t e = 0; e < ne; ++e) {
+          if (!t.usable((uint32_t)e)) continue;
+          for (unsigned d = 0; d < 2; ++d)
+            if (rm->emotion[2 * e + d] == 0) {
+              src.push_back(d ? rm->ev[e] : rm->eu[e]);
+              dst.push_back(d ? rm->eu[e] : rm->ev[e]);
+              item.push_back((uint32_t)(2 * e + d));
+            }
+        }
+      }
+      prechecked = true;
+    }
+    if (item.empty())
+      for (size_t i = 0; i + 1 < np; ++i)
+        if (rm->emotion[slot(i)] == 0) {
+          src.push_back(path[i]);
+          dst.push_back(path[i + 1]);
+          item.push_back((uint32_t)slot(i));
+        }
+    if (!item.empty()) {
+      const double t0 = now();
+      const int rc = roadmap_check_motion_items(rm, src, dst, &ok);
+      if (rc != ARTP_OK) return rc;
+      for (size_t k = 0; k < item.size(); ++k) rm->emotion[item[k]] = ok[k] ? 1 : 2;
+      t_check += now() - t0;
+      ++n_check_calls;
+      n_checked += item.size();
+      if (item.size() > 4096) {
+        t_pre += now() - t0;
+        n_pre += item.size();
+      }
+    }
+    size_t bad = np;
+    for (size_t i = np - 1; i-- > 0;)  // the reference walks from the goal backwards
+      if (rm->emotion[slot(i)] == 2) {
+        bad = i;
+        break;
+      }
+    if (bad == np) {
+      if (path_se3) {
+        if (cap_states < np) {
+          c->last_error = "path buffer too small";
+          *n_path = np;
+          return ARTP_ERR_CAPACITY;
+        }
+        for (size_t i = 0; i < np; ++i)
+          std::memcpy(path_se3 + i * 7, &rm->verts[(size_t)path[i] * 7], 7 * sizeof(double));
+      }
+      *n_path = np;
+      *cost = path_cost;
+      if (n_replans) *n_replans = replans;
+      report();
+      return ARTP_OK;
+    }
+    rm->eremoved[pedge[bad]] = 1;
+    rm->d_graph_dirty = true;
+    t.drop_edge(pedge[bad]);
+    if (!have_tree) {
+      const double t0 = now();
+      t.full();
+      t_full = now() - t0;
+      have_tree = true;
+    } else {
+      const double t0 = now();
+      t.repair(path[bad + 1]);  // the tree edge into path[bad + 1] is gone
+      t_repair += now() - t0;
+      sub_total += t.sub.size();
+    }
+    if (++replans > (int)rm->params.max_replans) {
+      c->last_error = "too many lazy edge removals";
+      if (n_replans) *n_replans = replans;
+      return ARTP_ERR_CAPACITY;
+    }
+  }
+}
+
+}  // namespace
+
 int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, size_t* n_path, double* cost,
                        int* n_replans) {
   if (!rm || !n_path || !cost) return ARTP_ERR_INVALID_ARG;
   artp_ctx* c = rm->ctx;
   *n_path = 0;
   *cost = INFINITY;
+  // roadmaps the host searches: the shortest-path tree with deletion repair and cached motion verdicts
+  if (rm->nv() < ARTP_SSSP_MIN_VERTICES && !std::getenv("ARTP_SOLVE_ASTAR"))
+    return roadmap_solve_tree(rm, path_se3, cap_states, n_path, cost, n_replans);
   int replans = 0;
   std::vector<uint32_t> path;
   std::vector<double> s1, s2;
