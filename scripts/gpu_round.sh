@@ -19,7 +19,7 @@ try:
     print("pmc", r["pmc_source"])
     b = r.get("binding")
     if b:
-        print("valu_busy_tw", b["valu_busy_time_weighted"], "traffic", r["traffic"])
+        print("bound", r["bound"], "frac", r["frac"], "fractions", r["occupancy_fractions"], "traffic", r["traffic"], "alg", r["algorithmic_hbm"]["ratio_to_peak"])
         for k, v in b["per_kernel"].items():
             print("  ", k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items()})
     for k in ("edges", "motion_cost_c3", "replan_cycle_c5", "c4_800_defaults", "preprocess_n2"):
