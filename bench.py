@@ -103,8 +103,19 @@ def pmc_child(args):
     else:
         se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
         valid = torch.empty(args.batch, dtype=torch.uint8, device=dev)
-        for i in range(4):
+        ctx.sample_and_validate_dev(42, 0, args.batch, se3, valid)
+        torch.cuda.synchronize()
+        # the step as HIP events see it IN THIS PROCESS: under `rocprofv3 --kernel-trace` every dispatch carries the
+        # profiler's completion signal and cache write-back, so the step is slower than in the unprofiled bench run and
+        # this figure -- not ms_per_step of the bench line -- is what the per-kernel durations of the trace add up to
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(1, 4):
             ctx.sample_and_validate_dev(42, i * args.batch, args.batch, se3, valid)
+        e1.record()
+        torch.cuda.synchronize()
+        print("PMC_CHILD_STEP_MS %.4f (HIP events around 3 fused sample + validate batches of %d states, in this process)"
+              % (e0.elapsed_time(e1) / 3, args.batch), flush=True)
     torch.cuda.synchronize()
     ctx.close()
 
