@@ -17,7 +17,52 @@ from art_planner_amd.context import Context, make_params  # noqa: E402
 from synthetic import make_map  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
+n_edges = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # edges per case through the three edge entry points (0 = none)
 rng = np.random.default_rng(2024)
+
+_EDGE_JOB = {}
+
+
+def _edge_chunk(lo_hi):
+    """Oracle verdicts of one chunk of the current case's edges (forked worker: the case lives in _EDGE_JOB)."""
+    lo, hi = lo_hi
+    om, rob, a, b = _EDGE_JOB["om"], _EDGE_JOB["rob"], _EDGE_JOB["a"][lo:hi], _EDGE_JOB["b"][lo:hi]
+    ok, t, st = om.check_motions_last_valid(rob, a, b)
+    ok0, _ = om.check_motions(rob, a, b)
+    oki, ni = om.edges_interp_valid(rob, a, b)
+    return ok, t, st, ok0, oki, ni
+
+
+def edge_campaign(ctx, gm, rob, se3, labels):
+    """n_edges edges between states of the case -- a state and a neighbour up to 2 m away with another attitude; a
+    third of them start at accepted states -- through artp_check_motions, artp_check_motions_last_valid and
+    artp_check_edges_interp against the CPU oracle (32 forked workers)."""
+    import multiprocessing as mp
+    m = n_edges
+    src = rng.integers(0, len(se3), m)
+    acc = np.flatnonzero(labels)
+    if len(acc):
+        src[::2] = acc[rng.integers(0, len(acc), len(src[::2]))]
+    a = se3[src].copy()
+    b = se3[rng.integers(0, len(se3), m)].copy()
+    d = rng.uniform(-1.4, 1.4, (m, 2))
+    b[:, 0], b[:, 1] = a[:, 0] + d[:, 0], a[:, 1] + d[:, 1]
+    b[:, 2] = a[:, 2] + rng.normal(0, 0.03, m)
+    b[::7] = a[::7]                                  # identical states (nd = 0)
+    b[1::11, :3] = a[1::11, :3]                        # rotation only
+    # (upload_map set the z bounds the oracle's z_extent uses: min / max finite elevation -+ reach.z / 2)
+    g_ok = ctx.check_motions(a, b)
+    g_ok2, g_t, g_st = ctx.check_motions_last_valid(a, b)
+    g_oki, g_ni = ctx.check_edges_interp(a, b)
+    _EDGE_JOB.update(om=O.OracleMap(gm), rob=rob, a=a, b=b)
+    chunks = [(i, min(i + 250, m)) for i in range(0, m, 250)]
+    with mp.get_context("fork").Pool(32) as pool:
+        parts = pool.map(_edge_chunk, chunks)
+    ok, t, st, ok0, oki, ni = (np.concatenate([p_[k] for p_ in parts]) for k in range(6))
+    bad = int((g_ok != ok0).sum()) + int((g_ok2 != ok).sum()) + int((g_t != t).sum()) + int((g_oki != oki).sum()) + \
+        int((g_ni != ni).sum()) + int((np.abs(g_st - st).max(axis=1) > 1e-12).sum())
+    return bad, float(ok0.mean()), float(oki.mean())
+
 base = make_map(240, 0.04, seed=31)
 
 
@@ -79,11 +124,18 @@ for mapname, robot in cases:
     few = np.concatenate([ctx.validate_states(se3[i:i + 16]) for i in range(0, 4096, 16)])
     bad_few = int((few != vo[:4096]).sum())
     bad_total += bad_few
+    edge_txt = ""
+    if n_edges:
+        bad_e, vf, vi = edge_campaign(ctx, gm, rob, se3, vo)
+        bad_total += bad_e
+        edge_txt = (f" | {n_edges} edges x (checkMotion, lastValid pair, 0.5 m rule + n_interp): mismatches={bad_e} "
+                    f"(valid {vf:.3f} / {vi:.3f})")
     lines.append(f"{mapname:9s} {robot:8s} states={n} valid={vg.mean():.3f} mismatches={bad} latency-path mismatches={bad_few}/4096 "
-                 f"counters={ctx.pipeline_counters()} ({time.time() - t0:.1f}s)")
-    print(lines[-1])
+                 f"counters={ctx.pipeline_counters()}{edge_txt} ({time.time() - t0:.1f}s)")
+    print(lines[-1], flush=True)
     ctx.close()
-lines.append(f"TOTAL MISMATCHES {bad_total} over {n * len(cases)} states (batch pipeline) + {4096 * len(cases)} (latency path)")
+lines.append(f"TOTAL MISMATCHES {bad_total} over {n * len(cases)} states (batch pipeline) + {4096 * len(cases)} (latency path)" +
+             (f" + {n_edges * len(cases)} edges through each of the three edge entry points" if n_edges else ""))
 print(lines[-1])
 out = os.path.join(ROOT, "gpurun_out", "parity_campaign.txt")
 os.makedirs(os.path.dirname(out), exist_ok=True)
