@@ -57,6 +57,8 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
+  bool edge_two_pass = true;  // artp_check_motions: coarse pass first ($ARTP_EDGE_TWO_PASS=0: one pass over all states)
+  int edge_coarse_stride = ARTP_COARSE_STRIDE;  // $ARTP_COARSE_STRIDE (tuning)
   // map tables (pipeline.h): per layer 6 levels of {max, min} + 6 levels of non-finite / NaN flag bytes, the
   // partner table and the raw cross products it is built from
   float* table_buf[2] = {nullptr, nullptr};
@@ -720,6 +722,8 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
     c->pin_labels_dev = static_cast<uint8_t*>(pld);
     const char* e = std::getenv("ARTP_NO_POLL");
     c->poll_labels = !(e && e[0] == '1');
+    if (const char* tp = std::getenv("ARTP_EDGE_TWO_PASS")) c->edge_two_pass = tp[0] != '0';
+    if (const char* cs = std::getenv("ARTP_COARSE_STRIDE")) c->edge_coarse_stride = std::atoi(cs) >= 2 ? std::atoi(cs) : ARTP_COARSE_STRIDE;
   }
   fill_robot(c);
   *out = c;
@@ -1619,8 +1623,9 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
     return ARTP_ERR_CAPACITY;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n) | first_bad (n) | total64, overflow flag | slerp constants (n x 24 B)
-  int rc = ensure_tmp(c, 2, (4 * n + 2) * sizeof(uint32_t) + 48 + n * sizeof(SlerpEdge));
+  // tmp[2]: counts (n+1) | offsets (n+1) | aux (n) | first_bad (n) | total64, overflow flag, total of pass 1, pad |
+  //         slerp constants (n x 24 B) | counts of the coarse pass (n+1) | their offsets (n+1)
+  int rc = ensure_tmp(c, 2, (6 * n + 4) * sizeof(uint32_t) + 64 + n * sizeof(SlerpEdge));
   if (rc) return rc;
   uint32_t* counts = static_cast<uint32_t*>(c->tmp[2]);
   uint32_t* offsets = counts + (n + 1);
@@ -1629,13 +1634,22 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   unsigned long long* d_total = reinterpret_cast<unsigned long long*>(
       (reinterpret_cast<uintptr_t>(first_bad + n) + 7) & ~(uintptr_t)7);
   int* d_overflow = reinterpret_cast<int*>(d_total + 1);
-  SlerpEdge* d_slerp = reinterpret_cast<SlerpEdge*>(d_total + 2);  // 8-byte aligned like d_total
+  unsigned long long* d_total1 = d_total + 2;
+  SlerpEdge* d_slerp = reinterpret_cast<SlerpEdge*>(d_total + 4);  // 8-byte aligned like d_total
+  uint32_t* counts1 = reinterpret_cast<uint32_t*>(d_slerp + n);
+  uint32_t* offsets1 = counts1 + (n + 1);
+  // checkMotion's first overload in two passes (kernels.h ARTP_COARSE_STRIDE): worth its second pipeline pass for real batches
+  const bool want_last_ = (mode == 0) && last_t;
+  const bool two_pass_possible = mode == 0 && !want_last_ && n >= 4096 && c->edge_two_pass;
   HIP_TRY(c, hipMemsetAsync(counts + n, 0, sizeof(uint32_t), c->stream));
-  HIP_TRY(c, hipMemsetAsync(d_total, 0, 16, c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_total, 0, 32, c->stream));
   size_t blocks = (n + 255) / 256;
   if (blocks > (size_t)c->n_cus * 4) blocks = (size_t)c->n_cus * 4;  // grid-stride; one atomic per workgroup on the total
+  if (two_pass_possible) HIP_TRY(c, hipMemsetAsync(counts1 + n, 0, sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(motion_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->geom,
-                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total, d_slerp);
+                     c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total, d_slerp,
+                     two_pass_possible ? counts1 : (uint32_t*)nullptr, two_pass_possible ? d_total1 : (unsigned long long*)nullptr,
+                     (uint32_t)c->edge_coarse_stride);
   HIP_TRY(c, hipGetLastError());
   size_t need = 0;
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(n + 1), c->stream));
@@ -1647,10 +1661,14 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   }
   size_t cap = c->cub_cap;
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, cap, counts, offsets, (int)(n + 1), c->stream));
+  if (two_pass_possible) {
+    cap = c->cub_cap;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, cap, counts1, offsets1, (int)(n + 1), c->stream));
+  }
   // expand every interior state into one state batch, validate it with the standard pipeline, then
   // fold the labels back onto the edges
-  struct { unsigned long long total; int overflow; int pad; } plan{0, 0, 0};
-  HIP_TRY(c, hipMemcpyAsync(&plan, d_total, 16, hipMemcpyDeviceToHost, c->stream));
+  struct { unsigned long long total; int overflow; int pad; unsigned long long total1; unsigned long long pad2; } plan{0, 0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(&plan, d_total, 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (plan.overflow) {
     c->last_error = "an edge has non-finite states or needs more than 2^22 interpolation states";
@@ -1661,10 +1679,47 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
     return ARTP_ERR_CAPACITY;
   }
   const uint32_t total = (uint32_t)plan.total;
-  const bool want_last = (mode == 0) && last_t;
+  const bool want_last = want_last_;
   if (want_last) HIP_TRY(c, hipMemsetAsync(first_bad, 0xff, n * sizeof(uint32_t), c->stream));
   size_t eb = ((size_t)total + 255) / 256;
   if (eb > (size_t)c->n_cus * 32) eb = (size_t)c->n_cus * 32;
+  if (two_pass_possible && plan.total >= 24ull * n) {
+    // ---- two passes: s2 + every 8th interior state of every edge, then the rest of the edges still alive ----
+    auto run_pass = [&](int pass, const uint32_t* offs, uint32_t tot) -> int {
+      if (tot == 0) return ARTP_OK;
+      size_t pb = ((size_t)tot + 255) / 256;
+      if (pb > (size_t)c->n_cus * 32) pb = (size_t)c->n_cus * 32;
+      int r = ensure_tmp(c, 3, (size_t)tot * (sizeof(uint32_t) + 1) + 64);
+      if (r) return r;
+      r = ensure_recs(c, tot);
+      if (r) return r;
+      uint32_t* edge_of = static_cast<uint32_t*>(c->tmp[3]);
+      uint8_t* ex_valid = reinterpret_cast<uint8_t*>(edge_of + tot);
+      hipLaunchKernelGGL(expand_edges_recs_kernel, dim3((unsigned)pb), dim3(256), 0, c->stream, c->field[0], mode, s1, s2, n,
+                         offs, (const uint32_t*)aux, (const SlerpEdge*)d_slerp, static_cast<PoseRec*>(c->tmp[7]), edge_of,
+                         pass, (uint32_t)c->edge_coarse_stride);
+      HIP_TRY(c, hipGetLastError());
+      r = launch_validate_pipeline(c, nullptr, tot, ex_valid, true);
+      if (r) return r;
+      hipLaunchKernelGGL(reduce_edges_kernel, dim3((unsigned)pb), dim3(256), 0, c->stream, (const uint8_t*)ex_valid,
+                         (const uint32_t*)edge_of, offs, n, valid);
+      HIP_TRY(c, hipGetLastError());
+      return ARTP_OK;
+    };
+    rc = run_pass(1, offsets1, (uint32_t)plan.total1);
+    if (rc) return rc;
+    // pass 2: counts of what is left, for the edges still valid (reuses the pass-1 arrays)
+    HIP_TRY(c, hipMemsetAsync(d_total1, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(coarse_pass2_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const uint32_t*)aux,
+                       (const uint8_t*)valid, n, (uint32_t)c->edge_coarse_stride, counts1, d_total1);
+    HIP_TRY(c, hipGetLastError());
+    cap = c->cub_cap;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp, cap, counts1, offsets1, (int)(n + 1), c->stream));
+    unsigned long long total2 = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total2, d_total1, sizeof(total2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return run_pass(2, offsets1, (uint32_t)total2);
+  }
   if (total != 0) {
     // tmp[3]: edge_of (total u32) | ex_valid (total bytes); the interior states themselves only exist as PoseRecs (tmp[7])
     rc = ensure_tmp(c, 3, (size_t)total * (sizeof(uint32_t) + 1) + 64);

@@ -838,6 +838,24 @@ __device__ __forceinline__ void se3_interpolate(const double* a, const double* b
   se3_interpolate_pre(a, b, t, slerp_edge(a + 3, b + 3), out);
 }
 
+// checkMotion in two passes (first overload only; ARTP_COARSE_STRIDE): an edge is valid iff ALL its states are, so the
+// order in which they are looked at is free.  Pass 1 validates s2 and every S-th interior state of every edge, pass 2 the
+// rest -- of the edges pass 1 left alive only.  An invalid edge usually fails in a run of consecutive states (a third of
+// its states on the bench's batch), so the subsample catches five in six of them and their other states are never
+// expanded.  Task j of an edge in a pass <-> task k of the edge:
+//   pass 0 (single pass): k = j;   pass 1: j = 0 -> k = 0 (s2), j >= 1 -> k = S j;   pass 2: k = j + j / (S - 1) + 1
+#define ARTP_COARSE_STRIDE 8   // default S (artp_ctx::edge_coarse_stride; 4 .. 16 measured: see DESIGN 4.3)
+__device__ __forceinline__ uint32_t edge_task_of_pass(int pass, uint32_t j, uint32_t S) {
+  if (pass == 1) return j * S;
+  if (pass == 2) return j + j / (S - 1u) + 1u;
+  return j;
+}
+// tasks of an edge with nd segments in a pass (nd >= 2: interior states 1 .. nd - 1)
+__device__ __forceinline__ uint32_t edge_tasks_in_pass(int pass, uint32_t nd, uint32_t S) {
+  const uint32_t interior = nd >= 2 ? nd - 1 : 0u, coarse = interior / S;
+  return pass == 1 ? 1u + coarse : interior - coarse;
+}
+
 // mode 0: DiscreteMotionValidator::checkMotion -> tasks = 1 (s2) + max(nd-1, 0), nd = validSegmentCount
 // mode 1: PRMMotionCost::addValidMilestone     -> tasks = n_interp = floor(lateral / 0.5)
 // counts[e] = number of wave-tasks of edge e, aux[e] = nd (mode 0) or n_interp (mode 1).
@@ -857,8 +875,10 @@ __global__ void __launch_bounds__(256)
 motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restrict__ s1,
                    const double* __restrict__ s2, size_t n, uint32_t* __restrict__ counts,
                    uint32_t* __restrict__ aux, uint8_t* __restrict__ valid, int* __restrict__ overflow,
-                   unsigned long long* __restrict__ total64, SlerpEdge* __restrict__ slerp) {
-  unsigned long long my_total = 0;
+                   unsigned long long* __restrict__ total64, SlerpEdge* __restrict__ slerp,
+                   uint32_t* __restrict__ counts_pass1 = nullptr, unsigned long long* __restrict__ total_pass1 = nullptr,
+                   uint32_t coarse_stride = ARTP_COARSE_STRIDE) {
+  unsigned long long my_total = 0, my_total1 = 0;
   int my_overflow = 0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (size_t)gridDim.x * blockDim.x) {
@@ -900,6 +920,11 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
     valid[e] = 1;
     if (slerp) slerp[e] = slerp_edge(a + 3, b + 3);
     my_total += cnt;
+    if (counts_pass1) {  // mode 0: s2 + every S-th interior state
+      const uint32_t c1 = edge_tasks_in_pass(1, ax, coarse_stride);
+      counts_pass1[e] = c1;
+      my_total1 += c1;
+    }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) my_total += __shfl_xor(my_total, m, 64);
@@ -913,6 +938,17 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
     if (tot) atomicAdd(total64, tot);
   }
   if (my_overflow) atomicExch(overflow, 1);
+  if (total_pass1) {  // wave-uniform
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) my_total1 += __shfl_xor(my_total1, m, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = my_total1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long tot = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+      if (tot) atomicAdd(total_pass1, tot);
+    }
+  }
 }
 
 // offsets = exclusive scan of counts (n+1 entries, offsets[n] = total).  One lane per task (edge e, interior state k):
@@ -921,10 +957,29 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
 // The interpolated state never leaves the registers: the validity pipeline only reads its PoseRec, so
 // the kernel emits that (coalesced through LDS) instead of 56 bytes of f64 state per lane for pose_rec_kernel to read
 // back (13 M states per 2^18 checkMotion edges: 0.74 GB written with 56-byte strides, read again, and a launch).
+// counts of pass 2: the remaining interior states of the edges pass 1 left alive; their sum to *total64
+__global__ void __launch_bounds__(256)
+coarse_pass2_counts_kernel(const uint32_t* __restrict__ aux, const uint8_t* __restrict__ valid, size_t n, uint32_t S,
+                           uint32_t* __restrict__ counts, unsigned long long* __restrict__ total64) {
+  unsigned long long mine = 0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t c = valid[e] ? edge_tasks_in_pass(2, aux[e], S) : 0u;
+    counts[e] = c;
+    mine += c;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
+  __shared__ unsigned long long ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0 && (ws[0] + ws[1] + ws[2] + ws[3])) atomicAdd(total64, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
 __global__ void __launch_bounds__(256)
 expand_edges_recs_kernel(FieldDev f, int mode, const double* __restrict__ s1, const double* __restrict__ s2, size_t n,
                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ aux,
-                         const SlerpEdge* __restrict__ slerp, PoseRec* __restrict__ recs, uint32_t* __restrict__ edge_of) {
+                         const SlerpEdge* __restrict__ slerp, PoseRec* __restrict__ recs, uint32_t* __restrict__ edge_of,
+                         int pass = 0, uint32_t coarse_stride = ARTP_COARSE_STRIDE) {
   __shared__ float4 stage[4][64 * 4];
   const int lane = threadIdx.x & 63;
   float4* rw = stage[threadIdx.x >> 6];
@@ -939,7 +994,7 @@ expand_edges_recs_kernel(FieldDev f, int mode, const double* __restrict__ s1, co
         if (offsets[mid] <= w) lo = mid; else hi = mid;
       }
       const size_t e = lo;
-      const uint32_t k = (uint32_t)(w - offsets[e]);
+      const uint32_t k = edge_task_of_pass(pass, (uint32_t)(w - offsets[e]), coarse_stride);
       const double* a = s1 + 7 * e;
       const double* b = s2 + 7 * e;
       double st[7];

@@ -798,6 +798,47 @@ def test_map_writes_are_ordered_against_the_other_lanes(big_map):
     ctx.close()
 
 
+def test_check_motion_two_pass_equals_one_pass_and_the_oracle(big_map, monkeypatch):
+    """artp_check_motions on batches of >= 4096 edges runs in two passes (s2 + every 8th interior state of every edge, then
+    the rest of the edges still alive: kernels.h ARTP_COARSE_STRIDE).  An edge is valid iff all its states are, so the
+    verdicts must equal the single pass's ($ARTP_EDGE_TWO_PASS=0) for every stride -- and the oracle's on a sample --
+    incl. edges of zero length, rotation-only edges and edges ending on invalid states."""
+    rob = O.robot("yaml")
+    om = O.OracleMap(big_map)
+    base = _ctx("yaml")
+    base.upload_map(big_map)
+    se3 = base.sample_states(3, 0, 60000)
+    lab = base.validate_states(se3)
+    acc = se3[lab != 0]
+    rng = np.random.default_rng(8)
+    m = 9000
+    a = acc[rng.integers(0, len(acc), m)].copy()
+    b = acc[rng.integers(0, len(acc), m)].copy()
+    near = rng.random(m) < 0.8                       # most edges between states closer than 2 m, like the planners'
+    d = rng.uniform(-1.4, 1.4, (m, 2))
+    b[near, 0], b[near, 1] = a[near, 0] + d[near, 0], a[near, 1] + d[near, 1]
+    b[::13] = a[::13]                                # nd = 0
+    b[1::17, :3] = a[1::17, :3]                      # rotation only
+    b[2::19] = se3[lab == 0][:len(b[2::19])]         # invalid end state
+    base.close()
+    got = {}
+    for name, env in (("one", {"ARTP_EDGE_TWO_PASS": "0"}), ("two", {}), ("two_s3", {"ARTP_COARSE_STRIDE": "3"}),
+                      ("two_s16", {"ARTP_COARSE_STRIDE": "16"})):
+        for k in ("ARTP_EDGE_TWO_PASS", "ARTP_COARSE_STRIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _ctx("yaml")
+        ctx.upload_map(big_map)
+        got[name] = ctx.check_motions(a, b)
+        ctx.close()
+    assert 0.05 < got["one"].mean() < 0.95
+    for name in ("two", "two_s3", "two_s16"):
+        assert np.array_equal(got[name], got["one"]), name
+    ref, _ = om.check_motions(rob, a[:1500], b[:1500])
+    assert np.array_equal(got["two"][:1500], ref)
+
+
 def test_huge_robot_uses_the_largest_table_levels(big_map):
     """A robot twice the size of ANYmal: torso windows of ~55 samples (32-sample blocks, three per axis), foot
     windows of ~20 (the feet's 2 x 2 tight cover of 16-sample blocks, or none) -- labels equal the oracle's."""
