@@ -42,8 +42,8 @@ for MODE in states check_motion sampler; do
   rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/child_$MODE -o trace -- python $GRAFT_REPO_ROOT/bench.py --pmc-child $MODE > $OUT/prof_$TAG/child_$MODE.log 2>&1
 done
 python $GRAFT_REPO_ROOT/scripts/prof_summary.py $OUT/prof_$TAG > $OUT/prof_$TAG/summary_all.txt 2>&1
-# the same child WITHOUT the profiler, and what it measured under it: the per-kernel durations of a trace add up to the
-# step time of the PROFILED process (every dispatch carries the profiler's completion signal), not to ms_per_step
+# the same child WITHOUT the profiler, and what it measured under it, cold (batches 2-4 of the process) and warm (41-48):
+# the warm_us column of child_states adds up to the warm figure = ms_per_step of the bench line
 echo "== step time of the states child by HIP events (same process as the trace / without the profiler)" >> $OUT/prof_$TAG/summary_all.txt
 grep PMC_CHILD_STEP_MS $OUT/prof_$TAG/child_states.log | sed 's/^/under rocprofv3 --kernel-trace: /' >> $OUT/prof_$TAG/summary_all.txt
 python $GRAFT_REPO_ROOT/bench.py --pmc-child states 2>/dev/null | grep PMC_CHILD_STEP_MS | sed 's/^/unprofiled:                     /' >> $OUT/prof_$TAG/summary_all.txt
