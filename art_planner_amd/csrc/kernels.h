@@ -987,13 +987,41 @@ expand_edges_recs_kernel(FieldDev f, int mode, const double* __restrict__ s1, co
   for (size_t w0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); w0 < total;
        w0 += (size_t)gridDim.x * blockDim.x) {  // w0: wave-uniform
     const size_t w = w0 + lane;
-    if (w < total) {
-      size_t lo = 0, hi = n;  // edge e with offsets[e] <= w < offsets[e+1]
+    // edge e with offsets[e] <= w < offsets[e+1].  The 64 tasks of a wavefront are consecutive: ONE search (wave-uniform,
+    // scalar loads) finds the edge of its first task, the next 64 offsets are held one per lane, and each lane counts
+    // how many of them lie at or below its task with six shuffles instead of log2(n) dependent loads of its own.
+    uint32_t e0;
+    {
+      const uint32_t w0u = __builtin_amdgcn_readfirstlane((uint32_t)w0);
+      uint32_t lo = 0, hi = (uint32_t)n;
       while (hi - lo > 1) {
-        const size_t mid = (lo + hi) >> 1;
-        if (offsets[mid] <= w) lo = mid; else hi = mid;
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= w0u) lo = mid; else hi = mid;
       }
-      const size_t e = lo;
+      e0 = lo;
+    }
+    const size_t probe = (size_t)e0 + 1 + lane;
+    const uint32_t mine = offsets[probe < n ? probe : n];  // offsets[n] = total > every task
+    uint32_t cnt = 0;  // number of j in [0, 64) with offsets[e0 + 1 + j] <= w (the sequence is non-decreasing)
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+      const uint32_t v = __shfl(mine, (int)(cnt + step - 1), 64);
+      if (v <= (uint32_t)w) cnt += step;
+    }
+    {
+      const uint32_t last = __shfl(mine, 63, 64);
+      if (cnt == 63 && last <= (uint32_t)w) cnt = 64;
+    }
+    if (w < total) {
+      size_t e = (size_t)e0 + cnt;
+      if (cnt == 64) {  // more than 64 edges (empty ones) start inside this wavefront's tasks: search on from there
+        size_t lo = e, hi = n;
+        while (hi - lo > 1) {
+          const size_t mid = (lo + hi) >> 1;
+          if (offsets[mid] <= w) lo = mid; else hi = mid;
+        }
+        e = lo;
+      }
       const uint32_t k = edge_task_of_pass(pass, (uint32_t)(w - offsets[e]), coarse_stride);
       const double* a = s1 + 7 * e;
       const double* b = s2 + 7 * e;

@@ -897,9 +897,18 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
         bool vhit = false;
         for (int xl = 0; xl < numX; ++xl) {
           const float vx = (float)(b.minX + xl) * ff.sample_w;
-          for (int zl = 0; zl < numZ; ++zl) {
+          // eight samples of the column are requested before the first is looked at: a lane on its own pays the full
+          // memory latency per dependent load, and ONE such box in a batch is the whole duration of this launch
+          for (int zl0 = 0; zl0 < numZ; zl0 += 8) {
+           float hh[8];
+#pragma unroll
+           for (int k = 0; k < 8; ++k) hh[k] = (zl0 + k < numZ) ? base[xl + (zl0 + k) * nW] : 0.0f;
+#pragma unroll
+           for (int k = 0; k < 8; ++k) {
+            const int zl = zl0 + k;
+            if (zl >= numZ) break;
             const float* c = base + xl + zl * nW;
-            const float h = c[0];
+            const float h = hh[k];
             w.maxY = (w.maxY > h) ? w.maxY : h;  // dMAX(maxY, h): a NaN replaces maxY
             if (is_finite(h)) {
               w.minY = (w.minY > h) ? h : w.minY;
@@ -922,6 +931,7 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
             } else {
               w.allFinite = false;
             }
+           }
           }
         }
         int result = 0, ec;

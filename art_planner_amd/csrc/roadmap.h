@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <queue>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -1977,6 +1978,14 @@ struct LazyTree {
   std::vector<uint8_t> in_s;
   std::vector<uint32_t> first_child, next_sib, prev_sib;  // the tree's child lists (0xffffffff = none)
   std::vector<uint32_t> sub;
+  std::vector<uint8_t> rel;  // empty = every vertex; else the vertices that can still lie on a start-goal path (restrict)
+  const double* to_other = nullptr;  // with rel: a lower bound of every vertex's distance to the terminal that is NOT the
+                                     // root (consistent: exact distances of an earlier, larger graph), and
+  double cost_max = INFINITY;        // the cost no start-goal path of this query will exceed (C* and a rounding margin)
+  // The tree hangs from one terminal (0 = start, 1 = goal) and the path is read off at the other.  Which one is a matter
+  // of cost only -- the removed edge's subtree is what a repair re-settles, and that is small when the edge lies FAR
+  // from the root: edges that fail near the start want the root at the goal, and the other way round.
+  uint32_t root = 0;
   using Item = std::pair<double, uint32_t>;
   // everything the searches touch per adjacency slot is contiguous (adj, adjw); dist / pred of 10^4 vertices stay in
   // the host's L1 / L2 (three random reads per slot into the per-edge arrays made a repair 10x slower)
@@ -1989,15 +1998,16 @@ struct LazyTree {
       for (uint32_t a = rm->row[v]; a < rm->row[v + 1]; ++a)
         if (rm->adj_edge[a] == e) rm->adjw[a] = INFINITY;
   }
-  void full() {
+  void full(uint32_t new_root) {
     const size_t nv = rm->nv();
+    root = new_root;
     dist.assign(nv, INFINITY);
     pred.assign(nv, 0xffffffffu);
     pred_edge.assign(nv, 0xffffffffu);
     in_s.assign(nv, 0);
     std::priority_queue<Item, std::vector<Item>, std::greater<Item>> open;
-    dist[0] = 0.0;
-    open.push({0.0, 0u});
+    dist[root] = 0.0;
+    open.push({0.0, root});
     const uint32_t* adj = rm->adj.data();
     const double* adjw = rm->adjw.data();
     while (!open.empty()) {
@@ -2009,7 +2019,7 @@ struct LazyTree {
       for (uint32_t a = rm->row[u], a1 = rm->row[u + 1]; a < a1; ++a) {
         const uint32_t v = adj[a];
         const double nd = du + adjw[a];  // +inf for an unusable slot: never an improvement
-        if (nd < dist[v]) {
+        if (nd < dist[v] && (!to_other || (rel[v] && nd + to_other[v] <= cost_max))) {
           dist[v] = nd;
           pred[v] = u;
           pred_edge[v] = rm->adj_edge[a];
@@ -2017,11 +2027,87 @@ struct LazyTree {
         }
       }
     }
+    if (to_other)
+      for (uint32_t v = 0; v < (uint32_t)nv; ++v)
+        if (rel[v] && v != root && pred[v] == 0xffffffffu) rel[v] = 0;  // out of reach from this side as well
     first_child.assign(nv, 0xffffffffu);
     next_sib.assign(nv, 0xffffffffu);
     prev_sib.assign(nv, 0xffffffffu);
     for (uint32_t v = 0; v < (uint32_t)nv; ++v)
       if (pred[v] != 0xffffffffu) link(v);
+  }
+  // distances to `root` over the usable slots (the graph is undirected: this is also the distance FROM root)
+  void distances_from(uint32_t root, std::vector<double>* out) const {
+    const size_t nv = rm->nv();
+    out->assign(nv, INFINITY);
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> open;
+    (*out)[root] = 0.0;
+    open.push({0.0, root});
+    const uint32_t* adj = rm->adj.data();
+    const double* adjw = rm->adjw.data();
+    double* d = out->data();
+    while (!open.empty()) {
+      const Item it = open.top();
+      open.pop();
+      const uint32_t u = it.second;
+      if (it.first > d[u]) continue;
+      for (uint32_t a = rm->row[u], a1 = rm->row[u + 1]; a < a1; ++a) {
+        const double nd = it.first + adjw[a];
+        if (nd < d[adj[a]]) {
+          d[adj[a]] = nd;
+          open.push({nd, adj[a]});
+        }
+      }
+    }
+  }
+  // Cost of the cheapest start-goal path over slots whose verdict is KNOWN VALID, among the vertices of `in` (A* with
+  // the exact distance-to-goal of the larger graph as its heuristic: consistent).  +inf if there is none.
+  double valid_only_cost(const std::vector<uint8_t>& in, const std::vector<double>& to_goal) const {
+    const size_t nv = rm->nv();
+    std::vector<double> g(nv, INFINITY);
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> open;
+    g[0] = 0.0;
+    open.push({to_goal[0], 0u});
+    while (!open.empty()) {
+      const Item it = open.top();
+      open.pop();
+      const uint32_t u = it.second;
+      if (it.first > g[u] + to_goal[u]) continue;
+      if (u == 1u) return g[1];
+      for (uint32_t a = rm->row[u], a1 = rm->row[u + 1]; a < a1; ++a) {
+        const uint32_t v = rm->adj[a], e = rm->adj_edge[a];
+        if (!in[v] || !std::isfinite(rm->adjw[a])) continue;
+        if (rm->emotion[2 * (size_t)e + (u == rm->eu[e] ? 0u : 1u)] != 1) continue;
+        const double ng = g[u] + rm->adjw[a];
+        if (ng < g[v]) {
+          g[v] = ng;
+          open.push({ng + to_goal[v], v});
+        }
+      }
+    }
+    return INFINITY;
+  }
+  // From now on the tree spans only the vertices of `keep` (closed under tree ancestors here): the others can no
+  // longer lie on a start-goal path, their distances are never needed again and their subtrees never re-settled.
+  void restrict(std::vector<uint8_t>&& keep, const double* other_bound, double cmax) {
+    const size_t nv = rm->nv();
+    rel = std::move(keep);
+    to_other = other_bound;
+    cost_max = cmax;
+    for (uint32_t v = 0; v < (uint32_t)nv; ++v)
+      if (rel[v])
+        for (uint32_t u = pred[v]; u != 0xffffffffu && !rel[u]; u = pred[u]) rel[u] = 1;
+    first_child.assign(nv, 0xffffffffu);
+    next_sib.assign(nv, 0xffffffffu);
+    prev_sib.assign(nv, 0xffffffffu);
+    for (uint32_t v = 0; v < (uint32_t)nv; ++v) {
+      if (!rel[v]) {
+        dist[v] = INFINITY;
+        pred[v] = pred_edge[v] = 0xffffffffu;
+      } else if (pred[v] != 0xffffffffu) {
+        link(v);
+      }
+    }
   }
   void link(uint32_t v) {  // v becomes the first child of pred[v]
     const uint32_t p = pred[v], f = first_child[p];
@@ -2075,7 +2161,10 @@ struct LazyTree {
           ba = a;
         }
       }
-      if (ba != 0xffffffffu) {
+      // a vertex that has moved out of reach (distance + what is left to the goal > the cost bound) stays out: every
+      // later graph only has fewer edges, and no vertex still in reach has its shortest path through it (the bound
+      // to the goal is consistent)
+      if (ba != 0xffffffffu && (!to_other || best + to_other[x] <= cost_max)) {
         dist[x] = best;
         pred[x] = adj[ba];
         pred_edge[x] = adje[ba];
@@ -2091,7 +2180,8 @@ struct LazyTree {
       for (uint32_t a = rm->row[u], a1 = rm->row[u + 1]; a < a1; ++a) {
         const uint32_t v = adj[a];
         const double nd = du + adjw[a];
-        if (nd < dist[v]) {  // only subtree vertices can improve: everything else holds its final distance
+        // only subtree vertices can improve: the rest is final
+        if (nd < dist[v] && (!to_other || (rel[v] && nd + to_other[v] <= cost_max))) {
           dist[v] = nd;
           pred[v] = u;
           pred_edge[v] = adje[a];
@@ -2102,6 +2192,7 @@ struct LazyTree {
     for (const uint32_t x : sub) {
       in_s[x] = 0;
       if (pred[x] != 0xffffffffu) link(x);
+      else if (to_other) rel[x] = 0;  // out of reach for good (or cut off)
     }
   }
 };
@@ -2124,18 +2215,16 @@ int roadmap_check_motion_items(artp_roadmap* rm, const std::vector<uint32_t>& sr
     if (rc != ARTP_OK) return rc;
     return hipStreamSynchronize(c->stream) == hipSuccess ? ARTP_OK : ARTP_ERR_HIP;
   }
-  double *d_v = nullptr, *d_s = nullptr;
-  uint32_t* d_uv = nullptr;
-  uint8_t* d_ok = nullptr;
-  auto cleanup = [&]() {
-    for (void* p : {(void*)d_v, (void*)d_s, (void*)d_uv, (void*)d_ok})
-      if (p) (void)hipFree(p);
-  };
+  // the context's host-entry staging slots (tmp[0], tmp[1]: the device entry point below does not touch them) instead of
+  // four hipMalloc / hipFree pairs per call -- a hipFree alone waits for the device
+  auto cleanup = []() {};
   RM_HIP(hipSetDevice(c->device));
-  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_v), nv * 7 * sizeof(double)));
-  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_uv), 2 * n * sizeof(uint32_t)));
-  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_s), 2 * n * 7 * sizeof(double)));
-  RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_ok), n));
+  RM_TRY(ensure_tmp(c, 0, nv * 7 * sizeof(double) + 2 * n * sizeof(uint32_t) + 64));
+  RM_TRY(ensure_tmp(c, 1, 2 * n * 7 * sizeof(double) + n + 64));
+  double* d_v = static_cast<double*>(c->tmp[0]);
+  uint32_t* d_uv = reinterpret_cast<uint32_t*>(d_v + nv * 7);
+  double* d_s = static_cast<double*>(c->tmp[1]);
+  uint8_t* d_ok = reinterpret_cast<uint8_t*>(d_s + 2 * n * 7);
   RM_HIP(hipMemcpyAsync(d_v, rm->verts.data(), nv * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   RM_HIP(hipMemcpyAsync(d_uv, src.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   RM_HIP(hipMemcpyAsync(d_uv + n, dst.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -2179,13 +2268,37 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
   // never pays for the whole tree; the tree is built when the first edge has to go
   bool have_tree = false;
   int replans = 0;
+  const char* env_inf = std::getenv("ARTP_LAZY_INFORMED");
+  bool informed = env_inf ? std::atoi(env_inf) != 0 : true;
+  const double informed_beta[5] = {1.06, 1.25, 1.6, 2.5, INFINITY};
+  int informed_round = 0, wrong_side = 0, since_switch = 0, n_switch = 0;
+  double bound = INFINITY, c_star = INFINITY, c_pre = 0, t_informed = 0;
+  size_t n_rel = 0;
+  std::vector<double> to_other;
+  std::vector<uint8_t> within;
+  struct SubStat { uint32_t n, bad, np; float ms; };
+  std::vector<SubStat> sub_sizes;
   auto report = [&]() {
+    if (timing && !sub_sizes.empty()) {
+      std::vector<SubStat> ss = sub_sizes;
+      std::sort(ss.begin(), ss.end(), [](const SubStat& a, const SubStat& b) { return a.n > b.n; });
+      std::fprintf(stderr, "[solve] largest repairs (vertices @ position/path states, ms):");
+      for (size_t i = 0; i < ss.size() && i < 12; ++i) std::fprintf(stderr, " %u@%u/%u %.3f", ss[i].n, ss[i].bad, ss[i].np, ss[i].ms);
+      std::fprintf(stderr, "; median %u\n", ss[ss.size() / 2].n);
+      if (std::getenv("ARTP_SOLVE_SEQUENCE")) {
+        std::fprintf(stderr, "[solve] sequence (position/states:vertices):");
+        for (const SubStat& q : sub_sizes) std::fprintf(stderr, " %u/%u:%u", q.bad, q.np, q.n);
+        std::fprintf(stderr, "\n");
+      }
+    }
     if (timing)
       std::fprintf(stderr, "[solve] nv %zu ne %zu: csr %.2f ms, full tree %.2f ms, %zu check calls (%zu motions) %.2f ms of which "
-                   "precheck %zu motions %.2f ms, %d repairs %.2f ms (subtree vertices %zu)\n", rm->nv(), ne, t_csr, t_full,
-                   n_check_calls, n_checked, t_check, n_pre, t_pre, replans, t_repair, sub_total);
+                   "precheck %zu motions %.2f ms, %d repairs %.2f ms (subtree vertices %zu); informed set %zu vertices "
+                   "(C* %.4f, cost at the precheck %.4f, shell %d) %.2f ms; root %u after %d switches\n", rm->nv(), ne, t_csr, t_full,
+                   n_check_calls, n_checked, t_check, n_pre, t_pre, replans, t_repair, sub_total, n_rel, c_star, c_pre,
+                   informed_round, t_informed, t.root, n_switch);
   };
-  bool prechecked = false;
+  bool prechecked = false, precheck_batch = false;
   std::vector<uint32_t> path, pedge, src, dst, item;
   std::vector<uint8_t> ok;
   for (;;) {
@@ -2203,20 +2316,23 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
         pedge.push_back(e);
       }
     } else {
-      if (!std::isfinite(t.dist[1])) {
+      const uint32_t far = t.root == 0u ? 1u : 0u;
+      if (!std::isfinite(t.dist[far])) {
         if (n_replans) *n_replans = replans;
         report();
         return ARTP_OK;
       }
       path.clear();
-      for (uint32_t v = 1; v != 0u; v = t.pred[v]) {
+      for (uint32_t v = far; v != t.root; v = t.pred[v]) {
         path.push_back(v);
         pedge.push_back(t.pred_edge[v]);
       }
-      path.push_back(0u);
-      std::reverse(path.begin(), path.end());
-      std::reverse(pedge.begin(), pedge.end());  // pedge[i] = edge path[i] -> path[i + 1]
-      path_cost = t.dist[1];
+      path.push_back(t.root);
+      if (t.root == 0u) {  // read from the goal back to the start
+        std::reverse(path.begin(), path.end());
+        std::reverse(pedge.begin(), pedge.end());
+      }  // either way pedge[i] = edge path[i] -> path[i + 1]
+      path_cost = t.dist[far];
     }
     const size_t np = path.size();
     auto slot = [&](size_t i) { return 2 * (size_t)pedge[i] + (path[i] == rm->eu[pedge[i]] ? 0u : 1u); };
@@ -2226,19 +2342,35 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
     dst.clear();
     item.clear();
     if (!prechecked && replans >= ARTP_LAZY_PRECHECK_AFTER) {
-      size_t unknown = 0;
-      for (size_t e = 0; e < ne; ++e)
-        if (t.usable((uint32_t)e)) unknown += (rm->emotion[2 * e] == 0) + (rm->emotion[2 * e + 1] == 0);
-      if (unknown <= ARTP_LAZY_PRECHECK_MAX) {
-        for (size_t e = 0; e < ne; ++e) {
-          if (!t.usable((uint32_t)e)) continue;
-          for (unsigned d = 0; d < 2; ++d)
-            if (rm->emotion[2 * e + d] == 0) {
-              src.push_back(d ? rm->ev[e] : rm->eu[e]);
-              dst.push_back(d ? rm->eu[e] : rm->ev[e]);
-              item.push_back((uint32_t)(2 * e + d));
-            }
-        }
+      // Every later path costs at least this one's cost c and at most C*, the cost of the cheapest path whose motions
+      // are all valid; a vertex v with d(start, v) + d(v, goal) > C* (distances in TODAY's graph: they only grow as
+      // edges go) can lie on none of them.  C* needs verdicts, so: guess C* <= beta c, check the motions among the
+      // vertices within beta c in one batch, find C* among them, widen beta if it was not there.
+      const double t0 = now();
+      if (informed && to_other.empty()) t.distances_from(t.root == 0u ? 1u : 0u, &to_other);
+      t_informed += now() - t0;
+      double beta = informed ? informed_beta[informed_round] : INFINITY;
+      bound = std::isfinite(beta) ? beta * path_cost * (1.0 + 1e-9) : INFINITY;
+      c_pre = path_cost;
+      within.assign(rm->nv(), 1);
+      if (std::isfinite(bound))
+        for (size_t v = 0; v < rm->nv(); ++v) within[v] = t.dist[v] + to_other[v] <= bound;
+      for (size_t e = 0; e < ne && item.size() <= ARTP_LAZY_PRECHECK_MAX; ++e) {
+        if (!within[rm->eu[e]] || !within[rm->ev[e]] || !t.usable((uint32_t)e)) continue;
+        for (unsigned d = 0; d < 2; ++d)
+          if (rm->emotion[2 * e + d] == 0) {
+            src.push_back(d ? rm->ev[e] : rm->eu[e]);
+            dst.push_back(d ? rm->eu[e] : rm->ev[e]);
+            item.push_back((uint32_t)(2 * e + d));
+          }
+      }
+      if (item.size() <= ARTP_LAZY_PRECHECK_MAX) {
+        precheck_batch = true;
+      } else {  // too many motions for one batch: the per-path checks go on, nothing is restricted
+        informed = false;
+        src.clear();
+        dst.clear();
+        item.clear();
       }
       prechecked = true;
     }
@@ -2257,9 +2389,28 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
       t_check += now() - t0;
       ++n_check_calls;
       n_checked += item.size();
-      if (item.size() > 4096) {
+      if (precheck_batch) {
         t_pre += now() - t0;
         n_pre += item.size();
+      }
+    }
+    if (precheck_batch) {
+      precheck_batch = false;
+      if (informed && t.rel.empty()) {
+        const double t0 = now();
+        const double cstar = t.valid_only_cost(within, t.root == 1u ? t.dist : to_other);  // heuristic: distance to the goal
+        if (cstar <= bound) {  // the true C*: a cheaper all-valid path would lie within the bound as well
+          std::vector<uint8_t> keep(rm->nv());
+          size_t kept = 0;
+          for (size_t v = 0; v < rm->nv(); ++v) kept += keep[v] = t.dist[v] + to_other[v] <= cstar * (1.0 + 1e-9);
+          t.restrict(std::move(keep), to_other.data(), cstar * (1.0 + 1e-9));
+          n_rel = kept;
+          c_star = cstar;
+        } else if (std::isfinite(bound)) {  // not within beta c: the next shell (the verdicts so far stay)
+          ++informed_round;
+          prechecked = false;
+        }
+        t_informed += now() - t0;
       }
     }
     size_t bad = np;
@@ -2287,16 +2438,40 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
     rm->eremoved[pedge[bad]] = 1;
     rm->d_graph_dirty = true;
     t.drop_edge(pedge[bad]);
+    // where along the path the edge failed: 0 = at the start, 1 = at the goal
+    const double where = np > 2 ? (double)bad / (double)(np - 2) : 0.5;
     if (!have_tree) {
       const double t0 = now();
-      t.full();
+      const uint32_t new_root = where < 0.5 ? 1u : 0u;  // the root goes to the far end
+      // the distances to the OTHER end (what the informed set of the precheck is made of) on a second host thread while
+      // this one builds the tree: both only read the adjacency, and the thread is joined before the next edge goes
+      std::thread side;
+      if (informed) side = std::thread([&]() { t.distances_from(new_root == 0u ? 1u : 0u, &to_other); });
+      t.full(new_root);
+      if (side.joinable()) side.join();
       t_full = now() - t0;
       have_tree = true;
     } else {
       const double t0 = now();
-      t.repair(path[bad + 1]);  // the tree edge into path[bad + 1] is gone
+      t.repair(t.root == 0u ? path[bad + 1] : path[bad]);  // the tree edge into that vertex is gone
       t_repair += now() - t0;
       sub_total += t.sub.size();
+      if (timing) sub_sizes.push_back({(uint32_t)t.sub.size(), (uint32_t)bad, (uint32_t)np, (float)(now() - t0)});
+      // the edges keep failing on the root's side of the path: hang the tree from the other end (a search over the
+      // vertices still in reach; the old root's exact distances become the bound towards it)
+      const bool root_side = t.root == 0u ? where < 0.35 : where > 0.65;
+      wrong_side = root_side ? wrong_side + 1 : 0;
+      if (++since_switch >= 12 && wrong_side >= 6 && t.to_other) {
+        const double t1 = now();
+        if (t.to_other) {
+          to_other = t.dist;
+          t.to_other = to_other.data();
+        }
+        t.full(t.root == 0u ? 1u : 0u);
+        t_full += now() - t1;
+        ++n_switch;
+        wrong_side = since_switch = 0;
+      }
     }
     if (++replans > (int)rm->params.max_replans) {
       c->last_error = "too many lazy edge removals";
