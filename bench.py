@@ -548,31 +548,9 @@ def main():
     if N > 1:  # rank 0's extras would keep the other ranks waiting at the last barrier for minutes
         args.skip_extras, args.no_cpu_baseline, args.no_pmc = True, True, True
     gather_error = None
-    grp = None
-    if multi and args.exchange == "group" and not args.no_gather and args.lanes == 1:
-        # the device group of the C ABI, one process per GPU: rank 0 makes the RCCL id, torch.distributed (already up
-        # for the barrier and the max-over-ranks clock) carries its 128 bytes to the others
-        wd.stage("artp_group_create_rank (RCCL communicator)", args.watchdog)
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(DeviceGroup.unique_id()), dtype=torch.uint8).to(dev)
-            dist.broadcast(uid, src=0)
-            grp = DeviceGroup.from_rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), "yaml")
-        except Exception as ex:  # pragma: no cover
-            gather_error = "group: " + repr(ex)
-            grp = None
-        # every rank must take the same path: fall back to the torch exchange everywhere if any rank failed
-        ok_t = torch.tensor([1 if grp is not None else 0], device=dev, dtype=torch.int64)
-        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-        if int(ok_t.item()) == 0 and grp is not None:
-            grp.close()
-            grp = None
-        wd.done()
-
     # synthetic inputs: raw terrain + traversability; every derived layer (masked elevation, normals, CDF) comes
     # from the product's device preprocessing, installed as the context's map
-    ctx = grp.contexts[0] if grp is not None else Context(local_rank, "yaml")
+    ctx = Context(local_rank, "yaml")
     gm = map_from_device(ctx, raw_map(args.map, args.res, seed=1234))
     # one explicit stream carries the kernels AND the HIP events that time them
     main_stream = torch.cuda.Stream(device=dev)
@@ -615,7 +593,7 @@ def main():
     bits_buf = gatherers = all_states = mat_states = mat_counts = idx_tmp = cnt_tmp = done_ev = None
     rccl_ranks_seen = None
 
-    use_grp = grp          # the device group that runs the exchange (None: torch.distributed does)
+    use_grp = None         # the device group that runs the exchange (None: torch.distributed does)
     grp_mat_cap = [None]
 
     def configure_group(mc):
@@ -681,9 +659,6 @@ def main():
         except Exception as ex:  # pragma: no cover
             gather_error = repr(ex)
             do_gather = False
-
-    if do_gather:
-        setup_gather()
 
     def materialise(j, wait=True):
         gb = gatherers[j & 1]
@@ -774,6 +749,8 @@ def main():
                                         "1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
                             "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}"}}
     no_exchange = None
+    if multi:
+        wd.partial = dict(base_line, value=None)   # whatever happens from here on, the line has its fixed fields
     if multi and do_gather:
         # first the same K steps WITHOUT any exchange (only the barrier and the clock cross ranks): if the exchange hangs
         # on this node, the watchdog's line still carries a measured aggregate -- flagged as such
@@ -786,7 +763,42 @@ def main():
         wd.partial = dict(base_line, value=no_exchange["states_per_s"], ms_per_step=no_exchange["ms_per_step"],
                           steps=k0, headline_includes_exchange=False,
                           distributed={"world_size": world, "rccl_ranks_seen": rccl_ranks_seen,
-                                       "no_exchange": no_exchange, "exchange": args.exchange if use_grp else "torch"})
+                                       "no_exchange": no_exchange, "exchange": "not reached"})
+    # Only now -- with a measured aggregate already in the watchdog's hands -- anything that can hang on a node nobody
+    # has run on before: the RCCL communicator of the C ABI's device group and the trial exchange.
+    if multi and do_gather and args.exchange == "group" and args.lanes == 1:
+        # the device group of the C ABI, one process per GPU: rank 0 makes the RCCL id, torch.distributed (already up
+        # for the barrier and the max-over-ranks clock) carries its 128 bytes to the others.  The group owns its own
+        # context (the map is replicated per member, as it is across ranks)
+        wd.stage("artp_group_create_rank (RCCL communicator)", args.watchdog)
+        grp = None
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(DeviceGroup.unique_id()), dtype=torch.uint8).to(dev)
+            dist.broadcast(uid, src=0)
+            grp = DeviceGroup.from_rank(local_rank, rank, world, bytes(uid.cpu().numpy().tobytes()), "yaml")
+            map_from_device(grp.contexts[0], raw_map(args.map, args.res, seed=1234))
+            with torch.cuda.stream(main_stream):
+                grp.contexts[0].use_torch_stream()
+        except Exception as ex:  # pragma: no cover
+            gather_error = "group: " + repr(ex)
+            if grp is not None:
+                try:
+                    grp.close()
+                except Exception:
+                    pass
+            grp = None
+        # every rank must take the same path: fall back to the torch exchange everywhere if any rank failed
+        ok_t = torch.tensor([1 if grp is not None else 0], device=dev, dtype=torch.int64)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if int(ok_t.item()) == 0 and grp is not None:
+            grp.close()
+            grp = None
+        use_grp = grp
+        wd.done()
+    if do_gather:
+        setup_gather()
     mat_cap = (cap if args.materialise < 0 else min(cap, args.materialise)) if do_gather else 0
     dt = timed_region(K)
     value = N * S * K / dt
