@@ -2109,6 +2109,12 @@ struct LazyTree {
       }
     }
   }
+  // Equal-cost ways into a vertex: a best-first search from scratch (roadmap_astar with the zero heuristic of the
+  // directional and the learned objective: (cost, id) heap, strict '<' on relaxation) keeps the parent it settles
+  // FIRST, the one with the smaller (distance, id).  The tree follows the same rule everywhere, so that it stays the
+  // tree that search would build -- with the directional objective equal sums are common (a chain of edges priced by
+  // their yaw differences costs exactly the difference of its end yaws whichever way it goes).
+  bool before(uint32_t u, uint32_t p) const { return dist[u] < dist[p] || (dist[u] == dist[p] && u < p); }
   void link(uint32_t v) {  // v becomes the first child of pred[v]
     const uint32_t p = pred[v], f = first_child[p];
     next_sib[v] = f;
@@ -2156,7 +2162,7 @@ struct LazyTree {
       uint32_t ba = 0xffffffffu;
       for (uint32_t a = rm->row[x], a1 = rm->row[x + 1]; a < a1; ++a) {
         const double nd = dist[adj[a]] + adjw[a];
-        if (nd < best) {
+        if (nd < best || (nd == best && nd < INFINITY && before(adj[a], adj[ba]))) {
           best = nd;
           ba = a;
         }
@@ -2181,11 +2187,25 @@ struct LazyTree {
         const uint32_t v = adj[a];
         const double nd = du + adjw[a];
         // only subtree vertices can improve: the rest is final
-        if (nd < dist[v] && (!to_other || (rel[v] && nd + to_other[v] <= cost_max))) {
-          dist[v] = nd;
-          pred[v] = u;
-          pred_edge[v] = adje[a];
-          open.push({nd, v});
+        if (nd < dist[v]) {
+          if (!to_other || (rel[v] && nd + to_other[v] <= cost_max)) {
+            dist[v] = nd;
+            pred[v] = u;
+            pred_edge[v] = adje[a];
+            open.push({nd, v});
+          }
+        } else if (nd == dist[v] && pred[v] != u && pred[v] != 0xffffffffu && before(u, pred[v])) {
+          // an equally short way in through a parent that a search from scratch settles earlier: that search would
+          // have kept it (see before()).  v may lie outside the subtree -- then its own subtree moves with it
+          if (!in_s[v]) {
+            unlink(v);
+            pred[v] = u;
+            pred_edge[v] = adje[a];
+            link(v);
+          } else {
+            pred[v] = u;
+            pred_edge[v] = adje[a];
+          }
         }
       }
     }
@@ -2271,7 +2291,7 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
   const char* env_inf = std::getenv("ARTP_LAZY_INFORMED");
   bool informed = env_inf ? std::atoi(env_inf) != 0 : true;
   const double informed_beta[5] = {1.06, 1.25, 1.6, 2.5, INFINITY};
-  int informed_round = 0, wrong_side = 0, since_switch = 0, n_switch = 0;
+  int informed_round = 0, wrong_side = 0, since_switch = 0, n_switch = 0, pinned_root = -1;
   double bound = INFINITY, c_star = INFINITY, c_pre = 0, t_informed = 0;
   size_t n_rel = 0;
   std::vector<double> to_other;
@@ -2442,7 +2462,12 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
     const double where = np > 2 ? (double)bad / (double)(np - 2) : 0.5;
     if (!have_tree) {
       const double t0 = now();
-      const uint32_t new_root = where < 0.5 ? 1u : 0u;  // the root goes to the far end
+      // the order among equal-cost paths is that of a search from the START (LazyTree::before): with the directional
+      // objective, where equal sums are real, the tree stays there
+      if (rm->params.objective == 1) pinned_root = 0;
+      const char* env_root = std::getenv("ARTP_LAZY_ROOT");  // tuning aid: 0 / 1 pins the root
+      if (env_root) pinned_root = std::atoi(env_root) != 0 ? 1 : 0;
+      const uint32_t new_root = pinned_root >= 0 ? (uint32_t)pinned_root : (where < 0.5 ? 1u : 0u);  // the far end
       // the distances to the OTHER end (what the informed set of the precheck is made of) on a second host thread while
       // this one builds the tree: both only read the adjacency, and the thread is joined before the next edge goes
       std::thread side;
@@ -2461,7 +2486,7 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
       // vertices still in reach; the old root's exact distances become the bound towards it)
       const bool root_side = t.root == 0u ? where < 0.35 : where > 0.65;
       wrong_side = root_side ? wrong_side + 1 : 0;
-      if (++since_switch >= 12 && wrong_side >= 6 && t.to_other) {
+      if (++since_switch >= 12 && wrong_side >= 6 && t.to_other && pinned_root < 0) {
         const double t1 = now();
         if (t.to_other) {
           to_other = t.dist;
