@@ -1291,9 +1291,9 @@ def main():
                              "edges": int(st["candidate_edges"]), "samples_drawn": int(st["samples_drawn"]),
                              "path_states": None if path is None else int(len(path)), "path_cost_s": cost,
                              "lazy_removals": rep,
-                             "solve": "shortest-path tree repaired per removal + motion verdicts of the whole graph in one "
-                                      "batch after 3 removals (roadmap.h roadmap_solve_tree); round 3: an A* and a device "
-                                      "call per removal"}
+                             "solve": "shortest-path tree hung from the far end, repaired per removal + motion verdicts "
+                                      "of the informed set in one batch after 3 removals (roadmap.h roadmap_solve_tree, "
+                                      "DESIGN 4.5); round 3: an A* and a device call per removal"}
     except Exception as ex:  # pragma: no cover
         roadmap = {"error": repr(ex)}
 
