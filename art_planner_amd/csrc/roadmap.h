@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <queue>
+#include <system_error>
 #include <thread>
 #include <tuple>
 #include <vector>
@@ -2471,7 +2472,12 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
       // the distances to the OTHER end (what the informed set of the precheck is made of) on a second host thread while
       // this one builds the tree: both only read the adjacency, and the thread is joined before the next edge goes
       std::thread side;
-      if (informed) side = std::thread([&]() { t.distances_from(new_root == 0u ? 1u : 0u, &to_other); });
+      if (informed) {
+        try {
+          side = std::thread([&]() { t.distances_from(new_root == 0u ? 1u : 0u, &to_other); });
+        } catch (const std::system_error&) {  // no thread to be had: the precheck computes the distances itself
+        }
+      }
       t.full(new_root);
       if (side.joinable()) side.join();
       t_full = now() - t0;
