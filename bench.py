@@ -482,6 +482,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spin-up", type=int, default=32,
+                    help="untimed batches in front of every timed region, on top of --warmup (see timed_region)")
     ap.add_argument("--batch", type=int, default=1 << 22, help="candidate states per GPU per step")
     ap.add_argument("--edges", type=int, default=1 << 18)
     ap.add_argument("--map", type=int, default=400)
@@ -715,6 +717,15 @@ def main():
         if do_gather and use_grp is not None:
             configure_group(mat_cap)     # (re)allocation outside the clock
         wd.stage(f"timed region '{tag}' ({n_steps} steps)", args.watchdog)
+        # Device spin-up, untimed, right in front of every timed region: after any pause (process start, the seconds of
+        # setup between regions, even a GEMM burst) the first ~15 batches = 18 ms of this workload run up to 7 % slower
+        # and decay to the steady state (scripts/cold_probe.py, profiles/r04_cold_probe.txt: the power management's
+        # ramp, not this code's caches -- the same curve after 2 s of idling).  The driver's W = 5 warm-up steps are
+        # 6 ms of a 1.1 ms step: without this, a K = 20 region is measured half inside the ramp.
+        if dist is not None and args.spin_up:
+            dist.barrier()   # a process's first barrier creates the communicator (seconds of idling): before the spin-up
+        for i in range(args.spin_up):
+            ctx.sample_and_validate_dev(seed, first_index(3000000 + i), S, se3, valid)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -747,7 +758,8 @@ def main():
                  "dtype": "f32", "data": "synthetic",
                  "config": {"workload": "C2: lazy_prm_star_min_update front end, 400x400@0.04m Perlin terrain (seed "
                                         "1234) + 12 obstacles, YAML robot, batch sampler + validity checker",
-                            "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}"}}
+                            "states_per_gpu_per_step": S, "map": f"{args.map}x{args.map}@{args.res}",
+                            "spin_up_batches_before_each_timed_region": args.spin_up}}
     no_exchange = None
     if multi:
         wd.partial = dict(base_line, value=None)   # whatever happens from here on, the line has its fixed fields
