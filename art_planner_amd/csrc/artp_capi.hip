@@ -114,6 +114,8 @@ struct artp_ctx {
   float* d_c12 = nullptr;              // conv1 o conv2 composed: [24][25] + [24] (conv12_pool_kernel)
   half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
+  char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
+  int fc_mfma = 1;                     // $ARTP_FC_MFMA=0: the fp32 VALU kernels (tuning / comparison)
   half_t* d_act[2] = {nullptr, nullptr};
   size_t act_cap = 0;
   half_t* d_feat = nullptr;            // NHWC [Fh][Fw][48]
@@ -768,6 +770,7 @@ void artp_destroy(artp_ctx* c) {
     if (c->d_convb[l]) (void)hipFree(c->d_convb[l]);
   }
   if (c->d_fc) (void)hipFree(c->d_fc);
+  if (c->d_fc_mfma) (void)hipFree(c->d_fc_mfma);
   if (c->d_c12) (void)hipFree(c->d_c12);
   for (int l = 0; l < 3; ++l)
     if (c->d_convw_chunk[l]) (void)hipFree(c->d_convw_chunk[l]);
@@ -2091,6 +2094,91 @@ inline uint16_t f32_to_f16_bits(float f) {  // round-to-nearest-even, host side
   return u;
 }
 
+// The FC part (FcWeights blob: tar0, out0, three heads, three outputs) in the fragment order fc_cost_mfma_kernel reads
+// (cost_kernels.h): tar0 composed into out0 in double, every weight as a half-float hi / lo pair.
+inline void fc_mfma_pack(const float* w, std::vector<unsigned char>* out) {
+  out->assign(FcMfma::TOTAL, 0);
+  auto put16 = [&](size_t byte_off, float v) {
+    const uint16_t b = f32_to_f16_bits(v);
+    std::memcpy(out->data() + byte_off, &b, 2);
+  };
+  auto f16_value = [](float v) {  // the float a half-float rounding of v stands for
+    const uint16_t h = f32_to_f16_bits(v);
+    const uint32_t sign = (h >> 15) & 1u, ex = (h >> 10) & 31u, man = h & 1023u;
+    double r;
+    if (ex == 0) r = std::ldexp((double)man, -24);
+    else if (ex == 31) r = man ? NAN : INFINITY;
+    else r = std::ldexp((double)(man | 1024u), (int)ex - 25);
+    return (float)(sign ? -r : r);
+  };
+  auto split = [&](double v, float* hi, float* lo) {
+    *hi = f16_value((float)v);
+    *lo = f16_value((float)(v - (double)*hi));
+  };
+  // out0 o tar0: k < 48 the map features, 48 .. 57 the ten geometric inputs, 58 the bias (input 1.0)
+  static double w0c[48][64];
+  for (int o = 0; o < 48; ++o) {
+    for (int k = 0; k < 64; ++k) w0c[o][k] = 0.0;
+    for (int k = 0; k < 48; ++k) w0c[o][k] = w[FcWeights::OUT0_W + o * 64 + k];
+    double bias = w[FcWeights::OUT0_B + o];
+    for (int m = 0; m < 16; ++m) {
+      const double a = w[FcWeights::OUT0_W + o * 64 + 48 + m];
+      for (int k = 0; k < 10; ++k) w0c[o][48 + k] += a * (double)w[FcWeights::TAR0_W + m * 10 + k];
+      bias += a * (double)w[FcWeights::TAR0_B + m];
+    }
+    w0c[o][58] = bias;
+  }
+  auto hidden_of_row = [](int r) {  // accumulator row of the first GEMM -> hidden unit (see the kernel's header)
+    if (r >= 32) return r;
+    const int t = r / 16, g = (r % 16) / 4, i = r % 4;
+    return 8 * g + 4 * t + i;
+  };
+  for (int s = 0; s < 2; ++s)
+    for (int t = 0; t < 3; ++t)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int o = hidden_of_row(16 * t + (l & 15)), k = 32 * s + 8 * (l >> 4) + j;
+          float hi, lo;
+          split(w0c[o][k], &hi, &lo);
+          put16(FcMfma::G1 + (size_t)((s * 3 + t) * 2 + 0) * 1024 + l * 16 + j * 2, hi);
+          put16(FcMfma::G1 + (size_t)((s * 3 + t) * 2 + 1) * 1024 + l * 16 + j * 2, lo);
+        }
+  auto head_w = [&](int u, int k) -> double {
+    if (u < 24) return w[FcWeights::H1_W + u * 48 + k];
+    if (u < 48) return w[FcWeights::H2_W + (u - 24) * 48 + k];
+    if (u < 84) return w[FcWeights::H3_W + (u - 48) * 48 + k];
+    return 0.0;
+  };
+  for (int t = 0; t < 6; ++t)
+    for (int l = 0; l < 64; ++l) {
+      const int u = 16 * t + (l & 15);
+      for (int j = 0; j < 8; ++j) {
+        float hi, lo;
+        split(head_w(u, 8 * (l >> 4) + j), &hi, &lo);
+        put16(FcMfma::G2A + (size_t)(t * 2 + 0) * 1024 + l * 16 + j * 2, hi);
+        put16(FcMfma::G2A + (size_t)(t * 2 + 1) * 1024 + l * 16 + j * 2, lo);
+      }
+      for (int j = 0; j < 4; ++j) {
+        float hi, lo;
+        split(head_w(u, 32 + 4 * (l >> 4) + j), &hi, &lo);
+        put16(FcMfma::G2B + (size_t)(t * 2 + 0) * 512 + l * 8 + j * 2, hi);
+        put16(FcMfma::G2B + (size_t)(t * 2 + 1) * 512 + l * 8 + j * 2, lo);
+      }
+    }
+  float* bias2 = reinterpret_cast<float*>(out->data() + FcMfma::BIAS2);
+  float* outw = reinterpret_cast<float*>(out->data() + FcMfma::OUT);
+  float* ob = reinterpret_cast<float*>(out->data() + FcMfma::OB);
+  for (int u = 0; u < 96; ++u) {
+    bias2[u] = u < 24 ? w[FcWeights::H1_B + u] : (u < 48 ? w[FcWeights::H2_B + u - 24] : (u < 84 ? w[FcWeights::H3_B + u - 48] : 0.f));
+    outw[0 * 96 + u] = u < 24 ? w[FcWeights::O1_W + u] : 0.f;
+    outw[1 * 96 + u] = (u >= 24 && u < 48) ? w[FcWeights::O2_W + u - 24] : 0.f;
+    outw[2 * 96 + u] = (u >= 48 && u < 84) ? w[FcWeights::O3_W + u - 48] : 0.f;
+  }
+  ob[0] = w[FcWeights::O1_B];
+  ob[1] = w[FcWeights::O2_B];
+  ob[2] = w[FcWeights::O3_B];
+}
+
 }  // namespace
 
 extern "C" {
@@ -2199,6 +2287,13 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
   }
   if (!c->d_fc) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_fc), FcWeights::TOTAL * sizeof(float)));
   HIP_TRY(c, hipMemcpy(c->d_fc, w, FcWeights::TOTAL * sizeof(float), hipMemcpyHostToDevice));
+  {
+    std::vector<unsigned char> blob;
+    fc_mfma_pack(w, &blob);
+    if (!c->d_fc_mfma) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_fc_mfma), blob.size()));
+    HIP_TRY(c, hipMemcpy(c->d_fc_mfma, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    if (const char* e = std::getenv("ARTP_FC_MFMA")) c->fc_mfma = std::atoi(e) != 0;
+  }
   c->have_weights = true;
   return ARTP_OK;
 }
@@ -2387,7 +2482,13 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
   HIP_TRY(c, hipSetDevice(c->device));
   // up to 2^16 edges (a roadmap update's query): four lanes per edge; above that a lane per edge fills the GPU.  Both
   // kernels accumulate every unit in the same order: the same bits
-  if (b <= (1u << 16))
+  if (c->fc_mfma) {
+    // the MLP as MFMA tiles (cost_kernels.h fc_cost_mfma_kernel): 64 edges per wavefront, 256 per workgroup
+    size_t blocks = (b + 255) / 256;
+    if (blocks > (size_t)c->n_cus * 3) blocks = (size_t)c->n_cus * 3;  // three workgroups per CU fit (50 KB of LDS each)
+    hipLaunchKernelGGL(fc_cost_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, edges, b,
+                       (const half_t*)c->d_feat, c->cost_geom, (const char*)c->d_fc_mfma, cost);
+  } else if (b <= (1u << 16))
     hipLaunchKernelGGL(fc_cost_split_kernel, dim3((unsigned)((b + FC_SPLIT_EDGES - 1) / FC_SPLIT_EDGES)), dim3(256), 0, c->stream,
                        edges, b, (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
   else

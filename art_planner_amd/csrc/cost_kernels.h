@@ -725,6 +725,226 @@ fc_cost_kernel(const float* __restrict__ edges, size_t B, const half_t* __restri
   cost[3 * e + 2] = 1.0f - prob;  // cost_query.py:65-69 returns cost[3] = 1 - prob
 }
 
+// ---- the same MLP on the matrix cores -----------------------------------------------------------------------------------
+// Per edge the network is two small GEMMs: 64 inputs -> 48 hidden units -> 84 head units (7 300 MACs), then three dot
+// products.  Batched over 16 edges they are v_mfma_f32_16x16x32_f16 tiles (weights = first operand: the transposed product,
+// a lane ends up with four consecutive units of ONE edge), and fp32 accuracy is kept by splitting every fp32 operand into a
+// half-float "hi" and the half-float "lo" of what hi missed (x = hi + lo to 22 bits; hi*hi + lo*hi + hi*lo in the fp32
+// accumulator; lo*lo is below fp32's last bit): three MFMAs per product instead of one, still ~40x fewer issue slots than
+// the 7 300 FMAs of a lane.  The map features are half floats already (lo = 0).
+//  * tar0 (10 geometric inputs -> 16, NO activation, network_light.py:135-137) is composed into out0 on the host, in double,
+//    like conv1 o conv2: K = 48 features + 10 inputs + 1 (the composed bias, input 1.0) = 59 of 64.
+//  * The hidden units are numbered so that the accumulator layout of the first GEMM IS the second GEMM's operand layout:
+//    a lane holds rows 16 t + 4 (lane >> 4) + i of tile t; the second GEMM wants k = 8 (lane >> 4) + j of a 32-wide step --
+//    hidden unit 8 g + 4 t + i sits in row 16 t + 4 g + i (t < 2), units 32 .. 47 stay where they are and go through a
+//    16-wide step (v_mfma_f32_16x16x16_f16: k = 4 (lane >> 4) + j).  No shuffles, no LDS between the layers.
+//  * A wavefront takes 64 edges: one lane per edge forms the gather offset and the geometric inputs (sqrt, atan2, two
+//    sin / cos pairs: the VALU part) and parks them in LDS; then four 16-edge tiles run through the GEMMs.
+// Blob (fc_mfma_pack on the host): [s][t][hi|lo] 1 KB fragments of the first GEMM (12), [t][hi|lo] of the second's 32-wide
+// step (12), [t][hi|lo] 512-byte fragments of its 16-wide step (12), head biases [96], output weights [3][96] zero-padded
+// per head, output biases [3].
+struct FcMfma {
+  enum {
+    G1 = 0, G2A = G1 + 12 * 1024, G2B = G2A + 12 * 1024, BIAS2 = G2B + 12 * 512, OUT = BIAS2 + 96 * 4,
+    OB = OUT + 3 * 96 * 4, TOTAL = OB + 16,
+    STAGE = 256 + 2 * 64 * 32  // per wavefront: 64 gather offsets, 64 x 16 halfs hi, 64 x 16 halfs lo
+  };
+  static_assert(TOTAL % 16 == 0, "16-byte copies");
+};
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+// Every MFMA of this kernel is followed by wait states with the scheduler fenced off.  Reason: ROCm 7.2's compiler
+// lets a VALU instruction overwrite a register that an in-flight gfx950 16x16x32 MFMA still has to read as its srcC two
+// or three cycles after issuing it (seen in the ISA: v_mfma ... v[72:75], v[60:63], v[8:11], v[12:15]; s_nop 2;
+// v_cvt_f32_f16 v14, ... -- and wrong sums on the device that move with every change of the code's shape).  The CNN kernels
+// accumulate in place over long loops and never met it; here accumulators are born from LDS loads and die into VALU code.
+#ifndef FCM_NOP
+#define FCM_NOP 9   // measured: 4 wait states are too few, 8 are enough (exact results); 10 with a margin
+#endif
+#define FCM_WAIT()                                  \
+  do {                                              \
+    __builtin_amdgcn_sched_barrier(0);              \
+    asm volatile("s_nop %0" ::"n"(FCM_NOP));        \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+#define FCM_MFMA32(acc, a, b)                                            \
+  do {                                                                   \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);    \
+    FCM_WAIT();                                                          \
+  } while (0)
+#define FCM_MFMA16(acc, a, b)                                            \
+  do {                                                                   \
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);     \
+    FCM_WAIT();                                                          \
+  } while (0)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+fc_cost_mfma_kernel(const float* __restrict__ edges, size_t B, const half_t* __restrict__ feat, CostMapGeom g,
+                    const char* __restrict__ blob, float* __restrict__ cost) {
+  __shared__ __attribute__((aligned(16))) char sw[FcMfma::TOTAL];
+  __shared__ __attribute__((aligned(16))) char stage_all[4][FcMfma::STAGE];
+  for (int i = threadIdx.x; i < FcMfma::TOTAL / 16; i += blockDim.x)
+    reinterpret_cast<uint4*>(sw)[i] = reinterpret_cast<const uint4*>(blob)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  char* st = stage_all[wave];
+  int* s_off = reinterpret_cast<int*>(st);
+  half_t* s_hi = reinterpret_cast<half_t*>(st + 256);
+  half_t* s_lo = reinterpret_cast<half_t*>(st + 256 + 64 * 32);
+  const size_t n_chunks = (B + 63) / 64;
+  for (size_t chunk = (size_t)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (size_t)gridDim.x * 4) {
+    {  // one lane per edge: gather offset and the ten geometric inputs (network_light.py:118-132), hi / lo halves
+      const size_t e_raw = chunk * 64 + lane;
+      const size_t e = e_raw < B ? e_raw : B - 1;
+      const float* ed = edges + 6 * e;
+      const double tx = ed[0], ty = ed[1], tyaw = ed[2], sx = ed[3], sy = ed[4], syaw = ed[5];
+      int row, col;
+      cost_query_cell(g, sx, sy, &row, &col);  // cost_query.py:51-55
+      s_off[lane] = (row * g.Fw + col) * 48;
+      const float dx = (float)(tx - sx), dy = (float)(ty - sy);
+      float dyaw = (float)(tyaw - syaw);
+      const float PI = 3.14159265358979323846f;
+      if (dyaw > PI) dyaw -= 2.0f * PI;
+      if (dyaw < -PI) dyaw += 2.0f * PI;
+      const float sya = (float)syaw;
+      float t[16];
+      t[0] = dx;
+      t[1] = dy;
+      t[2] = sqrtf(dx * dx + dy * dy);
+      t[3] = atan2f(dy, dx);
+      t[4] = dyaw;
+      t[5] = cosf(dyaw);
+      t[6] = sinf(dyaw);
+      t[7] = sya;
+      t[8] = cosf(sya);
+      t[9] = sinf(sya);
+      t[10] = 1.0f;  // the composed bias rides on this input
+      t[11] = t[12] = t[13] = t[14] = t[15] = 0.0f;
+      half8 h0, h1, l0, l1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        h0[k] = (half_t)t[k];
+        l0[k] = (half_t)(t[k] - (float)h0[k]);
+        h1[k] = (half_t)t[8 + k];
+        l1[k] = (half_t)(t[8 + k] - (float)h1[k]);
+      }
+      reinterpret_cast<half8*>(s_hi + lane * 16)[0] = h0;
+      reinterpret_cast<half8*>(s_hi + lane * 16)[1] = h1;
+      reinterpret_cast<half8*>(s_lo + lane * 16)[0] = l0;
+      reinterpret_cast<half8*>(s_lo + lane * 16)[1] = l1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int tile = 0; tile < 4; ++tile) {
+      // the weight fragments are READ FROM LDS IN EVERY TILE (36 reads, 30 KB per wavefront and tile): held in registers
+      // across the loop they are 150 VGPRs and one wavefront per SIMD -- nothing to cover the feature gather with.  The
+      // opaque offset keeps the compiler from hoisting them
+      int woff = lane * 16;
+      asm volatile("" : "+v"(woff));
+      const char* wl = sw + woff;              // this lane's 16 bytes of a 1 KB fragment
+      const char* wl8 = sw + (woff >> 1);      // ... 8 bytes of a 512-byte fragment
+      const int el = tile * 16 + li;
+      const half_t* fp = feat + s_off[el];
+      // operands of the first GEMM: lane = edge li, k = 32 s + 8 kg + j
+      const half8 x0 = *reinterpret_cast<const half8*>(fp + 8 * kg);
+      half8 x1, x1lo;
+      if (kg < 2) {
+        x1 = *reinterpret_cast<const half8*>(fp + 32 + 8 * kg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x1lo[j] = (half_t)0.0f;
+      } else {
+        x1 = *reinterpret_cast<const half8*>(s_hi + el * 16 + 8 * (kg - 2));
+        x1lo = *reinterpret_cast<const half8*>(s_lo + el * 16 + 8 * (kg - 2));
+      }
+      floatx4 a1[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const half8 w0h = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((0 * 3 + t) * 2 + 0) * 1024);
+        const half8 w0l = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((0 * 3 + t) * 2 + 1) * 1024);
+        const half8 w1h = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((1 * 3 + t) * 2 + 0) * 1024);
+        const half8 w1l = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((1 * 3 + t) * 2 + 1) * 1024);
+        FCM_MFMA32(acc, w0l, x0);
+        FCM_MFMA32(acc, w1l, x1);
+        FCM_MFMA32(acc, w1h, x1lo);
+        FCM_MFMA32(acc, w0h, x0);
+        FCM_MFMA32(acc, w1h, x1);
+        a1[t] = acc;
+      }
+      // leaky-ReLU (0.3), hi / lo halves: already in the second GEMM's operand layout (see above)
+      half8 hA, hAlo;
+      half4_t hB, hBlo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v0 = a1[0][j], v1 = a1[1][j], v2 = a1[2][j];
+        v0 = v0 > 0.f ? v0 : 0.3f * v0;
+        v1 = v1 > 0.f ? v1 : 0.3f * v1;
+        v2 = v2 > 0.f ? v2 : 0.3f * v2;
+        hA[j] = (half_t)v0;
+        hAlo[j] = (half_t)(v0 - (float)hA[j]);
+        hA[4 + j] = (half_t)v1;
+        hAlo[4 + j] = (half_t)(v1 - (float)hA[4 + j]);
+        hB[j] = (half_t)v2;
+        hBlo[j] = (half_t)(v2 - (float)hB[j]);
+      }
+      float p = 0.f, q = 0.f, r = 0.f;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        floatx4 acc = *reinterpret_cast<const floatx4*>(sw + FcMfma::BIAS2 + (16 * t + 4 * kg) * 4);
+        const half8 wah = *reinterpret_cast<const half8*>(wl + FcMfma::G2A + (t * 2 + 0) * 1024);
+        const half8 wal = *reinterpret_cast<const half8*>(wl + FcMfma::G2A + (t * 2 + 1) * 1024);
+        const half4_t wbh = *reinterpret_cast<const half4_t*>(wl8 + FcMfma::G2B + (t * 2 + 0) * 512);
+        const half4_t wbl = *reinterpret_cast<const half4_t*>(wl8 + FcMfma::G2B + (t * 2 + 1) * 512);
+        FCM_MFMA32(acc, wal, hA);
+        FCM_MFMA32(acc, wah, hAlo);
+        FCM_MFMA16(acc, wbl, hB);
+        FCM_MFMA16(acc, wbh, hBlo);
+        FCM_MFMA32(acc, wah, hA);
+        FCM_MFMA16(acc, wbh, hB);
+        // head units 16 t + 4 kg + i: leaky-ReLU, then their share of the three output dot products (the output weight
+        // vectors are zero outside their head: tile 0 is all energy, tile 1 half energy half time, ...)
+        const int u0 = (16 * t + 4 * kg) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.3f * acc[i];
+        if (t <= 1) {
+          const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 0 * 384 + u0);
+          p += acc[0] * o[0] + acc[1] * o[1] + acc[2] * o[2] + acc[3] * o[3];
+        }
+        if (t >= 1 && t <= 2) {
+          const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 1 * 384 + u0);
+          q += acc[0] * o[0] + acc[1] * o[1] + acc[2] * o[2] + acc[3] * o[3];
+        }
+        if (t >= 3) {
+          const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 2 * 384 + u0);
+          r += acc[0] * o[0] + acc[1] * o[1] + acc[2] * o[2] + acc[3] * o[3];
+        }
+      }
+      // the four lane groups of an edge hold a quarter of the units each
+      p += __shfl_xor(p, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      r += __shfl_xor(r, 16, 64);
+      p += __shfl_xor(p, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      r += __shfl_xor(r, 32, 64);
+      const size_t e = chunk * 64 + el;
+      if (kg == 0 && e < B) {
+        const float* ob = reinterpret_cast<const float*>(sw + FcMfma::OB);
+        float power = p + ob[0], tim = q + ob[1], prob = r + ob[2];
+        power = power > 0.f ? power : 0.f;
+        tim = tim > 0.f ? tim : 0.f;
+        prob = 1.0f / (1.0f + expf(-prob));
+        cost[3 * e + 0] = power;
+        cost[3 * e + 1] = tim;
+        cost[3 * e + 2] = 1.0f - prob;  // cost_query.py:65-69 returns cost[3] = 1 - prob
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the staging area is rewritten by the next chunk
+  }
+}
+
 // Small batches (a roadmap update of the reference queries ~50 000 edges): one lane per edge leaves most of the GPU idle
 // behind ~7 300 dependent FMAs per lane (76 us for 50 000 edges).  Here FOUR lanes share an edge: every lane forms the
 // edge's 64 inputs itself (the loads hit the L1, tar0 is 160 FMAs), then computes a quarter of the 48 hidden units, and
