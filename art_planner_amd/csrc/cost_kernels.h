@@ -772,6 +772,18 @@ typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);    \
     FCM_WAIT();                                                          \
   } while (0)
+#define FCM_MFMA32X2(c0, c1, a, b0, b1)                                  \
+  do {                                                                   \
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, c0, 0, 0, 0);     \
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, c1, 0, 0, 0);     \
+    FCM_WAIT();                                                          \
+  } while (0)
+#define FCM_MFMA16X2(c0, c1, a, b0, b1)                                  \
+  do {                                                                   \
+    c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b0, c0, 0, 0, 0);      \
+    c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b1, c1, 0, 0, 0);      \
+    FCM_WAIT();                                                          \
+  } while (0)
 #define FCM_MFMA16(acc, a, b)                                            \
   do {                                                                   \
     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);     \
@@ -837,107 +849,124 @@ fc_cost_mfma_kernel(const float* __restrict__ edges, size_t B, const half_t* __r
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
-    for (int tile = 0; tile < 4; ++tile) {
-      // the weight fragments are READ FROM LDS IN EVERY TILE (36 reads, 30 KB per wavefront and tile): held in registers
-      // across the loop they are 150 VGPRs and one wavefront per SIMD -- nothing to cover the feature gather with.  The
-      // opaque offset keeps the compiler from hoisting them
+    for (int pair = 0; pair < 2; ++pair) {
+      // TWO 16-edge tiles per pass: a weight fragment read from LDS feeds two MFMAs, and the two share one wait (FCM_WAIT).
+      // The fragments are READ FROM LDS IN EVERY PASS (36 reads, 30 KB per wavefront): held in registers across the loop they
+      // are 150 VGPRs and one wavefront per SIMD -- nothing to cover the feature gather with.  The opaque offset keeps the
+      // compiler from hoisting them
       int woff = lane * 16;
       asm volatile("" : "+v"(woff));
       const char* wl = sw + woff;              // this lane's 16 bytes of a 1 KB fragment
       const char* wl8 = sw + (woff >> 1);      // ... 8 bytes of a 512-byte fragment
-      const int el = tile * 16 + li;
-      const half_t* fp = feat + s_off[el];
-      // operands of the first GEMM: lane = edge li, k = 32 s + 8 kg + j
-      const half8 x0 = *reinterpret_cast<const half8*>(fp + 8 * kg);
-      half8 x1, x1lo;
-      if (kg < 2) {
-        x1 = *reinterpret_cast<const half8*>(fp + 32 + 8 * kg);
+      int el[2];
+      half8 x0[2], x1[2], x1lo[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x1lo[j] = (half_t)0.0f;
-      } else {
-        x1 = *reinterpret_cast<const half8*>(s_hi + el * 16 + 8 * (kg - 2));
-        x1lo = *reinterpret_cast<const half8*>(s_lo + el * 16 + 8 * (kg - 2));
+      for (int u = 0; u < 2; ++u) {
+        el[u] = (pair * 2 + u) * 16 + li;
+        const half_t* fp = feat + s_off[el[u]];
+        // operands of the first GEMM: lane = edge li, k = 32 s + 8 kg + j
+        x0[u] = *reinterpret_cast<const half8*>(fp + 8 * kg);
+        if (kg < 2) {
+          x1[u] = *reinterpret_cast<const half8*>(fp + 32 + 8 * kg);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x1lo[u][j] = (half_t)0.0f;
+        } else {
+          x1[u] = *reinterpret_cast<const half8*>(s_hi + el[u] * 16 + 8 * (kg - 2));
+          x1lo[u] = *reinterpret_cast<const half8*>(s_lo + el[u] * 16 + 8 * (kg - 2));
+        }
       }
-      floatx4 a1[3];
+      floatx4 a1[2][3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        floatx4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
         const half8 w0h = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((0 * 3 + t) * 2 + 0) * 1024);
         const half8 w0l = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((0 * 3 + t) * 2 + 1) * 1024);
         const half8 w1h = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((1 * 3 + t) * 2 + 0) * 1024);
         const half8 w1l = *reinterpret_cast<const half8*>(wl + FcMfma::G1 + ((1 * 3 + t) * 2 + 1) * 1024);
-        FCM_MFMA32(acc, w0l, x0);
-        FCM_MFMA32(acc, w1l, x1);
-        FCM_MFMA32(acc, w1h, x1lo);
-        FCM_MFMA32(acc, w0h, x0);
-        FCM_MFMA32(acc, w1h, x1);
-        a1[t] = acc;
+        FCM_MFMA32X2(c0, c1, w0l, x0[0], x0[1]);
+        FCM_MFMA32X2(c0, c1, w1l, x1[0], x1[1]);
+        FCM_MFMA32X2(c0, c1, w1h, x1lo[0], x1lo[1]);
+        FCM_MFMA32X2(c0, c1, w0h, x0[0], x0[1]);
+        FCM_MFMA32X2(c0, c1, w1h, x1[0], x1[1]);
+        a1[0][t] = c0;
+        a1[1][t] = c1;
       }
       // leaky-ReLU (0.3), hi / lo halves: already in the second GEMM's operand layout (see above)
-      half8 hA, hAlo;
-      half4_t hB, hBlo;
+      half8 hA[2], hAlo[2];
+      half4_t hB[2], hBlo[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v0 = a1[0][j], v1 = a1[1][j], v2 = a1[2][j];
-        v0 = v0 > 0.f ? v0 : 0.3f * v0;
-        v1 = v1 > 0.f ? v1 : 0.3f * v1;
-        v2 = v2 > 0.f ? v2 : 0.3f * v2;
-        hA[j] = (half_t)v0;
-        hAlo[j] = (half_t)(v0 - (float)hA[j]);
-        hA[4 + j] = (half_t)v1;
-        hAlo[4 + j] = (half_t)(v1 - (float)hA[4 + j]);
-        hB[j] = (half_t)v2;
-        hBlo[j] = (half_t)(v2 - (float)hB[j]);
-      }
-      float p = 0.f, q = 0.f, r = 0.f;
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v0 = a1[u][0][j], v1 = a1[u][1][j], v2 = a1[u][2][j];
+          v0 = v0 > 0.f ? v0 : 0.3f * v0;
+          v1 = v1 > 0.f ? v1 : 0.3f * v1;
+          v2 = v2 > 0.f ? v2 : 0.3f * v2;
+          hA[u][j] = (half_t)v0;
+          hAlo[u][j] = (half_t)(v0 - (float)hA[u][j]);
+          hA[u][4 + j] = (half_t)v1;
+          hAlo[u][4 + j] = (half_t)(v1 - (float)hA[u][4 + j]);
+          hB[u][j] = (half_t)v2;
+          hBlo[u][j] = (half_t)(v2 - (float)hB[u][j]);
+        }
+      float p[2] = {0.f, 0.f}, q[2] = {0.f, 0.f}, r[2] = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
-        floatx4 acc = *reinterpret_cast<const floatx4*>(sw + FcMfma::BIAS2 + (16 * t + 4 * kg) * 4);
+        const floatx4 bias = *reinterpret_cast<const floatx4*>(sw + FcMfma::BIAS2 + (16 * t + 4 * kg) * 4);
+        floatx4 c0 = bias, c1 = bias;
         const half8 wah = *reinterpret_cast<const half8*>(wl + FcMfma::G2A + (t * 2 + 0) * 1024);
         const half8 wal = *reinterpret_cast<const half8*>(wl + FcMfma::G2A + (t * 2 + 1) * 1024);
         const half4_t wbh = *reinterpret_cast<const half4_t*>(wl8 + FcMfma::G2B + (t * 2 + 0) * 512);
         const half4_t wbl = *reinterpret_cast<const half4_t*>(wl8 + FcMfma::G2B + (t * 2 + 1) * 512);
-        FCM_MFMA32(acc, wal, hA);
-        FCM_MFMA32(acc, wah, hAlo);
-        FCM_MFMA16(acc, wbl, hB);
-        FCM_MFMA16(acc, wbh, hBlo);
-        FCM_MFMA32(acc, wah, hA);
-        FCM_MFMA16(acc, wbh, hB);
+        FCM_MFMA32X2(c0, c1, wal, hA[0], hA[1]);
+        FCM_MFMA32X2(c0, c1, wah, hAlo[0], hAlo[1]);
+        FCM_MFMA16X2(c0, c1, wbl, hB[0], hB[1]);
+        FCM_MFMA16X2(c0, c1, wbh, hBlo[0], hBlo[1]);
+        FCM_MFMA32X2(c0, c1, wah, hA[0], hA[1]);
+        FCM_MFMA16X2(c0, c1, wbh, hB[0], hB[1]);
         // head units 16 t + 4 kg + i: leaky-ReLU, then their share of the three output dot products (the output weight
         // vectors are zero outside their head: tile 0 is all energy, tile 1 half energy half time, ...)
         const int u0 = (16 * t + 4 * kg) * 4;
+        floatx4 cc[2] = {c0, c1};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.3f * acc[i];
-        if (t <= 1) {
-          const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 0 * 384 + u0);
-          p += acc[0] * o[0] + acc[1] * o[1] + acc[2] * o[2] + acc[3] * o[3];
-        }
-        if (t >= 1 && t <= 2) {
-          const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 1 * 384 + u0);
-          q += acc[0] * o[0] + acc[1] * o[1] + acc[2] * o[2] + acc[3] * o[3];
-        }
-        if (t >= 3) {
-          const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 2 * 384 + u0);
-          r += acc[0] * o[0] + acc[1] * o[1] + acc[2] * o[2] + acc[3] * o[3];
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cc[u][i] = cc[u][i] > 0.f ? cc[u][i] : 0.3f * cc[u][i];
+          if (t <= 1) {
+            const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 0 * 384 + u0);
+            p[u] += cc[u][0] * o[0] + cc[u][1] * o[1] + cc[u][2] * o[2] + cc[u][3] * o[3];
+          }
+          if (t >= 1 && t <= 2) {
+            const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 1 * 384 + u0);
+            q[u] += cc[u][0] * o[0] + cc[u][1] * o[1] + cc[u][2] * o[2] + cc[u][3] * o[3];
+          }
+          if (t >= 3) {
+            const floatx4 o = *reinterpret_cast<const floatx4*>(sw + FcMfma::OUT + 2 * 384 + u0);
+            r[u] += cc[u][0] * o[0] + cc[u][1] * o[1] + cc[u][2] * o[2] + cc[u][3] * o[3];
+          }
         }
       }
-      // the four lane groups of an edge hold a quarter of the units each
-      p += __shfl_xor(p, 16, 64);
-      q += __shfl_xor(q, 16, 64);
-      r += __shfl_xor(r, 16, 64);
-      p += __shfl_xor(p, 32, 64);
-      q += __shfl_xor(q, 32, 64);
-      r += __shfl_xor(r, 32, 64);
-      const size_t e = chunk * 64 + el;
-      if (kg == 0 && e < B) {
-        const float* ob = reinterpret_cast<const float*>(sw + FcMfma::OB);
-        float power = p + ob[0], tim = q + ob[1], prob = r + ob[2];
-        power = power > 0.f ? power : 0.f;
-        tim = tim > 0.f ? tim : 0.f;
-        prob = 1.0f / (1.0f + expf(-prob));
-        cost[3 * e + 0] = power;
-        cost[3 * e + 1] = tim;
-        cost[3 * e + 2] = 1.0f - prob;  // cost_query.py:65-69 returns cost[3] = 1 - prob
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        // the four lane groups of an edge hold a quarter of the units each
+        float pp = p[u], qq = q[u], rr = r[u];
+        pp += __shfl_xor(pp, 16, 64);
+        qq += __shfl_xor(qq, 16, 64);
+        rr += __shfl_xor(rr, 16, 64);
+        pp += __shfl_xor(pp, 32, 64);
+        qq += __shfl_xor(qq, 32, 64);
+        rr += __shfl_xor(rr, 32, 64);
+        const size_t e = chunk * 64 + el[u];
+        if (kg == 0 && e < B) {
+          const float* ob = reinterpret_cast<const float*>(sw + FcMfma::OB);
+          float power = pp + ob[0], tim = qq + ob[1], prob = rr + ob[2];
+          power = power > 0.f ? power : 0.f;
+          tim = tim > 0.f ? tim : 0.f;
+          prob = 1.0f / (1.0f + expf(-prob));
+          cost[3 * e + 0] = power;
+          cost[3 * e + 1] = tim;
+          cost[3 * e + 2] = 1.0f - prob;  // cost_query.py:65-69 returns cost[3] = 1 - prob
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
