@@ -10,7 +10,8 @@
 //     v_mfma_f32_16x16x32_f16 (fp32 accumulate).  Weights are pre-packed on the host in fragment order.
 // R9  CostQuery.__call__ + network.FCpart (cost_query.py:39-69, network_light.py:113-165): per edge,
 //     gather the 48 features of the start cell, build the 10 geometric inputs, 1x1-conv MLP with three
-//     heads -> (energy, time, 1 - prob).  One lane per edge, fp32 math, weights broadcast from LDS.
+//     heads -> (energy, time, 1 - prob).  fc_cost_mfma_kernel: the two layers as MFMA tiles over 16 edges, fp32 accuracy
+//     from half-float hi / lo operand pairs (fc_cost_kernel / fc_cost_split_kernel: the fp32 VALU forms, $ARTP_FC_MFMA=0).
 #pragma once
 
 #include <hip/hip_runtime.h>
