@@ -267,10 +267,22 @@ def test_gpu_cost_full_map_properties(big_map):
     assert (c1[:, 0] >= 0).all() and (c1[:, 1] >= 0).all() and ((c1[:, 2] >= 0) & (c1[:, 2] <= 1)).all()
     # against the numpy oracle fed with the GPU's own feature map (isolates the per-edge MLP, fp32)
     co = mo.fc_costs(p, np.transpose(f, (2, 0, 1)), e[:4096], big_map.res, big_map.len_x, big_map.len_y)
-    assert np.abs(c1[:4096] - co).max() < 1e-3
-    # batches up to 2^16 edges run four lanes per edge, larger ones a lane per edge: every unit is accumulated in the same
-    # order by both, so the same edge gets the same bits whichever batch it arrives in (ragged sizes included)
-    big = np.tile(e, (2, 1))[:70001]                       # > 2^16: the lane-per-edge kernel
+    # the MLP runs as MFMA tiles with half-float hi / lo operand pairs (cost_kernels.h fc_cost_mfma_kernel): fp32 accuracy
+    assert np.abs(c1[:4096] - co).max() < 5e-5
+    # ... and equals the fp32 VALU kernels (a lane per edge / four lanes per edge; $ARTP_FC_MFMA=0 at weight load)
+    import os
+    os.environ["ARTP_FC_MFMA"] = "0"
+    try:
+        ctx_v = Context(0, "yaml")
+        ctx_v.cost_load_weights(convert_weights.to_blob(p))
+    finally:
+        os.environ.pop("ARTP_FC_MFMA", None)
+    ctx_v.cost_update_map(elv, big_map.res, big_map.len_x, big_map.len_y)
+    c_v = ctx_v.cost_query(e)
+    assert np.abs(c1 - c_v).max() < 2e-5 and not np.array_equal(c1, c_v)   # two different kernels, the same numbers
+    ctx_v.close()
+    # an edge's result does not depend on the batch it arrives in (tile position, ragged sizes, small and large batches)
+    big = np.tile(e, (2, 1))[:70001]
     cb = ctx.cost_query(big)
     assert np.array_equal(cb[:B], c1) and np.array_equal(cb[B:], c1[:70001 - B])
     for n_small in (1, 63, 64, 65, 4097):
