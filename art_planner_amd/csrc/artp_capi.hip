@@ -576,7 +576,8 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   if (rc) return rc;
   // tmp[5]: 8 counters | pad to 128 B | 2 * ARTP_NSUB sub-queue counters, one per 128-byte line | index queues
   const size_t ctr_bytes = 128 + (size_t)2 * ARTP_NSUB * 128;
-  rc = ensure_tmp(c, 5, ctr_bytes + (5 + 4 + 4 + 4 + 1) * n * sizeof(unsigned) + 64);
+  // index queues: q2 (5 n), q3 (4 n), q5 (4 n) | q4 and q6 in ARTP_NSUB segments like the big queues (4 seg_t / seg_t each)
+  rc = ensure_tmp(c, 5, ctr_bytes + ((5 + 4 + 4) * n + 5 * (size_t)ARTP_NSUB * seg_t) * sizeof(unsigned) + 64);
   if (rc) return rc;
   PipelineQueues q;
   q.q1 = static_cast<PendingBox*>(c->tmp[4]);
@@ -587,7 +588,7 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
   q.q3 = q.q2 + 5 * n;
   q.q5 = q.q3 + 4 * n;
   q.q4 = q.q5 + 4 * n;
-  q.q6 = q.q4 + 4 * n;
+  q.q6 = q.q4 + 4 * (size_t)ARTP_NSUB * seg_t;
   q.feet_base = (unsigned long long)ARTP_NSUB * seg_t;
   HIP_TRY(c, hipMemsetAsync(q.counters, 0, ctr_bytes, c->stream));
   const size_t per_block = 64 * ARTP_CLASSIFY_SUB;
@@ -1823,10 +1824,12 @@ int artp_debug_pipeline_counters(artp_ctx* c, uint64_t out[8]) {
   HIP_TRY(c, hipMemcpyAsync(raw, c->tmp[5], sizeof(raw), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int k = 0; k < 8; ++k) out[k] = raw[k];
-  out[0] = out[4] = 0;  // the torso / foot queues are the sums over their sub-queues
+  out[0] = out[4] = out[2] = out[7] = 0;  // the torso / foot queues and the two fallback queues: sums over the sub-queues
   for (int s = 0; s < ARTP_NSUB; ++s) {
     out[0] += raw[16 + (size_t)s * 16];
     out[4] += raw[16 + (size_t)(ARTP_NSUB + s) * 16];
+    out[2] += raw[16 + (size_t)s * 16 + 2];                  // queue 6: torso boxes for the staged pass
+    out[7] += raw[16 + (size_t)(ARTP_NSUB + s) * 16 + 2];    // queue 4: foot boxes for the lane scan
   }
   return ARTP_OK;
 }

@@ -399,7 +399,23 @@ __device__ __forceinline__ bool table_window_stats(const FieldDev& f, const Tabl
       }
     }
   }
-  if (flags & 2u) return false;  // a NaN in the window: the running-dMAX quirk needs the ordered scan
+  if (flags & 2u) {
+    // A NaN in the window: ODE's running dMAX (maxY = (maxY > h) ? maxY : h over the scan, x outer, z inner) makes the
+    // maximum depend on the ORDER -- a NaN replaces it, what follows starts over -- and the ordered scan of the fallback
+    // stages is needed.  Except where NOTHING in the window is finite or +inf (min over the finite samples = +inf; max with
+    // NaN counted as -inf = -inf): every sample is then a NaN or -inf, every step of the fold takes h, and the result is the
+    // LAST sample scanned, (maxX, maxZ): NaN or -inf.  That is the window of a state out in unknown / untraversable
+    // terrain -- on a map with an unknown margin half of all boxes -- and with (maxY, minY = +inf, not all finite) the
+    // exits decide it right here like the scan would.
+    if (vmin == INFINITY && vmax == -INFINITY) {
+      const unsigned last = gather32(t.fl, (unsigned)(b.maxX + b.maxZ * f.nW));  // level 0 = the samples themselves
+      w.maxY = (last & 2u) ? __builtin_nanf("") : -INFINITY;
+      w.minY = INFINITY;
+      w.allFinite = false;
+      return true;
+    }
+    return false;
+  }
   w.allFinite = !(flags & 1u);
   w.maxY = vmax;
   w.minY = vmin;
@@ -435,7 +451,7 @@ struct PipelineQueues {
   unsigned* q4;                  // foot boxes whose exits the tables could not evaluate (lane-scan path)
   unsigned* q5;                  // foot boxes whose corner candidates may have partners (list pass)
   unsigned* q6;                  // torso boxes the streaming pass cannot finish (staged pass)
-  unsigned long long* counters;  // [1] q2, [2] q6, [5] q3, [6] q5, [7] q4 counts
+  unsigned long long* counters;  // [1] q2, [5] q3, [6] q5 counts (queues 4 and 6 are segmented: sub_fwd)
   unsigned long long feet_base;  // = ARTP_NSUB * seg_t
 };
 
@@ -452,6 +468,51 @@ __device__ __forceinline__ unsigned long long* sub_cursor(const PipelineQueues& 
 // first record of sub-queue s of the torso (kind 0) / foot (kind 1) queue
 __device__ __forceinline__ unsigned long long sub_base(const PipelineQueues& q, int kind, int s) {
   return kind ? q.feet_base + (unsigned long long)s * 4ull * q.seg_t : (unsigned long long)s * q.seg_t;
+}
+
+// Boxes a streaming kernel hands on to a fallback stage (foot boxes without a table verdict -> queue 4, torso boxes the
+// streaming pass cannot finish -> queue 6).  On a map without unknown cells that is a handful; on a map WITH them (a band
+// of NaN across the C2 map) it is millions per batch, and one atomicAdd per box on ONE counter word made the two streaming
+// kernels 12 - 15 ms each (the L2 atomic unit does ~3 ns per operation).  So: the fallback queues are split like the big
+// ones -- segment s of queue 4 / 6 belongs to sub-queue s, its counter shares the sub-queue's line (slot [2]) --, and a
+// wavefront collects what it forwards per chunk (fwd_flush_slots) and it leaves with ONE atomic.
+__device__ __forceinline__ unsigned long long* sub_fwd(const PipelineQueues& q, int kind, int s) {
+  return sub_counter(q, kind, s) + 2;
+}
+__device__ __forceinline__ unsigned long long fwd_base(const PipelineQueues& q, int kind, int s) {  // segment start in q4 / q6
+  return kind ? (unsigned long long)s * 4ull * q.seg_t : (unsigned long long)s * q.seg_t;
+}
+// A wavefront's forwards of one chunk: box k of the chunk puts (item + 1) into slot k of a few bytes of LDS -- written inside
+// the (rare) branch that decides it, so the hot path carries no extra registers --, and at the end of the chunk the filled
+// slots leave together.  CHUNK <= 64; slots are zero when the chunk starts (flush leaves them so).
+template <int CHUNK>
+__device__ __forceinline__ void fwd_flush_slots(unsigned* slots, unsigned long long* counter, unsigned* segment, int lane) {
+  const unsigned v = lane < CHUNK ? slots[lane] : 0u;
+  const unsigned long long bal = __ballot(v != 0u);
+  if (bal == 0) return;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(bal));
+  base = __shfl(base, 0, 64);
+  if (v != 0u) {
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    segment[base + (unsigned long long)__popcll(bal & lt)] = v - 1u;
+    slots[lane] = 0u;
+  }
+}
+// item `it` of a segmented fallback queue (kind 1: queue 4, kind 0: queue 6); total = the sum of the segment counts
+__device__ __forceinline__ unsigned long long fwd_total(const PipelineQueues& q, int kind) {
+  unsigned long long t = 0;
+  for (int s = 0; s < ARTP_NSUB; ++s) t += *sub_fwd(q, kind, s);
+  return t;
+}
+__device__ __forceinline__ unsigned fwd_item(const PipelineQueues& q, int kind, const unsigned* queue, unsigned long long it) {
+  int s = 0;
+  for (; s < ARTP_NSUB - 1; ++s) {
+    const unsigned long long c = *sub_fwd(q, kind, s);
+    if (it < c) break;
+    it -= c;
+  }
+  return queue[fwd_base(q, kind, s) + it];
 }
 
 __device__ __forceinline__ void box_from_record(const PendingBox& r, const RobotDev& rb, BoxHF& b) {
@@ -735,9 +796,12 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
       float4 r6[6];
       stage_record(b, body, (unsigned)i, 0u, r6);
       const int sq = blockIdx.x % ARTP_NSUB, kind = body ? 0 : 1;
-      float4* out = reinterpret_cast<float4*>(q.q1 + sub_base(q, kind, sq) + atomicAdd(sub_counter(q, kind, sq), 1ull));
+      const unsigned long long at = sub_base(q, kind, sq) + atomicAdd(sub_counter(q, kind, sq), 1ull);
+      float4* out = reinterpret_cast<float4*>(q.q1 + at);
 #pragma unroll
       for (int j = 0; j < 6; ++j) out[j] = r6[j];
+      // a foot record without a table verdict is the lane scan's (queue 4; phase C lists the others of that kind)
+      if (!body) q.q4[fwd_base(q, 1, sq) + atomicAdd(sub_fwd(q, 1, sq), 1ull)] = (unsigned)at;
       codes[sub][k][lane] = 3;
     }
   }
@@ -821,6 +885,23 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
         base = sub_base(q, list_t ? 0 : 1, sq) + atomicAdd(sub_counter(q, list_t ? 0 : 1, sq), (unsigned long long)pc);
       }
       base = __shfl(base, 0);
+      if (!list_t) {
+        // foot records WITHOUT a table verdict (code 3: a NaN in the window, a window thinner than the smallest block) also go
+        // on the lane scan's list (queue 4, the segment of this sub-queue) right here, one atomic per wavefront that has any
+        // -- feet_stream_kernel used to forward them with an atomic per box on one word: 15 ms per batch on a map with a
+        // band of unknown cells, 0.3 ms for everything else it does
+        const bool nostat = pending && code2 == 3;
+        const unsigned long long nbal = __ballot(nostat);
+        if (nbal) {
+          const int sq = blockIdx.x % ARTP_NSUB;
+          unsigned long long fb = 0;
+          if (lane == 0) fb = atomicAdd(sub_fwd(q, 1, sq), (unsigned long long)__popcll(nbal));
+          fb = __shfl(fb, 0);
+          if (nostat)
+            q.q4[fwd_base(q, 1, sq) + fb + (unsigned long long)__popcll(nbal & lt_mask)] =
+                (unsigned)(base + (unsigned long long)__popcll(pbal & lt_mask));
+        }
+      }
       wave_lds_sync();
       float4* out = reinterpret_cast<float4*>(q.q1 + base);
       const unsigned short* pl = plist + wave * 64;
@@ -872,13 +953,13 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const unsigned long long count = q.counters[7];
+  const unsigned long long count = fwd_total(q, 1);
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long rounds = (count + stride - 1) / stride;  // uniform trip count: ballots below
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
     const unsigned long long it = rnd * stride + (unsigned long long)blockIdx.x * blockDim.x + tid;
     const bool live = it < count;
-    const unsigned long long item = live ? (unsigned long long)q.q4[it] : q.feet_base;  // dead lanes: a valid address
+    const unsigned long long item = live ? (unsigned long long)fwd_item(q, 1, q.q4, it) : q.feet_base;  // dead lanes: a valid address
     bool undecided = false;
     if (live) {
       const PendingBox rec = q.q1[item];
@@ -987,9 +1068,7 @@ feet_stream_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restri
         const unsigned long long item = first + it;
         const PendingBox rec = q.q1[item];
         if (valid[rec.state] != 0) {  // else another box of this state already failed
-          if (!(rec.kind & ARTP_REC_EXITS_NEGATIVE)) {
-            if (gl == 0) q.q4[atomicAdd(&q.counters[7], 1ull)] = (unsigned)item;
-          } else {
+          if (rec.kind & ARTP_REC_EXITS_NEGATIVE) {  // (records without a table verdict are the lane scan's: classify listed them)
             BoxHF b;
             box_from_record(rec, rb, b);
 #ifdef ARTP_STAGE_TIMING
@@ -1056,7 +1135,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   // PASS 0 walks torso sub-queue blockIdx % ARTP_NSUB; the other passes walk their (short) index queues
   const int sq = blockIdx.x % ARTP_NSUB;
   const unsigned long long count =
-      PASS == 0 ? *sub_counter(q, 0, sq) : q.counters[PASS == 1 ? 5 : (PASS == 2 ? 6 : 2)];
+      PASS == 0 ? *sub_counter(q, 0, sq) : (PASS == 3 ? fwd_total(q, 0) : q.counters[PASS == 1 ? 5 : 6]);
   const unsigned long long first = PASS == 0 ? sub_base(q, 0, sq) : 0ull;
   const unsigned long long nblk = PASS == 0 ? gridDim.x / ARTP_NSUB : gridDim.x;
   const unsigned long long blk = PASS == 0 ? blockIdx.x / ARTP_NSUB : blockIdx.x;
@@ -1068,14 +1147,21 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   // PASS 0: every wavefront takes ARTP_TORSO_CHUNK boxes at a time from the sub-queue's cursor (see sub_cursor);
   // the other passes stride statically over their short index queues
   unsigned long long next = PASS == 0 ? 0ull : blk * WAVES * GPW + unit_in_block, chunk_end = 0ull;
+  // PASS 0: boxes handed on to the staged pass (queue 6) leave once per chunk
+  __shared__ unsigned fwd_slots[PASS == 0 ? WAVES : 1][ARTP_TORSO_CHUNK];
+  unsigned* fs = fwd_slots[PASS == 0 ? (threadIdx.x >> 6) : 0];
+  if (PASS == 0 && lane < ARTP_TORSO_CHUNK) fs[lane] = 0u;
+  unsigned long long chunk_first = 0ull;
   for (;;) {
     if constexpr (PASS == 0) {
       if (next >= chunk_end) {
+        fwd_flush_slots<ARTP_TORSO_CHUNK>(fs, sub_fwd(q, 0, sq), q.q6 + fwd_base(q, 0, sq), lane);
         unsigned long long c0 = 0;
         if (lane == 0) c0 = atomicAdd(sub_cursor(q, 0, sq), (unsigned long long)ARTP_TORSO_CHUNK);
         c0 = __shfl(c0, 0);
         if (c0 >= count) break;
         next = c0;
+        chunk_first = c0;
         chunk_end = c0 + ARTP_TORSO_CHUNK < count ? c0 + ARTP_TORSO_CHUNK : count;
       }
     } else {
@@ -1084,7 +1170,8 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
     const unsigned long long it = next;
     next += PASS == 0 ? 1ull : stride;
     const unsigned long long item =
-        PASS == 0 ? first + it : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : q.q6[it]));
+        PASS == 0 ? first + it
+                  : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : fwd_item(q, 0, q.q6, it)));
 #ifdef ARTP_STAGE_TIMING
     long long t_prev = clock64();
 #endif
@@ -1117,7 +1204,7 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
         ARTP_T_MARK(4);
       }
       if (!decided) {
-        if (gl == 0) q.q6[atomicAdd(&q.counters[2], 1ull)] = (unsigned)item;
+        if (gl == 0) fs[it - chunk_first] = (unsigned)item + 1u;
       } else if (gl == 0 && result != 0) {
         valid[rec.state] = 0;  // the torso touches
       }
