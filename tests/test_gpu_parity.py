@@ -961,3 +961,32 @@ def test_c5_upper_bound_layer_with_rectangle_updates():
     assert np.array_equal(ctx.validate_states(big), ctx2.validate_states(big))
     ctx.close()
     ctx2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["band", "margin"])
+def test_unknown_regions_go_through_the_segmented_fallback_queues(big_map, shape):
+    """A robot-centric map has a MARGIN of unknown (NaN) cells, a mapping gap a BAND of them: a large share of all boxes
+    then has a NaN in its window and goes through the ordered-scan stages.  The two streaming kernels hand those boxes
+    on through segmented queues with one atomic per wavefront (pipeline.h sub_fwd / fwd_flush_slots; classify lists the
+    foot records itself) -- labels equal to the oracle's, and the counters show that the fallback stages really ran."""
+    import copy
+    gm = copy.deepcopy(common.crop_map(big_map, 60, 60, 200))
+    for name in ("elevation", "elevation_masked"):
+        a = np.array(gm[name], dtype=np.float32, order="F")
+        if shape == "band":
+            a[80:120, :] = np.nan
+        else:
+            a[:30, :] = np.nan; a[-30:, :] = np.nan; a[:, :30] = np.nan; a[:, -30:] = np.nan
+        gm.layers[name] = np.asfortranarray(a)
+    rng = np.random.default_rng(5)
+    ctx = _ctx("yaml")
+    ctx.upload_map(gm, sampler=False)
+    se3 = common.random_states(gm, 60000, rng, z_off=(0.02, 0.12), tilt=0.15, spread=0.5)
+    vg = ctx.validate_states(se3)
+    cnt = ctx.pipeline_counters()
+    vo = O.OracleMap(gm).states_valid(O.robot("yaml"), se3)
+    assert np.array_equal(vg, vo), f"{(vg != vo).sum()} mismatches"
+    assert cnt["torso_staged_pass"] > 1000, cnt     # torso boxes with a NaN in the window: the staged pass
+    assert 0.02 < vg.mean() < 0.9
+    ctx.close()
