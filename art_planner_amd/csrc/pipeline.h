@@ -931,6 +931,13 @@ classify_states_kernel(FieldDev fb, FieldDev ff, TablesDev tb, TablesDev tf, Map
 // all-finite triangle inside the box"; then exits (b)-(e), then (f).  Boxes still undecided (they need the
 // plane stage) are compacted into queue 3 for the lane-group stage, one atomic per wavefront.
 #define ARTP_LANE_THREADS 256
+// One lane per box is the way to get through MILLIONS of such boxes (a map with unknown regions: 64 boxes per wavefront in
+// flight), and the slowest way to get through a handful: a lane on its own pays every memory latency and ~10^4 dependent
+// instructions -- 50 us, the duration of the launch, for ONE box of an edge batch.  Below this many boxes the lane scan steps
+// aside and the 16-lanes-per-box staged pass (PASS 1) does exits, (f) and the corner stage itself.
+#ifndef ARTP_LANE_SCAN_MIN
+#define ARTP_LANE_SCAN_MIN 65536ull
+#endif
 #define ARTP_STREAM_WAVES 4
 #ifndef ARTP_TORSO_WGS_PER_CU
 #define ARTP_TORSO_WGS_PER_CU 14  // 2 wavefronts each: 7 per SIMD (65 VGPRs)
@@ -954,6 +961,7 @@ feet_lane_kernel(FieldDev ff, RobotDev rb, PipelineQueues q, uint8_t* __restrict
   const int lane = tid & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const unsigned long long count = fwd_total(q, 1);
+  if (count < ARTP_LANE_SCAN_MIN) return;  // a few boxes: resolve_boxes_kernel<., 16, 1> takes them straight from queue 4
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long rounds = (count + stride - 1) / stride;  // uniform trip count: ballots below
   for (unsigned long long rnd = 0; rnd < rounds; ++rnd) {
@@ -1131,11 +1139,15 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
   const int gl = lane & (G - 1);
   const int unit_in_block = (threadIdx.x >> 6) * GPW + (lane / G);
   const WaveScratch s = carve_scratch(smem, unit_in_block, caps);
-  const bool feet = (PASS == 1 || PASS == 2);  // feet: only the boxes the lane-per-box stages handed over
+  // PASS 1 in "direct" mode (few boxes without a table verdict: the lane scan stepped aside) takes queue 4 itself and does
+  // exits and (f); otherwise it takes what the lane scan left (queue 3), like PASS 2 takes queue 5: exits and (f) behind them
+  const bool direct = PASS == 1 && fwd_total(q, 1) < ARTP_LANE_SCAN_MIN;
+  const bool feet = (PASS == 1 && !direct) || PASS == 2;
   // PASS 0 walks torso sub-queue blockIdx % ARTP_NSUB; the other passes walk their (short) index queues
   const int sq = blockIdx.x % ARTP_NSUB;
   const unsigned long long count =
-      PASS == 0 ? *sub_counter(q, 0, sq) : (PASS == 3 ? fwd_total(q, 0) : q.counters[PASS == 1 ? 5 : 6]);
+      PASS == 0 ? *sub_counter(q, 0, sq)
+                : (PASS == 3 ? fwd_total(q, 0) : (direct ? fwd_total(q, 1) : q.counters[PASS == 1 ? 5 : 6]));
   const unsigned long long first = PASS == 0 ? sub_base(q, 0, sq) : 0ull;
   const unsigned long long nblk = PASS == 0 ? gridDim.x / ARTP_NSUB : gridDim.x;
   const unsigned long long blk = PASS == 0 ? blockIdx.x / ARTP_NSUB : blockIdx.x;
@@ -1171,7 +1183,8 @@ resolve_boxes_kernel(FieldDev fld, RobotDev rb, PipelineQueues q, uint8_t* __res
     next += PASS == 0 ? 1ull : stride;
     const unsigned long long item =
         PASS == 0 ? first + it
-                  : (unsigned long long)(PASS == 1 ? q.q3[it] : (PASS == 2 ? q.q5[it] : fwd_item(q, 0, q.q6, it)));
+                  : (unsigned long long)(PASS == 1 ? (direct ? fwd_item(q, 1, q.q4, it) : q.q3[it])
+                                                   : (PASS == 2 ? q.q5[it] : fwd_item(q, 0, q.q6, it)));
 #ifdef ARTP_STAGE_TIMING
     long long t_prev = clock64();
 #endif
