@@ -2119,7 +2119,7 @@ inline void fc_mfma_pack(const float* w, std::vector<unsigned char>* out) {
     *lo = f16_value((float)(v - (double)*hi));
   };
   // out0 o tar0: k < 48 the map features, 48 .. 57 the ten geometric inputs, 58 the bias (input 1.0)
-  static double w0c[48][64];
+  double w0c[48][64];  // 24 KB of stack: no shared state between contexts loading weights on different threads
   for (int o = 0; o < 48; ++o) {
     for (int k = 0; k < 64; ++k) w0c[o][k] = 0.0;
     for (int k = 0; k < 48; ++k) w0c[o][k] = w[FcWeights::OUT0_W + o * 64 + k];
