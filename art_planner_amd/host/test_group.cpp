@@ -19,6 +19,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "artp_c.h"
+#include "art_planner/device_group.h"
 
 namespace {
 
@@ -266,6 +267,53 @@ int run_group(const char* name, const std::vector<int>& devices, int transport, 
 
 }  // namespace
 
+// The same through the host mirror's class (art_planner/device_group.h): a two-rank peer-copy group on device 0, two steps,
+// every rank's accepted count on member 0 against a plain context's count for that rank's shard; errors are exceptions.
+int run_class(const MapData& map, artp_ctx* ref, const artp_params& params) {
+  try {
+    art_planner::DeviceGroup grp(std::vector<int>{0, 0}, params, ARTP_GROUP_PEER_COPY);
+    art_planner::DeviceGroup moved(std::move(grp));  // movable, not copyable
+    CHECK(moved.worldSize() == 2 && moved.localCount() == 2 && moved.rank(1) == 1, "class: sizes");
+    for (int m = 0; m < moved.localCount(); ++m) CHECK(upload_map(moved.context(m), map) == 0, "class: map upload");
+    CHECK(moved.ranksSeen() == 2, "class: ranks seen");
+    const size_t S = 1 << 14;
+    moved.configure(11, S, 256);
+    double* d_se3 = nullptr;
+    uint8_t* d_valid = nullptr;
+    CHECK(hipMalloc(reinterpret_cast<void**>(&d_se3), S * 7 * sizeof(double)) == hipSuccess, "hipMalloc");
+    CHECK(hipMalloc(reinterpret_cast<void**>(&d_valid), S) == hipSuccess, "hipMalloc");
+    for (uint64_t step = 0; step < 2; ++step) {
+      moved.step(step);
+      moved.synchronize(20000);
+      const art_planner::DeviceGroup::StepBuffers b = moved.stepBuffers(0, step);
+      uint64_t counts[2] = {0, 0};
+      CHECK(hipMemcpy(counts, b.counts, sizeof(counts), hipMemcpyDeviceToHost) == hipSuccess, "class: counts");
+      for (int r = 0; r < 2; ++r) {
+        uint64_t want = 0;
+        CHECK(artp_sample_and_validate_dev(ref, 11, art_planner::DeviceGroup::shardFirstIndex(step, r, 2, S), S, d_se3, d_valid, &want) == 0,
+              "class: reference shard");
+        CHECK(artp_synchronize(ref) == 0, "class: reference sync");
+        CHECK(counts[r] == want, "class: accepted count of rank %d at step %llu: %llu vs %llu", r, (unsigned long long)step,
+              (unsigned long long)counts[r], (unsigned long long)want);
+      }
+    }
+    (void)hipFree(d_se3);
+    (void)hipFree(d_valid);
+    bool threw = false;
+    try {
+      moved.exchangeEdges({}, 16);  // one entry per local member is required
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    CHECK(threw, "class: argument check");
+  } catch (const std::exception& e) {
+    std::printf("FAIL: art_planner::DeviceGroup: %s\n", e.what());
+    return 1;
+  }
+  std::printf("art_planner::DeviceGroup (class): ok\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -305,6 +353,7 @@ int main(int argc, char** argv) {
   if (run_group("rccl_all_devices", all, ARTP_GROUP_RCCL, map, ref, params, &json)) return 1;
   if (run_group("peer_copy_3_ranks_on_device_0", {0, 0, 0}, ARTP_GROUP_PEER_COPY, map, ref, params, &json)) return 1;
   if (n_dev > 1 && run_group("peer_copy_all_devices", all, ARTP_GROUP_PEER_COPY, map, ref, params, &json)) return 1;
+  if (run_class(map, ref, params)) return 1;
   artp_destroy(ref);
   if (argc > 2) {
     std::ofstream o(argv[2]);

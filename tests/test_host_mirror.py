@@ -77,6 +77,7 @@ def test_device_group_through_the_c_abi(tmp_path):
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "test_group ok" in r.stdout
+    assert "art_planner::DeviceGroup (class): ok" in r.stdout   # the same through host/include/art_planner/device_group.h
 
 
 def test_real_library_branches_compile():
