@@ -2386,6 +2386,40 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
       return ARTP_OK;
     };
     int rcl;
+    // round 5: the persistent strip-walking form (conv_kwalk_kernel): one workgroup per CU for the whole launch, a run
+    // of vertically adjacent tiles each.  Tile height = the candidate with the shortest longest run (rows per CU).
+    const char* evk = std::getenv("ARTP_KWALK");
+    const bool kwalk = evk ? std::atoi(evk) != 0 : true;
+    if (kwalk) {
+      int trk = 8;
+      long costk = -1;
+      for (int tr : cands) {
+        const long tiles = (long)((wf + 15) / 16) * ((hf + tr - 1) / tr);
+        const long g = tiles < c->n_cus ? tiles : c->n_cus;
+        const long cost = ((tiles + g - 1) / g) * tr;
+        if (costk < 0 || cost < costk) {
+          costk = cost;
+          trk = tr;
+        }
+      }
+      if (const char* ev = std::getenv("ARTP_KWALK_TR")) trk = std::atoi(ev);  // tuning
+      auto launch_w = [&](auto kfn, int lds, int tr, int threads) -> int {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int tps = (hf + tr - 1) / tr, tiles = ((wf + 15) / 16) * tps;
+        const int g = tiles < c->n_cus ? tiles : c->n_cus;
+        hipLaunchKernelGGL(kfn, dim3((unsigned)g), dim3(threads), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw[4],
+                           (const float*)c->d_convb[4], c->d_feat, tps, tiles);
+        return ARTP_OK;
+      };
+      rcl = trk == 9    ? launch_w(conv_kwalk_kernel<9>, KwalkCfg<9>::LDS_BYTES, 9, KwalkCfg<9>::NTH)
+            : trk == 10 ? launch_w(conv_kwalk_kernel<10>, KwalkCfg<10>::LDS_BYTES, 10, KwalkCfg<10>::NTH)
+                        : launch_w(conv_kwalk_kernel<8>, KwalkCfg<8>::LDS_BYTES, 8, KwalkCfg<8>::NTH);
+      if (rcl != ARTP_OK) return rcl;
+      HIP_TRY(c, hipGetLastError());
+      c->feat_h = hf;
+      c->feat_w = wf;
+      return ARTP_OK;
+    }
     // no more 8-row tiles than CUs (C3: 242): one 8-wavefront workgroup per CU, two wavefronts per SIMD
     const long tiles8 = (long)((wf + 15) / 16) * ((hf + 7) / 8);
     const char* ev8 = std::getenv("ARTP_KSPLIT_NWV");
@@ -2577,6 +2611,11 @@ extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (reset) {
     unsigned long long z4[4] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_feet_cycles), z4, sizeof(z4)) != hipSuccess) return -1;
+  }
+  if (reset == 5) {  // the strip-walking 15 x 15 kernel's phase counters (read + reset)
+    if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_kwalk_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z8[8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(artp::g_kwalk_cycles), z8, sizeof(z8)) == hipSuccess ? 0 : -1;
   }
   if (reset == 4) {  // the feature extractor's phase counters (read + reset)
     if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_cnn_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;

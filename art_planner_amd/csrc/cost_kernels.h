@@ -226,6 +226,210 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   }
 }
 
+// ---- round 5: the 15 x 15 layer as a PERSISTENT kernel that walks down 16-pixel column strips -------------------------
+// One workgroup per CU for the whole launch; it owns a run of vertically adjacent TR-row x 16-pixel tiles.
+//  * The patch rows live in an LDS RING of PR + TR rows: the tile below needs only TR new rows (24-27 KB instead of the
+//    65 KB patch), and they are fetched while the current tile's MFMAs run -- by the wavefronts that own the SHORT K
+//    slice (23 k-steps over 4 slices = 6, 6, 6, 5: those three wavefronts are done a sixth early and would only wait at
+//    the barrier).  Their loads are not in the main loop's vmcnt stream (loads retire in order: a slow row fetch
+//    in front of the B ring would stall every MFMA step behind it).
+//  * 12 wavefronts = 3 (channel tiles, N) x 4 (K slices): a wavefront accumulates TR x ONE channel tile, so per k-step it
+//    needs one B fragment (global -> VGPR ring, 4 steps ahead, never drains -- not even across tiles: the weights are the
+//    same) and one new A row (LDS, register ring over the kernel rows as in conv_ksplit_kernel) for TR MFMAs.  Only the
+//    4 K slices meet in LDS at the end of a tile: 96-108 KB of partial sums per tile against 192 KB for an 8-way K split
+//    (LDS stores run at ~79 B/clk/CU: the 8-way reduction cost a seventh of a tile's MFMA time).
+//  * Three wavefronts per SIMD (<= 168 registers): one's LDS / global latency and the reduction's barriers run under the
+//    others' MFMAs.
+//  * The finished sums leave as 8-byte stores (four consecutive channels of one pixel: the transposed product).
+template <int TR>
+struct KwalkCfg {
+  using P = ConvLdsCfg<15, 15, 48, 48, 3, true, TR>;
+  static constexpr int NK = 4, NN = 3, NWV = NK * NN, NTH = 64 * NWV;
+  static constexpr int KSTEPS = P::KSTEPS, PR = P::PR, RING = PR + TR, ROW_B = P::ROW_B, CPR = ROW_B / 16;
+  static constexpr int RING_B = RING * ROW_B;
+  static constexpr int RPP_MAX = (160 * 1024 - RING_B) / (NWV * 1024);   // rows of partial sums that fit beside the ring
+  static constexpr int NPASS = (TR + RPP_MAX - 1) / RPP_MAX;
+  static constexpr int RPP = (TR + NPASS - 1) / NPASS;
+  static constexpr int LDS_BYTES = RING_B + NWV * RPP * 1024;
+  static constexpr int BD = 5;        // B ring depth: 4 steps ahead; 15 kernel rows = 3 turns, so slot = kh % 5 across k-steps
+  static_assert(KSTEPS == 23 && KSTEPS % NK == 3, "the last K slice is the short one (it fetches the next tile's rows)");
+  static_assert(LDS_BYTES <= 160 * 1024 && RPP >= 1, "one workgroup per CU");
+  static_assert(RING_B % 16 == 0, "16-byte chunks");
+};
+
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_kwalk_cycles[8];  // [0] prologue / strip change, [1] main loop, [2] row fetch (short slice), [3] reduction, [7] tiles
+#define ARTP_KW_MARK(slot) do { if (tid == 0) { const long long n_ = clock64(); atomicAdd(&g_kwalk_cycles[slot], (unsigned long long)(n_ - t_prev)); t_prev = n_; } } while (0)
+#else
+#define ARTP_KW_MARK(slot) do { } while (0)
+#endif
+
+template <int TR>
+__global__ void __launch_bounds__(KwalkCfg<TR>::NTH, 3)
+conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
+                  const float* __restrict__ bias, half_t* __restrict__ out, int tiles_per_strip, int n_tiles) {
+  using Cfg = KwalkCfg<TR>;
+  constexpr int KSTEPS = Cfg::KSTEPS, PR = Cfg::PR, RING = Cfg::RING, ROW_B = Cfg::ROW_B, CPR = Cfg::CPR, NTH = Cfg::NTH;
+  constexpr int BD = Cfg::BD, KH = 15;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  floatx4* red = reinterpret_cast<floatx4*>(smem + Cfg::RING_B);
+  const int Hout = Hin - 14, Wout = Win - 14;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int nt = wave % 3, kq = wave / 3;     // waves {s, s+4, s+8} share a SIMD: every SIMD gets all three channel tiles'
+                                              // worth of different K slices (18 / 17 / 17 / 17 k-step units)
+  // this workgroup's run of tiles (strip-major: consecutive tiles are vertically adjacent).  Workgroups that share an XCD
+  // (blockIdx % 8) take neighbouring runs: their halo rows meet in that XCD's L2.
+  int b = (int)blockIdx.x;
+  const int G = (int)gridDim.x;
+  if ((G & 7) == 0) b = (b & 7) * (G >> 3) + (b >> 3);
+  const int t0 = (int)(((long)b * n_tiles) / G), t1 = (int)(((long)(b + 1) * n_tiles) / G);
+  const long row_bytes = (long)Win * 96;
+#ifdef ARTP_STAGE_TIMING
+  long long t_prev = clock64();
+#endif
+
+  // B ring (this wavefront's channel tile): step = (jj, kh) with ks = kq + 4 jj; slot = kh % BD
+  const int nj = (KSTEPS - kq + 3) / 4;
+  const half8* wl = wp + (size_t)nt * 64 + lane;
+  auto b_ptr = [&](int ks, int kh) { return wl + (size_t)(kh * KSTEPS + ks) * 3 * 64; };
+  half8 bq[BD];
+#pragma unroll
+  for (int s = 0; s < BD - 1; ++s) bq[s] = *b_ptr(kq, s);
+
+  floatx4 acc[TR];
+  const int a_lane = li * 96 + kg * 16;
+  int base = 0;   // ring slot of the current tile's patch row 0
+  for (int t = t0; t < t1; ++t) {
+    const int strip = t / tiles_per_strip, rt = t - strip * tiles_per_strip;
+    const int oy0 = rt * TR, ox0 = strip * 16;
+    if (t == t0 || rt == 0) {
+      // first tile of the run / of a strip: the whole patch (rows are contiguous byte runs of the NHWC image; zeros
+      // outside it).  Every wavefront is past the previous tile's reduction barriers: the ring is free.
+      constexpr int NIT = (PR * CPR + NTH - 1) / NTH;
+      half8 v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = tid + it * NTH;
+        const int r = c / CPR, cc = c - r * CPR;
+        const long off = (long)ox0 * 96 + (long)cc * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] = (half_t)0;
+        if (c < PR * CPR && oy0 + r < Hin && off + 16 <= row_bytes)
+          v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + r) * row_bytes + off);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = tid + it * NTH;
+        if (c < PR * CPR) *reinterpret_cast<half8*>(ring + c * 16) = v[it];
+      }
+      base = 0;
+      __syncthreads();
+      ARTP_KW_MARK(0);
+    }
+    const bool has_next = t + 1 < t1 && rt + 1 < tiles_per_strip;
+#pragma unroll
+    for (int m = 0; m < TR; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto row_ptr = [&](int r) {   // patch row r of the current tile (r is a compile-time constant at every use)
+      const int s = base + r;
+      return ring + (s >= RING ? s - RING : s) * ROW_B + a_lane;
+    };
+    for (int jj = 0; jj < nj; ++jj) {
+      const int ks = kq + 4 * jj;
+      const int ks_nx = jj + 1 < nj ? ks + 4 : kq;   // wraps into the next tile's first k-step: the same weights
+      half8 a[TR];   // ring: slot (r % TR) holds patch row r
+#pragma unroll
+      for (int r = 0; r < TR - 1; ++r) a[r] = *reinterpret_cast<const half8*>(row_ptr(r) + ks * 64);
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        a[(kh + TR - 1) % TR] = *reinterpret_cast<const half8*>(row_ptr(kh + TR - 1) + ks * 64);
+        bq[(kh + BD - 1) % BD] = kh + BD - 1 < KH ? *b_ptr(ks, kh + BD - 1) : *b_ptr(ks_nx, kh + BD - 1 - KH);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < TR; ++m)   // m = TR - 1 uses the row requested just above: it goes last
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[kh % BD], a[(kh + m) % TR], acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef ARTP_KW_NOGUARD
+        // The register allocator rotates the accumulators (an MFMA's destination is not its srcC), so a group's last
+        // srcC registers are dead behind it and the address arithmetic of the next step lands in them three wait states
+        // later (scripts/mfma_hazard_check.py): the srcC write-after-read distance of the FCM_WAIT note.  The wait
+        // states cost this wavefront 8 cycles per 130-160 of MFMAs, and the SIMD's other two wavefronts issue under them.
+        asm volatile("s_nop 7");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    }
+    ARTP_KW_MARK(1);
+    if (kq == 3 && has_next) {
+      // the short K slice's three wavefronts fetch the TR rows the tile below adds (patch rows PR .. PR + TR - 1 -> the
+      // ring slots the current tile does not use)
+      constexpr int NL = 192, NIT = (TR * CPR + NL - 1) / NL;
+      const int t3 = nt * 64 + lane;
+      half8 v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = t3 + it * NL;
+        const int r = c / CPR, cc = c - r * CPR;
+        const long off = (long)ox0 * 96 + (long)cc * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] = (half_t)0;
+        if (c < TR * CPR && oy0 + PR + r < Hin && off + 16 <= row_bytes)
+          v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + PR + r) * row_bytes + off);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = t3 + it * NL;
+        const int r = c / CPR, cc = c - r * CPR;
+        const int s = base + PR + r;
+        if (c < TR * CPR) *reinterpret_cast<half8*>(ring + (s >= RING ? s - RING : s) * ROW_B + cc * 16) = v[it];
+      }
+      ARTP_KW_MARK(2);
+    }
+    // The four K slices of a channel tile meet in LDS, RPP rows at a time; element e of a pass = (row j, channel tile n,
+    // lane l) is summed over the slices in a fixed order by thread e (mod NTH), gets bias + leaky-ReLU and leaves as four
+    // consecutive channels of one pixel (transposed product: column l & 15 = pixel, row 4 (l >> 4) + r = channel).
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int h = 0; h < Cfg::NPASS; ++h) {
+      constexpr int RPP = Cfg::RPP;
+      const int rows = (h + 1) * RPP <= TR ? RPP : TR - h * RPP;
+      __syncthreads();   // h = 0: every wavefront has left the main loop and the new rows are in the ring
+#pragma unroll
+      for (int j = 0; j < RPP; ++j)
+        if (h * RPP + j < TR) red[(wave * RPP + j) * 64 + lane] = acc[h * RPP + j];
+      __syncthreads();
+      for (int e = tid; e < rows * 192; e += NTH) {
+        const int j = e / 192, rem = e - j * 192, n = rem >> 6, l = rem & 63;
+        floatx4 v = red[((n + 0) * RPP + j) * 64 + l];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const floatx4 p = red[((n + 3 * q) * RPP + j) * 64 + l];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p[r];
+        }
+        const int ch = n * 16 + (l >> 4) * 4, px = ox0 + (l & 15), oy = oy0 + h * RPP + j;
+        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+        half4_t y4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = v[r] + bv[r];
+          y = fmaxf(y, 0.3f * y);
+          y4[r] = (half_t)y;
+        }
+        if (oy < Hout && px < Wout) *reinterpret_cast<half4_t*>(out + ((size_t)oy * Wout + px) * 48 + ch) = y4;
+      }
+    }
+    base += TR;
+    if (base >= RING) base -= RING;
+#ifdef ARTP_STAGE_TIMING
+    ARTP_KW_MARK(3);
+    if (tid == 0) atomicAdd(&g_kwalk_cycles[7], 1ull);
+#endif
+  }
+}
+
 // ======================================================================================================
 // Fused front of the feature extractor (round 3): the eight launch-/latency-bound launches in front of the
 // 15 x 15 layer become two kernels whose intermediate activations never leave the CU.
@@ -497,7 +701,12 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
     bv4[n] = *reinterpret_cast<const floatx4*>(b4 + n * 16 + (lane >> 4) * 4);
     bv5[n] = *reinterpret_cast<const floatx4*>(b5 + n * 16 + (lane >> 4) * 4);
   }
+  // ALL three layers' weight fragments are requested up front (round 5): loads retire in order, so waiting for the patch
+  // and conv3's weights (requested first) does not wait for the others -- conv4's have the whole of conv3 to arrive and
+  // conv5's the whole of conv3 and conv4 (requested a phase ahead, 256 workgroups fetching the same 43 KB at the same
+  // moment waited 4-6 k cycles at each commit).  60 registers until the commits.
   WRegs<7> rw3;
+  WRegs<14> rw, rw5;
   w_prefetch<7>(w3, rw3, tid);  // conv3's weights travel with the patch
   // input patch (T+8)^2 x 24 channels -> X; rows are contiguous byte runs of the NHWC image, zeros outside it
   {
@@ -522,11 +731,11 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
       if (c < NCH) *reinterpret_cast<half8*>(X + c * 16) = v[it];
     }
   }
+  w_prefetch<14>(w4, rw, tid);
+  w_prefetch<14>(w5, rw5, tid);
   w_commit<7>(W3, rw3, tid);
   __syncthreads();
   ARTP_CNN_MARK(0);
-  WRegs<14> rw;
-  w_prefetch<14>(w4, rw, tid);  // conv4's weights travel under conv3
   {  // conv3: X (24 ch) -> Y
     constexpr int MTW = (Cfg::R3 * Cfg::R3 + 16 * NW - 1) / (16 * NW);
     floatx4 acc[MTW][3];
@@ -539,7 +748,6 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
   w_commit<14>(Wl, rw, tid);          // (own region: no wavefront reads it before the barrier)
   __syncthreads();
   ARTP_CNN_MARK(3);
-  w_prefetch<14>(w5, rw, tid);   // conv5's weights travel under conv4
   {  // conv4: Y -> X (the patch is dead)
     constexpr int MTW = (Cfg::R4 * Cfg::R4 + 16 * NW - 1) / (16 * NW);
     floatx4 acc[MTW][3];
@@ -549,29 +757,24 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
     ARTP_CNN_MARK(5);
   }
   __syncthreads();               // conv4's weights are dead, X is complete
-  w_commit<14>(Wl, rw, tid);
+  w_commit<14>(Wl, rw5, tid);
   ARTP_CNN_MARK(6);
-  {  // max_pool 3 / 1: X -> Y.  A thread owns (column x, 8-channel chunk c, a quarter of the rows) and walks down the
-     // column with the horizontal 3-max of the last three rows in registers: 3 reads per output instead of 9.
-    constexpr int RP = Cfg::RP, R4 = Cfg::R4, PARTS = NT_ / 128, ROWS = (RP + PARTS - 1) / PARTS;
-    const int strip = tid / PARTS, part = tid - strip * PARTS;
-    if (strip < RP * 6) {
-      const int x = strip / 6, c = strip - x * 6;
-      const int y0 = part * ROWS, y1 = (y0 + ROWS < RP) ? y0 + ROWS : RP;
-      auto hmax = [&](int y) {
+  {  // max_pool 3 / 1: X -> Y.  An item = (pooled pixel, 8-channel chunk): nine independent 16-byte reads, a max tree, one
+     // store; the items are dealt out thread by thread, fully unrolled (round 5: the column walk with three rows in
+     // registers read a third as much but as a chain of dependent LDS round trips -- 6 k cycles for 1.2 k of LDS time).
+    constexpr int RP = Cfg::RP, R4 = Cfg::R4, NITEM = RP * RP * 6, NIT = (NITEM + NT_ - 1) / NT_;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int item = tid + it * NT_;
+      if (item < NITEM) {
+        const int p = item / 6, c = item - p * 6;
+        const int y = p / RP, x = p - y * RP;
         const char* src = X + ((y * R4 + x) * 96 + c * 16);
-        const half8 v0 = *reinterpret_cast<const half8*>(src), v1 = *reinterpret_cast<const half8*>(src + 96),
-                    v2 = *reinterpret_cast<const half8*>(src + 192);
-        return __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), v2);
-      };
-      if (y0 < y1) {
-        half8 r0 = hmax(y0), r1 = hmax(y0 + 1);
-        for (int y = y0; y < y1; ++y) {
-          const half8 r2 = hmax(y + 2);
-          *reinterpret_cast<half8*>(Y + (y * RP + x) * 96 + c * 16) = __builtin_elementwise_max(__builtin_elementwise_max(r0, r1), r2);
-          r0 = r1;
-          r1 = r2;
-        }
+        half8 m = *reinterpret_cast<const half8*>(src);
+#pragma unroll
+        for (int k = 1; k < 9; ++k)
+          m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(src + ((k / 3) * R4 + (k % 3)) * 96));
+        *reinterpret_cast<half8*>(Y + p * 96 + c * 16) = m;
       }
     }
   }
