@@ -334,6 +334,12 @@ class Context:
                                                      cols.ctypes.data), "artp_cost_debug_query_cells")
         return rows, cols
 
+    def cost_fc_path(self):
+        """{'mfma': 0/1, 'selfcheck': -1/0/1, 'max_abs_diff': float} -- which kernel answers cost queries (artp_cost_fc_path)."""
+        m, sc, d = C.c_int32(0), C.c_int32(0), C.c_float(0)
+        self._chk(self.L.artp_cost_fc_path(self.h, C.byref(m), C.byref(sc), C.byref(d)), "artp_cost_fc_path")
+        return {"mfma": int(m.value), "selfcheck": int(sc.value), "max_abs_diff": float(d.value)}
+
     def cost_query_dev(self, edges_t, cost_t):
         self._chk(self.L.artp_cost_query_dev(self.h, edges_t.data_ptr(), edges_t.shape[0], cost_t.data_ptr()),
                   "artp_cost_query_dev")

@@ -116,6 +116,9 @@ struct artp_ctx {
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
   int fc_mfma = 1;                     // $ARTP_FC_MFMA=0: the fp32 VALU kernels (tuning / comparison)
+  int fc_selfcheck = -1;               // artp_cost_load_weights' probe batch: 1 = the MFMA kernel agreed with the fp32 one,
+                                       // 0 = it did not (fc_mfma forced to 0), -1 = not run
+  float fc_selfcheck_err = 0.f;        // largest |MFMA - fp32| of the probe batch
   half_t* d_act[2] = {nullptr, nullptr};
   size_t act_cap = 0;
   half_t* d_feat = nullptr;            // NHWC [Fh][Fw][48]
@@ -2184,6 +2187,72 @@ inline void fc_mfma_pack(const float* w, std::vector<unsigned char>* out) {
 
 }  // namespace
 
+// A 512-edge probe batch on a 6 x 6 pseudo-random feature map through fc_cost_mfma_kernel and fc_cost_kernel (same
+// weights, same gather): fills fc_selfcheck / fc_selfcheck_err, clears fc_mfma when they differ by more than the hi / lo
+// split's own error (a few 1e-6 in practice; 1e-4 absolute + 1e-4 relative allowed).
+static int cost_fc_selfcheck(artp_ctx* c) {
+  constexpr int F = 6, B = 512;
+  std::vector<uint16_t> feat((size_t)F * F * 48);
+  std::vector<float> edges((size_t)B * 6);
+  uint32_t s = 0x9E3779B9u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    return (float)((s >> 8) & 0xFFFFu) / 65536.0f;   // [0, 1)
+  };
+  for (auto& v : feat) v = f32_to_f16_bits(2.0f * rnd() - 0.5f);
+  for (int e = 0; e < B; ++e) {
+    const float sx = 1.0f + 4.0f * rnd(), sy = 1.0f + 4.0f * rnd();
+    edges[6 * e + 3] = sx;
+    edges[6 * e + 4] = sy;
+    edges[6 * e + 5] = 6.0f * rnd() - 3.0f;
+    edges[6 * e + 0] = sx + rnd() - 0.5f;
+    edges[6 * e + 1] = sy + rnd() - 0.5f;
+    edges[6 * e + 2] = 6.0f * rnd() - 3.0f;
+  }
+  CostMapGeom g;
+  g.Fh = g.Fw = F;
+  g.feat_res = 1.0;
+  g.row_bias = g.col_bias = 0;
+  g.cx = g.cy = 0.0;
+  char* d = nullptr;
+  const size_t fb = feat.size() * 2, eb = edges.size() * 4, cb = (size_t)B * 3 * 4;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d), fb + eb + 2 * cb + 64));
+  half_t* d_feat = reinterpret_cast<half_t*>(d);
+  float* d_edges = reinterpret_cast<float*>(d + ((fb + 15) & ~(size_t)15));
+  float* d_c0 = d_edges + edges.size();
+  float* d_c1 = d_c0 + (size_t)B * 3;
+  hipError_t e1 = hipMemcpyAsync(d_feat, feat.data(), fb, hipMemcpyHostToDevice, c->stream);
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_edges, edges.data(), eb, hipMemcpyHostToDevice, c->stream);
+  std::vector<float> c0((size_t)B * 3), c1((size_t)B * 3);
+  if (e1 == hipSuccess) {
+    hipLaunchKernelGGL(fc_cost_mfma_kernel, dim3(2), dim3(256), 0, c->stream, (const float*)d_edges, (size_t)B, (const half_t*)d_feat, g,
+                       (const char*)c->d_fc_mfma, d_c0);
+    hipLaunchKernelGGL(fc_cost_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream, (const float*)d_edges, (size_t)B,
+                       (const half_t*)d_feat, g, (const float*)c->d_fc, d_c1);
+    e1 = hipGetLastError();
+  }
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(c0.data(), d_c0, cb, hipMemcpyDeviceToHost, c->stream);
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(c1.data(), d_c1, cb, hipMemcpyDeviceToHost, c->stream);
+  if (e1 == hipSuccess) e1 = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  HIP_TRY(c, e1);
+  float worst = 0.f;
+  bool ok = true;
+  for (size_t i = 0; i < c0.size(); ++i) {
+    const float diff = std::fabs(c0[i] - c1[i]);
+    if (!(diff <= 1e-4f + 1e-4f * std::fabs(c1[i]))) ok = false;   // also catches NaN
+    if (diff > worst || diff != diff) worst = diff;
+  }
+  c->fc_selfcheck = ok ? 1 : 0;
+  c->fc_selfcheck_err = worst;
+  if (!ok) {
+    c->fc_mfma = 0;
+    c->last_error = "motion cost: the MFMA form of the per-edge MLP disagreed with the fp32 kernel on the probe batch; "
+                    "using the fp32 VALU kernels (see cost_kernels.h FCM_SHAPE_CHANGE)";
+  }
+  return ARTP_OK;
+}
+
 extern "C" {
 
 size_t artp_cost_blob_bytes(void) { return 8 + cost_blob_floats() * sizeof(float); }
@@ -2295,9 +2364,26 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
     fc_mfma_pack(w, &blob);
     if (!c->d_fc_mfma) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_fc_mfma), blob.size()));
     HIP_TRY(c, hipMemcpy(c->d_fc_mfma, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    c->fc_mfma = 1;
     if (const char* e = std::getenv("ARTP_FC_MFMA")) c->fc_mfma = std::atoi(e) != 0;
   }
   c->have_weights = true;
+  // The MFMA form of the MLP depends on a software-managed hazard of the matrix pipe (cost_kernels.h FCM_SHAPE_CHANGE) that
+  // only the device can confirm for the toolchain that built this library: a probe batch goes through it and through the
+  // fp32 VALU kernel; if they disagree the context falls back to the fp32 kernels and says so (artp_cost_fc_path).
+  if (c->fc_mfma) {
+    const int rc = cost_fc_selfcheck(c);
+    if (rc != ARTP_OK) return rc;
+  }
+  return ARTP_OK;
+}
+
+int artp_cost_fc_path(artp_ctx* c, int* mfma, int* selfcheck, float* max_abs_diff) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (mfma) *mfma = c->fc_mfma;
+  if (selfcheck) *selfcheck = c->fc_selfcheck;
+  if (max_abs_diff) *max_abs_diff = c->fc_selfcheck_err;
   return ARTP_OK;
 }
 
@@ -2355,9 +2441,14 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     for (int t : {12, 18})
       if (rounds_cost(t) < rounds_cost(t_best)) t_best = t;
     if (const char* ev = std::getenv("ARTP_C345_T")) t_best = std::atoi(ev);  // tuning
-    const int rcb = t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
-                    : t_best == 12 ? launch_b(conv345_kernel<12>, C345Cfg<12>::LDS_BYTES, 12)
-                                   : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16);
+    const char* evx = std::getenv("ARTP_CNN_XCD");   // tuning: 0 = tiles in launch order (rounds 3-4)
+    const bool xcd = evx ? std::atoi(evx) != 0 : true;
+    const int rcb = xcd ? (t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
+                           : t_best == 12 ? launch_b(conv345_kernel<12>, C345Cfg<12>::LDS_BYTES, 12)
+                                          : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16))
+                        : (t_best == 18   ? launch_b(conv345_kernel<18, false>, C345Cfg<18>::LDS_BYTES, 18)
+                           : t_best == 12 ? launch_b(conv345_kernel<12, false>, C345Cfg<12>::LDS_BYTES, 12)
+                                          : launch_b(conv345_kernel<16, false>, C345Cfg<16>::LDS_BYTES, 16));
     if (rcb != ARTP_OK) return rcb;
     HIP_TRY(c, hipGetLastError());
     A = Bf;  // the 15 x 15 layer below reads conv5's output
@@ -2389,7 +2480,7 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     // round 5: the persistent strip-walking form (conv_kwalk_kernel): one workgroup per CU for the whole launch, a run
     // of vertically adjacent tiles each.  Tile height = the candidate with the shortest longest run (rows per CU).
     const char* evk = std::getenv("ARTP_KWALK");
-    const bool kwalk = evk ? std::atoi(evk) != 0 : true;
+    const bool kwalk = evk ? std::atoi(evk) != 0 : false;   // measured (profiles/r05_cnn_variants.txt): fewer cycles, lower clock, no faster
     if (kwalk) {
       int trk = 8;
       long costk = -1;
@@ -2411,9 +2502,16 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
                            (const float*)c->d_convb[4], c->d_feat, tps, tiles);
         return ARTP_OK;
       };
-      rcl = trk == 9    ? launch_w(conv_kwalk_kernel<9>, KwalkCfg<9>::LDS_BYTES, 9, KwalkCfg<9>::NTH)
-            : trk == 10 ? launch_w(conv_kwalk_kernel<10>, KwalkCfg<10>::LDS_BYTES, 10, KwalkCfg<10>::NTH)
-                        : launch_w(conv_kwalk_kernel<8>, KwalkCfg<8>::LDS_BYTES, 8, KwalkCfg<8>::NTH);
+      int variant = 0;   // 0: BD 5, rows early; 1: BD 5, rows late; 2: BD 15, rows late  (tuning)
+      if (const char* ev = std::getenv("ARTP_KWALK_VARIANT")) variant = std::atoi(ev);
+#define ARTP_KW_LAUNCH(TRv, BDv, EARLYv) launch_w(conv_kwalk_kernel<TRv, BDv, EARLYv>, KwalkCfg<TRv, BDv>::LDS_BYTES, TRv, KwalkCfg<TRv, BDv>::NTH)
+      if (variant == 2)
+        rcl = trk == 9 ? ARTP_KW_LAUNCH(9, 15, false) : trk == 10 ? ARTP_KW_LAUNCH(10, 15, false) : ARTP_KW_LAUNCH(8, 15, false);
+      else if (variant == 1)
+        rcl = trk == 9 ? ARTP_KW_LAUNCH(9, 5, false) : trk == 10 ? ARTP_KW_LAUNCH(10, 5, false) : ARTP_KW_LAUNCH(8, 5, false);
+      else
+        rcl = trk == 9 ? ARTP_KW_LAUNCH(9, 5, true) : trk == 10 ? ARTP_KW_LAUNCH(10, 5, true) : ARTP_KW_LAUNCH(8, 5, true);
+#undef ARTP_KW_LAUNCH
       if (rcl != ARTP_OK) return rcl;
       HIP_TRY(c, hipGetLastError());
       c->feat_h = hf;
@@ -2424,8 +2522,14 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     const long tiles8 = (long)((wf + 15) / 16) * ((hf + 7) / 8);
     const char* ev8 = std::getenv("ARTP_KSPLIT_NWV");
     const bool wide = ev8 ? std::atoi(ev8) == 8 : tiles8 <= c->n_cus;
-    if (wide)
+    const char* evx2 = std::getenv("ARTP_CNN_XCD");   // tuning: 0 = tiles in launch order (rounds 3-4)
+    const bool xcd2 = evx2 ? std::atoi(evx2) != 0 : true;
+    if (wide && !xcd2)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8, false>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
+    else if (wide)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
+    else if (best == 9 && !xcd2)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9, 4, false>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9>::LDS_BYTES, 9);
     else if (best == 9)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9>::LDS_BYTES, 9);
     else if (best == 10)
@@ -2612,10 +2716,16 @@ extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
     unsigned long long z4[4] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_feet_cycles), z4, sizeof(z4)) != hipSuccess) return -1;
   }
-  if (reset == 5) {  // the strip-walking 15 x 15 kernel's phase counters (read + reset)
-    if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_kwalk_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    unsigned long long z8[8] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(artp::g_kwalk_cycles), z8, sizeof(z8)) == hipSuccess ? 0 : -1;
+  if (reset == 5) {  // the strip-walking 15 x 15 kernel: out20[0..47] = cycles per (wavefront, phase) summed over the workgroups
+    static unsigned long long all[256 * 12 * 4];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(artp::g_kwalk_cycles), sizeof(all)) != hipSuccess) return -1;
+    if (out20)
+      for (int k = 0; k < 48; ++k) {
+        out20[k] = 0;
+        for (int b = 0; b < 256; ++b) out20[k] += all[b * 48 + k];
+      }
+    std::memset(all, 0, sizeof(all));
+    return hipMemcpyToSymbol(HIP_SYMBOL(artp::g_kwalk_cycles), all, sizeof(all)) == hipSuccess ? 0 : -1;
   }
   if (reset == 4) {  // the feature extractor's phase counters (read + reset)
     if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_cnn_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;

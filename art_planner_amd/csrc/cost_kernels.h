@@ -23,6 +23,15 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Workgroups are dealt to the 8 XCDs round robin (blockIdx % 8), each XCD with its own 4 MB L2.  xcd_contiguous() renumbers the
+// workgroups so that those sharing an XCD own CONTIGUOUS tile indices: spatial neighbours' halo rows then meet in that XCD's
+// L2 instead of being fetched once per workgroup from the Infinity Cache / HBM (a CU fills from there at ~4 B/clk when every CU
+// of the chip does it at once -- round 5, phase counters of conv_kwalk_kernel -- against ~25 B/clk from its L2).
+__device__ __forceinline__ int xcd_contiguous(int b, int G) {
+  const int x = b & 7, i = b >> 3, q = G >> 3, r = G & 7;
+  return x * q + (x < r ? x : r) + i;
+}
+
 // ---- the same implicit GEMM for large kernels (the 15 x 15 flatten layer): LDS-staged input patch ---------
 // A workgroup of 4 wavefronts computes a TR-row x 16-pixel output tile for all channels from a
 // (TR+KH-1) x (16+KW) pixel input patch staged once in LDS (NHWC, 2*CIN bytes per pixel: with CIN = 48 the 16
@@ -72,7 +81,7 @@ struct ConvKsplitCfg {
   static_assert((COUT * 2) % 16 == 0, "a pixel is a whole number of 16-byte chunks");
 };
 
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4>
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4, bool XCD = true>
 __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1)
 conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
                    const float* __restrict__ bias, half_t* __restrict__ out) {
@@ -83,7 +92,8 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   char* As = smem;
   const int Hout = Hin - KH + 1, Wout = Win - KW + 1;
   const int tiles_x = (Wout + Cfg::TP - 1) / Cfg::TP;
-  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int tile = XCD ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bx = tile % tiles_x, by = tile / tiles_x;
   const int oy0 = by * TR, ox0 = bx * Cfg::TP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
@@ -234,14 +244,14 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
 //    the barrier).  Their loads are not in the main loop's vmcnt stream (loads retire in order: a slow row fetch
 //    in front of the B ring would stall every MFMA step behind it).
 //  * 12 wavefronts = 3 (channel tiles, N) x 4 (K slices): a wavefront accumulates TR x ONE channel tile, so per k-step it
-//    needs one B fragment (global -> VGPR ring, 4 steps ahead, never drains -- not even across tiles: the weights are the
-//    same) and one new A row (LDS, register ring over the kernel rows as in conv_ksplit_kernel) for TR MFMAs.  Only the
+//    needs one B fragment (global -> VGPR ring, a whole 15-row k-step column ahead, never drains -- not even across tiles:
+//    the weights are the same; the order of the k-steps rotates with the workgroup) and one new A row (LDS, register ring over the kernel rows as in conv_ksplit_kernel) for TR MFMAs.  Only the
 //    4 K slices meet in LDS at the end of a tile: 96-108 KB of partial sums per tile against 192 KB for an 8-way K split
 //    (LDS stores run at ~79 B/clk/CU: the 8-way reduction cost a seventh of a tile's MFMA time).
 //  * Three wavefronts per SIMD (<= 168 registers): one's LDS / global latency and the reduction's barriers run under the
 //    others' MFMAs.
 //  * The finished sums leave as 8-byte stores (four consecutive channels of one pixel: the transposed product).
-template <int TR>
+template <int TR, int BD_ = 5>
 struct KwalkCfg {
   using P = ConvLdsCfg<15, 15, 48, 48, 3, true, TR>;
   static constexpr int NK = 4, NN = 3, NWV = NK * NN, NTH = 64 * NWV;
@@ -250,25 +260,30 @@ struct KwalkCfg {
   static constexpr int RPP_MAX = (160 * 1024 - RING_B) / (NWV * 1024);   // rows of partial sums that fit beside the ring
   static constexpr int NPASS = (TR + RPP_MAX - 1) / RPP_MAX;
   static constexpr int RPP = (TR + NPASS - 1) / NPASS;
-  static constexpr int LDS_BYTES = RING_B + NWV * RPP * 1024;
-  static constexpr int BD = 5;        // B ring depth: 4 steps ahead; 15 kernel rows = 3 turns, so slot = kh % 5 across k-steps
+  static constexpr int BIAS_OFF = RING_B + NWV * RPP * 1024;
+  static constexpr int LDS_BYTES = BIAS_OFF + 256;   // + the layer's 48 biases (the reduction reads them per element)
+  static constexpr int BD = BD_;      // B ring depth: BD - 1 steps ahead; 15 kernel rows = a whole number of turns, so slot = kh % BD
+  static_assert(15 % BD == 0, "slot = kh % BD across k-steps");
   static_assert(KSTEPS == 23 && KSTEPS % NK == 3, "the last K slice is the short one (it fetches the next tile's rows)");
   static_assert(LDS_BYTES <= 160 * 1024 && RPP >= 1, "one workgroup per CU");
   static_assert(RING_B % 16 == 0, "16-byte chunks");
 };
 
 #ifdef ARTP_STAGE_TIMING
-__device__ unsigned long long g_kwalk_cycles[8];  // [0] prologue / strip change, [1] main loop, [2] row fetch (short slice), [3] reduction, [7] tiles
-#define ARTP_KW_MARK(slot) do { if (tid == 0) { const long long n_ = clock64(); atomicAdd(&g_kwalk_cycles[slot], (unsigned long long)(n_ - t_prev)); t_prev = n_; } } while (0)
+// per workgroup (mod 256) and wavefront: cycles in [0] patch loads, [1] the main loop, [2] from its end to the first
+// reduction barrier's release (waiting for the slower wavefronts; the short K slice's row fetch), [3] the reduction.
+// Accumulated in registers, stored once at the end of the kernel: the marks cost an s_memtime each and nothing else.
+__device__ unsigned long long g_kwalk_cycles[256 * 12 * 4];
+#define ARTP_KW_MARK(slot) do { const long long n_ = clock64(); kw_c[slot] += (unsigned long long)(n_ - t_prev); t_prev = n_; } while (0)
 #else
 #define ARTP_KW_MARK(slot) do { } while (0)
 #endif
 
-template <int TR>
-__global__ void __launch_bounds__(KwalkCfg<TR>::NTH, 3)
+template <int TR, int BD_ = 5, bool EARLY = true>
+__global__ void __launch_bounds__(768, 3)
 conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
                   const float* __restrict__ bias, half_t* __restrict__ out, int tiles_per_strip, int n_tiles) {
-  using Cfg = KwalkCfg<TR>;
+  using Cfg = KwalkCfg<TR, BD_>;
   constexpr int KSTEPS = Cfg::KSTEPS, PR = Cfg::PR, RING = Cfg::RING, ROW_B = Cfg::ROW_B, CPR = Cfg::CPR, NTH = Cfg::NTH;
   constexpr int BD = Cfg::BD, KH = 15;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -282,22 +297,33 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
                                               // worth of different K slices (18 / 17 / 17 / 17 k-step units)
   // this workgroup's run of tiles (strip-major: consecutive tiles are vertically adjacent).  Workgroups that share an XCD
   // (blockIdx % 8) take neighbouring runs: their halo rows meet in that XCD's L2.
-  int b = (int)blockIdx.x;
   const int G = (int)gridDim.x;
-  if ((G & 7) == 0) b = (b & 7) * (G >> 3) + (b >> 3);
+  const int b = xcd_contiguous((int)blockIdx.x, G);
   const int t0 = (int)(((long)b * n_tiles) / G), t1 = (int)(((long)(b + 1) * n_tiles) / G);
   const long row_bytes = (long)Win * 96;
 #ifdef ARTP_STAGE_TIMING
   long long t_prev = clock64();
+  unsigned long long kw_c[4] = {0, 0, 0, 0};
 #endif
 
-  // B ring (this wavefront's channel tile): step = (jj, kh) with ks = kq + 4 jj; slot = kh % BD
+  // B ring (this wavefront's channel tile): step = (jj, kh) with ks = kq + 4 ((jj + j0) mod nj); slot = kh.  The k-step a
+  // workgroup starts with rotates with its index: the workgroups of a launch stream the same 1 MB of fragments, no two
+  // neighbours in the same order.
   const int nj = (KSTEPS - kq + 3) / 4;
-  const half8* wl = wp + (size_t)nt * 64 + lane;
-  auto b_ptr = [&](int ks, int kh) { return wl + (size_t)(kh * KSTEPS + ks) * 3 * 64; };
+  const int j0 = (int)(blockIdx.x % (unsigned)nj);
+  auto ks_of = [&](int jj) {
+    const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
+    return kq + 4 * j;
+  };
+  // the fragment's address = a wave-uniform pointer (scalar registers) + the lane's 16 bytes: no 64-bit pointer per slot
+  auto b_ptr = [&](int ks, int kh) { return wp + ((size_t)(kh * KSTEPS + ks) * 3 + nt) * 64 + lane; };
   half8 bq[BD];
+  {
+    const int ks0 = ks_of(0);
 #pragma unroll
-  for (int s = 0; s < BD - 1; ++s) bq[s] = *b_ptr(kq, s);
+    for (int s = 0; s < BD - 1; ++s) bq[s] = *b_ptr(ks0, s);
+  }
+  if (tid < 48) reinterpret_cast<float*>(smem + Cfg::BIAS_OFF)[tid] = bias[tid];
 
   floatx4 acc[TR];
   const int a_lane = li * 96 + kg * 16;
@@ -336,9 +362,60 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
       const int s = base + r;
       return ring + (s >= RING ? s - RING : s) * ROW_B + a_lane;
     };
+    // The TR rows the tile below adds (patch rows PR .. PR + TR - 1 -> the ring slots the current tile does not use) are
+    // fetched by the short K slice's three wavefronts.  EARLY: as LDS-DMA (global_load_lds_dwordx4: no registers, 1 KB per
+    // wave-instruction, three per row) issued at the START of the tile -- a CU fills from the Infinity Cache at only
+    // ~4 B/clk when every CU does (27 KB = 16 k cycles, phase counters), and loads retire in order, so the wavefront parks
+    // at its first B fragment younger than the DMAs while the SIMD's other two wavefronts keep the matrix pipe busy; it
+    // has a column less to do.  Chunks outside the image are zeroed by ordinary stores.  !EARLY: through registers, after
+    // the wavefront's last column.
+    constexpr int NLR = 192, NITR = (TR * CPR + NLR - 1) / NLR;
+    const int t3 = nt * 64 + lane;
+    auto rows_dma = [&]() {
+#pragma unroll
+      for (int i0 = 0; i0 < TR * 3; i0 += 3) {
+        const int i = i0 + nt;               // (row, 1 KB segment) pairs dealt to the three wavefronts
+        const int r = i / 3, seg = i - r * 3;
+        const int c = seg * 64 + lane;
+        const int sl = base + PR + r;
+        char* dst = ring + (sl >= RING ? sl - RING : sl) * ROW_B + seg * 1024;
+        const long off = (long)ox0 * 96 + (long)c * 16;
+        const bool in_img = oy0 + PR + r < Hin && off + 16 <= row_bytes;
+        if (c < CPR) {
+          if (in_img)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(in) + (long)(oy0 + PR + r) * row_bytes + off),
+                (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          else
+            *reinterpret_cast<half8*>(dst + lane * 16) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+    };
+    auto rows_through_registers = [&]() {
+      half8 vr[NITR];
+#pragma unroll
+      for (int it = 0; it < NITR; ++it) {
+        const int c = t3 + it * NLR;
+        const int r = c / CPR, cc = c - r * CPR;
+        const long off = (long)ox0 * 96 + (long)cc * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vr[it][j] = (half_t)0;
+        if (c < TR * CPR && oy0 + PR + r < Hin && off + 16 <= row_bytes)
+          vr[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + PR + r) * row_bytes + off);
+      }
+#pragma unroll
+      for (int it = 0; it < NITR; ++it) {
+        const int c = t3 + it * NLR;
+        const int r = c / CPR, cc = c - r * CPR;
+        const int s = base + PR + r;
+        if (c < TR * CPR) *reinterpret_cast<half8*>(ring + (s >= RING ? s - RING : s) * ROW_B + cc * 16) = vr[it];
+      }
+    };
+    const bool fetch = kq == 3 && has_next;
+    if (EARLY && fetch) rows_dma();
     for (int jj = 0; jj < nj; ++jj) {
-      const int ks = kq + 4 * jj;
-      const int ks_nx = jj + 1 < nj ? ks + 4 : kq;   // wraps into the next tile's first k-step: the same weights
+      const int ks = ks_of(jj);
+      const int ks_nx = ks_of(jj + 1 < nj ? jj + 1 : 0);   // wraps into the next tile's first k-step: the same weights
       half8 a[TR];   // ring: slot (r % TR) holds patch row r
 #pragma unroll
       for (int r = 0; r < TR - 1; ++r) a[r] = *reinterpret_cast<const half8*>(row_ptr(r) + ks * 64);
@@ -351,42 +428,10 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
         for (int m = 0; m < TR; ++m)   // m = TR - 1 uses the row requested just above: it goes last
           acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[kh % BD], a[(kh + m) % TR], acc[m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef ARTP_KW_NOGUARD
-        // The register allocator rotates the accumulators (an MFMA's destination is not its srcC), so a group's last
-        // srcC registers are dead behind it and the address arithmetic of the next step lands in them three wait states
-        // later (scripts/mfma_hazard_check.py): the srcC write-after-read distance of the FCM_WAIT note.  The wait
-        // states cost this wavefront 8 cycles per 130-160 of MFMAs, and the SIMD's other two wavefronts issue under them.
-        asm volatile("s_nop 7");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     }
     ARTP_KW_MARK(1);
-    if (kq == 3 && has_next) {
-      // the short K slice's three wavefronts fetch the TR rows the tile below adds (patch rows PR .. PR + TR - 1 -> the
-      // ring slots the current tile does not use)
-      constexpr int NL = 192, NIT = (TR * CPR + NL - 1) / NL;
-      const int t3 = nt * 64 + lane;
-      half8 v[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int c = t3 + it * NL;
-        const int r = c / CPR, cc = c - r * CPR;
-        const long off = (long)ox0 * 96 + (long)cc * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[it][j] = (half_t)0;
-        if (c < TR * CPR && oy0 + PR + r < Hin && off + 16 <= row_bytes)
-          v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + PR + r) * row_bytes + off);
-      }
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int c = t3 + it * NL;
-        const int r = c / CPR, cc = c - r * CPR;
-        const int s = base + PR + r;
-        if (c < TR * CPR) *reinterpret_cast<half8*>(ring + (s >= RING ? s - RING : s) * ROW_B + cc * 16) = v[it];
-      }
-      ARTP_KW_MARK(2);
-    }
+    if (!EARLY && fetch) rows_through_registers();
     // The four K slices of a channel tile meet in LDS, RPP rows at a time; element e of a pass = (row j, channel tile n,
     // lane l) is summed over the slices in a fixed order by thread e (mod NTH), gets bias + leaky-ReLU and leaves as four
     // consecutive channels of one pixel (transposed product: column l & 15 = pixel, row 4 (l >> 4) + r = channel).
@@ -396,6 +441,7 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
       constexpr int RPP = Cfg::RPP;
       const int rows = (h + 1) * RPP <= TR ? RPP : TR - h * RPP;
       __syncthreads();   // h = 0: every wavefront has left the main loop and the new rows are in the ring
+      if (h == 0) ARTP_KW_MARK(2);
 #pragma unroll
       for (int j = 0; j < RPP; ++j)
         if (h * RPP + j < TR) red[(wave * RPP + j) * 64 + lane] = acc[h * RPP + j];
@@ -410,7 +456,7 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
           for (int r = 0; r < 4; ++r) v[r] += p[r];
         }
         const int ch = n * 16 + (l >> 4) * 4, px = ox0 + (l & 15), oy = oy0 + h * RPP + j;
-        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+        const floatx4 bv = *reinterpret_cast<const floatx4*>(smem + Cfg::BIAS_OFF + ch * 4);
         half4_t y4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -423,11 +469,12 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
     }
     base += TR;
     if (base >= RING) base -= RING;
-#ifdef ARTP_STAGE_TIMING
     ARTP_KW_MARK(3);
-    if (tid == 0) atomicAdd(&g_kwalk_cycles[7], 1ull);
-#endif
   }
+#ifdef ARTP_STAGE_TIMING
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) g_kwalk_cycles[(((int)blockIdx.x & 255) * 12 + wave) * 4 + k] = kw_c[k];
+#endif
 }
 
 // ======================================================================================================
@@ -670,7 +717,7 @@ __device__ unsigned long long g_cnn_cycles[16];  // conv345 phases (cycles of wa
 #define ARTP_CNN_MARK(slot) do { } while (0)
 #endif
 
-template <int T>
+template <int T, bool XCD = true>
 __global__ void __launch_bounds__(C345_NT)
 conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Win,
                const half8* __restrict__ w3, const float* __restrict__ b3, const half8* __restrict__ w4,
@@ -685,7 +732,8 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
   char* Wl = W3 + Cfg::W3_B;
   const int Hout = Hin - 8, Wout = Win - 8;
   const int tiles_x = (Wout + T - 1) / T;
-  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int tile = XCD ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bx = tile % tiles_x, by = tile / tiles_x;
   const int oy0 = by * T, ox0 = bx * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef ARTP_STAGE_TIMING
@@ -957,41 +1005,31 @@ struct FcMfma {
 };
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
-// Every MFMA of this kernel is followed by wait states with the scheduler fenced off.  Reason: ROCm 7.2's compiler
-// lets a VALU instruction overwrite a register that an in-flight gfx950 16x16x32 MFMA still has to read as its srcC two
-// or three cycles after issuing it (seen in the ISA: v_mfma ... v[72:75], v[60:63], v[8:11], v[12:15]; s_nop 2;
-// v_cvt_f32_f16 v14, ... -- and wrong sums on the device that move with every change of the code's shape).  The CNN kernels
-// accumulate in place over long loops and never met it; here accumulators are born from LDS loads and die into VALU code.
+// MIXED-SHAPE accumulation needs software wait states on gfx950, and ROCm 7.2's compiler does not insert them: a
+// v_mfma_f32_16x16x16_f16 that accumulates into the registers a v_mfma_f32_16x16x32_f16 is still writing (or the other way
+// round) reads a stale srcC unless >= 5 wait states lie between them (tests/cpp/mfma_hazard_probe.hip measures it on the
+// device: probes B / B3; same-shape chains are interlocked, probe B2).  hipcc puts the two back to back.  Round 4 saw the
+// wrong sums, mis-attributed them to "VALU overwrites srcC" (probe A: no such hazard) and fenced EVERY MFMA with ten wait
+// states; round 5 orders each accumulator's MFMAs by shape -- all 32-wide steps, FCM_SHAPE_CHANGE(), all 16-wide steps --
+// so a tile pays one wait.  scripts/mfma_hazard_check.py checks the distance in the ISA of every kernel of this file.
 #ifndef FCM_NOP
-#define FCM_NOP 9   // measured: 4 wait states are too few, 8 are enough (exact results); 10 with a margin
+#define FCM_NOP 7   // 8 wait states: >= 5 needed, measured
 #endif
-#define FCM_WAIT()                                  \
+#define FCM_SHAPE_CHANGE()                          \
   do {                                              \
     __builtin_amdgcn_sched_barrier(0);              \
     asm volatile("s_nop %0" ::"n"(FCM_NOP));        \
     __builtin_amdgcn_sched_barrier(0);              \
   } while (0)
-#define FCM_MFMA32(acc, a, b)                                            \
-  do {                                                                   \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);    \
-    FCM_WAIT();                                                          \
-  } while (0)
 #define FCM_MFMA32X2(c0, c1, a, b0, b1)                                  \
   do {                                                                   \
     c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, c0, 0, 0, 0);     \
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, c1, 0, 0, 0);     \
-    FCM_WAIT();                                                          \
   } while (0)
 #define FCM_MFMA16X2(c0, c1, a, b0, b1)                                  \
   do {                                                                   \
     c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b0, c0, 0, 0, 0);      \
     c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b1, c1, 0, 0, 0);      \
-    FCM_WAIT();                                                          \
-  } while (0)
-#define FCM_MFMA16(acc, a, b)                                            \
-  do {                                                                   \
-    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);     \
-    FCM_WAIT();                                                          \
   } while (0)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 fc_cost_mfma_kernel(const float* __restrict__ edges, size_t B, const half_t* __restrict__ feat, CostMapGeom g,
@@ -1054,7 +1092,7 @@ fc_cost_mfma_kernel(const float* __restrict__ edges, size_t B, const half_t* __r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {
-      // TWO 16-edge tiles per pass: a weight fragment read from LDS feeds two MFMAs, and the two share one wait (FCM_WAIT).
+      // TWO 16-edge tiles per pass: a weight fragment read from LDS feeds two MFMAs.
       // The fragments are READ FROM LDS IN EVERY PASS (36 reads, 30 KB per wavefront): held in registers across the loop they
       // are 150 VGPRs and one wavefront per SIMD -- nothing to cover the feature gather with.  The opaque offset keeps the
       // compiler from hoisting them
@@ -1122,11 +1160,13 @@ fc_cost_mfma_kernel(const float* __restrict__ edges, size_t B, const half_t* __r
         const half8 wal = *reinterpret_cast<const half8*>(wl + FcMfma::G2A + (t * 2 + 1) * 1024);
         const half4_t wbh = *reinterpret_cast<const half4_t*>(wl8 + FcMfma::G2B + (t * 2 + 0) * 512);
         const half4_t wbl = *reinterpret_cast<const half4_t*>(wl8 + FcMfma::G2B + (t * 2 + 1) * 512);
+        // small terms first within a shape (lo x hi, hi x lo, then hi x hi), the 32-wide steps before the 16-wide ones
         FCM_MFMA32X2(c0, c1, wal, hA[0], hA[1]);
         FCM_MFMA32X2(c0, c1, wah, hAlo[0], hAlo[1]);
+        FCM_MFMA32X2(c0, c1, wah, hA[0], hA[1]);
+        FCM_SHAPE_CHANGE();
         FCM_MFMA16X2(c0, c1, wbl, hB[0], hB[1]);
         FCM_MFMA16X2(c0, c1, wbh, hBlo[0], hBlo[1]);
-        FCM_MFMA32X2(c0, c1, wah, hA[0], hA[1]);
         FCM_MFMA16X2(c0, c1, wbh, hB[0], hB[1]);
         // head units 16 t + 4 kg + i: leaky-ReLU, then their share of the three output dot products (the output weight
         // vectors are zero outside their head: tile 0 is all energy, tile 1 half energy half time, ...)

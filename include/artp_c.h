@@ -504,6 +504,10 @@ void artp_preprocessed_destroy(artp_preprocessed* pp);
  * torch state_dict. */
 size_t artp_cost_blob_bytes(void);
 int artp_cost_load_weights(artp_ctx* ctx, const void* blob, size_t bytes);
+/* Which kernel answers artp_cost_query: *mfma = 1 the MFMA form of FCpart (network_light.py:113-165), 0 the fp32 VALU kernels.
+ * artp_cost_load_weights runs a probe batch through both and falls back to fp32 if they disagree (*selfcheck: 1 agreed,
+ * 0 disagreed, -1 not run; *max_abs_diff = the probe's largest difference).  Any pointer may be NULL. */
+int artp_cost_fc_path(artp_ctx* ctx, int* mfma, int* selfcheck, float* max_abs_diff);
 /* CostPredictor.updateFeatures (predictor.py:28-36) + CostQuery.setMapParams (cost_query.py:26-35):
  * elev_xy is the server's map array [rows][cols] row-major with index a growing along world x and b
  * along world y (cost_query_server.py:66-74), holes already inpainted; (cx, cy) = map centre. */

@@ -25,6 +25,8 @@ ctx.use_torch_stream()
 for n, seed in ((400, 1234), (800, 77)):
     g = raw_map(n, 0.04, seed=seed)
     elv = torch.from_numpy(np.ascontiguousarray(g["elevation"][::-1, ::-1]).astype(np.float32)).to(dev)
+    if os.environ.get("ARTP_BENCH_FLAT") == "1":   # DVFS probe: a constant map (every activation of a layer the same value)
+        elv.zero_()
     for _ in range(3):
         ctx.cost_update_map_dev(elv, g.res, g.len_x, g.len_y)
     torch.cuda.synchronize()

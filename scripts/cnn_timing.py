@@ -27,12 +27,15 @@ for n, seed in ((400, 1234), (800, 77)):
     print(f"map {n}: {int(wg)} workgroups, cycles per workgroup (wavefront 0): total {a[:11].sum() / wg:.0f}")
     for k, nm in enumerate(names):
         print(f"   {nm:24s} {a[k] / wg:9.0f}")
-    out8 = (C.c_ulonglong * 20)()
+    out8 = (C.c_ulonglong * 48)()
     L.artp_debug_stage_cycles(out8, 5)
     ctx.cost_update_map(elv, g.res, g.len_x, g.len_y)
     L.artp_debug_stage_cycles(out8, 5)
-    k = np.array(list(out8)[:8], dtype=np.float64)
-    if k[7] > 0:
-        print(f"   conv_kwalk_kernel: {int(k[7])} tiles; cycles per tile (wavefront 0): prologue / strip change {k[0] / k[7]:.0f}, "
-              f"main loop {k[1] / k[7]:.0f}, row fetch {k[2] / k[7]:.0f}, reduction {k[3] / k[7]:.0f}")
+    k = np.array(list(out8), dtype=np.float64).reshape(12, 4)
+    nwg = 242 if n == 400 else 256
+    print(f"   conv_kwalk_kernel: cycles per workgroup and wavefront (wave = nt + 3 kq; sum over the workgroup's tiles), {nwg} workgroups")
+    print("      wave   patch loads   main loop   wait at barrier   reduction      total")
+    for w in range(12):
+        r = k[w] / nwg
+        print(f"      {w:4d} {r[0]:12.0f} {r[1]:11.0f} {r[2]:17.0f} {r[3]:11.0f} {r.sum():10.0f}")
 ctx.close()

@@ -1,25 +1,24 @@
 #!/usr/bin/env python3
-"""ISA-level guard for the gfx950 MFMA srcC hazard (cost_kernels.h FCM_WAIT).
+"""ISA-level guard for the gfx950 MFMA hazards the compiler leaves to the author (cost_kernels.h FCM_SHAPE_CHANGE).
 
-ROCm 7.2's compiler pads the "VALU writes a register an in-flight MFMA still reads as srcC" hazard of
-v_mfma_f32_16x16x32_f16 (8 passes on gfx950) as if the instruction had fewer passes: measured on the device,
-fewer than 8 wait states between the MFMA and the overwriting VALU instruction give wrong sums.  This script compiles
-artp_capi.hip to gfx950 assembly and, for every MFMA of the named kernels, walks the straight-line code behind it and
-reports the smallest number of wait states before
-  (a) a VALU (or LDS-return / SALU-to-VGPR) instruction WRITES one of the MFMA's srcC registers that is not also its
-      destination (write-after-read on srcC: the round-4 bug), and
-  (b) a non-MFMA VALU instruction reads or writes the MFMA's DESTINATION registers (the ordinary result hazard; reported,
-      the compiler's own table covers it).
-A wait state = one issued instruction; `s_nop N` = N + 1; a branch / label ends the walk (conservative: the walk also
-follows fall-through labels).  usage: mfma_hazard_check.py [--asm FILE] [--min N] kernel-substring ...
-exit status 1 if any (a) distance is below --min (default 8)."""
+Measured on the device by tests/cpp/mfma_hazard_probe.hip (profiles/r05_mfma_hazard_probe.txt), wait states needed behind a
+v_mfma_f32_16x16x32_f16 / 16x16x16_f16:
+  MIX  a dependent MFMA of the OTHER shape (its srcC overlaps the first one's destination)   >= 5   hipcc emits 0-1
+  RD   a VALU instruction reads the destination                                             >= 7   hipcc pads it (s_nop 7)
+  WR   a VALU instruction overwrites the destination                                        >= 4   hipcc pads it
+  (a VALU write to a srcC register that is not the destination needs none: probe A -- round 4's theory, refuted)
+This script compiles artp_capi.hip to gfx950 assembly and, for every MFMA of the named kernels, walks the straight-line
+code behind it and reports the smallest distance of each kind; it fails (exit 1) when one is below its measured minimum.
+A wait state = one issued instruction; `s_nop N` = N + 1; a branch / barrier ends the walk (labels are walked through).
+usage: mfma_hazard_check.py [--asm FILE] kernel-substring ..."""
 import os
 import re
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_KERNELS = ["fc_cost_mfma_kernel", "conv345_kernel", "conv_ksplit_kernel", "conv_kwalk_kernel", "conv345p_kernel"]
+DEFAULT_KERNELS = ["fc_cost_mfma_kernel", "conv345_kernel", "conv_ksplit_kernel", "conv_kwalk_kernel"]
+MIN_MIX, MIN_RD, MIN_WR = 5, 7, 4
 WINDOW = 24  # wait states looked at behind an MFMA
 
 
@@ -91,6 +90,11 @@ def kernels_of(asm_lines, wanted):
         i += 1
 
 
+def mfma_shape(op):
+    m = re.search(r"_(\d+x\d+x\d+)_?", op)
+    return m.group(1) if m else op
+
+
 def check_kernel(body):
     ins = []
     for l in body:
@@ -101,13 +105,21 @@ def check_kernel(body):
             ins.append(("label", []))
             continue
         ins.append(operands(t))
-    res = {"mfma": 0, "min_srcc_war": None, "min_dst": None, "worst": None}
+    res = {"mfma": 0, "shapes": set(), "mix": None, "rd": None, "wr": None, "srcc_war": None, "worst": {}}
+
+    def note(kind, ws, a, b):
+        if res[kind] is None or ws < res[kind]:
+            res[kind] = ws
+            res["worst"][kind] = (" ".join([a[0]] + a[1]), " ".join([b[0]] + b[1]))
+
     for i, (op, ops) in enumerate(ins):
         if not op.startswith("v_mfma"):
             continue
         res["mfma"] += 1
+        res["shapes"].add(mfma_shape(op))
         dst, srcc = regs_of(ops[0]), regs_of(ops[3]) if len(ops) > 3 else set()
         war = srcc - dst
+        live = set(dst)   # destination registers not yet rewritten by something later
         ws = 0
         for j in range(i + 1, len(ins)):
             o2, p2 = ins[j]
@@ -115,48 +127,65 @@ def check_kernel(body):
                 continue
             if o2.startswith("s_cbranch") or o2.startswith("s_branch") or o2 == "s_endpgm" or o2 == "s_barrier":
                 break
-            if not o2.startswith("v_mfma"):
+            if o2.startswith("v_mfma"):
+                c2 = regs_of(p2[3]) if len(p2) > 3 else set()
+                if (c2 & live) and mfma_shape(o2) != mfma_shape(op):
+                    note("mix", ws, (op, ops), (o2, p2))
+                live -= regs_of(p2[0])
+            else:
                 w = vgpr_writes(o2, p2)
+                r = vgpr_reads(o2, p2)
                 if war and (w & war):
-                    if res["min_srcc_war"] is None or ws < res["min_srcc_war"]:
-                        res["min_srcc_war"] = ws
-                        res["worst"] = (" ".join([op] + ops), " ".join([o2] + p2))
+                    note("srcc_war", ws, (op, ops), (o2, p2))
                     war = war - w
-                if (w | vgpr_reads(o2, p2)) & dst:
-                    if res["min_dst"] is None or ws < res["min_dst"]:
-                        res["min_dst"] = ws
+                if r & live:
+                    note("rd", ws, (op, ops), (o2, p2))
+                if w & live:
+                    note("wr", ws, (op, ops), (o2, p2))
+                    live -= w
+            if not live and not war:
+                break
             ws += wait_states(o2, p2)
             if ws >= WINDOW:
                 break
     return res
 
 
+def check_file(asm, names):
+    """[(kernel, result dict, [violations])] for the kernels of an assembly file whose mangled name holds one of `names`"""
+    lines = open(asm).read().split("\n")
+    out = []
+    for name, body in kernels_of(lines, names):
+        r = check_kernel(body)
+        bad = []
+        for kind, lim in (("mix", MIN_MIX), ("rd", MIN_RD), ("wr", MIN_WR)):
+            if r[kind] is not None and r[kind] < lim:
+                bad.append(f"{kind} {r[kind]} < {lim}: " + " | ".join(r["worst"][kind]))
+        out.append((name, r, bad))
+    return out
+
+
 def main(argv):
     asm = None
-    minimum = 8
     names = []
     it = iter(argv)
     for a in it:
         if a == "--asm":
             asm = next(it)
-        elif a == "--min":
-            minimum = int(next(it))
         else:
             names.append(a)
     names = names or DEFAULT_KERNELS
     if asm is None:
         asm = compile_asm(os.path.join(ROOT, "gpurun_out", "isa", "artp.s"))
-    lines = open(asm).read().split("\n")
-    bad = 0
-    for name, body in kernels_of(lines, names):
-        r = check_kernel(body)
+    nbad = 0
+    for name, r, bad in check_file(asm, names):
         short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
-        flag = ""
-        if r["min_srcc_war"] is not None and r["min_srcc_war"] < minimum:
-            bad += 1
-            flag = "  <-- srcC overwritten too early: " + " | ".join(r["worst"])
-        print(f"{short[:90]:90s} mfma {r['mfma']:4d}  min wait states: srcC-WAR {r['min_srcc_war']}  dst-use {r['min_dst']}{flag}")
-    return 1 if bad else 0
+        print(f"{short[:84]:84s} mfma {r['mfma']:4d} {'+'.join(sorted(r['shapes'])):17s} min wait states: other-shape acc {r['mix']}  "
+              f"VALU reads dst {r['rd']}  VALU writes dst {r['wr']}  (srcC overwritten {r['srcc_war']}: harmless)")
+        for b in bad:
+            nbad += 1
+            print("    VIOLATION " + b)
+    return 1 if nbad else 0
 
 
 if __name__ == "__main__":

@@ -6,6 +6,7 @@
 //
 //   A  srcC write-after-read:   MFMA(dst D, srcC C != D); K wait states; VALU overwrites C      (the round-4 bug)
 //   B  dependent MFMA, other shape: 16x16x32 -> K -> 16x16x16 accumulating into the same registers
+//   B3 dependent MFMA, other shape: 16x16x16 -> K -> 16x16x32
 //   B2 dependent MFMA, same shape:  16x16x32 -> K -> 16x16x32
 //   C  VALU reads the MFMA's result after K wait states
 //   E  VALU overwrites the MFMA's destination after K wait states (the MFMA's own write must not land later)
@@ -84,6 +85,13 @@ __global__ void probe_kernel(const half8* __restrict__ a, const half8* __restric
     else                                                                                                                    \
       asm volatile(SETUP "v_mov_b32 v104, 0\n v_mov_b32 v105, 0\n v_mov_b32 v106, 0\n v_mov_b32 v107, 0\n" NOPS16           \
                    "v_mfma_f32_16x16x32_f16 v[104:107], %[a], %[b], v[100:103]\n" GAPSTR RESULT LONG_WAIT : OUTS : INS : CLOB); \
+  } else if (PROBE == 5) {                                                                                                  \
+    if (PRE)                                                                                                                \
+      asm volatile(SETUP PRE_MFMA "v_mfma_f32_16x16x16_f16 v[104:107], %[a4], %[b4], v[100:103]\n"                          \
+                   GAPSTR "v_mfma_f32_16x16x32_f16 v[104:107], %[a], %[b], v[104:107]\n" LONG_WAIT RESULT : OUTS : INS : CLOB); \
+    else                                                                                                                    \
+      asm volatile(SETUP "v_mfma_f32_16x16x16_f16 v[104:107], %[a4], %[b4], v[100:103]\n"                                   \
+                   GAPSTR "v_mfma_f32_16x16x32_f16 v[104:107], %[a], %[b], v[104:107]\n" LONG_WAIT RESULT : OUTS : INS : CLOB); \
   } else {                                                                                                                  \
     if (PRE)                                                                                                                \
       asm volatile(SETUP PRE_MFMA "v_mfma_f32_16x16x32_f16 v[104:107], %[a], %[b], v[100:103]\n" \
@@ -219,6 +227,8 @@ int main() {
   rc |= probe<0, 1>(d, "A srcC-WAR (VALU write)");
   rc |= probe<1, 0>(d, "B mfma32 -> mfma16 same acc");
   rc |= probe<1, 1>(d, "B mfma32 -> mfma16 same acc");
+  rc |= probe<5, 0>(d, "B3 mfma16 -> mfma32 same acc");
+  rc |= probe<5, 1>(d, "B3 mfma16 -> mfma32 same acc");
   rc |= probe<2, 0>(d, "B2 mfma32 -> mfma32 same acc");
   rc |= probe<2, 1>(d, "B2 mfma32 -> mfma32 same acc");
   rc |= probe<3, 0>(d, "C VALU reads result");

@@ -233,8 +233,10 @@ def test_gpu_gather_and_costs_equal_the_reference_cost_query(tag):
     e = g[f"{tag}_edges"]
     rows, cols = ctx.cost_query_cells(e)
     assert np.array_equal(rows, g[f"{tag}_rows"]) and np.array_equal(cols, g[f"{tag}_cols"])
-    c = ctx.cost_query(e)                                   # <= 2^16 edges: four lanes per edge
-    big = np.tile(e, (24, 1))                               # > 2^16 edges: the lane-per-edge kernel
+    fc = ctx.cost_fc_path()                                 # the MFMA form passed its probe batch at weight load
+    assert fc["mfma"] == 1 and fc["selfcheck"] == 1 and fc["max_abs_diff"] < 1e-4, fc
+    c = ctx.cost_query(e)
+    big = np.tile(e, (24, 1))                               # an edge's cost does not depend on the batch around it
     assert np.array_equal(ctx.cost_query(big)[:len(e)], c)
     ce = np.abs(c - g[f"{tag}_costs"])
     a = ANCHOR["golden_112"]
@@ -278,8 +280,12 @@ def test_gpu_cost_full_map_properties(big_map):
     finally:
         os.environ.pop("ARTP_FC_MFMA", None)
     ctx_v.cost_update_map(elv, big_map.res, big_map.len_x, big_map.len_y)
-    c_v = ctx_v.cost_query(e)
+    assert ctx_v.cost_fc_path() == {"mfma": 0, "selfcheck": -1, "max_abs_diff": 0.0}
+    c_v = ctx_v.cost_query(e)                               # 50 000 edges <= 2^16: fc_cost_split_kernel, four lanes per edge
     assert np.abs(c1 - c_v).max() < 2e-5 and not np.array_equal(c1, c_v)   # two different kernels, the same numbers
+    # the two fp32 VALU kernels accumulate every unit in the same order: bit-identical (> 2^16 edges: fc_cost_kernel, a lane per edge)
+    c_vb = ctx_v.cost_query(np.tile(e, (2, 1)))
+    assert np.array_equal(c_vb[:B], c_v) and np.array_equal(c_vb[B:], c_v)
     ctx_v.close()
     # an edge's result does not depend on the batch it arrives in (tile position, ragged sizes, small and large batches)
     big = np.tile(e, (2, 1))[:70001]
