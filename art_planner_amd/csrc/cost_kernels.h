@@ -416,17 +416,21 @@ conv_kwalk_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* 
     for (int jj = 0; jj < nj; ++jj) {
       const int ks = ks_of(jj);
       const int ks_nx = ks_of(jj + 1 < nj ? jj + 1 : 0);   // wraps into the next tile's first k-step: the same weights
-      half8 a[TR];   // ring: slot (r % TR) holds patch row r
+      // A ring of TR + 1 fragments: slot (r % (TR + 1)) holds patch row r; a row is requested a whole step before the MFMA
+      // that needs it (with TR = 9 MFMAs per step the row asked for at the head of a step came back ~130 cycles later, right
+      // when the step's last MFMA wanted it: LDS latency with 12 wavefronts reading was the stall)
+      constexpr int AR = TR + 1;
+      half8 a[AR];
 #pragma unroll
-      for (int r = 0; r < TR - 1; ++r) a[r] = *reinterpret_cast<const half8*>(row_ptr(r) + ks * 64);
+      for (int r = 0; r < TR; ++r) a[r] = *reinterpret_cast<const half8*>(row_ptr(r) + ks * 64);
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
-        a[(kh + TR - 1) % TR] = *reinterpret_cast<const half8*>(row_ptr(kh + TR - 1) + ks * 64);
+        if (kh + TR < PR) a[(kh + TR) % AR] = *reinterpret_cast<const half8*>(row_ptr(kh + TR) + ks * 64);
         bq[(kh + BD - 1) % BD] = kh + BD - 1 < KH ? *b_ptr(ks, kh + BD - 1) : *b_ptr(ks_nx, kh + BD - 1 - KH);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < TR; ++m)   // m = TR - 1 uses the row requested just above: it goes last
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[kh % BD], a[(kh + m) % TR], acc[m], 0, 0, 0);
+        for (int m = 0; m < TR; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[kh % BD], a[(kh + m) % AR], acc[m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -48,6 +48,9 @@ PMC_PASSES = [
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
     ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
      "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+    # lane utilisation: thread-cycles of VALU work / (64 lanes x VALU instructions), both from THIS pass.  Calibration:
+    # kernels that run with a full EXEC mask (copyBuffer, pre_fill_kernel, morph_kernel) read 1.000 (profiles/r05_lane_util.txt)
+    ["SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU"],
 ]
 
 
@@ -94,7 +97,9 @@ def pmc_child(args):
         s1 = torch.from_numpy(np.ascontiguousarray(acc[ii])).to(dev)
         s2 = torch.from_numpy(np.ascontiguousarray(acc[jj])).to(dev)
         ev = torch.empty(len(ii), dtype=torch.uint8, device=dev)
-        for _ in range(4):
+        # --pmc-reps R batches (default 4; 0 = the setup alone: collect_pmc_live subtracts it, so that EVERY dispatch of a
+        # batch is accounted for -- two validity passes per batch, not just each kernel's largest launch)
+        for _ in range(args.pmc_reps):
             ctx.check_motions_dev(s1, s2, ev)
     elif mode == "sampler":
         se3 = torch.empty((args.batch, 7), dtype=torch.float64, device=dev)
@@ -143,14 +148,33 @@ def _read_pass(db_path):
         # "max_us" = the duration of the kernel's LARGE launches in the warm state: the median over the dispatches within
         # a factor 2 of the longest one (the S-state launches; the first few of a process run ~7 % slower than the rest)
         big = sorted(d for d in ds if 2 * d >= mx)
-        out[name] = {"n": len(ds), "avg_us": sum(ds) / len(ds) / 1e3, "max_us": big[len(big) // 2] / 1e3}
+        out[name] = {"n": len(ds), "avg_us": sum(ds) / len(ds) / 1e3, "max_us": big[len(big) // 2] / 1e3,
+                     "sum_us": sum(ds) / 1e3}
     try:
-        rows = db.execute("select kernel_name, counter_name, avg(value), max(value) from counters_collection "
+        rows = db.execute("select kernel_name, counter_name, avg(value), max(value), sum(value) from counters_collection "
                           "group by kernel_name, counter_name").fetchall()
     except sqlite3.OperationalError:
         rows = []
-    for kn, cn, avg, mx in rows:
+    for kn, cn, avg, mx, sm in rows:
         out.setdefault(kn, {})[cn] = mx  # the S-state launch is the largest dispatch of its kernel
+        out[kn].setdefault("sums", {})[cn] = sm
+    return out
+
+
+def per_batch_from_two_runs(with_reps, setup_only, reps):
+    """Per-kernel figures of ONE batch from two profiles of the same child -- `with_reps` ran the setup and `reps` batches,
+    `setup_only` the setup alone: (sum over all dispatches of A - the same of B) / reps, durations and counters alike.
+    Every dispatch of a batch is in the result (a two-pass checkMotion launches each pipeline kernel twice)."""
+    out = {}
+    for kn, a in with_reps.items():
+        b = setup_only.get(kn, {})
+        n = (a.get("n", 0) - b.get("n", 0)) / float(reps)
+        if n <= 0:
+            continue
+        d = {"dispatches_per_batch": n, "max_us": (a.get("sum_us", 0.0) - b.get("sum_us", 0.0)) / reps}
+        for cn, sm in a.get("sums", {}).items():
+            d[cn] = (sm - b.get("sums", {}).get(cn, 0.0)) / reps
+        out[kn] = d
     return out
 
 
@@ -164,28 +188,47 @@ def collect_pmc_live(args, mode="states", timeout_s=150):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     merged = {}
+
+    def run_child(i, counters, reps, tag):
+        out_dir = os.path.join(work, f"p{i}{tag}")
+        cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", out_dir, "-o", f"p{i}", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", mode, "--batch", str(args.batch),
+               "--map", str(args.map), "--res", str(args.res), "--edges", str(args.edges), "--pmc-reps", str(reps)]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        dbs = glob.glob(os.path.join(out_dir, "**", "*_results.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            raise RuntimeError(f"rocprofv3 pass {i}{tag} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}")
+        return _read_pass(dbs[0])
+
     try:
         for i, counters in enumerate(PMC_PASSES):
-            out_dir = os.path.join(work, f"p{i}")
-            cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", out_dir, "-o", f"p{i}", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", mode, "--batch", str(args.batch),
-                   "--map", str(args.map), "--res", str(args.res), "--edges", str(args.edges)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
-            dbs = glob.glob(os.path.join(out_dir, "**", "*_results.db"), recursive=True)
-            if r.returncode != 0 or not dbs:
-                return None, f"rocprofv3 pass {i} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
-            for kn, vals in _read_pass(dbs[0]).items():
+            if mode == "check_motion":
+                # all dispatches of a batch: (setup + 4 batches) - (setup alone), per kernel
+                res = per_batch_from_two_runs(run_child(i, counters, 4, "a"), run_child(i, counters, 0, "b"), 4)
+            else:
+                res = run_child(i, counters, 4, "")
+            for kn, vals in res.items():
                 m = merged.setdefault(kn, {})
+                if vals.get("SQ_THREAD_CYCLES_VALU") is not None and vals.get("SQ_INSTS_VALU"):
+                    m["valu_lane_util"] = lane_utilisation(vals["SQ_THREAD_CYCLES_VALU"], vals["SQ_INSTS_VALU"])
                 for key, v in vals.items():
                     if key == "max_us":
                         m.setdefault("max_us_by_pass", []).append(v)
-                    elif key not in ("n", "avg_us"):
+                    elif key not in ("n", "avg_us", "sum_us", "sums"):
                         m[key] = v
+    except RuntimeError as ex:
+        return None, str(ex)
     except Exception as ex:  # pragma: no cover
         return None, f"pmc collection failed: {ex!r}"
     finally:
         shutil.rmtree(work, ignore_errors=True)
     return summarise_pmc(merged, EDGE_KERNELS if mode == "check_motion" else ()), "live"
+
+
+def lane_utilisation(thread_cycles_valu, insts_valu):
+    """Useful lanes per VALU instruction: SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).  1.0 = every VALU instruction ran
+    with a full EXEC mask (calibrated on full-mask kernels: 1.000); an instruction issued for 16 of 64 lanes counts 0.25."""
+    return float(thread_cycles_valu) / (64.0 * float(insts_valu)) if insts_valu else None
 
 
 def summarise_pmc(per_kernel, extra_kernels=()):
@@ -195,7 +238,7 @@ def summarise_pmc(per_kernel, extra_kernels=()):
     kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs."""
     kernels = {}
     tot_fetch = tot_write = tot_us = 0.0
-    w_valu = w_lds = 0.0
+    w_valu = w_lds = w_lane = w_useful = w_lane_us = 0.0
     for kn, v in per_kernel.items():
         pk = next((p for p in list(PIPELINE) + list(extra_kernels) if p in kn), None)
         if pk is None or "GRBM_GUI_ACTIVE" not in v:
@@ -212,7 +255,10 @@ def summarise_pmc(per_kernel, extra_kernels=()):
              # every LDS wave-instruction moves at least 64 lanes x 4 B: a lower bound of the LDS traffic
              "lds_gbs_min": (v.get("SQ_INSTS_LDS", 0.0) * 256.0 / (us * 1e-6) / 1e9) if us else None,
              "wait_frac": (v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]) if v.get("SQ_WAVE_CYCLES") else None,
-             "l2_hit": hit / (hit + miss) if hit + miss else None}
+             "l2_hit": hit / (hit + miss) if hit + miss else None,
+             # useful lanes per VALU instruction (its own PMC pass) and issue occupancy x lane utilisation
+             "valu_lane_util": v.get("valu_lane_util"), "dispatches_per_batch": v.get("dispatches_per_batch")}
+        k["valu_useful"] = (k["valu_busy"] * k["valu_lane_util"]) if (k["valu_busy"] is not None and k["valu_lane_util"] is not None) else None
         kernels[pk] = k
         if pk not in ("sample_states_kernel",):
             tot_fetch += fetch
@@ -221,11 +267,17 @@ def summarise_pmc(per_kernel, extra_kernels=()):
                 tot_us += us
                 w_valu += (k["valu_busy"] or 0.0) * us
                 w_lds += (k["lds_busy"] or 0.0) * us
+                if k["valu_lane_util"] is not None:
+                    w_lane_us += us
+                    w_lane += k["valu_lane_util"] * us
+                    w_useful += (k["valu_useful"] or 0.0) * us
     if not kernels:
         return None
     return {"kernels": kernels, "validity_hbm_bytes_per_launch": tot_fetch + tot_write,
             "validity_kernel_us_sum": tot_us, "valu_busy_time_weighted": w_valu / tot_us if tot_us else None,
-            "lds_busy_time_weighted": w_lds / tot_us if tot_us else None, "csrc_hash": csrc_hash()}
+            "lds_busy_time_weighted": w_lds / tot_us if tot_us else None,
+            "valu_lane_util_time_weighted": w_lane / w_lane_us if w_lane_us else None,
+            "valu_useful_time_weighted": w_useful / w_lane_us if w_lane_us else None, "csrc_hash": csrc_hash()}
 
 
 def binding_fractions(pmc, hbm_traffic_frac):
@@ -237,6 +289,17 @@ def binding_fractions(pmc, hbm_traffic_frac):
     if hbm_traffic_frac is not None:
         out["hbm"] = float(hbm_traffic_frac)
     return out
+
+
+def roofline_fraction(pmc, bound, fracs):
+    """`roofline.frac`: for the VALU bound, issue occupancy x lane utilisation (an instruction issued for a quarter of the
+    lanes fills the issue port like a full one; only the product says how much of the vector unit does needed work); for
+    the other bounds the occupancy fraction itself."""
+    if bound is None:
+        return None
+    if bound == "valu_issue" and pmc and pmc.get("valu_useful_time_weighted") is not None:
+        return min(1.0, float(pmc["valu_useful_time_weighted"]))
+    return min(1.0, fracs[bound])
 
 
 def load_committed_pmc():
@@ -262,40 +325,149 @@ def load_committed_pmc():
 # ---------------------------------------------------------------------------------------------------------
 # CPU baseline legs (the ONLY users of the oracle in this file)
 # ---------------------------------------------------------------------------------------------------------
-def cpu_baseline(gm, states, target_s=12.0):
-    """The CPU oracle ("port": bit-identical restatement of the reference OMPL+ODE validity path,
-    faithful algorithmic structure) timed on this box's host cores on a bounded sample of the SAME
-    states the GPU validated.  Only the checker is used here -- never the product path."""
-    import oracle_py as O
-    rob = O.robot("yaml")
-    om = O.OracleMap(gm)
-    n1 = min(16384, len(states))
-    t0 = time.perf_counter()
-    v1 = om.states_valid(rob, states[:n1])
-    t1 = time.perf_counter()
-    r1 = n1 / (t1 - t0)
-    cores = os.cpu_count() or 1
-    n = int(min(len(states), max(n1, r1 * target_s * min(cores, 8) / 2)))
-    chunks = np.array_split(np.arange(n), cores)
-    out = np.empty(n, np.uint8)
-    maps = [O.OracleMap(gm) for _ in range(cores)]  # one private checker pair per thread
+def parse_cpu_max(text):
+    """cgroup v2 cpu.max: "max 100000" -> None (no quota), "800000 100000" -> 8.0 CPUs."""
+    parts = text.split()
+    if len(parts) < 2 or parts[0] == "max":
+        return None
+    try:
+        q, per = float(parts[0]), float(parts[1])
+    except ValueError:
+        return None
+    return q / per if q > 0 and per > 0 else None
 
-    def work(k):
-        idx = chunks[k]
-        if len(idx):
-            out[idx] = maps[k].states_valid(rob, states[idx])
 
-    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+def cgroup_cpu_quota(root="/sys/fs/cgroup"):
+    """CPUs the cgroup's bandwidth quota allows (None = unlimited / unknown): v2 cpu.max, v1 cpu.cfs_quota_us / period."""
+    try:
+        return parse_cpu_max(open(os.path.join(root, "cpu.max")).read())
+    except OSError:
+        pass
+    try:
+        q = float(open(os.path.join(root, "cpu", "cpu.cfs_quota_us")).read())
+        per = float(open(os.path.join(root, "cpu", "cpu.cfs_period_us")).read())
+        return q / per if q > 0 and per > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def host_cores(affinity=None, quota="probe"):
+    """(cores this process can really use, how that was derived): the scheduler affinity mask capped by the cgroup quota --
+    os.cpu_count() reports the MACHINE's logical CPUs, which a container may not get (`cores: 256` beside
+    an 8.3x speed-up)."""
+    if affinity is None:
+        affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if quota == "probe":
+        quota = cgroup_cpu_quota()
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 1e-9)))
+    return usable, {"os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "cgroup_quota_cpus": quota}
+
+
+def sweep_thread_counts(affinity):
+    """Thread counts of the CPU legs: 1, 8, 32, 64, 128 and every CPU of the affinity mask."""
+    return sorted({t for t in (1, 8, 32, 64, 128, affinity) if 1 <= t <= affinity})
+
+
+def run_threads(n_threads, work):
+    """work(k) on n_threads Python threads (the oracle calls release the GIL); returns the wall time."""
+    th = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
     t0 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
         t.join()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "states/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} sampler states of batch 0 (seed 42), oracle/artp_oracle.c faithful mode, "
-                      f"{cores} threads with private checkers; single thread: {r1:.0f} states/s on {n1}",
-            "single_core_value": r1}, out, v1
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(gm, states, target_s=14.0):
+    """The CPU oracle ("port": bit-identical restatement of the reference OMPL+ODE validity path, faithful algorithmic
+    structure) timed on this box's host cores on bounded samples of the SAME states the GPU validated: a sweep over
+    thread counts (one private checker pair per thread, static partition), the best point is `value`.  `cores` = what this
+    process may use (host_cores()).  Only the checker is used here -- never the product path."""
+    import oracle_py as O
+    rob = O.robot("yaml")
+    cores, how = host_cores()
+    aff = how["sched_affinity"]
+    counts = sweep_thread_counts(aff)
+    maps = [O.OracleMap(gm) for _ in range(max(counts))]  # one private checker pair per thread
+    n1 = min(16384, len(states))
+    t0 = time.perf_counter()
+    v1 = maps[0].states_valid(rob, states[:n1])
+    r1 = n1 / (time.perf_counter() - t0)
+    t_point = target_s / max(len(counts), 1)
+    sweep, best, best_labels = [], None, v1
+    for nt in counts:
+        # sized for ~t_point seconds if the threads scaled like min(nt, 16) cores; a point that scales worse just takes longer
+        n = int(min(len(states), max(n1, r1 * t_point * min(nt, 16))))
+        chunks = np.array_split(np.arange(n), nt)
+        out = np.empty(n, np.uint8)
+
+        def work(k, chunks=chunks, out=out):
+            idx = chunks[k]
+            if len(idx):
+                out[idx] = maps[k].states_valid(rob, states[idx])
+
+        dt = run_threads(nt, work)
+        pt = {"threads": nt, "states_per_s": n / dt, "states": n, "speedup_vs_1_thread": (n / dt) / r1}
+        sweep.append(pt)
+        if best is None or pt["states_per_s"] > best["states_per_s"]:
+            best, best_labels = pt, out
+    eff = best["states_per_s"] / r1
+    return {"value": best["states_per_s"], "unit": "states/s", "cores": cores, "cores_how": how, "kind": "port",
+            "threads_at_best": best["threads"], "thread_sweep": sweep,
+            "effective_cores_at_best": eff,
+            "sample": f"first {best['states']} sampler states of batch 0 (seed 42), oracle/artp_oracle.c faithful mode, "
+                      f"best of a sweep over {counts} threads (private checkers, static partition); single thread: "
+                      f"{r1:.0f} states/s on {n1}; the best point runs {eff:.1f}x one thread",
+            "single_core_value": r1}, best_labels, v1
+
+
+def reference_ode_rates(gm, states, labels, thread_counts, m=20000):
+    """The REAL patched ODE (oracle/_ref, kind "reference") driven like HeightMapBoxChecker, same states: one thread and the
+    given thread counts (every thread: dAllocateODEDataForThread + its own world / space / geoms)."""
+    import oracle_py as O
+    rob = O.robot("yaml")
+    om = O.OracleMap(gm)
+    m = min(m, len(states))
+    poses, inside = om.state_poses(rob, states[:m])
+    ok_all = np.zeros(m, np.uint8)
+
+    def leg(nt):
+        chunks = np.array_split(np.arange(m), nt)
+        gate = threading.Barrier(nt + 1)   # the clock starts when every thread has its ODE world and height fields
+
+        def work(k):
+            O.ref_lib().artp_ref_thread_init()
+            rb = O.RefChecker(rob.torso, gm["elevation"], gm.len_x, gm.len_y)
+            rf = O.RefChecker(rob.foot, gm["elevation_masked"], gm.len_x, gm.len_y)
+            gate.wait()
+            idx0 = chunks[k]
+            if len(idx0):
+                hb = rb.check(poses[idx0, 0])
+                ok = (hb == 0) | (inside[idx0, 0] == 0)
+                for f in range(4):  # same short-circuit as the reference
+                    sel = np.flatnonzero(ok)
+                    hk = rf.check(poses[idx0[sel], 1 + f])
+                    ok[sel] = np.where(inside[idx0[sel], 1 + f] != 0, hk != 0, False)
+                ok_all[idx0] = ok.astype(np.uint8)
+            rb.close()
+            rf.close()
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(nt)]
+        for t in th:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        return m / (time.perf_counter() - t0)
+
+    out = {"states": m, "threads": {}}
+    for nt in thread_counts:
+        out["threads"][str(nt)] = leg(nt)
+        out.setdefault("labels_match_gpu", True)
+        out["labels_match_gpu"] = bool(out["labels_match_gpu"] and np.array_equal(ok_all, labels[:m]))
+    return out
 
 
 def c1_leg(local_rank):
@@ -493,6 +665,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
     ap.add_argument("--pmc-child", nargs="?", const="states", default=None,
                     choices=["states", "check_motion", "sampler"], help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-reps", type=int, default=4, help=argparse.SUPPRESS)
     ap.add_argument("--skip-extras", action="store_true", help="no edge / motion-cost measurements (profiling)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="parts of a step's batch validated side by side on as many streams of the context (1..4); "
@@ -751,6 +924,19 @@ def main():
             per_rank_ms[tag] = [t_local / n_steps * 1e3]
         wd.done()
         return dt_
+
+    # ---- the cold step: the first batches after the device idled (a 10 Hz replanner never reaches the steady state the
+    # headline region is measured in; profiles/r04_cold_probe.txt) -- HIP events around 4 batches after 2 s without work
+    cold_ms = None
+    if not multi and not args.skip_extras:
+        time.sleep(2.0)
+        e0c, e1c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0c.record()
+        for i in range(4):
+            ctx.sample_and_validate_dev(seed, first_index(5000000 + i), S, se3, valid)
+        e1c.record()
+        torch.cuda.synchronize()
+        cold_ms = e0c.elapsed_time(e1c) / 4
 
     # ---- the headline region -----------------------------------------------------------------------
     base_line = {"metric": "validated states/sec on 400x400@0.04m map (sample + validity check)", "unit": "states/s",
@@ -1021,7 +1207,10 @@ def main():
                                "time-weighted over the pipeline's kernels",
                  "lds": "fraction of LDS issue cycles", "hbm": "fraction of the 8 TB/s HBM peak (PMC traffic / time)",
                  None: None}[bound],
-        "frac": None if bound is None else min(1.0, fracs[bound]),
+        "frac": roofline_fraction(pmc, bound, fracs),
+        "frac_is": "VALU issue occupancy x VALU lane utilisation, time-weighted over the pipeline's kernels (bound valu_issue); "
+                   "the occupancy fraction itself for the other bounds",
+        "valu_lane_util_time_weighted": None if not pmc else pmc.get("valu_lane_util_time_weighted"),
         "occupancy_fractions": fracs,
         "traffic": traffic, "hbm_traffic_frac": hbm_traffic_frac,
         "kernel": "validity pipeline (artp_validate_states_dev)", "kernel_ms": k_ms,
@@ -1099,13 +1288,16 @@ def main():
                 edges["check_motion"]["binding"] = {
                     "bound": max(fr_e, key=fr_e.get), "occupancy_fractions": fr_e,
                     "valu_busy_time_weighted": pmc_e["valu_busy_time_weighted"],
+                    "valu_lane_util_time_weighted": pmc_e.get("valu_lane_util_time_weighted"),
+                    "valu_useful_time_weighted": pmc_e.get("valu_useful_time_weighted"),
                     "lds_busy_time_weighted": pmc_e["lds_busy_time_weighted"],
                     "hbm_bytes_per_batch": pmc_e["validity_hbm_bytes_per_launch"],
                     "hbm_traffic_frac_of_peak": pmc_e["validity_hbm_bytes_per_launch"] / (ms_cm * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "pmc_kernel_us_sum_vs_hip_events_ms": [pmc_e["validity_kernel_us_sum"], ms_cm],
                     "per_kernel": pmc_e["kernels"], "pmc_source": note_e,
-                    "what": "one artp_check_motions_dev batch of E edges alone under rocprofv3 --pmc (bench.py --pmc-child "
-                            "check_motion): plan + scan + expand, the validity pipeline on the expanded states, reduce"}
+                    "what": "one artp_check_motions_dev batch of E edges under rocprofv3 --pmc, ALL its dispatches (both "
+                            "validity passes): (setup + 4 batches) - (setup alone), per kernel, / 4 (bench.py --pmc-child "
+                            "check_motion --pmc-reps 4 / 0): plan + scan + expand, the validity pipeline twice, reduce"}
             else:
                 edges["check_motion"]["binding"] = {"error": note_e}
 
@@ -1395,26 +1587,16 @@ def main():
         cpu, cpu_labels, _ = cpu_baseline(gm, states)
         n_cpu = len(cpu_labels)
         cpu["labels_match_gpu"] = bool(np.array_equal(cpu_labels, labels[:n_cpu]))
-        # the real patched ODE (kind "reference"), single thread, when oracle/_ref travelled here
+        # the real patched ODE (kind "reference") when oracle/_ref travelled here: one thread and the sweep's best count
         try:
             import oracle_py as O
             if O.have_ref():
-                rob = O.robot("yaml")
-                om = O.OracleMap(gm)
-                m = min(20000, len(states))
-                poses, inside = om.state_poses(rob, states[:m])
-                rb = O.RefChecker(rob.torso, gm["elevation"], gm.len_x, gm.len_y)
-                rf = O.RefChecker(rob.foot, gm["elevation_masked"], gm.len_x, gm.len_y)
-                t0 = time.perf_counter()
-                hb = rb.check(poses[:, 0])
-                ok = (hb == 0) | (inside[:, 0] == 0)
-                for k in range(4):  # same short-circuit as the reference
-                    idx = np.flatnonzero(ok)
-                    hk = rf.check(poses[idx, 1 + k])
-                    ok[idx] = np.where(inside[idx, 1 + k] != 0, hk != 0, False)
-                dtr = time.perf_counter() - t0
-                cpu["reference_ode_single_core_states_per_s"] = m / dtr
-                cpu["reference_ode_labels_match_gpu"] = bool(np.array_equal(ok.astype(np.uint8), labels[:m]))
+                tcs = sorted({1, min(8, cpu["cores_how"]["sched_affinity"]), cpu["threads_at_best"]})
+                ref = reference_ode_rates(gm, states, labels, tcs)
+                cpu["reference_ode"] = ref
+                cpu["reference_ode_single_core_states_per_s"] = ref["threads"]["1"]
+                cpu["reference_ode_best_states_per_s"] = max(ref["threads"].values())
+                cpu["reference_ode_labels_match_gpu"] = ref["labels_match_gpu"]
         except Exception as e:  # pragma: no cover
             cpu["reference_ode_error"] = repr(e)
         # edges/s of the CPU path on a bounded sample of the same edges (single thread)
@@ -1440,6 +1622,26 @@ def main():
         except Exception as e:  # pragma: no cover
             cpu["c1"] = {"error": repr(e)}
 
+    # a roofline fraction for every kernel that has one of its own
+    kernel_rooflines = {
+        "sampler": {"bound": "hbm", "bytes_per_batch": 56.0 * S, "ms": sample_ms,
+                    "achieved_GBps": 56.0 * S / (sample_ms * 1e-3) / 1e9, "frac": 56.0 * S / (sample_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "what": "artp_sample_states_dev alone: 7 f64 written per state (algorithmic bytes; the CDF tables stay in L2)"}}
+    if motion_cost and "error" not in motion_cost:
+        for Bq in (50000, 1 << 20):
+            q = motion_cost.get(f"cost_queries_{Bq}")
+            if q:
+                kernel_rooflines[f"cost_query_{Bq}"] = {
+                    "bound": "hbm", "bytes_per_batch": 132.0 * Bq, "ms": q["ms"], "achieved_GBps": 132.0 * Bq / (q["ms"] * 1e-3) / 1e9,
+                    "frac": 132.0 * Bq / (q["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "what": "fc_cost_mfma_kernel: 24 B edge row + 96 B gathered features + 12 B costs per edge (SURVEY 8d)"}
+        for tag in ("c3_400", "c4_800"):
+            m_ = motion_cost.get(tag)
+            if m_:
+                kernel_rooflines[f"cnn_{tag}"] = {"bound": "mfma", "gflop": m_["cnn_gflop"], "ms": m_["cnn_kernels_ms"],
+                                                  "achieved_TFLOPs": m_["cnn_kernels_tflops"], "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS,
+                                                  "frac": m_["cnn_kernels_frac_of_mfma_f16_peak"]}
+
     out = {
         "metric": "validated states/sec on 400x400@0.04m map (sample + validity check)",
         "value": value, "unit": "states/s", "n_gpus": N, "steps": K, "warmup": W,
@@ -1457,6 +1659,25 @@ def main():
                                 f"{'all' if args.materialise < 0 else args.materialise} accepted states of every rank per step "
                                 "re-materialised on every rank" if do_gather else "")},
         # the metric's second half (BASELINE.json: "validated states/sec + edges/sec"): E edges per batch, HIP events
+        # the figures a reader wants first, flat and near the front (the tail of a long line gets truncated in records)
+        "headline": {
+            "value_edges": edges.get("check_motion", {}).get("edges_per_s"),
+            "value_edges_interp": edges.get("interp_0p5m", {}).get("edges_per_s"),
+            "ms_per_step_cold_after_2s_idle": cold_ms,
+            "roofline_bound": roofline["bound"], "roofline_frac": roofline["frac"],
+            "valu_issue_occupancy": roofline["occupancy_fractions"].get("valu_issue") if roofline["occupancy_fractions"] else None,
+            "valu_lane_util": roofline["valu_lane_util_time_weighted"],
+            "hbm_traffic_frac": roofline["hbm_traffic_frac"],
+            "cnn_c3_frac_of_mfma_f16_peak": ((motion_cost or {}).get("c3_400") or {}).get("cnn_kernels_frac_of_mfma_f16_peak"),
+            "cnn_c4_frac_of_mfma_f16_peak": ((motion_cost or {}).get("c4_800") or {}).get("cnn_kernels_frac_of_mfma_f16_peak"),
+            "cost_queries_per_s_2e20": ((motion_cost or {}).get(f"cost_queries_{1 << 20}") or {}).get("queries_per_s"),
+            "c5_cycle_ms_median": (c5 or {}).get("cycle_ms_median"), "c5_sustained_states_per_s": (c5 or {}).get("sustained_states_per_s"),
+            "cpu_port_states_per_s": (cpu or {}).get("value"), "cpu_cores": (cpu or {}).get("cores"),
+            "cpu_threads_at_best": (cpu or {}).get("threads_at_best"),
+            "cpu_reference_ode_best_states_per_s": (cpu or {}).get("reference_ode_best_states_per_s"),
+            "labels_match_cpu": (cpu or {}).get("labels_match_gpu"),
+        },
+        "kernel_rooflines": kernel_rooflines,
         "metric_edges": "validated edges/sec on the same map: OMPL DiscreteMotionValidator::checkMotion (value_edges) and "
                         "the 0.5 m interpolation rule of PRMMotionCost::addValidMilestone (value_edges_interp)",
         "value_edges": edges.get("check_motion", {}).get("edges_per_s"),

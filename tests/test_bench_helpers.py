@@ -113,3 +113,85 @@ def test_the_reported_bound_is_derived_from_the_counters():
     fr = bench.binding_fractions({"valu_busy_time_weighted": 0.2, "lds_busy_time_weighted": 0.1}, 0.7)
     assert max(fr, key=fr.get) == "hbm"
     assert set(bench.binding_fractions(pmc, None)) == {"valu_issue", "lds"}
+
+
+def test_host_core_count_is_the_affinity_mask_capped_by_the_cgroup_quota():
+    """`cores` must be what the process may use, not the machine's logical CPU count."""
+    assert bench.parse_cpu_max("max 100000\n") is None
+    assert bench.parse_cpu_max("800000 100000") == 8.0
+    assert bench.parse_cpu_max("150000 100000") == 1.5
+    assert bench.parse_cpu_max("garbage") is None
+    assert bench.host_cores(affinity=256, quota=8.0)[0] == 8
+    assert bench.host_cores(affinity=256, quota=None)[0] == 256
+    assert bench.host_cores(affinity=4, quota=8.0)[0] == 4
+    assert bench.host_cores(affinity=16, quota=0.5)[0] == 1
+    n, how = bench.host_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and how["sched_affinity"] >= n
+    assert bench.sweep_thread_counts(256) == [1, 8, 32, 64, 128, 256]
+    assert bench.sweep_thread_counts(8) == [1, 8]
+    assert bench.sweep_thread_counts(48) == [1, 8, 32, 48]
+    assert bench.sweep_thread_counts(1) == [1]
+
+
+def test_cgroup_quota_is_read_from_v2_and_v1_files(tmp_path):
+    (tmp_path / "cpu.max").write_text("400000 100000\n")
+    assert bench.cgroup_cpu_quota(str(tmp_path)) == 4.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cgroup_cpu_quota(str(tmp_path)) is None
+    v1 = tmp_path / "v1"
+    os.makedirs(v1 / "cpu")
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cgroup_cpu_quota(str(v1)) == 2.5
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.cgroup_cpu_quota(str(v1)) is None
+    assert bench.cgroup_cpu_quota(str(tmp_path / "nowhere")) is None
+
+
+def test_cpu_thread_legs_run_the_work_of_every_thread():
+    hits = []
+    dt = bench.run_threads(5, lambda k: hits.append(k))
+    assert sorted(hits) == [0, 1, 2, 3, 4] and dt >= 0.0
+
+
+def test_per_batch_pmc_figures_count_every_dispatch_of_a_batch():
+    """a two-pass checkMotion launches each pipeline kernel twice per batch; the summary must carry
+    both (it kept the largest dispatch only: 1.44 of 1.98 ms).  (setup + 4 batches) - (setup alone), per kernel, / 4."""
+    setup = {"classify": {"n": 1, "sum_us": 400.0, "sums": {"GRBM_GUI_ACTIVE": 8e5, "SQ_ACTIVE_INST_VALU": 1e5}},
+             "preproc": {"n": 7, "sum_us": 90.0, "sums": {"GRBM_GUI_ACTIVE": 1e5}}}
+    full = {"classify": {"n": 1 + 4 * 2, "sum_us": 400.0 + 4 * (170.0 + 730.0),
+                         "sums": {"GRBM_GUI_ACTIVE": 8e5 + 4 * (3e5 + 13e5), "SQ_ACTIVE_INST_VALU": 1e5 + 4 * 6e5}},
+            "preproc": {"n": 7, "sum_us": 90.0, "sums": {"GRBM_GUI_ACTIVE": 1e5}},
+            "expand": {"n": 8, "sum_us": 4 * (55.0 + 211.0), "sums": {"GRBM_GUI_ACTIVE": 4 * 5e5}}}
+    pb = bench.per_batch_from_two_runs(full, setup, 4)
+    assert set(pb) == {"classify", "expand"}                       # the setup's own kernels cancel
+    assert pb["classify"]["dispatches_per_batch"] == 2.0 and abs(pb["classify"]["max_us"] - 900.0) < 1e-9
+    assert abs(pb["classify"]["GRBM_GUI_ACTIVE"] - 16e5) < 1e-6 and abs(pb["classify"]["SQ_ACTIVE_INST_VALU"] - 6e5) < 1e-6
+    assert abs(pb["expand"]["max_us"] - 266.0) < 1e-9
+
+
+def test_lane_utilisation_and_the_roofline_fraction():
+    """issue occupancy alone counts an instruction issued for 16 lanes like a full one."""
+    assert bench.lane_utilisation(64.0 * 1000, 1000) == 1.0
+    assert bench.lane_utilisation(16.0 * 1000, 1000) == 0.25
+    assert bench.lane_utilisation(1.0, 0) is None
+    cyc = 2.0e6
+    per_kernel = {
+        "void artp::feet_stream_kernel<4>(...)": {
+            "GRBM_GUI_ACTIVE": 8 * cyc, "SQ_ACTIVE_INST_VALU": 1.0 * bench.N_SIMD * cyc / 4, "SQ_ACTIVE_INST_LDS": 0.0,
+            "valu_lane_util": 0.5, "max_us_by_pass": [300.0]},
+        "void artp::classify_states_kernel(...)": {
+            "GRBM_GUI_ACTIVE": 8 * cyc, "SQ_ACTIVE_INST_VALU": 0.6 * bench.N_SIMD * cyc / 4, "SQ_ACTIVE_INST_LDS": 0.0,
+            "valu_lane_util": 0.75, "max_us_by_pass": [100.0]},
+    }
+    s = bench.summarise_pmc(per_kernel)
+    assert abs(s["kernels"]["feet_stream_kernel"]["valu_useful"] - 0.5) < 1e-12
+    assert abs(s["kernels"]["classify_states_kernel"]["valu_useful"] - 0.45) < 1e-12
+    assert abs(s["valu_busy_time_weighted"] - 0.9) < 1e-12
+    assert abs(s["valu_lane_util_time_weighted"] - (0.5 * 300 + 0.75 * 100) / 400) < 1e-12
+    assert abs(s["valu_useful_time_weighted"] - (0.5 * 300 + 0.45 * 100) / 400) < 1e-12
+    fr = bench.binding_fractions(s, 0.1)
+    assert max(fr, key=fr.get) == "valu_issue"
+    assert abs(bench.roofline_fraction(s, "valu_issue", fr) - s["valu_useful_time_weighted"]) < 1e-12
+    assert bench.roofline_fraction(s, "hbm", {"hbm": 0.7}) == 0.7
+    assert bench.roofline_fraction(None, None, {}) is None
