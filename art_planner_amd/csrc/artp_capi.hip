@@ -115,6 +115,7 @@ struct artp_ctx {
   half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
+  double r3_extent_override = 0.0;     // artp_set_r3_extent: > 0 = checkMotion's R^3 maxExtent, whatever the installed map's bounds
   int fc_mfma = 1;                     // $ARTP_FC_MFMA=0: the fp32 VALU kernels (tuning / comparison)
   int fc_selfcheck = -1;               // artp_cost_load_weights' probe batch: 1 = the MFMA kernel agreed with the fp32 one,
                                        // 0 = it did not (fc_mfma forced to 0), -1 = not run
@@ -1604,6 +1605,13 @@ int artp_sample_and_validate(artp_ctx* c, uint64_t seed, uint64_t first_index, s
   return check_error_flag(c);
 }
 
+int artp_set_r3_extent(artp_ctx* c, double max_extent) {
+  if (!c || !(max_extent >= 0.0)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->r3_extent_override = max_extent;
+  return ARTP_OK;
+}
+
 int artp_set_z_bounds(artp_ctx* c, double z_low, double z_high) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1656,7 +1664,7 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   hipLaunchKernelGGL(motion_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->geom,
                      c->z_high - c->z_low, mode, s1, s2, n, counts, aux, valid, d_overflow, d_total, d_slerp,
                      two_pass_possible ? counts1 : (uint32_t*)nullptr, two_pass_possible ? d_total1 : (unsigned long long*)nullptr,
-                     (uint32_t)c->edge_coarse_stride);
+                     (uint32_t)c->edge_coarse_stride, c->r3_extent_override);
   HIP_TRY(c, hipGetLastError());
   size_t need = 0;
   HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(n + 1), c->stream));

@@ -877,7 +877,7 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
                    uint32_t* __restrict__ aux, uint8_t* __restrict__ valid, int* __restrict__ overflow,
                    unsigned long long* __restrict__ total64, SlerpEdge* __restrict__ slerp,
                    uint32_t* __restrict__ counts_pass1 = nullptr, unsigned long long* __restrict__ total_pass1 = nullptr,
-                   uint32_t coarse_stride = ARTP_COARSE_STRIDE) {
+                   uint32_t coarse_stride = ARTP_COARSE_STRIDE, double r3_extent_override = 0.0) {
   unsigned long long my_total = 0, my_total1 = 0;
   int my_overflow = 0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
@@ -894,7 +894,9 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
       ext += ex * ex;
       ext += ey * ey;
       ext += z_extent * z_extent;
-      const double seg_r3 = sqrt(ext) * 0.01;
+      // artp_set_r3_extent: the R^3 maxExtent frozen at an earlier map's bounds (OMPL keeps longestValidSegment_ from
+      // the first StateSpace::setup(), planner.cpp:146-163 never re-runs it)
+      const double seg_r3 = (r3_extent_override > 0.0 ? r3_extent_override : sqrt(ext)) * 0.01;
       double d2 = 0.0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {

@@ -178,8 +178,25 @@ class BatchPRM {
     return v;
   }
 
+  // the roadmap's candidate edges: uv (n x 2, u < v), the interpolation-rule verdict, "removed by the lazy path check",
+  // the objective's cost (any pointer may be null)
+  void edges(std::vector<uint32_t>* uv, std::vector<uint8_t>* valid, std::vector<uint8_t>* removed,
+             std::vector<double>* cost) const {
+    const size_t n = rm_ ? stat(1) : 0;
+    if (uv) uv->assign(2 * n, 0u);
+    if (valid) valid->assign(n, 0);
+    if (removed) removed->assign(n, 0);
+    if (cost) cost->assign(n, 0.0);
+    if (n)
+      throwOnError(gpu_->get(),
+                   artp_roadmap_export(rm_, nullptr, nullptr, nullptr, uv ? uv->data() : nullptr, valid ? valid->data() : nullptr,
+                                       nullptr, cost ? cost->data() : nullptr, removed ? removed->data() : nullptr),
+                   "artp_roadmap_export");
+  }
+
   size_t numVertices() const { return stat(0); }
   size_t numEdges() const { return stat(2); }
+  size_t numCandidateEdges() const { return stat(1); }
 
   static StateArray flatten(const ob::SE3StateSpace::StateType& s) {
     return {s.getX(), s.getY(), s.getZ(), s.rotation().x, s.rotation().y, s.rotation().z, s.rotation().w};
@@ -198,6 +215,14 @@ class BatchPRM {
   int construction_{0};
   artp_preprocessed* density_map_{nullptr};
   artp_preprocess_params density_params_{};
+};
+
+// The roadmap as art_planner::Planner and the ob::Planner shell set as ss_'s planner (planners/prm_motion_cost.h,
+// planners/lazy_prm_star_min_update.h) share it: one graph, whoever drives it.
+struct RoadmapHandle {
+  std::shared_ptr<BatchPRM> prm;
+  ParamsConstPtr params;
+  bool built{false};   // sampleGraph has run for the current graph (Planner's have_roadmap_)
 };
 
 }  // namespace art_planner

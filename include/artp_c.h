@@ -169,6 +169,11 @@ int artp_sample_and_validate(artp_ctx* ctx, uint64_t seed, uint64_t first_index,
  * R^3 bounds for validSegmentCount follow planner.cpp:146-156; z bounds come from
  * artp_set_z_bounds (min/max finite elevation -/+ reach.z/2). */
 int artp_set_z_bounds(artp_ctx* ctx, double z_low, double z_high);
+/* checkMotion's R^3 maxExtent (the diagonal of the state space's x / y / z bounds; the segment length is 1 % of it)
+ * fixed to max_extent instead of following the installed map and the z bounds; 0 = follow them (default).  For hosts that
+ * want OMPL's own behaviour: Planner::setMap calls space_->setBounds (planner.cpp:146-163) but nothing re-runs
+ * StateSpace::setup(), so longestValidSegment_ stays at the FIRST planned map's extents. */
+int artp_set_r3_extent(artp_ctx* ctx, double max_extent);
 int artp_check_motions(artp_ctx* ctx, const double* s1, const double* s2, size_t n, uint8_t* valid);
 int artp_check_motions_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
                            uint8_t* valid);

@@ -2,17 +2,17 @@
 // (planner.h:70) and PlannerRos's converter (pathOmplToRos walks getStates()) use it.
 #pragma once
 #include <vector>
-#include "art_planner/ompl_standins.h"
+#include "art_planner/ompl_standins_planning.h"
 namespace ompl {
 namespace geometric {
-class PathGeometric {
+class PathGeometric : public base::Path {
  public:
-  explicit PathGeometric(const base::SpaceInformationPtr& si) : si_(si) {}
-  PathGeometric(const PathGeometric& other) : si_(other.si_) {
+  explicit PathGeometric(const base::SpaceInformationPtr& si) : base::Path(si) {}
+  PathGeometric(const PathGeometric& other) : base::Path(other.si_) {
     for (const base::State* s : other.states_) append(s);
   }
   PathGeometric& operator=(const PathGeometric&) = delete;
-  ~PathGeometric() {
+  ~PathGeometric() override {
     for (base::State* s : states_) si_->freeState(s);
   }
   void append(const base::State* state) {  // copies, like OMPL
@@ -24,10 +24,8 @@ class PathGeometric {
   base::State* getState(unsigned int index) { return states_[index]; }
   const base::State* getState(unsigned int index) const { return states_[index]; }
   std::vector<base::State*>& getStates() { return states_; }
-  const base::SpaceInformationPtr& getSpaceInformation() const { return si_; }
 
  private:
-  base::SpaceInformationPtr si_;
   std::vector<base::State*> states_;
 };
 }  // namespace geometric
