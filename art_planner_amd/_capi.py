@@ -38,7 +38,7 @@ SYMBOLS = [
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
     "artp_inpaint_layer", "artp_cost_set_hole_filling",
     "artp_cost_blob_bytes", "artp_cost_load_weights", "artp_cost_update_map_layer",
-    "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features", "artp_cost_debug_query_cells", "artp_cost_fc_path", "artp_set_r3_extent",
+    "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features", "artp_cost_debug_query_cells", "artp_cost_fc_path", "artp_set_r3_extent", "artp_telea_inpaint_u8",
 ]
 
 
@@ -213,6 +213,7 @@ def load():
     L.artp_cost_debug_query_cells.argtypes = [vp, vp, sz, vp, vp]
     L.artp_cost_get_features.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.artp_set_r3_extent.argtypes = [vp, dbl]
+    L.artp_telea_inpaint_u8.argtypes = [vp, vp, i32, i32, i32, vp]
     L.artp_cost_fc_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     for name in SYMBOLS:
         fn = getattr(L, name)

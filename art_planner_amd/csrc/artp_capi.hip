@@ -130,6 +130,7 @@ struct artp_ctx {
   int feat_h = 0, feat_w = 0;
   bool have_features = false;
   bool cost_fill_holes = false;        // artp_cost_set_hole_filling
+  bool cost_fill_telea = false;   // artp_cost_set_hole_filling(ctx, 2): Telea's fast-marching fill (telea.h)
   std::string last_error;
   std::string arch;
   std::recursive_mutex mu;  // recursive: host entry points hold it across the _dev calls they are built from

@@ -13,6 +13,7 @@
 // pixels) and inpainting is left to the caller -- parity for this row is unpinned; the tests compare with
 // the numpy restatement that also generates the benchmark maps (art_planner_amd/synthetic.py).
 #pragma once
+#include "telea.h"
 
 namespace artp {
 
@@ -964,6 +965,7 @@ static int inpaint_dev(artp_ctx* c, const float* d_in, int rows, int cols, int m
   };
   if (hipMemsetAsync(d_holes, 0, 8, st) != hipSuccess) return fail(ARTP_ERR_HIP);
   if (!any || !(hi > lo)) {
+    mode &= 1;
     // no valid cell at all, or a constant layer (the reference divides by max - min = 0 here): holes take the
     // constant, nothing is quantised
     hipLaunchKernelGGL(artp::inpaint_quantise_kernel, grid, blk, 0, st, d_in, (int)n, mode, 0.0f, 1.0f, q, known, d_holes);
@@ -978,6 +980,8 @@ static int inpaint_dev(artp_ctx* c, const float* d_in, int rows, int cols, int m
     if (hipMemcpy(d_out, tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(ARTP_ERR_HIP);
     return fail(ARTP_OK);
   }
+  const bool telea = (mode & ARTP_INPAINT_TELEA) != 0;
+  mode &= 1;
   hipLaunchKernelGGL(artp::inpaint_quantise_kernel, grid, blk, 0, st, d_in, (int)n, mode, lo, hi, q, known, d_holes);
   unsigned long long h = 0;
   if (hipMemcpyAsync(&h, d_holes, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
@@ -989,7 +993,30 @@ static int inpaint_dev(artp_ctx* c, const float* d_in, int rows, int cols, int m
     if (hipStreamSynchronize(st) != hipSuccess) return fail(ARTP_ERR_HIP);
     return fail(ARTP_OK);
   }
-  for (int group = 0; group < (rows + cols) / 3 + 2; ++group) {
+  if (telea) {
+    // Telea's fast-marching fill (telea.h) on the host, on the image as the reference hands it to cv::inpaint: the planner
+    // wraps the column-major layer as a cv::Mat(cols, rows) (utils.cpp:16-19: the buffer read row-major), the cost node
+    // works on a[r][c] = layer(rows - 1 - r, cols - 1 - c) (cost_query_server.py:74)
+    std::vector<unsigned char> hq(n), hk(n), img(n), msk(n);
+    if (hipMemcpyAsync(hq.data(), q, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(hk.data(), known, n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+    auto src_of = [&](size_t i) {   // image index -> layer index
+      if (mode == 0) return i;
+      const size_t r = i / (size_t)cols, cc = i % (size_t)cols;
+      return ((size_t)rows - 1 - r) + ((size_t)cols - 1 - cc) * (size_t)rows;
+    };
+    for (size_t i = 0; i < n; ++i) {
+      img[i] = hq[src_of(i)];
+      msk[i] = hk[src_of(i)] ? 0 : 1;
+    }
+    if (mode == 0) artp_telea::inpaint_u8(cols, rows, img.data(), msk.data(), 3);
+    else artp_telea::inpaint_u8(rows, cols, img.data(), msk.data(), 3);
+    for (size_t i = 0; i < n; ++i) hq[src_of(i)] = img[i];
+    if (hipMemcpyAsync(q, hq.data(), n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(ARTP_ERR_HIP);
+  }
+  for (int group = 0; !telea && group < (rows + cols) / 3 + 2; ++group) {
     if (hipMemsetAsync(d_left, 0, 4, st) != hipSuccess) return fail(ARTP_ERR_HIP);
     for (int p = 0; p < 4; ++p) {  // an even number of passes: the result is back in (q, known)
       hipLaunchKernelGGL(artp::inpaint_fill_pass_kernel, grid, blk, 0, st, (const unsigned char*)q,
@@ -1009,7 +1036,7 @@ static int inpaint_dev(artp_ctx* c, const float* d_in, int rows, int cols, int m
 }
 
 int artp_inpaint_layer(artp_ctx* c, const float* layer, int rows, int cols, int mode, float* out, uint64_t* n_holes) {
-  if (!c || !layer || !out || rows < 1 || cols < 1 || mode < 0 || mode > 1) return ARTP_ERR_INVALID_ARG;
+  if (!c || !layer || !out || rows < 1 || cols < 1 || mode < 0 || mode > 3) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t n = (size_t)rows * cols;
@@ -1022,10 +1049,18 @@ int artp_inpaint_layer(artp_ctx* c, const float* layer, int rows, int cols, int 
   return rc;
 }
 
+int artp_telea_inpaint_u8(const uint8_t* img, const uint8_t* mask, int h, int w, int range, uint8_t* out) {
+  if (!img || !mask || !out || h < 1 || w < 1 || range < 1 || range > 16) return ARTP_ERR_INVALID_ARG;
+  if (out != img) std::memcpy(out, img, (size_t)h * w);
+  artp_telea::inpaint_u8(h, w, out, mask, range);
+  return ARTP_OK;
+}
+
 int artp_cost_set_hole_filling(artp_ctx* c, int enabled) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  c->cost_fill_holes = enabled != 0;
+  c->cost_fill_holes = enabled != 0;      // 2: with Telea's fill (ARTP_INPAINT_TELEA)
+  c->cost_fill_telea = enabled == 2;
   return ARTP_OK;
 }
 
@@ -1034,7 +1069,8 @@ int cost_update_map_layer_filled(artp_ctx* c, const float* layer, int rows, int 
                                  double len_y, double pos_x, double pos_y) {
   std::vector<float> filled((size_t)rows * cols);
   uint64_t holes = 0;
-  const int rc = artp_inpaint_layer(c, layer, rows, cols, ARTP_INPAINT_COST_NODE, filled.data(), &holes);
+  const int rc = artp_inpaint_layer(c, layer, rows, cols, ARTP_INPAINT_COST_NODE | (c->cost_fill_telea ? ARTP_INPAINT_TELEA : 0),
+                                    filled.data(), &holes);
   if (rc != ARTP_OK) return rc;
   c->cost_fill_holes = false;  // the filled layer has no holes; avoid recursion
   const int rc2 = artp_cost_update_map_layer(c, filled.data(), rows, cols, res, len_x, len_y, pos_x, pos_y);

@@ -475,11 +475,19 @@ int artp_preprocessed_change(artp_ctx* ctx, artp_preprocessed* map_new, const ar
  * ARTP_INPAINT_PLANNER: NaN cells are the holes, cv::convertTo rounding, column 0 := column 1 / row 0 := row 1
  * afterwards) and the cost node's _elvMapProcess (cost_query_server.py:92-111, ARTP_INPAINT_COST_NODE: non-finite
  * cells are the holes, numpy truncation).  Like the reference the WHOLE layer comes back quantised to 8 bit over
- * [min, max] of its valid cells -- that part is restated exactly; the fill of the hole cells is a rim-inwards
- * distance-weighted mean (radius 3), NOT OpenCV's Telea marching (OpenCV is not available: unpinned).  A layer
- * without holes is returned unchanged.  *n_holes (optional) = hole cells. */
-enum { ARTP_INPAINT_PLANNER = 0, ARTP_INPAINT_COST_NODE = 1 };
+ * [min, max] of its valid cells -- that part is restated exactly; the fill of the hole cells is by default a rim-inwards
+ * distance-weighted mean (radius 3, on the device), with ARTP_INPAINT_TELEA Telea's marching like cv::inpaint (host).
+ * OpenCV is not available here: both fills are unpinned.  A layer without holes is returned unchanged.
+ * *n_holes (optional) = hole cells. */
+enum { ARTP_INPAINT_PLANNER = 0, ARTP_INPAINT_COST_NODE = 1,
+       /* OR-ed in: fill the holes by Telea's fast-marching method with cv::inpaint's conventions (radius 3; csrc/telea.h:
+        * a restatement of the published algorithm, unpinned like everything OpenCV) on the image as the reference hands it
+        * to cv::inpaint, instead of the rim-inwards mean.  Host code, ~10 ms for a 400 x 400 layer. */
+       ARTP_INPAINT_TELEA = 2 };
 int artp_inpaint_layer(artp_ctx* ctx, const float* layer, int rows, int cols, int mode, float* out, uint64_t* n_holes);
+/* The fill alone (no context, no GPU): h x w row-major 8-bit image, mask != 0 = pixels to fill, radius `range`
+ * (cv::inpaint(img, mask, out, range, cv::INPAINT_TELEA)); out may alias img. */
+int artp_telea_inpaint_u8(const uint8_t* img, const uint8_t* mask, int h, int w, int range, uint8_t* out);
 /* name: elevation, traversability, normal_x/_y/_z, plane_fit_std_dev, traversability_thresholded_no_safety,
  * traversability_thresholded, elevation_masked, sample_probability, cum_prob, observed, n_samples (the blurred
  * vertex density), traversability_sample_filter, updated (rows x cols floats each) or cum_prob_rowwise (rows). */
@@ -527,7 +535,8 @@ int artp_cost_update_map_dev(artp_ctx* ctx, const float* elev_xy_dev, int rows, 
 int artp_cost_update_map_layer(artp_ctx* ctx, const float* layer, int rows, int cols, double res, double len_x,
                                double len_y, double pos_x, double pos_y);
 /* enabled != 0: artp_cost_update_map_layer fills the holes of its layer itself (artp_inpaint_layer,
- * ARTP_INPAINT_COST_NODE) instead of rejecting it -- the node's behaviour (cost_query_server.py:92-111). */
+ * ARTP_INPAINT_COST_NODE) instead of rejecting it -- the node's behaviour (cost_query_server.py:92-111).
+ * enabled == 2: with Telea's fill (ARTP_INPAINT_TELEA), the algorithm the node calls. */
 int artp_cost_set_hole_filling(artp_ctx* ctx, int enabled);
 /* MotionCostFunc: edges [B][6] = target x y yaw, start x y yaw (prm_motion_cost.cpp:41-52);
  * cost [B][3] = energy, time, risk (= 1 - prob; cost_query.py:65-69). */
