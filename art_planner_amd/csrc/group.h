@@ -10,7 +10,37 @@
 #pragma once
 
 #include <dlfcn.h>
+// librccl is bound at run time (dlopen); its HEADER is only needed for the types.  A ROCm installation without the RCCL
+// development files still builds libartp.so: the few declarations used here are spelled out below (rccl.h 2.x ABI) and
+// artp_group_create* reports ARTP_ERR_COMM when no librccl can be loaded.
+#if !defined(ARTP_NO_RCCL_HEADER) && defined(__has_include) && __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7, ncclNumResults = 8 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                           ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
+#include <atomic>
 
 #include <condition_variable>
 #include <functional>
@@ -167,7 +197,8 @@ struct artp_group {
   artp_group_detail::RcclApi* rccl = nullptr;
   uint64_t seed = 0;
   size_t batch = 0, words = 0, mat_cap = 0, prefix = 0;
-  bool configured = false, aborted = false;
+  bool configured = false;
+  std::atomic<bool> aborted{false};   // set by artp_group_abort without g->mu: a synchronize waiting for a peer sees it
   std::string last_error;
   std::mutex mu;  // group calls are serialised
 };
@@ -484,40 +515,46 @@ int artp_group_create_rank(int device, int rank, int world, const uint8_t id[ART
 int artp_group_synchronize(artp_group* g, int timeout_ms) {
   using namespace artp_group_detail;
   if (!g) return ARTP_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(g->mu);
+  // The streams to wait for are read under the lock; the POLL runs without it, so that artp_group_abort (and any other
+  // call) gets through while this thread waits for a peer that never arrives (synchronize(-1) could not be
+  // aborted).  Member streams live as long as the group; destroying the group while a thread waits on it is the caller's
+  // bug, as with any handle.
+  struct Wait { hipStream_t stream; ncclComm_t comm; int device, rank; size_t member; const char* what; };
+  std::vector<Wait> waits;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    for (size_t i = 0; i < g->m.size(); ++i) {
+      Member& mem = g->m[i];
+      waits.push_back({compute_stream(mem), mem.comm, mem.device, mem.rank, i, "compute stream"});
+      waits.push_back({mem.comm_stream, mem.comm, mem.device, mem.rank, i, "exchange stream"});
+    }
+  }
+  auto fail = [&](int code, const std::string& msg) {
+    std::lock_guard<std::mutex> lock(g->mu);
+    g->last_error = msg;
+    return code;
+  };
   const auto t0 = std::chrono::steady_clock::now();
-  for (size_t i = 0; i < g->m.size(); ++i) {
-    Member& mem = g->m[i];
-    if (hipSetDevice(mem.device) != hipSuccess) return ARTP_ERR_HIP;
-    std::vector<std::pair<hipStream_t, const char*>> streams;
-    streams.emplace_back(compute_stream(mem), "compute stream");
-    streams.emplace_back(mem.comm_stream, "exchange stream");
-    for (auto& s : streams) {
-      for (;;) {
-        const hipError_t q = hipStreamQuery(s.first);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) {
-          g->last_error = "member " + std::to_string(i) + " " + s.second + ": " + hipGetErrorString(q);
-          return ARTP_ERR_HIP;
-        }
-        if (mem.comm && g->rccl) {
-          ncclResult_t ar = ncclSuccess;
-          if (g->rccl->CommGetAsyncError(mem.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
-            g->last_error = "member " + std::to_string(i) + ": RCCL async error: " + g->rccl->GetErrorString(ar);
-            return ARTP_ERR_COMM;
-          }
-        }
-        if (timeout_ms >= 0) {
-          const double ms =
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-          if (ms > (double)timeout_ms) {
-            g->last_error = "member " + std::to_string(i) + " (rank " + std::to_string(mem.rank) + "): " + s.second +
-                            " still busy after " + std::to_string(timeout_ms) + " ms";
-            return ARTP_ERR_TIMEOUT;
-          }
-        }
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
+  for (const Wait& w : waits) {
+    if (hipSetDevice(w.device) != hipSuccess) return ARTP_ERR_HIP;
+    for (;;) {
+      if (g->aborted.load(std::memory_order_acquire)) return fail(ARTP_ERR_COMM, "group was aborted");
+      const hipError_t q = hipStreamQuery(w.stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady)
+        return fail(ARTP_ERR_HIP, "member " + std::to_string(w.member) + " " + w.what + ": " + hipGetErrorString(q));
+      if (w.comm && g->rccl && !g->aborted.load(std::memory_order_acquire)) {
+        ncclResult_t ar = ncclSuccess;
+        if (g->rccl->CommGetAsyncError(w.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+          return fail(ARTP_ERR_COMM, "member " + std::to_string(w.member) + ": RCCL async error: " + g->rccl->GetErrorString(ar));
       }
+      if (timeout_ms >= 0) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (double)timeout_ms)
+          return fail(ARTP_ERR_TIMEOUT, "member " + std::to_string(w.member) + " (rank " + std::to_string(w.rank) + "): " + w.what +
+                                            " still busy after " + std::to_string(timeout_ms) + " ms");
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
   }
   return ARTP_OK;
@@ -525,8 +562,8 @@ int artp_group_synchronize(artp_group* g, int timeout_ms) {
 
 int artp_group_abort(artp_group* g) {
   if (!g) return ARTP_ERR_INVALID_ARG;
+  g->aborted.store(true, std::memory_order_release);   // waiters in artp_group_synchronize leave at their next poll
   std::lock_guard<std::mutex> lock(g->mu);
-  g->aborted = true;
   for (auto& mem : g->m)
     if (mem.comm && g->rccl) {
       (void)g->rccl->CommAbort(mem.comm);
@@ -595,7 +632,11 @@ int artp_group_configure(artp_group* g, uint64_t seed, size_t batch, size_t mate
   if (prefix == 0 || prefix > batch) prefix = batch;
   if (materialise_cap > prefix) materialise_cap = prefix;
   {
-    const int rc = artp_group_synchronize(g, -1);
+    // the previous configuration's work must have drained before its buffers go; bounded: a peer that never arrived must
+    // not hang a re-configuration for ever ($ARTP_GROUP_CONFIGURE_TIMEOUT_MS, default one minute)
+    int wait_ms = 60000;
+    if (const char* ev = std::getenv("ARTP_GROUP_CONFIGURE_TIMEOUT_MS")) wait_ms = std::atoi(ev);
+    const int rc = artp_group_synchronize(g, wait_ms);
     if (rc != ARTP_OK) return rc;
   }
   std::lock_guard<std::mutex> lock(g->mu);
@@ -690,7 +731,12 @@ int artp_group_sample_and_validate_step(artp_group* g, uint64_t step) {
 
 int artp_group_step_buffers(artp_group* g, int local, uint64_t step, const double** se3, const uint8_t** valid,
                             const uint64_t** bits, const double** states, const uint64_t** counts) {
-  if (!g || local < 0 || local >= (int)g->m.size() || !g->configured) return ARTP_ERR_INVALID_ARG;
+  if (!g || local < 0) return ARTP_ERR_INVALID_ARG;
+  // The pointers stay valid until the next artp_group_configure.  Buffers alternate by step parity: step k + 2 overwrites
+  // what step k produced as soon as the group's OWN work of step k is done -- a consumer that reads them asynchronously on
+  // its own stream must have finished (or be ordered in front of the enqueue of step k + 2) by then.
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (local >= (int)g->m.size() || !g->configured) return ARTP_ERR_INVALID_ARG;
   const artp_group_detail::Member& mem = g->m[local];
   const int b = (int)(step & 1);
   if (se3) *se3 = mem.se3;
@@ -771,7 +817,9 @@ int artp_group_exchange_edges(artp_group* g, const artp_group_edges* per_local, 
 }
 
 int artp_group_edge_buffers(artp_group* g, int local, const uint32_t** records, const uint64_t** counts) {
-  if (!g || local < 0 || local >= (int)g->m.size()) return ARTP_ERR_INVALID_ARG;
+  if (!g || local < 0) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g->mu);   // artp_group_exchange_edges (re)allocates these under the same lock
+  if (local >= (int)g->m.size()) return ARTP_ERR_INVALID_ARG;
   if (records) *records = g->m[local].rec_gathered;
   if (counts) *counts = g->m[local].rec_counts;
   return ARTP_OK;

@@ -2338,6 +2338,18 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
       }
     } else {
       const uint32_t far = t.root == 0u ? 1u : 0u;
+      if (!std::isfinite(t.dist[far]) && !t.rel.empty()) {
+        // The tree was restricted to the vertices within C*, the cost of the cheapest path whose FORWARD verdicts were all
+        // valid.  Verdicts are cached per direction while the reference keeps one undirected VALIDITY_TRUE bit per edge
+        // (lazy_prm_star_min_update.cpp:707-726): should the two directions of an edge ever disagree (floating point
+        // only), a later path can remove an edge of the C* path and the restricted tree loses the goal where the
+        // reference would still solve.  Before concluding "not connected": the whole roadmap again.
+        t.rel.clear();
+        t.to_other = nullptr;
+        t.cost_max = INFINITY;
+        informed = false;
+        t.full(t.root);
+      }
       if (!std::isfinite(t.dist[far])) {
         if (n_replans) *n_replans = replans;
         report();
