@@ -298,7 +298,7 @@ def test_hole_filling_quantisation_matches_the_reference_arithmetic(mode):
             same[:, 0] = same[:, 1]
             same[0, :] = same[1, :]
         assert np.array_equal(out[same], plain[same]) and not np.array_equal(out[holes], plain[holes])
-        assert np.abs(out[holes] - plain[holes]).max() <= (hi - lo) * 0.2
+        assert np.abs(out[holes] - plain[holes]).max() <= (hi - lo) * 0.5   # an obstacle edge inside a wide hole: the two fills differ by up to its height
     # a layer without holes comes back untouched (the reference only inpaints when something is missing)
     whole, n0 = ctx.inpaint_layer(gm["elevation"], mode | (2 if telea else 0))
     assert n0 == 0 and np.array_equal(whole, gm["elevation"])
