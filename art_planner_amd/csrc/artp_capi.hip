@@ -115,6 +115,7 @@ struct artp_ctx {
   half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
+  int feet_dense = 0;                  // $ARTP_FEET_DENSE=1: feet_stream2_kernel (corner arithmetic on dense lanes; measured: no faster)
   double r3_extent_override = 0.0;     // artp_set_r3_extent: > 0 = checkMotion's R^3 maxExtent, whatever the installed map's bounds
   int fc_mfma = 1;                     // $ARTP_FC_MFMA=0: the fp32 VALU kernels (tuning / comparison)
   int fc_selfcheck = -1;               // artp_cost_load_weights' probe batch: 1 = the MFMA kernel agreed with the fp32 one,
@@ -601,8 +602,12 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
                      dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, (const PoseRec*)recs, n,
                      valid, q);
-  hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, ARTP_FEET_WAVES_PER_SIMD)), dim3(64 * ARTP_STREAM_WAVES), 0,
-                     c->stream, c->field[1], c->robot, q, valid);
+  if (c->feet_dense)   // round 5 experiment: the corner stage's plane / contact arithmetic on dense lanes (pipeline.h feet_stream2_kernel)
+    hipLaunchKernelGGL(feet_stream2_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, ARTP_FEET_WAVES_PER_SIMD)), dim3(64 * ARTP_STREAM_WAVES), 0,
+                       c->stream, c->field[1], c->robot, q, valid);
+  else
+    hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, ARTP_FEET_WAVES_PER_SIMD)), dim3(64 * ARTP_STREAM_WAVES), 0,
+                       c->stream, c->field[1], c->robot, q, valid);
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
                      c->field[1], c->robot, q, valid);
   {
@@ -731,6 +736,7 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
     const char* e = std::getenv("ARTP_NO_POLL");
     c->poll_labels = !(e && e[0] == '1');
     if (const char* tp = std::getenv("ARTP_EDGE_TWO_PASS")) c->edge_two_pass = tp[0] != '0';
+    if (const char* fd = std::getenv("ARTP_FEET_DENSE")) c->feet_dense = fd[0] != '0';
     if (const char* cs = std::getenv("ARTP_COARSE_STRIDE")) c->edge_coarse_stride = std::atoi(cs) >= 2 ? std::atoi(cs) : ARTP_COARSE_STRIDE;
   }
   fill_robot(c);

@@ -52,6 +52,31 @@ def test_validate_states_golden(name, rname):
 
 
 @pytest.mark.parametrize("name", golden_io.MAPS)
+def test_dense_feet_stream_variant_gives_the_same_labels(name, big_map, monkeypatch):
+    """$ARTP_FEET_DENSE=1 selects feet_stream2_kernel (the corner stage's plane / contact arithmetic on dense lanes: round 5's
+    lane-utilisation experiment, kept although it is no faster): same labels as the real ODE's on the bulk states and as
+    the default kernel's on 2^19 sampler states of the C2 map."""
+    from art_planner_amd.context import Context
+    gm, _, states, _ = golden_io.load_bulk(name)
+    monkeypatch.setenv("ARTP_FEET_DENSE", "1")
+    dense = {r: Context(0, r) for r in ("yaml", "defaults")}
+    monkeypatch.delenv("ARTP_FEET_DENSE")
+    for rname, ctx in dense.items():
+        ctx.upload_map(gm, sampler=False)
+        assert np.array_equal(ctx.validate_states(states[rname]["se3"]), states[rname]["valid"]), f"{name}/{rname}"
+    if name == golden_io.MAPS[0]:
+        ref = _ctx("yaml")
+        ref.upload_map(big_map)
+        se3 = ref.sample_states(42, 0, 1 << 19)
+        want = ref.validate_states(se3)
+        dense["yaml"].upload_map(big_map)
+        assert np.array_equal(dense["yaml"].validate_states(se3), want)
+        ref.close()
+    for ctx in dense.values():
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", golden_io.MAPS)
 def test_bulk_reference_golden(name):
     """SURVEY.md 8c volumes on the GPU box: 20 000 dPoses per (map, box), 20 000 states and 2 000 edges per (map,
     robot) against the real patched ODE's labels (tests/golden/bulk_*.npz; ~320 k box poses, 120 k states, 12 k edges
