@@ -247,6 +247,39 @@ def test_gpu_gather_and_costs_equal_the_reference_cost_query(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [400, 800, 141])
+def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypatch):
+    """Round 5 kept two things behind environment switches (read at every feature-map update): the persistent strip-walking
+    form of the 15 x 15 layer (conv_kwalk_kernel, ARTP_KWALK=1, three variants and two tile heights: built, measured slower) and
+    the launch-order tile numbering (ARTP_CNN_XCD=0).  Every one of them must produce the default's features: the same
+    products in fp32 accumulators, only the summation order of the K slices differs (<= 2e-3 at values up to +-5), and equal
+    the numpy oracle like the default does."""
+    from art_planner_amd.context import Context
+    from synthetic import make_map
+    gm = make_map(n, 0.04, seed=1234 if n == 400 else 77)
+    elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float16).astype(np.float32)
+    p = mo.random_params(0)
+    ctx = Context(0, "yaml")
+    ctx.cost_load_weights(convert_weights.to_blob(p))
+    base = _gpu_features(ctx, elv, gm.res)
+    _assert_features_close(base, mo.cnn_features(p, elv), f"default {n}")
+    settings = [{"ARTP_CNN_XCD": "0"}, {"ARTP_KWALK": "1"}, {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "1"},
+                {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "2"}, {"ARTP_KWALK": "1", "ARTP_KWALK_TR": "8"},
+                {"ARTP_KWALK": "1", "ARTP_KWALK_TR": "10", "ARTP_CNN_XCD": "0"}]
+    for env in settings:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        f = _gpu_features(ctx, elv, gm.res)
+        for k in env:
+            monkeypatch.delenv(k)
+        d = np.abs(f - base)
+        assert d.max() < 4e-3 and d.mean() < 1e-4, (env, float(d.max()), float(d.mean()))
+        if env == {"ARTP_CNN_XCD": "0"}:
+            assert np.array_equal(f, base)      # the tile order changes nothing but which CU computes a tile
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_cost_full_map_properties(big_map):
     """C3 size (400x400): feature map 176x176; queries are deterministic, depend only on the start cell
     and the delta pose, and clamp at the feature-map border like the reference."""
