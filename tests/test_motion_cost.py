@@ -274,8 +274,8 @@ def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypa
             monkeypatch.delenv(k)
         d = np.abs(f - base)
         assert d.max() < 4e-3 and d.mean() < 1e-4, (env, float(d.max()), float(d.mean()))
-        if env == {"ARTP_CNN_XCD": "0"}:
-            assert np.array_equal(f, base)      # the tile order changes nothing but which CU computes a tile
+        # (not bit-equal even for the tile order alone: conv_ksplit_kernel rotates the order of its K slices with the
+        # workgroup index, so another workgroup sums a tile's partial products in another order)
     ctx.close()
 
 
