@@ -94,8 +94,7 @@ class Context:
         fin = elev[np.isfinite(elev)]
         lo = float(fin.min()) if fin.size else 0.0
         hi = float(fin.max()) if fin.size else 0.0
-        self._chk(self.L.artp_set_z_bounds(self.h, lo - self.params.reach_z / 2, hi + self.params.reach_z / 2),
-                  "artp_set_z_bounds")
+        self.set_z_bounds(lo - self.params.reach_z / 2, hi + self.params.reach_z / 2)
         if sampler and "cum_prob" in gm.layers:
             ls = [_f32F(gm["cum_prob"]), np.ascontiguousarray(gm["cum_prob_rowwise"], np.float32),
                   _f32F(gm[body_layer]), _f32F(gm["normal_x"]), _f32F(gm["normal_y"]),
@@ -139,6 +138,15 @@ class Context:
         self._chk(self.L.artp_check_motions(self.h, s1.ctypes.data, s2.ctypes.data, s1.shape[0],
                                             valid.ctypes.data), "artp_check_motions")
         return valid
+
+    def set_z_bounds(self, z_low, z_high):
+        """artp_set_z_bounds; the pair is kept as `z_bounds`."""
+        self._chk(self.L.artp_set_z_bounds(self.h, float(z_low), float(z_high)), "artp_set_z_bounds")
+        self.z_bounds = (float(z_low), float(z_high))
+
+    def set_r3_extent(self, max_extent):
+        """checkMotion's R^3 maxExtent fixed to max_extent (0 = follow the installed map and z bounds): artp_set_r3_extent."""
+        self._chk(self.L.artp_set_r3_extent(self.h, float(max_extent)), "artp_set_r3_extent")
 
     def check_motions_last_valid(self, s1, s2):
         """(valid, lastValid.second, *lastValid.first) of checkMotion's second overload; t = 1 / s2 where valid."""

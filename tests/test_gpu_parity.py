@@ -51,6 +51,37 @@ def test_validate_states_golden(name, rname):
     ctx.close()
 
 
+def test_frozen_motion_resolution_keeps_the_first_maps_segment_length(big_map):
+    """artp_set_r3_extent (Planner::setFreezeMotionResolution): OMPL never re-runs StateSpace::setup() after
+    Planner::setMap's setBounds (planner.cpp:146-163), so the reference's checkMotion keeps the longest valid segment of the
+    FIRST planned map.  With the extent frozen, changing the z bounds must not change a single lastValid fraction
+    ((j - 1) / nd exposes the segment count nd); unfrozen it does."""
+    ctx = _ctx("yaml")
+    ctx.upload_map(big_map)
+    se3 = ctx.sample_states(7, 0, 1 << 15)
+    acc = se3[ctx.validate_states(se3) != 0]
+    a = acc[:-1][:4000].copy()
+    b = acc[1:][:4000].copy()
+    b[:, 3:] = a[:, 3:]                       # same attitude: the R^3 distance alone sets the segment count
+    keep = np.hypot(b[:, 0] - a[:, 0], b[:, 1] - a[:, 1]) < 6.0
+    a, b = a[keep], b[keep]
+    lo, hi = ctx.z_bounds
+    ex, ey = 2.0 * big_map.len_x, 2.0 * big_map.len_y
+    ok1, t1, _ = ctx.check_motions_last_valid(a, b)
+    assert (ok1 == 0).sum() > 50
+    ctx.set_z_bounds(lo - 40.0, hi + 40.0)    # a later map with a far larger height range
+    ok2, t2, _ = ctx.check_motions_last_valid(a, b)
+    assert not np.array_equal(t1, t2)         # coarser segments: other fractions (and possibly other verdicts)
+    ctx.set_r3_extent(float(np.sqrt(ex * ex + ey * ey + (hi - lo) ** 2)))   # the first map's maxExtent
+    ok3, t3, _ = ctx.check_motions_last_valid(a, b)
+    assert np.array_equal(ok3, ok1) and np.array_equal(t3, t1)
+    assert np.array_equal(ctx.check_motions(a, b), ok1)
+    ctx.set_r3_extent(0.0)
+    ok4, t4, _ = ctx.check_motions_last_valid(a, b)
+    assert np.array_equal(t4, t2) and np.array_equal(ok4, ok2)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", golden_io.MAPS)
 def test_dense_feet_stream_variant_gives_the_same_labels(name, big_map, monkeypatch):
     """$ARTP_FEET_DENSE=1 selects feet_stream2_kernel (the corner stage's plane / contact arithmetic on dense lanes: round 5's
