@@ -252,7 +252,7 @@ def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypa
     """Round 5 kept two things behind environment switches (read at every feature-map update): the persistent strip-walking
     form of the 15 x 15 layer (conv_kwalk_kernel, ARTP_KWALK=1, three variants and two tile heights: built, measured slower) and
     the launch-order tile numbering (ARTP_CNN_XCD=0).  Every one of them must produce the default's features: the same
-    products in fp32 accumulators, only the summation order of the K slices differs (<= 2e-3 at values up to +-5), and equal
+    products in fp32 accumulators, only the summation order of the K slices differs (one fp16 ulp of the stored feature), and equal
     the numpy oracle like the default does."""
     from art_planner_amd.context import Context
     from synthetic import make_map
@@ -273,7 +273,8 @@ def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypa
         for k in env:
             monkeypatch.delenv(k)
         d = np.abs(f - base)
-        assert d.max() < 4e-3 and d.mean() < 1e-4, (env, float(d.max()), float(d.mean()))
+        # one fp16 unit in the last place of the stored feature at most (another order of the same fp32 partial sums)
+        assert (d <= 1.0e-3 + np.abs(base) * 2.0 ** -9).all() and d.mean() < 1e-4, (env, float(d.max()), float(d.mean()))
         # (not bit-equal even for the tile order alone: conv_ksplit_kernel rotates the order of its K slices with the
         # workgroup index, so another workgroup sums a tile's partial products in another order)
     ctx.close()
