@@ -112,6 +112,8 @@ struct artp_ctx {
   half8* d_convw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: the 15 x 15 layer's B fragments, per-row packing
   float* d_convb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* d_c12 = nullptr;              // conv1 o conv2 composed: [24][25] + [24] (conv12_pool_kernel)
+  unsigned char* d_c12m = nullptr;     // the same as MFMA fragments, hi / lo half floats + bias[32] (conv12_mfma_kernel)
+  int conv12_mfma = 1;                 // $ARTP_CONV12_MFMA=0: the VALU form (rounds 3-4)
   half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
@@ -784,6 +786,7 @@ void artp_destroy(artp_ctx* c) {
   if (c->d_fc) (void)hipFree(c->d_fc);
   if (c->d_fc_mfma) (void)hipFree(c->d_fc_mfma);
   if (c->d_c12) (void)hipFree(c->d_c12);
+  if (c->d_c12m) (void)hipFree(c->d_c12m);
   for (int l = 0; l < 3; ++l)
     if (c->d_convw_chunk[l]) (void)hipFree(c->d_convw_chunk[l]);
   for (int l = 0; l < 2; ++l)
@@ -2346,6 +2349,28 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
     }
     if (!c->d_c12) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_c12), sizeof(h12)));
     HIP_TRY(c, hipMemcpy(c->d_c12, h12, sizeof(h12), hipMemcpyHostToDevice));
+    {
+      // conv12_mfma_kernel's operand: [channel tile t][hi, lo][lane][8 half floats] + bias[32].  Lane l = (m = l & 15, g = l >> 4)
+      // holds channel 16 t + m, K slots 8 g .. 8 g + 7; slot s < 30 = window row s / 6, tap s % 6 (tap 5 and slots 30, 31: 0).
+      // w = hi + lo, both half floats, split from the double (22 bits).
+      std::vector<unsigned char> blob((size_t)C12M_FRAG_HALFS * 2 + 32 * sizeof(float), 0);
+      for (int t = 0; t < 2; ++t)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int ch = 16 * t + (l & 15), sl = 8 * (l >> 4) + j;
+            double v = 0.0;
+            if (ch < 24 && sl < 30 && sl % 6 < 5) v = wc[ch][(sl / 6) * 5 + sl % 6];
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (double)hi);
+            std::memcpy(blob.data() + ((((size_t)t * 2 + 0) * 64 + l) * 8 + j) * 2, &hi, 2);
+            std::memcpy(blob.data() + ((((size_t)t * 2 + 1) * 64 + l) * 8 + j) * 2, &lo, 2);
+          }
+      float b32[32] = {0};
+      for (int co = 0; co < 24; ++co) b32[co] = (float)bc[co];
+      std::memcpy(blob.data() + (size_t)C12M_FRAG_HALFS * 2, b32, sizeof(b32));
+      if (!c->d_c12m) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_c12m), blob.size()));
+      HIP_TRY(c, hipMemcpy(c->d_c12m, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    }
     // conv3..5 for conv345_kernel: K walked in 16-byte chunks over the whole (kh, kw, cin) window; fragment
     // [ks][nt][lane][8]: lane l, element j holds B[k][n] with chunk q = 4 ks + (l >> 4), k = 8 q + j, n = 16 nt + (l & 15)
     const float* wl = w2 + 24 * 24 * 9 + 24;
@@ -2431,12 +2456,27 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
   half_t* A = c->d_act[0];
   half_t* Bf = c->d_act[1];
   hipStream_t st = c->stream;
+  bool fuse12 = false;
   {
     // round 3: three launches.  (A) conv1 o conv2 + lrelu + pool2 straight from the f32 map -> A [hp][wpp][24];
     // (B) conv3 -> conv4 -> pool3 -> conv5 with LDS-resident halo tiles -> Bf [h5][w5][48]; (C) the 15 x 15 layer.
-    const unsigned blocks_a = (unsigned)(((wpp + C12_PT - 1) / C12_PT) * ((hp + C12_PT - 1) / C12_PT));
-    hipLaunchKernelGGL(conv12_pool_kernel, dim3(blocks_a), dim3(256), 0, st, d_map, H, W,
-                       (const float*)c->d_c12, (const float*)(c->d_c12 + 600), A);
+    // round 5: (A) on the matrix cores -- inside (B)'s patch phase (conv345_kernel<T, true, true>: no launch, no 24-channel
+    // image), or as a launch of its own ($ARTP_CONV12_FUSED=0: conv12_mfma_kernel); the VALU form stays behind $ARTP_CONV12_MFMA=0
+    const char* ecm = std::getenv("ARTP_CONV12_MFMA");   // tuning / tests, read at every update like the switches below
+    const char* ecf = std::getenv("ARTP_CONV12_FUSED");
+    const char* ecx = std::getenv("ARTP_CNN_XCD");
+    const bool c12m = ecm ? ecm[0] != '0' : c->conv12_mfma != 0;
+    fuse12 = c12m && (ecf ? ecf[0] != '0' : true) && (ecx ? ecx[0] != '0' : true);
+    if (fuse12) {
+    } else if (c12m) {
+      const unsigned blocks_m = (unsigned)(((wpp + C12M_PX - 1) / C12M_PX) * ((hp + C12M_PY - 1) / C12M_PY));
+      hipLaunchKernelGGL(conv12_mfma_kernel, dim3(blocks_m), dim3(256), 0, st, d_map, H, W, (const half8*)c->d_c12m,
+                         (const float*)(c->d_c12m + (size_t)C12M_FRAG_HALFS * 2), A);
+    } else {
+      const unsigned blocks_a = (unsigned)(((wpp + C12_PT - 1) / C12_PT) * ((hp + C12_PT - 1) / C12_PT));
+      hipLaunchKernelGGL(conv12_pool_kernel, dim3(blocks_a), dim3(256), 0, st, d_map, H, W,
+                         (const float*)c->d_c12, (const float*)(c->d_c12 + 600), A);
+    }
     // tile edge of (B): one workgroup per CU, and a partly filled last round costs a full round -- rounds x patch
     // area decides (400 x 400: 144 tiles of 16 = one round; 800 x 800: 484 tiles of 18 = two rounds against three of 16)
     auto rounds_cost = [&](int t) {
@@ -2448,7 +2488,9 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
       const unsigned blocks_b = (unsigned)(((w5 + t - 1) / t) * ((h5 + t - 1) / t));
       hipLaunchKernelGGL(k345, dim3(blocks_b), dim3(C345_NT), lds, st, (const half_t*)A, hp, wpp,
                          (const half8*)c->d_convw_chunk[0], (const float*)c->d_convb[1], (const half8*)c->d_convw_chunk[1],
-                         (const float*)c->d_convb[2], (const half8*)c->d_convw_chunk[2], (const float*)c->d_convb[3], Bf);
+                         (const float*)c->d_convb[2], (const half8*)c->d_convw_chunk[2], (const float*)c->d_convb[3], Bf,
+                         (const float*)d_map, H, W, (const half8*)c->d_c12m,
+                         (const float*)(c->d_c12m + (size_t)C12M_FRAG_HALFS * 2));
       return ARTP_OK;
     };
     // (round 4: 12 added -- 400 x 400 is 256 tiles of 12 = ONE round on all 256 CUs against 144 tiles of 16 on 144 CUs)
@@ -2458,7 +2500,10 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     if (const char* ev = std::getenv("ARTP_C345_T")) t_best = std::atoi(ev);  // tuning
     const char* evx = std::getenv("ARTP_CNN_XCD");   // tuning: 0 = tiles in launch order (rounds 3-4)
     const bool xcd = evx ? std::atoi(evx) != 0 : true;
-    const int rcb = xcd ? (t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
+    const int rcb = fuse12 ? (t_best == 18   ? launch_b(conv345_kernel<18, true, true>, C345Cfg<18>::LDS_BYTES, 18)
+                              : t_best == 12 ? launch_b(conv345_kernel<12, true, true>, C345Cfg<12>::LDS_BYTES, 12)
+                                             : launch_b(conv345_kernel<16, true, true>, C345Cfg<16>::LDS_BYTES, 16))
+                    : xcd ? (t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
                            : t_best == 12 ? launch_b(conv345_kernel<12>, C345Cfg<12>::LDS_BYTES, 12)
                                           : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16))
                         : (t_best == 18   ? launch_b(conv345_kernel<18, false>, C345Cfg<18>::LDS_BYTES, 18)

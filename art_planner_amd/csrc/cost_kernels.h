@@ -581,6 +581,146 @@ conv12_pool_kernel(const float* __restrict__ in, int H, int W, const float* __re
   }
 }
 
+// (A') conv12_mfma_kernel: the same composed 5 x 5 layer on the matrix cores (round 5).  The VALU form above issues 300
+//     packed FMAs per lane behind 150 scalar weight loads and runs at a third of the VALU rate (5.3 us at C3, 14.3 us at
+//     C4 = 12 % / 9 % of the extractor's time for 0.1 % of its FLOPs).  As a GEMM it is channels x pixels with K = the
+//     window: the weights are the first operand (16 channels x 32 k), the pixels the second (32 k x 16 pixels), a lane
+//     ends up with 4 consecutive channels of one pixel.  K = 32 slots = 5 window rows x 6 taps (the 6th has weight 0) + 2
+//     spare: lane group g supplies slots 8 g .. 8 g + 7 = FOUR dwords of the half-float patch, dword D = 4 g + j being
+//     dword D % 3 of window row D / 3 -- and a window row starts on a dword because the patch is kept twice, shifted by
+//     one pixel (copy 1 [x] = copy 0 [x + 1]): the 16 pixels of a tile all have the same x parity (below), so a tile reads one
+//     copy with 16 consecutive dwords per lane group.  The 6th tap is masked out of the dword rather than left to its zero
+//     weight (a non-finite neighbour would turn 0 * x into NaN where the VALU form never looked).
+//     The f32 weights keep their precision: w = hi + lo as two half floats (22 bits), two MFMAs per tile (the FC kernel's
+//     scheme), fp32 accumulation from the bias -- the same sums as the VALU form up to the order of fp32 additions.
+//     2 x 2 pooling without leaving the lane: the four pool partners (2 py + dy, 2 px + dx) are pixel n of FOUR tiles
+//     (dy, dx), n = px: the maximum is elementwise over four accumulators.  A workgroup = 16 x 8 pooled pixels (4
+//     wavefronts x 2 pooled rows), its 20 x 36 input window in 3.2 KB of LDS.
+constexpr int C12M_PX = 16;                  // pooled pixels per tile row = the N of an MFMA tile
+constexpr int C12M_PY = 8;                   // pooled rows per tile
+constexpr int C12M_IH = 2 * C12M_PY + 4;     // input rows of a tile
+constexpr int C12M_RS = 20;                  // LDS row stride in dwords: 40 half floats >= 2 * 16 + 4 (+ the masked 6th tap)
+constexpr int C12M_FRAG_HALFS = 2 * 2 * 64 * 8;  // [channel tile][hi, lo][lane][8]
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+// What a lane keeps for the composed layer: the weight fragments (two channel tiles, hi / lo), its bias, and where its four
+// dwords of a window lie relative to the window's first dword (row stride rsd dwords) + the masks of the 6th tap.
+struct C12Frag {
+  half8 whi0, wlo0, whi1, wlo1;
+  floatx4 b0, b1;
+  int off[4];
+  unsigned mask[4];
+};
+__device__ __forceinline__ void c12_frag_load(C12Frag& f, const half8* __restrict__ wfrag, const float* __restrict__ bias,
+                                              int lane, int rsd) {
+  const int g = lane >> 4;
+  f.whi0 = wfrag[lane];
+  f.wlo0 = wfrag[64 + lane];
+  f.whi1 = wfrag[128 + lane];
+  f.wlo1 = wfrag[192 + lane];
+  f.b0 = *reinterpret_cast<const floatx4*>(bias + 4 * g);
+  f.b1 = *reinterpret_cast<const floatx4*>(bias + 16 + 4 * g);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int D = 4 * g + j, row = D == 15 ? 4 : D / 3, d = D == 15 ? 2 : D % 3;
+    f.off[j] = row * rsd + d;
+    f.mask[j] = D == 15 ? 0u : (d == 2 ? 0xffffu : 0xffffffffu);
+  }
+}
+// 16 pooled pixels (one per lane & 15): the 2 x 2 conv outputs of each as four MFMA tiles, their maximum, leaky-ReLU, half floats.
+// patch: the two copies of the half-float window (copy 1 at + COPY dwords), row stride RSD dwords; base = the dword of the
+// pooled pixel's window corner in copy 0 ((2 y) * RSD + x).  o0 = channels 4 g .. 4 g + 3, o1 = 16 + 4 g .. (g < 2).
+template <int RSD, int COPY>
+__device__ __forceinline__ void conv12_pooled16(const unsigned* __restrict__ patch, int base, const C12Frag& f, half4_t& o0,
+                                                half4_t& o1) {
+  typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+  floatx4 m0, m1;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const unsigned* src = patch + dx * COPY + dy * RSD + base;
+      uint4_t xw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xw[j] = src[f.off[j]] & f.mask[j];
+      const half8 xb = __builtin_bit_cast(half8, xw);
+      floatx4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.whi0, xb, f.b0, 0, 0, 0);
+      floatx4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.whi1, xb, f.b1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wlo0, xb, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wlo1, xb, a1, 0, 0, 0);
+      if (dy == 0 && dx == 0) {
+        m0 = a0;
+        m1 = a1;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          m0[i] = fmaxf(m0[i], a0[i]);
+          m1[i] = fmaxf(m1[i], a1[i]);
+        }
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v0 = m0[i] > 0.f ? m0[i] : 0.3f * m0[i];
+    const float v1 = m1[i] > 0.f ? m1[i] : 0.3f * m1[i];
+    o0[i] = (half_t)v0;
+    o1[i] = (half_t)v1;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+conv12_mfma_kernel(const float* __restrict__ in, int H, int W, const half8* __restrict__ wfrag /*[2][2][64]*/,
+                   const float* __restrict__ bias /*[32]*/, half_t* __restrict__ out /*[hp][wp][24]*/) {
+  __shared__ unsigned patch[2 * C12M_IH * C12M_RS];
+  half_t* const p0 = reinterpret_cast<half_t*>(patch);
+  half_t* const p1 = reinterpret_cast<half_t*>(patch + C12M_IH * C12M_RS);
+  const int hp = (H - 4) / 2, wp = (W - 4) / 2;
+  const int tiles_x = (wp + C12M_PX - 1) / C12M_PX;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int iy0 = by * 2 * C12M_PY, ix0 = bx * 2 * C12M_PX;
+  const int tid = threadIdx.x;
+  {
+    constexpr int NEL = C12M_IH * 2 * C12M_RS, NIT = (NEL + 255) / 256;
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {  // unconditional loads from clamped addresses: conditional ones are serialised (conv345_kernel)
+      const int i = tid + it * 256;
+      const int r = i / (2 * C12M_RS), c = i - r * (2 * C12M_RS);
+      const int y = iy0 + r, x = ix0 + c;
+      const bool ok = i < NEL && y < H && x < W;
+      const float t = in[ok ? (size_t)y * W + x : (size_t)0];
+      v[it] = ok ? t : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int r = i / (2 * C12M_RS), c = i - r * (2 * C12M_RS);
+      if (i < NEL) {
+        const half_t h = (half_t)v[it];
+        p0[r * 2 * C12M_RS + c] = h;
+        if (c > 0) p1[r * 2 * C12M_RS + c - 1] = h;
+      }
+    }
+  }
+  const int lane = tid & 63, wv = tid >> 6;
+  C12Frag f;
+  c12_frag_load(f, wfrag, bias, lane, C12M_RS);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pyl = 2 * wv + q;
+    half4_t o0, o1;
+    conv12_pooled16<C12M_RS, C12M_IH * C12M_RS>(patch, 2 * pyl * C12M_RS + (lane & 15), f, o0, o1);
+    const int gy = by * C12M_PY + pyl, gx = bx * C12M_PX + (lane & 15), g = lane >> 4;
+    if (gy < hp && gx < wp) {
+      half_t* dst = out + ((size_t)gy * wp + gx) * 24;
+      *reinterpret_cast<half4_t*>(dst + 4 * g) = o0;
+      if (g < 2) *reinterpret_cast<half4_t*>(dst + 16 + 4 * g) = o1;
+    }
+  }
+}
+
 // ---- (B) conv3 -> conv4 -> pool3 -> conv5 ------------------------------------------------------------------
 template <int T>
 struct C345Cfg {
@@ -716,17 +856,27 @@ __device__ __forceinline__ void store_region_lds(char* __restrict__ out, const f
 
 #ifdef ARTP_STAGE_TIMING
 __device__ unsigned long long g_cnn_cycles[16];  // conv345 phases (cycles of wavefront 0, summed over workgroups), [15] = workgroups
-#define ARTP_CNN_MARK(slot) do { if (tid == 0) { const long long n_ = clock64(); atomicAdd(&g_cnn_cycles[slot], (unsigned long long)(n_ - t_prev)); t_prev = n_; } } while (0)
+// The stamps stay in registers until the end of the kernel (round 5): an atomic per mark sat in front of the weight commits'
+// s_waitcnt vmcnt -- returns are counted in order -- and 256 workgroups' atomics on one address made those waits look like
+// 24 k cycles of "waiting for conv5's weights".
+#define ARTP_CNN_MARK(slot) do { const long long n_ = clock64(); t_mark[slot] = (unsigned long long)(n_ - t_prev); t_prev = n_; } while (0)
+#define ARTP_CNN_FLUSH() do { if (tid == 0) { for (int s_ = 0; s_ < 13; ++s_) atomicAdd(&g_cnn_cycles[s_], t_mark[s_]); } } while (0)
 #else
 #define ARTP_CNN_MARK(slot) do { } while (0)
+#define ARTP_CNN_FLUSH() do { } while (0)
 #endif
 
-template <int T, bool XCD = true>
+// F12 (round 5): the composed conv1 o conv2 + pool layer is computed HERE, into the patch, from the tile's window of the f32 map
+// (conv12_pooled16, the arithmetic of conv12_mfma_kernel: the same bits): `in` is not read, no 24-channel image exists, and
+// the launch in front is gone.  The window of a (T+8)^2 patch is (2 T + 20)^2 floats -- fewer bytes than the patch itself --,
+// kept as half floats (twice, see conv12_mfma_kernel) in conv3's still unused output region.
+template <int T, bool XCD = true, bool F12 = false>
 __global__ void __launch_bounds__(C345_NT)
 conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Win,
                const half8* __restrict__ w3, const float* __restrict__ b3, const half8* __restrict__ w4,
                const float* __restrict__ b4, const half8* __restrict__ w5, const float* __restrict__ b5,
-               half_t* __restrict__ out /*[Hin-8][Win-8][48]*/) {
+               half_t* __restrict__ out /*[Hin-8][Win-8][48]*/, const float* __restrict__ raw = nullptr /*[H][W]*/, int H = 0,
+               int W = 0, const half8* __restrict__ w12 = nullptr, const float* __restrict__ b12 = nullptr) {
   using Cfg = C345Cfg<T>;
   constexpr int NW = C345_NW, NT_ = C345_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -742,7 +892,7 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef ARTP_STAGE_TIMING
   long long t_prev = clock64();
-  if (tid == 0) atomicAdd(&g_cnn_cycles[15], 1ull);
+  unsigned long long t_mark[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   // the three layers' biases (transposed product: four consecutive channels per lane) up front: a global load in
   // front of a layer's first MFMA would sit in its critical path
@@ -760,6 +910,66 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
   WRegs<7> rw3;
   WRegs<14> rw, rw5;
   w_prefetch<7>(w3, rw3, tid);  // conv3's weights travel with the patch
+  if constexpr (F12) {
+    // the tile's window of the map -> half floats in Y, twice (copy 1 shifted by one pixel); zeros outside the map
+    constexpr int RI = Cfg::RI, WIN = 2 * RI + 4, RSD = RI + 3, COPY = WIN * RSD;
+    static_assert(2 * COPY * 4 <= Cfg::Y_B, "the window fits conv3's region");
+    constexpr int NEL = WIN * WIN, NIT = (NEL + NT_ - 1) / NT_;
+    half_t* const p0 = reinterpret_cast<half_t*>(Y);
+    half_t* const p1 = reinterpret_cast<half_t*>(Y + COPY * 4);
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * NT_;
+      const int r = i / WIN, c = i - r * WIN;
+      const int y = 2 * oy0 + r, x = 2 * ox0 + c;
+      // an UNCONDITIONAL load from a clamped address: a load under a condition becomes a branch, and hipcc waits for each
+      // (s_waitcnt vmcnt(0)) before the next block -- seven serial trips to memory (10.4 k cycles per tile) instead of one
+      const bool ok = i < NEL && y < H && x < W;
+      const float t = raw[ok ? (size_t)y * W + x : (size_t)0];
+      v[it] = ok ? t : 0.0f;
+    }
+    C12Frag f;
+    c12_frag_load(f, w12, b12, lane, RSD);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * NT_;
+      const int r = i / WIN, c = i - r * WIN;
+      if (i < NEL) {
+        const half_t h = (half_t)v[it];
+        p0[r * 2 * RSD + c] = h;
+        if (c > 0) p1[r * 2 * RSD + c - 1] = h;
+      }
+    }
+    w_prefetch<14>(w4, rw, tid);
+    w_prefetch<14>(w5, rw5, tid);
+    w_commit<7>(W3, rw3, tid);
+    __syncthreads();
+    ARTP_CNN_MARK(11);
+    // the patch: 16 pooled pixels per step and wavefront, linear pixel index over the RI x RI patch
+    constexpr int NPX = RI * RI, NQ = (NPX + 15) / 16;
+    for (int q = wave; q < NQ; q += NW) {
+      int pp = q * 16 + (lane & 15);
+      const bool live = pp < NPX;
+      pp = live ? pp : NPX - 1;
+      const int y = pp / RI, x = pp - y * RI;
+      half4_t o0, o1;
+      conv12_pooled16<RSD, COPY>(reinterpret_cast<const unsigned*>(Y), 2 * y * RSD + x, f, o0, o1);
+      if (!(oy0 + y < Hin && ox0 + x < Win)) {   // outside the pooled image: zeros, as the patch load below
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = (half_t)0;
+          o1[i] = (half_t)0;
+        }
+      }
+      if (live) {
+        const int g = lane >> 4;
+        *reinterpret_cast<half4_t*>(X + pp * 48 + 8 * g) = o0;
+        if (g < 2) *reinterpret_cast<half4_t*>(X + pp * 48 + 32 + 8 * g) = o1;
+      }
+    }
+    ARTP_CNN_MARK(12);
+  } else {
   // input patch (T+8)^2 x 24 channels -> X; rows are contiguous byte runs of the NHWC image, zeros outside it
   {
     constexpr int CPR = Cfg::RI * 48 / 16;  // 16-byte chunks per patch row
@@ -772,10 +982,11 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
       const int c = tid + it * NT_;
       const int r = c / CPR, cc = c - r * CPR;
       const long off = (long)ox0 * 48 + (long)cc * 16;
+      // unconditional load from a clamped address (see the fused branch above: conditional loads are serialised)
+      const bool ok = c < NCH && oy0 + r < Hin && off + 16 <= row_bytes;
+      const half8 t = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (ok ? (long)(oy0 + r) * row_bytes + off : 0l));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = (half_t)0;
-      if (c < NCH && oy0 + r < Hin && off + 16 <= row_bytes)
-        v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + r) * row_bytes + off);
+      for (int j = 0; j < 8; ++j) v[it][j] = ok ? t[j] : (half_t)0;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -786,6 +997,7 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
   w_prefetch<14>(w4, rw, tid);
   w_prefetch<14>(w5, rw5, tid);
   w_commit<7>(W3, rw3, tid);
+  }
   __syncthreads();
   ARTP_CNN_MARK(0);
   {  // conv3: X (24 ch) -> Y
@@ -852,6 +1064,10 @@ conv345_kernel(const half_t* __restrict__ in /*[Hin][Win][24]*/, int Hin, int Wi
     }
   }
   ARTP_CNN_MARK(10);
+  ARTP_CNN_FLUSH();
+#ifdef ARTP_STAGE_TIMING
+  if (tid == 0) atomicAdd(&g_cnn_cycles[15], 1ull);
+#endif
 }
 
 // ---- R9: per-edge cost ---------------------------------------------------------------------------------

@@ -551,7 +551,8 @@ def cnn_flops(n):
 
 def cnn_flops_executed(n):
     """What the kernels execute: conv1 and conv2 (no activation in between) are composed on the host into one 5 x 5
-    layer 1 -> 24 (cost_kernels.h conv12_pool_kernel), everything else as counted by cnn_flops."""
+    layer 1 -> 24 (cost_kernels.h conv12_pooled16, inside conv345_kernel's patch phase), everything else as counted by
+    cnn_flops (unique outputs: the halo recomputation of the fused tiles and the hi / lo weight pairs are not counted)."""
     h1, h2 = n - 2, n - 4
     return cnn_flops(n) - 2.0 * 9 * 1 * 24 * h1 * h1 - 2.0 * 9 * 24 * 24 * h2 * h2 + 2.0 * 25 * 1 * 24 * h2 * h2
 
@@ -1333,9 +1334,9 @@ def main():
             gfx = cnn_flops_executed(n_map) / 1e9
             motion_cost[tag] = {"cnn_gflop": gf, "cnn_gflop_executed": gfx,
                                 "cnn_gflop_note": "cnn_gflop = SURVEY 8a-R8's algorithmic count (six layers); executed = conv1 and "
-                                                  "conv2 composed into one 5 x 5 layer on the host (VALU), the other four on MFMA",
+                                                  "conv2 composed into one 5 x 5 layer on the host; all of it on MFMA",
                                 "cnn_ms_incl_h2d": wall_ms, "cnn_kernels_ms": kern_ms,
-                                "cnn_launches": "conv12_pool_kernel + conv345_kernel + conv_ksplit_kernel (15 x 15)",
+                                "cnn_launches": "conv345_kernel (conv1 o conv2 + pool inside its patch phase) + conv_ksplit_kernel (15 x 15)",
                                 "cnn_kernels_tflops": gf / kern_ms,
                                 "cnn_kernels_frac_of_mfma_f16_peak": gf / kern_ms / MFMA_F16_PEAK_TFLOPS,
                                 "cnn_kernels_frac_of_mfma_f16_peak_executed_flops": gfx / kern_ms / MFMA_F16_PEAK_TFLOPS,

@@ -13,7 +13,7 @@ L = _capi.load()
 ctx = Context(0, "yaml")
 ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
 names = ["patch load+barrier", "conv3 mfma", "conv3 store", "barrier", "conv4 mfma", "conv4 store", "barrier", "pool+barrier",
-         "conv5 mfma", "conv5 store+barrier", "tile store"]
+         "conv5 mfma", "conv5 store+barrier", "tile store", "(fused) window -> LDS + barrier", "(fused) conv1 o conv2 -> patch"]
 for n, seed in ((400, 1234), (800, 77)):
     g = raw_map(n, 0.04, seed=seed)
     elv = np.ascontiguousarray(g["elevation"][::-1, ::-1]).astype(np.float32)
@@ -24,7 +24,7 @@ for n, seed in ((400, 1234), (800, 77)):
     L.artp_debug_stage_cycles(out, 4)
     a = np.array(list(out)[:16], dtype=np.float64)
     wg = a[15]
-    print(f"map {n}: {int(wg)} workgroups, cycles per workgroup (wavefront 0): total {a[:11].sum() / wg:.0f}")
+    print(f"map {n}: {int(wg)} workgroups, cycles per workgroup (wavefront 0): total {a[:13].sum() / wg:.0f}")
     for k, nm in enumerate(names):
         print(f"   {nm:24s} {a[k] / wg:9.0f}")
     out8 = (C.c_ulonglong * 48)()
