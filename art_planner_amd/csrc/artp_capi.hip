@@ -2530,6 +2530,9 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
       }
     }
     auto launch = [&](auto kfn, int lds, int tr, int threads = 256) -> int {
+      if (const char* evp = std::getenv("ARTP_KSPLIT_ONE_PER_CU")) {   // experiment: a workgroup on its own (LDS padded past half a CU's)
+        if (evp[0] != '0' && lds < 96 * 1024) lds = 96 * 1024;
+      }
       HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       const unsigned blocks = (unsigned)(((wf + 15) / 16) * ((hf + tr - 1) / tr));
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(threads), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw[4],
@@ -2775,6 +2778,9 @@ extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (reset) {
     unsigned long long z4[4] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(artp::g_feet_cycles), z4, sizeof(z4)) != hipSuccess) return -1;
+  }
+  if (reset == 6) {  // conv_ksplit_kernel's per-workgroup records: out20[0 .. 6143] (1024 x {HW_ID, XCC_ID, 4 x s_memrealtime})
+    return out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_ks_trace), 1024 * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
   }
   if (reset == 5) {  // the strip-walking 15 x 15 kernel: out20[0..47] = cycles per (wavefront, phase) summed over the workgroups
     static unsigned long long all[256 * 12 * 4];

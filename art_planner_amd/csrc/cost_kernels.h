@@ -81,7 +81,23 @@ struct ConvKsplitCfg {
   static_assert((COUT * 2) % 16 == 0, "a pixel is a whole number of 16-byte chunks");
 };
 
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4, bool XCD = true>
+#ifdef ARTP_STAGE_TIMING
+// conv_kwalk_kernel and (round 5) conv_ksplit_kernel, per workgroup (mod 256) and wavefront: cycles in [0] patch loads, [1] the main loop, [2] from its end to the first
+// reduction barrier's release (waiting for the slower wavefronts; the short K slice's row fetch), [3] the reduction.
+// Accumulated in registers, stored once at the end of the kernel: the marks cost an s_memtime each and nothing else.
+__device__ unsigned long long g_kwalk_cycles[256 * 12 * 4];
+// conv_ksplit_kernel, one record per workgroup (wavefront 0): HW_ID, XCC_ID, then s_memrealtime (100 MHz) at the start, at the
+// first MFMA step, at the end of the main loop and at the end of the kernel -- the launch as a Gantt chart per CU
+__device__ unsigned long long g_ks_trace[1024 * 6];
+__device__ __forceinline__ unsigned ks_hw_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
+__device__ __forceinline__ unsigned ks_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v; }
+#define ARTP_KW_MARK(slot) do { const long long n_ = clock64(); kw_c[slot] += (unsigned long long)(n_ - t_prev); t_prev = n_; } while (0)
+#else
+#define ARTP_KW_MARK(slot) do { } while (0)
+#endif
+// RD = slots of the B ring: a fragment is requested RD - 1 steps (of TR x NT MFMAs) before its use (3 = two steps ahead, ~860
+// cycles; 5 was measured in round 5: no change -- the fragments are there in time).
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4, bool XCD = true, int RD = 3>
 __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1)
 conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
                    const float* __restrict__ bias, half_t* __restrict__ out) {
@@ -97,7 +113,27 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   const int oy0 = by * TR, ox0 = bx * Cfg::TP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
+#ifdef ARTP_STAGE_TIMING
+  long long t_prev = clock64();
+  unsigned long long kw_c[4] = {0, 0, 0, 0};
+  unsigned long long ks_t[4];
+  ks_t[0] = wall_clock64();
+#endif
 
+  const char* a_lane = As + li * Cfg::PIX_B + kg * 16;
+  // which k-steps a wavefront takes, and in which order, rotates with the workgroup index (the workgroups of a launch
+  // stream the same 1 MB of B fragments; no two neighbours in the same order)
+  const int ks_first = (wave + (int)(blockIdx.x & (unsigned)(NWV - 1))) & (NWV - 1);
+  const int nj = (KSTEPS - ks_first + NWV - 1) / NWV;
+  const int j0 = (int)((blockIdx.x >> 2) % (unsigned)nj);
+  static_assert(KH % RD == 0 || KH == 1, "the B ring runs on across k-steps: slot = (step index) % RD");
+  static_assert(KSTEPS >= NWV, "every wavefront takes at least one k-step");
+  auto ks_of = [&](int jj) {
+    const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
+    return ks_first + NWV * j;
+  };
+  half8 b[RD][NT];  // ring over (k-step, kernel row), RD - 1 ahead -- it never drains: the last RD - 1 kernel rows of a k-step
+                    // prefetch the first ones of the wavefront's next k-step
   // input patch -> LDS (rows are contiguous byte runs of the NHWC image; out-of-image chunks are zero).
   // All of a thread's loads are in flight before the first LDS store (one memory round trip, not 16).
   {
@@ -115,6 +151,19 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
       if (c < Cfg::PR * CPR && oy0 + r < Hin && off + 16 <= row_bytes)
         v[it] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (long)(oy0 + r) * row_bytes + off);
     }
+    // the ring's first two B fragments are requested BEHIND the patch (loads return in order: waiting for the patch does
+    // not wait for them) and in front of the barrier, not after it: one L2 round trip per tile less (round 5)
+    {
+      const half8* b0 = wp + (size_t)ks_of(0) * NT * 64 + lane;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        b[0][n] = b0[n * 64];
+        if (KH > 1) {
+#pragma unroll
+          for (int d = 1; d < RD - 1; ++d) b[d][n] = b0[(size_t)d * KSTEPS * NT * 64 + n * 64];
+        }
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = tid + it * NTH;
@@ -123,6 +172,10 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
     }
   }
   __syncthreads();
+  ARTP_KW_MARK(0);
+#ifdef ARTP_STAGE_TIMING
+  ks_t[1] = wall_clock64();
+#endif
 
   floatx4 acc[TR][NT];
 #pragma unroll
@@ -130,28 +183,12 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  const char* a_lane = As + li * Cfg::PIX_B + kg * 16;
-  // which k-steps a wavefront takes, and in which order, rotates with the workgroup index (the workgroups of a launch
-  // stream the same 1 MB of B fragments; no two neighbours in the same order)
-  const int ks_first = (wave + (int)(blockIdx.x & (unsigned)(NWV - 1))) & (NWV - 1);
-  const int nj = (KSTEPS - ks_first + NWV - 1) / NWV;
-  const int j0 = (int)((blockIdx.x >> 2) % (unsigned)nj);
-  static_assert(KH % 3 == 0 || KH == 1, "the B ring (3 slots) runs on across k-steps: slot = (step index) % 3");
-  static_assert(KSTEPS >= NWV, "every wavefront takes at least one k-step");
-  auto ks_of = [&](int jj) {
-    const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
-    return ks_first + NWV * j;
-  };
-  half8 b[3][NT];  // ring over (k-step, kernel row), two ahead -- it never drains: the last two kernel rows of a k-step
-                   // prefetch the first two of the wavefront's next k-step
-  {
-    const half8* b0 = wp + (size_t)ks_of(0) * NT * 64 + lane;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      b[0][n] = b0[n * 64];
-      if (KH > 1) b[1][n] = b0[(size_t)KSTEPS * NT * 64 + n * 64];
-    }
-  }
+  // (Round 5, measured and left out again -- profiles/r05_cnn_variants.txt: a ring 4 steps deep (RD 5), the step's loads spread
+  // between its MFMAs (sched_group_barrier), and s_setprio turns between a CU's two workgroups: no change at 400^2 or 800^2.
+  // A wavefront ON ITS OWN issues one of these MFMAs per 26 cycles, two per SIMD one per 17 (tests/cpp/mfma_clock_probe.hip);
+  // the SIMD serves oldest first, so the older workgroup's tile is done when the younger one's is half way, and for 36 of the
+  // launch's 105 us at 800^2 a SIMD holds ONE wavefront in its main loop (scripts/ksplit_gantt.py).  A third resident workgroup
+  // would need <= 168 registers and <= 53 KB of LDS: the 9-row tile has 180 live registers in the loop and a 66 KB patch.)
   for (int jj = 0; jj < nj; ++jj) {
     const int ks = ks_of(jj);
     const char* a_ks = a_lane + ks * 64;
@@ -164,16 +201,17 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
     for (int kh = 0; kh < KH; ++kh) {
       a[(kh + TR - 1) % TR] = *reinterpret_cast<const half8*>(a_ks + (kh + TR - 1) * Cfg::ROW_B);
       {
-        const half8* src = kh + 2 < KH ? b_ks + (size_t)(kh + 2) * KSTEPS * NT * 64 : b_nx + (size_t)(kh + 2 - KH) * KSTEPS * NT * 64;
+        const half8* src = kh + RD - 1 < KH ? b_ks + (size_t)(kh + RD - 1) * KSTEPS * NT * 64
+                                            : b_nx + (size_t)(kh + RD - 1 - KH) * KSTEPS * NT * 64;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[(kh + 2) % 3][n] = src[n * 64];
+        for (int n = 0; n < NT; ++n) b[(kh + RD - 1) % RD][n] = src[n * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < TR; ++m)  // m = TR - 1 uses the row requested just above: it goes last
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[kh % 3][n], a[(kh + m) % TR], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[kh % RD][n], a[(kh + m) % TR], acc[m][n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -183,6 +221,10 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   // The four partial tiles meet in LDS four rows at a time (the patch is dead); wavefront w finishes row 4 h + w.
   // The finished halfs are staged as the NHWC tile [TR][16][COUT] behind the partial rows, then leave as whole
   // 16-byte lanes (a tile row is one contiguous 16*COUT*2-byte run of the output image).
+  ARTP_KW_MARK(1);
+#ifdef ARTP_STAGE_TIMING
+  ks_t[2] = wall_clock64();
+#endif
   using KCfg = ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU, TR, NWV>;
   typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
   floatx4* red = reinterpret_cast<floatx4*>(smem);
@@ -224,6 +266,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
     }
   }
   __syncthreads();
+  ARTP_KW_MARK(2);
   {
     constexpr int CPR = 16 * COUT * 2 / 16;  // 16-byte chunks per tile row
     for (int c = tid; c < TR * CPR; c += NTH) {
@@ -234,6 +277,18 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
             *reinterpret_cast<const half8*>(stage + m * CPR * 16 + cc * 16);
     }
   }
+  ARTP_KW_MARK(3);
+#ifdef ARTP_STAGE_TIMING
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) g_kwalk_cycles[(((int)blockIdx.x & 255) * 12 + wave) * 4 + k] = kw_c[k];
+  if (tid == 0 && blockIdx.x < 1024) {
+    ks_t[3] = wall_clock64();
+    unsigned long long* r = g_ks_trace + (size_t)blockIdx.x * 6;
+    r[0] = ks_hw_id();
+    r[1] = ks_xcc_id();
+    for (int k = 0; k < 4; ++k) r[2 + k] = ks_t[k];
+  }
+#endif
 }
 
 // ---- round 5: the 15 x 15 layer as a PERSISTENT kernel that walks down 16-pixel column strips -------------------------
@@ -269,15 +324,6 @@ struct KwalkCfg {
   static_assert(RING_B % 16 == 0, "16-byte chunks");
 };
 
-#ifdef ARTP_STAGE_TIMING
-// per workgroup (mod 256) and wavefront: cycles in [0] patch loads, [1] the main loop, [2] from its end to the first
-// reduction barrier's release (waiting for the slower wavefronts; the short K slice's row fetch), [3] the reduction.
-// Accumulated in registers, stored once at the end of the kernel: the marks cost an s_memtime each and nothing else.
-__device__ unsigned long long g_kwalk_cycles[256 * 12 * 4];
-#define ARTP_KW_MARK(slot) do { const long long n_ = clock64(); kw_c[slot] += (unsigned long long)(n_ - t_prev); t_prev = n_; } while (0)
-#else
-#define ARTP_KW_MARK(slot) do { } while (0)
-#endif
 
 template <int TR, int BD_ = 5, bool EARLY = true>
 __global__ void __launch_bounds__(768, 3)

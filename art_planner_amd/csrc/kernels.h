@@ -216,9 +216,14 @@ pose_rec_kernel(FieldDev f, const double* __restrict__ se3, size_t n, PoseRec* _
   if (i0 >= n) return;
   const size_t live = n - i0 < 64 ? n - i0 : 64;
   const double* in = se3 + 7 * i0;
+  // seven loads in flight, then seven LDS stores: a load under a condition becomes a branch that hipcc waits for before the
+  // next one (round 5: seven serial trips to memory per wavefront) -- so the loads are unconditional, from a clamped index
+  double v7[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) v7[k] = in[(size_t)(k * 64 + lane) < live * 7 ? k * 64 + lane : 0];
 #pragma unroll
   for (int k = 0; k < 7; ++k)
-    if ((size_t)(k * 64 + lane) < live * 7) sw[k * 64 + lane] = in[k * 64 + lane];
+    if ((size_t)(k * 64 + lane) < live * 7) sw[k * 64 + lane] = v7[k];
   wave_lds_sync();
   float4 r[4];
   const bool have = (size_t)lane < live;

@@ -549,6 +549,29 @@ def cnn_flops(n):
     return tot
 
 
+def mfma_clock_probe(timeout_s=90):
+    """tests/cpp/mfma_clock_probe.hip compiled and run on this box: what the matrix cores sustain with no memory traffic at all
+    (two wavefronts per SIMD: ~17 cycles per v_mfma_f32_16x16x32_f16 at the clock the part keeps under that load; one: ~26).
+    Returns the probe's JSON record, or {"error": ...} (no hipcc, no GPU)."""
+    import shutil
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "tests", "cpp", "mfma_clock_probe.hip")
+    if not (os.path.exists(hipcc) and os.path.exists(src)):
+        return {"error": "hipcc or the probe source is missing"}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            exe = os.path.join(td, "mfma_clock_probe")
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-o", exe, src], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, timeout=timeout_s)
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=timeout_s)
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        rec["source"] = "tests/cpp/mfma_clock_probe.hip, compiled and run by bench.py on this box"
+        return rec
+    except Exception as e:  # noqa: BLE001 -- a reported figure, never a reason to fail the bench
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def cnn_flops_executed(n):
     """What the kernels execute: conv1 and conv2 (no activation in between) are composed on the host into one 5 x 5
     layer 1 -> 24 (cost_kernels.h conv12_pooled16, inside conv345_kernel's patch phase), everything else as counted by
@@ -1341,6 +1364,11 @@ def main():
                                 "cnn_kernels_frac_of_mfma_f16_peak": gf / kern_ms / MFMA_F16_PEAK_TFLOPS,
                                 "cnn_kernels_frac_of_mfma_f16_peak_executed_flops": gfx / kern_ms / MFMA_F16_PEAK_TFLOPS,
                                 "feature_map": list(ctx.cost_features().shape[:2])}
+        probe = mfma_clock_probe()
+        motion_cost["mfma_probe"] = probe
+        if "error" not in probe:
+            for tag in ("c3_400", "c4_800"):
+                motion_cost[tag]["cnn_kernels_frac_of_measured_mfma_rate"] = motion_cost[tag]["cnn_kernels_tflops"] / probe["two_per_simd_tflops"]
         # back to the C3 map for the queries
         elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)
         ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y)
@@ -1641,7 +1669,9 @@ def main():
             if m_:
                 kernel_rooflines[f"cnn_{tag}"] = {"bound": "mfma", "gflop": m_["cnn_gflop"], "ms": m_["cnn_kernels_ms"],
                                                   "achieved_TFLOPs": m_["cnn_kernels_tflops"], "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS,
-                                                  "frac": m_["cnn_kernels_frac_of_mfma_f16_peak"]}
+                                                  "frac": m_["cnn_kernels_frac_of_mfma_f16_peak"],
+                                                  "frac_of_measured_mfma_rate": m_.get("cnn_kernels_frac_of_measured_mfma_rate"),
+                                                  "measured_mfma_rate_TFLOPs": (motion_cost.get("mfma_probe") or {}).get("two_per_simd_tflops")}
 
     out = {
         "metric": "validated states/sec on 400x400@0.04m map (sample + validity check)",

@@ -33,8 +33,9 @@ for n, seed in ((400, 1234), (800, 77)):
     L.artp_debug_stage_cycles(out8, 5)
     k = np.array(list(out8), dtype=np.float64).reshape(12, 4)
     nwg = 242 if n == 400 else 256
-    print(f"   conv_kwalk_kernel: cycles per workgroup and wavefront (wave = nt + 3 kq; sum over the workgroup's tiles), {nwg} workgroups")
-    print("      wave   patch loads   main loop   wait at barrier   reduction      total")
+    print(f"   the 15 x 15 kernel (conv_ksplit_kernel: patch / main loop / reduction / tile store; conv_kwalk_kernel: wave = nt + 3 kq,"
+          f" sums over its tiles): cycles per workgroup and wavefront, {nwg} workgroup slots")
+    print("      wave   patch loads   main loop   [2]               [3]            total")
     for w in range(12):
         r = k[w] / nwg
         print(f"      {w:4d} {r[0]:12.0f} {r[1]:11.0f} {r[2]:17.0f} {r[3]:11.0f} {r.sum():10.0f}")

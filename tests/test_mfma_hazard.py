@@ -107,3 +107,25 @@ def test_device_needs_no_more_wait_states_than_the_checker_assumes(tmp_path):
     assert need["B2"] == 0                     # same-shape accumulation is interlocked
     assert 1 <= max(need["B"], need["B3"]) <= H.MIN_MIX   # the other shape is not -- the reason for FCM_SHAPE_CHANGE
     assert need["C"] <= H.MIN_RD and need["E"] <= H.MIN_WR
+
+
+@pytest.mark.gpu
+@needs_hipcc
+def test_what_the_matrix_cores_sustain(tmp_path):
+    """tests/cpp/mfma_clock_probe.hip: every SIMD issues independent v_mfma_f32_16x16x32_f16 with no memory traffic.  The figures
+    the CNN's roofline is read against: two wavefronts per SIMD reach ~17 cycles per MFMA at the clock the part keeps
+    under that load (~2.0 GHz, not the 2.4 GHz of the nominal 2.5 PFLOP/s); ONE wavefront per SIMD issues only every ~26 cycles --
+    why a workgroup alone on a CU cannot fill the pipe.  The bounds are wide: this pins the mechanism, not a number."""
+    import json
+    exe = str(tmp_path / "mfma_clock_probe")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O2", "-o", exe,
+                           os.path.join(common.ROOT, "tests", "cpp", "mfma_clock_probe.hip")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    os.makedirs(os.path.join(common.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(common.ROOT, "gpurun_out", "mfma_clock_probe.txt"), "w") as f:
+        f.write(out.stdout)
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert 15.5 <= r["two_per_simd_cycles_per_mfma"] <= 20.0, r          # the pipe takes one per 16 cycles at best
+    assert r["one_per_simd_cycles_per_mfma"] >= 1.2 * r["two_per_simd_cycles_per_mfma"], r   # a lone wavefront cannot fill it
+    assert 0.5 * r["nominal_dense_f16_tflops"] <= r["two_per_simd_tflops"] <= 1.02 * r["nominal_dense_f16_tflops"], r
