@@ -2587,10 +2587,17 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     const bool wide = ev8 ? std::atoi(ev8) == 8 : tiles8 <= c->n_cus;
     const char* evx2 = std::getenv("ARTP_CNN_XCD");   // tuning: 0 = tiles in launch order (rounds 3-4)
     const bool xcd2 = evx2 ? std::atoi(evx2) != 0 : true;
+    // $ARTP_KSPLIT_MS=2 (more tiles than CUs, 800^2): 18-row tiles, one 8-wavefront workgroup per CU, K slice x row half
+    // (conv_ksplit_kernel MS = 2).  Built to keep two wavefronts per SIMD in the main loop at all times; measured the same
+    // (launch 111.6 us against 108-111: the main loop runs at 17 cycles per MFMA either way, at ~1.65 GHz), so not the default.
+    const char* evm = std::getenv("ARTP_KSPLIT_MS");
+    const bool ms2 = !wide && xcd2 && evm && std::atoi(evm) == 2;
     if (wide && !xcd2)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8, false>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
     else if (wide)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
+    else if (ms2)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9, 8, true, 3, 2>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9, 8, 2>::LDS_BYTES, 18, 512);
     else if (best == 9 && !xcd2)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9, 4, false>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9>::LDS_BYTES, 9);
     else if (best == 9)

@@ -69,11 +69,11 @@ struct ConvLdsCfg {
 //    (C3: 242 tiles on 256 CUs, where a 4-wavefront workgroup left every SIMD with a single wavefront and nothing to
 //    issue MFMAs while it waits for its B fragments or its LDS row: MFMA busy 0.40).  Same tile, same B traffic, two
 //    wavefronts per SIMD; the reduction takes eight partial tiles instead of four.
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR = 8, int NWV = 4>
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR = 8, int NWV = 4, int MS = 1>
 struct ConvKsplitCfg {
-  using P = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
+  using P = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR * MS>;   // MS > 1: the tile is MS x TR rows (conv_ksplit_kernel)
   static constexpr int RED_BYTES = NWV * 4 * NT * 1024;         // the wavefronts' partial rows, four rows at a time
-  static constexpr int STAGE_BYTES = TR * P::TP * COUT * 2;     // finished NHWC tile
+  static constexpr int STAGE_BYTES = TR * MS * P::TP * COUT * 2;  // finished NHWC tile
   static constexpr int STAGE_OFF = RED_BYTES;
   static constexpr int LDS_BYTES = P::A_BYTES > RED_BYTES + STAGE_BYTES ? P::A_BYTES : RED_BYTES + STAGE_BYTES;
   static_assert(NWV == 4 || NWV == 8, "k-steps are dealt out modulo a power of two");
@@ -97,22 +97,32 @@ __device__ __forceinline__ unsigned ks_xcc_id() { unsigned v; asm volatile("s_ge
 #endif
 // RD = slots of the B ring: a fragment is requested RD - 1 steps (of TR x NT MFMAs) before its use (3 = two steps ahead, ~860
 // cycles; 5 was measured in round 5: no change -- the fragments are there in time).
-template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4, bool XCD = true, int RD = 3>
+// MS (round 5) = row groups: the NWV wavefronts are NK = NWV / MS K slices x MS row groups of TR rows each, the tile is MS x TR rows.
+// MS = 2, NWV = 8: wavefronts k and k + 4 -- the two that share a SIMD -- take the SAME K slice for the upper and the lower half of
+// an 18-row tile: a SIMD always holds two wavefronts in the main loop (one alone issues an MFMA per 26 cycles, two one per 17:
+// tests/cpp/mfma_clock_probe.hip; with two independent 4-wavefront workgroups per CU a SIMD held ONE for a third of the 800^2
+// launch), the pair's B fragments are the same lines, and only four partial sums meet per output row.  Measured: the same time
+// (800^2: 111.6 us against 108-111) -- a tile's main loop is 2 x 2329 MFMAs per SIMD at 17 cycles = 79 k cycles at ~1.65 GHz either
+// way; what the lone wavefronts lose in issue rate the part gives back in clock.  Opt-in ($ARTP_KSPLIT_MS=2), tested.
+template <int KH, int KW, int CIN, int COUT, int NT, bool LRELU, int TR, int NWV = 4, bool XCD = true, int RD = 3, int MS = 1>
 __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1)
 conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
                    const float* __restrict__ bias, half_t* __restrict__ out) {
-  using Cfg = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR>;
+  using Cfg = ConvLdsCfg<KH, KW, CIN, COUT, NT, LRELU, TR * MS>;
   constexpr int KSTEPS = Cfg::KSTEPS;
   constexpr int NTH = 64 * NWV;
+  constexpr int NK = NWV / MS;   // K slices
+  static_assert(NK * MS == NWV && (NK & (NK - 1)) == 0 && NK >= 4, "NK K slices (a power of two, >= the 4 rows of a reduction pass)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;
   const int Hout = Hin - KH + 1, Wout = Win - KW + 1;
   const int tiles_x = (Wout + Cfg::TP - 1) / Cfg::TP;
   const int tile = XCD ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int bx = tile % tiles_x, by = tile / tiles_x;
-  const int oy0 = by * TR, ox0 = bx * Cfg::TP;
+  const int oy0 = by * TR * MS, ox0 = bx * Cfg::TP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
+  const int kslice = wave & (NK - 1), grp = wave / NK;   // K slice, row group (rows grp * TR .. of the tile)
 #ifdef ARTP_STAGE_TIMING
   long long t_prev = clock64();
   unsigned long long kw_c[4] = {0, 0, 0, 0};
@@ -120,17 +130,17 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   ks_t[0] = wall_clock64();
 #endif
 
-  const char* a_lane = As + li * Cfg::PIX_B + kg * 16;
+  const char* a_lane = As + grp * TR * Cfg::ROW_B + li * Cfg::PIX_B + kg * 16;
   // which k-steps a wavefront takes, and in which order, rotates with the workgroup index (the workgroups of a launch
   // stream the same 1 MB of B fragments; no two neighbours in the same order)
-  const int ks_first = (wave + (int)(blockIdx.x & (unsigned)(NWV - 1))) & (NWV - 1);
-  const int nj = (KSTEPS - ks_first + NWV - 1) / NWV;
+  const int ks_first = (kslice + (int)(blockIdx.x & (unsigned)(NK - 1))) & (NK - 1);
+  const int nj = (KSTEPS - ks_first + NK - 1) / NK;
   const int j0 = (int)((blockIdx.x >> 2) % (unsigned)nj);
   static_assert(KH % RD == 0 || KH == 1, "the B ring runs on across k-steps: slot = (step index) % RD");
-  static_assert(KSTEPS >= NWV, "every wavefront takes at least one k-step");
+  static_assert(KSTEPS >= NK, "every wavefront takes at least one k-step");
   auto ks_of = [&](int jj) {
     const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
-    return ks_first + NWV * j;
+    return ks_first + NK * j;
   };
   half8 b[RD][NT];  // ring over (k-step, kernel row), RD - 1 ahead -- it never drains: the last RD - 1 kernel rows of a k-step
                     // prefetch the first ones of the wavefront's next k-step
@@ -225,7 +235,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
 #ifdef ARTP_STAGE_TIMING
   ks_t[2] = wall_clock64();
 #endif
-  using KCfg = ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU, TR, NWV>;
+  using KCfg = ConvKsplitCfg<KH, KW, CIN, COUT, NT, LRELU, TR, NWV, MS>;
   typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
   floatx4* red = reinterpret_cast<floatx4*>(smem);
   char* stage = smem + KCfg::STAGE_OFF;
@@ -240,14 +250,15 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
         for (int n = 0; n < NT; ++n) red[((wave * 4 + mm) * NT + n) * 64 + lane] = acc[4 * h + mm][n];
       }
     __syncthreads();
-    const int m = 4 * h + wave;
-    if (wave < 4 && m < TR) {  // wavefront w < 4 finishes row 4 h + w (the others only contribute their partials)
+    const int m = 4 * h + kslice;
+    if (kslice < 4 && m < TR) {  // K slice k < 4 of a row group finishes the group's row 4 h + k: the sum over the group's NK slices
+      const int w0 = grp * NK;   // (the other slices only contribute their partials)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        floatx4 v = red[((0 * 4 + wave) * NT + n) * 64 + lane];
+        floatx4 v = red[((w0 * 4 + kslice) * NT + n) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < NWV; ++w) {
-          const floatx4 p = red[((w * 4 + wave) * NT + n) * 64 + lane];
+        for (int w = 1; w < NK; ++w) {
+          const floatx4 p = red[(((w0 + w) * 4 + kslice) * NT + n) * 64 + lane];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += p[r];
         }
@@ -261,7 +272,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
           if (LRELU) y = fmaxf(y, 0.3f * y);
           y4[r] = (half_t)y;
         }
-        *reinterpret_cast<half4_t*>(stage + ((m * 16 + li) * COUT + ch) * 2) = y4;
+        *reinterpret_cast<half4_t*>(stage + (((grp * TR + m) * 16 + li) * COUT + ch) * 2) = y4;
       }
     }
   }
@@ -269,7 +280,7 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
   ARTP_KW_MARK(2);
   {
     constexpr int CPR = 16 * COUT * 2 / 16;  // 16-byte chunks per tile row
-    for (int c = tid; c < TR * CPR; c += NTH) {
+    for (int c = tid; c < TR * MS * CPR; c += NTH) {
       const int m = c / CPR, cc = c - m * CPR;
       const int px = (cc * 16) / (COUT * 2);
       if (oy0 + m < Hout && ox0 + px < Wout)

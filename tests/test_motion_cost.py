@@ -250,7 +250,7 @@ def test_gpu_gather_and_costs_equal_the_reference_cost_query(tag):
 @pytest.mark.parametrize("n", [400, 800, 141])
 def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypatch):
     """Round 5 kept these behind environment switches: conv1 o conv2 as its own launch or fused (ARTP_CONV12_FUSED=0 / 1), its
-    VALU form (ARTP_CONV12_MFMA=0), and two things (read at every feature-map update): the persistent strip-walking
+    VALU form (ARTP_CONV12_MFMA=0), the 15 x 15 layer as K slice x row half on 18-row tiles (ARTP_KSPLIT_MS=2, 800^2 only), and two things (read at every feature-map update): the persistent strip-walking
     form of the 15 x 15 layer (conv_kwalk_kernel, ARTP_KWALK=1, three variants and two tile heights: built, measured slower) and
     the launch-order tile numbering (ARTP_CNN_XCD=0).  Every one of them must produce the default's features: the same
     products in fp32 accumulators, only the summation order of the K slices differs (one fp16 ulp of the stored feature), and equal
@@ -264,7 +264,7 @@ def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypa
     ctx.cost_load_weights(convert_weights.to_blob(p))
     base = _gpu_features(ctx, elv, gm.res)
     _assert_features_close(base, mo.cnn_features(p, elv), f"default {n}")
-    settings = [{"ARTP_CONV12_FUSED": "0"}, {"ARTP_CONV12_FUSED": "1"}, {"ARTP_CONV12_MFMA": "0"}, {"ARTP_CNN_XCD": "0"}, {"ARTP_KWALK": "1"}, {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "1"},
+    settings = [{"ARTP_CONV12_FUSED": "0"}, {"ARTP_CONV12_FUSED": "1"}, {"ARTP_CONV12_MFMA": "0"}, {"ARTP_CNN_XCD": "0"}, {"ARTP_KSPLIT_MS": "2"}, {"ARTP_KWALK": "1"}, {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "1"},
                 {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "2"}, {"ARTP_KWALK": "1", "ARTP_KWALK_TR": "8"},
                 {"ARTP_KWALK": "1", "ARTP_KWALK_TR": "10", "ARTP_CNN_XCD": "0"}]
     for env in settings:
