@@ -565,6 +565,8 @@ def mfma_clock_probe(timeout_s=90):
             subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-o", exe, src], stdout=subprocess.DEVNULL,
                                   stderr=subprocess.DEVNULL, timeout=timeout_s)
             out = subprocess.run([exe], capture_output=True, text=True, timeout=timeout_s)
+        if out.returncode != 0:
+            return {"error": (out.stderr.strip() or f"the probe exited with {out.returncode}")[-200:]}
         rec = json.loads(out.stdout.strip().splitlines()[-1])
         rec["source"] = "tests/cpp/mfma_clock_probe.hip, compiled and run by bench.py on this box"
         return rec

@@ -35,7 +35,10 @@ __global__ void __launch_bounds__(256) mfma_loop(int iters, float* out, unsigned
 
 int main() {
   hipDeviceProp_t p;
-  (void)hipGetDeviceProperties(&p, 0);
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess || p.multiProcessorCount < 1) {
+    fprintf(stderr, "mfma_clock_probe: no HIP device\n");
+    return 1;
+  }
   const int cus = p.multiProcessorCount;
   printf("device %s, %d CUs, clockRate %d kHz\n", p.gcnArchName, cus, p.clockRate);
   float* d_out;

@@ -1,6 +1,7 @@
 """CPU suite: the host-side logic of bench.py that does not need a GPU -- the PMC summary arithmetic, the
 staleness rule for the committed PMC fallback, the edge pairing and the CNN flop count of SURVEY.md 8a-R8."""
 import json
+import pytest
 import os
 
 import numpy as np
@@ -195,3 +196,13 @@ def test_lane_utilisation_and_the_roofline_fraction():
     assert abs(bench.roofline_fraction(s, "valu_issue", fr) - s["valu_useful_time_weighted"]) < 1e-12
     assert bench.roofline_fraction(s, "hbm", {"hbm": 0.7}) == 0.7
     assert bench.roofline_fraction(None, None, {}) is None
+
+
+def test_mfma_clock_probe_reports_an_error_instead_of_failing_the_bench_without_a_gpu():
+    """bench.mfma_clock_probe compiles tests/cpp/mfma_clock_probe.hip and runs it; where there is no device (this container) or no
+    hipcc it returns {"error": ...} -- a reported figure is never a reason for the bench line to be missing."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the probe's figures are checked by tests/test_mfma_hazard.py")
+    r = bench.mfma_clock_probe(timeout_s=120)
+    assert set(r) == {"error"} and r["error"], r
