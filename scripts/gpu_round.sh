@@ -13,7 +13,10 @@ echo "bench rc $?"
 python - <<PY
 import json
 try:
-    d = json.loads(open("$OUT/bench_$TAG.json").read().strip().splitlines()[-1])
+    lines = open("$OUT/bench_$TAG.json").read().strip().splitlines()
+    short = lines[-1]
+    print("contract line bytes", len(short), "parses", bool(json.loads(short)))
+    d = json.loads([l for l in lines if l.startswith("BENCH_DETAIL ")][-1][len("BENCH_DETAIL "):])
     r = d["roofline"]
     print("value", d["value"], "ms/step", d["ms_per_step"], "kernel_ms", r["kernel_ms"], "fused_ms", r.get("fused_sample_validate_ms"))
     print("pmc", r["pmc_source"])

@@ -206,3 +206,85 @@ def test_mfma_clock_probe_reports_an_error_instead_of_failing_the_bench_without_
         pytest.skip("a GPU is present: the probe's figures are checked by tests/test_mfma_hazard.py")
     r = bench.mfma_clock_probe(timeout_s=120)
     assert set(r) == {"error"} and r["error"], r
+
+
+def _canned_full_result(pad=1):
+    """A full bench result of round 5's shape and worse: long prose, per-kernel tables, NaN / inf in the extras."""
+    prose = "x" * 700
+    per_kernel = {f"kernel_{i}": {"valu_busy": 0.7, "lds_busy": 0.1, "us": 400.0 + i, "note": prose} for i in range(12 * pad)}
+    return {
+        "metric": "validated states/sec on 400x400@0.04m map (sample + validity check)", "value": 3.667e9, "unit": "states/s",
+        "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 1.1437, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: " + prose, "states_per_gpu_per_step": 1 << 22, "map": "400x400@0.04", "lanes": prose,
+                   "sharding": prose, "spin_up_batches": 32},
+        "headline": {"value_edges": 1.33e8, "value_edges_interp": 2.0e8, "ms_per_step_cold_after_2s_idle": 1.264,
+                     "roofline_frac": 0.5, "c5_cycle_ms_median": float("nan")},
+        "kernel_rooflines": {f"k{i}": {"what": prose, "frac": 0.1} for i in range(8 * pad)},
+        "value_edges": 1.33e8, "value_edges_interp": 2.0e8, "unit_edges": "edges/s",
+        "roofline": {"bound": "valu_issue", "achieved": 0.85, "peak": 1.0, "unit": prose, "frac": 0.52, "frac_is": prose,
+                     "traffic": 8.75e8, "hbm_traffic_frac": 0.0957, "kernel": "validity pipeline", "kernel_ms": 1.12,
+                     "occupancy_fractions": {"valu_issue": 0.85, "lds": 0.2, "hbm": 0.1}, "note": prose,
+                     "algorithmic_hbm": {"achieved": 20000.0, "peak": 8000.0, "unit": "GB/s", "ratio_to_peak": 2.5,
+                                         "bytes_per_launch": 2.292e10, "bytes_per_state": 5464.0, "note": prose},
+                     "binding": {"per_kernel": per_kernel, "valu_busy_note": prose}, "pmc_source": "live",
+                     "csrc_hash": "f06808b994e8a4a7"},
+        "cpu_baseline": {"value": 9.66e5, "unit": "states/s", "cores": 16, "kind": "port", "sample": prose,
+                         "threads_at_best": 32, "single_core_value": 6.0e4, "labels_match_gpu": True,
+                         "thread_sweep": [{"threads": t, "states_per_s": 1e5 * t, "note": prose} for t in range(1, 40 * pad)],
+                         "reference_ode": {"threads": {str(t): 5e4 * t for t in range(64)}},
+                         "reference_ode_single_core_states_per_s": 5.5e4, "reference_ode_best_states_per_s": 2.9e5,
+                         "reference_ode_labels_match_gpu": True,
+                         "edges": {"check_motion_edges_per_s": 6900.0, "verdicts_match_gpu": True, "sample": prose},
+                         "c1": {"cpu_lazy_prm_star": {"x": [prose] * 20}}},
+        "valid_fraction": 0.31, "label_hash_batch0": "0123456789abcdef", "sampler_ms_per_batch": 0.05,
+        "edges": {"check_motion": {"binding": {"per_kernel": per_kernel}}}, "pipeline_counts_batch0": list(range(400)),
+        "motion_cost_c3": {"c3_400": {"cnn_kernels_ms": float("inf")}, "blob": prose * 5},
+        "replan_cycle_c5": {"cycles": [1.0] * 300}, "roadmap_n1": {"a": prose}, "preprocess_n2": {"a": prose},
+        "c4_800_defaults": {"a": prose}, "distributed": None, "device": "gfx950:sramecc+:xnack-", "gather_error": None,
+    }
+
+
+@pytest.mark.parametrize("pad", [1, 20])
+def test_the_contract_line_is_one_short_line_whatever_the_extras_hold(pad):
+    """round 5's final line grew to 25.5 kB and the driver's record parsed nothing.  The last line
+    bench.py prints carries the contract keys + config + headline + roofline + cpu_baseline and nothing bulky."""
+    full = _canned_full_result(pad)
+    line = bench.contract_line(full)
+    assert "\n" not in line and len(line.encode()) < 6144 < 8192
+    for tok in ("NaN", "Infinity"):
+        assert tok not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"] and d["config"]["states_per_gpu_per_step"] == 1 << 22
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["algorithmic_hbm"]["ratio_to_peak"] == 2.5 and "binding" not in d["roofline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "reference_ode_best_states_per_s", "labels_match_gpu"):
+        assert k in d["cpu_baseline"], k
+    assert "thread_sweep" not in d["cpu_baseline"] and "c1" not in d["cpu_baseline"]
+    assert d["headline"]["c5_cycle_ms_median"] is None        # NaN became null
+    for bulky in ("kernel_rooflines", "edges", "motion_cost_c3", "replan_cycle_c5", "roadmap_n1", "pipeline_counts_batch0"):
+        assert bulky not in d
+
+
+def test_emit_prints_the_detail_line_first_and_the_contract_line_last(tmp_path, monkeypatch):
+    import io
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    buf = io.StringIO()
+    bench.emit(_canned_full_result(), buf)
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("BENCH_DETAIL ")
+    detail = json.loads(lines[0][len("BENCH_DETAIL "):])
+    assert "kernel_rooflines" in detail and "roadmap_n1" in detail
+    last = json.loads(lines[-1])
+    assert last["metric"].startswith("validated states/sec") and len(lines[-1]) < 6144
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json"))["value"] == last["value"]
+
+
+def test_watchdog_partial_line_is_short_too():
+    part = {"metric": "m", "value": 1.0, "unit": "states/s", "n_gpus": 2, "distributed": {"exchange": "x" * 5000, "blob": ["y" * 100] * 100}}
+    line = bench.contract_line(part)
+    assert len(line) < 6144 and json.loads(line)["value"] == 1.0
