@@ -19,7 +19,7 @@ SYMBOLS = [
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_sample_and_validate", "artp_check_motions_last_valid", "artp_check_motions_last_valid_dev",
-    "artp_set_z_bounds", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
+    "artp_set_z_bounds", "artp_set_few_edges", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_pack_edge_results_dev", "artp_cost_update_map_dev", "artp_pack_valid_bits_dev", "artp_indices_from_bits_dev",
     "artp_materialise_from_bits_dev",
@@ -136,6 +136,7 @@ def load():
     L.artp_map_version.argtypes = [vp]
     L.artp_map_version.restype = C.c_uint64
     L.artp_set_z_bounds.argtypes = [vp, dbl, dbl]
+    L.artp_set_few_edges.argtypes = [vp, i32]
     for name in ("artp_check_motions_last_valid", "artp_check_motions_last_valid_dev"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, vp]
     for name in ("artp_check_motions", "artp_check_motions_dev"):

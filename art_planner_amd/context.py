@@ -131,6 +131,10 @@ class Context:
                   "artp_sample_states")
         return out
 
+    def set_few_edges(self, enabled=True):
+        """<= 64 edges per host call: the one-launch latency kernel (default) or the batch pipeline (enabled=False)."""
+        self._chk(self.L.artp_set_few_edges(self.h, 1 if enabled else 0), "artp_set_few_edges")
+
     def check_motions(self, s1, s2):
         s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
         s2 = np.ascontiguousarray(s2, np.float64).reshape(-1, 7)

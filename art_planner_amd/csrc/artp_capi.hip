@@ -22,6 +22,14 @@
 using namespace artp;
 
 #define ARTP_FEW_STATES 16
+// mapped block of the edge latency path: offsets of its parts (see artp_ctx::pin_edges)
+#define FEW_EDGE_S1 0
+#define FEW_EDGE_S2 (ARTP_FEW_EDGES * 7 * sizeof(double))
+#define FEW_EDGE_LAST_T (2 * ARTP_FEW_EDGES * 7 * sizeof(double))
+#define FEW_EDGE_LAST_STATE (FEW_EDGE_LAST_T + ARTP_FEW_EDGES * sizeof(double))
+#define FEW_EDGE_AUX (FEW_EDGE_LAST_STATE + ARTP_FEW_EDGES * 7 * sizeof(double))
+#define FEW_EDGE_STATUS (FEW_EDGE_AUX + ARTP_FEW_EDGES * sizeof(uint32_t))
+#define FEW_EDGE_BLOCK_BYTES (FEW_EDGE_STATUS + ARTP_FEW_EDGES)
 #define ARTP_MAX_LANES 4
 
 struct artp_ctx {
@@ -57,6 +65,7 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
+  bool few_edges = true;      // <= ARTP_FEW_EDGES edges per HOST call: the one-launch latency kernel (artp_set_few_edges)
   bool edge_two_pass = true;  // artp_check_motions: coarse pass first ($ARTP_EDGE_TWO_PASS=0: one pass over all states)
   int edge_coarse_stride = ARTP_COARSE_STRIDE;  // $ARTP_COARSE_STRIDE (tuning)
   // map tables (pipeline.h): per layer 6 levels of {max, min} + 6 levels of non-finite / NaN flag bytes, the
@@ -84,6 +93,13 @@ struct artp_ctx {
   double* pin_states_dev = nullptr;       // device view of the same memory
   uint8_t* pin_labels_dev = nullptr;
   bool poll_labels = true;                // spin on the mapped labels instead of hipStreamSynchronize
+  // latency path of the edge checks (<= ARTP_FEW_EDGES edges per call): one mapped block
+  //   s1 | s2 (64 x 7 f64 each) | last_t (64 f64) | last_state (64 x 7 f64) | aux (64 u32) | status (64 u8)
+  char* pin_edges_in = nullptr;           // s1 | s2 of a call, host view (non-coherent mapping)
+  char* pin_edges_in_dev = nullptr;
+  char* pin_edges = nullptr;              // host view
+  char* pin_edges_dev = nullptr;          // device view
+  FewEdgeSync* d_few_sync = nullptr;      // device, armed {~0, 0, 0} per edge (the kernel re-arms what it used)
   // device scratch
   int* d_error = nullptr;
   unsigned long long* d_count = nullptr;
@@ -336,6 +352,8 @@ int set_kernel_lds(artp_ctx* c) {
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(plane_stage_kernel<1>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(validate_few_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few(c)));
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(check_motions_few_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few(c)));
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_boxes_kernel<ARTP_WAVES_PER_BLOCK, 64, 3>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan(c)));
@@ -731,6 +749,34 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
       artp_destroy(c);
       return ARTP_ERR_HIP;
     }
+    {
+      void *pe = nullptr, *ped = nullptr;
+      std::vector<FewEdgeSync> armed(ARTP_FEW_EDGES, FewEdgeSync{0xffffffffu, 0u, 0u, {0u}});
+      void *pi = nullptr, *pid = nullptr;
+      // the edges (host -> device): NON-coherent mapped memory, i.e. cacheable in the device's L2 for the length of a
+      // kernel -- every workgroup of a call reads its edge, and only the first read of a line crosses PCIe.  The
+      // results (device -> host, polled) stay in coherent memory.
+      if (hipHostMalloc(&pi, 2 * ARTP_FEW_EDGES * 7 * sizeof(double), hipHostMallocMapped | hipHostMallocNonCoherent) == hipSuccess &&
+          hipHostGetDevicePointer(&pid, pi, 0) == hipSuccess) {
+        c->pin_edges_in = static_cast<char*>(pi);
+        c->pin_edges_in_dev = static_cast<char*>(pid);
+      } else if (pi) {
+        (void)hipHostFree(pi);
+      }
+      if (!c->pin_edges_in ||
+          hipHostMalloc(&pe, FEW_EDGE_BLOCK_BYTES, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer(&ped, pe, 0) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&c->d_few_sync), ARTP_FEW_EDGES * sizeof(FewEdgeSync)) != hipSuccess ||
+          hipMemcpy(c->d_few_sync, armed.data(), ARTP_FEW_EDGES * sizeof(FewEdgeSync), hipMemcpyHostToDevice) != hipSuccess) {
+        if (pe) (void)hipHostFree(pe);
+        (void)hipHostFree(ps);
+        (void)hipHostFree(pl);
+        artp_destroy(c);
+        return ARTP_ERR_HIP;
+      }
+      c->pin_edges = static_cast<char*>(pe);
+      c->pin_edges_dev = static_cast<char*>(ped);
+    }
     c->pin_states = static_cast<double*>(ps);
     c->pin_labels = static_cast<volatile uint8_t*>(pl);
     c->pin_states_dev = static_cast<double*>(psd);
@@ -794,6 +840,9 @@ void artp_destroy(artp_ctx* c) {
   if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->d_map_f32) (void)hipFree(c->d_map_f32);
   if (c->d_diff) (void)hipFree(c->d_diff);
+  if (c->pin_edges) (void)hipHostFree(c->pin_edges);
+  if (c->pin_edges_in) (void)hipHostFree(c->pin_edges_in);
+  if (c->d_few_sync) (void)hipFree(c->d_few_sync);
   if (c->pin_states) (void)hipHostFree(c->pin_states);
   if (c->pin_labels) (void)hipHostFree(const_cast<uint8_t*>(c->pin_labels));
   delete c;  // d_error / d_count of every lane went with the lanes above
@@ -1775,6 +1824,98 @@ static int run_edges_dev(artp_ctx* c, int mode, const double* s1, const double* 
   return ARTP_OK;
 }
 
+// Estimate of the wave-tasks of a small edge batch in plain host arithmetic: the total chooses the path (latency kernel or
+// batch pipeline), the largest per-edge count sizes the latency kernel's grid.  Estimates only -- the kernels form the
+// exact counts themselves, and an edge with more tasks than workgroups just loops.  Non-finite input -> huge, i.e. the
+// batch path and its error.
+static double few_edges_task_estimate(const artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
+                                      double* max_per_edge) {
+  double total = 0.0, mx = 1.0;
+  const double ex = 2.0 * c->geom.len_x, ey = 2.0 * c->geom.len_y, ez = c->z_high - c->z_low;
+  const double seg = (c->r3_extent_override > 0.0 ? c->r3_extent_override : std::sqrt(ex * ex + ey * ey + ez * ez)) * 0.01;
+  for (size_t e = 0; e < n; ++e) {
+    const double* a = s1 + 7 * e;
+    const double* b = s2 + 7 * e;
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    double t;
+    if (mode == 0) {
+      const double r3 = std::sqrt(dx * dx + dy * dy + dz * dz) / seg;
+      double dq = std::fabs(a[3] * b[3] + a[4] * b[4] + a[5] * b[5] + a[6] * b[6]);
+      const double so3 = (dq < 1.0 ? std::acos(dq) : 0.0) / (0.005 * 3.14159265358979323846);
+      t = (r3 > so3 ? r3 : so3) + 2.0;
+    } else {
+      t = std::sqrt(dx * dx + dy * dy) / 0.5 + 1.0;
+    }
+    if (!(t < 1e9)) return 1e30;
+    total += t;
+    mx = t > mx ? t : mx;
+  }
+  *max_per_edge = mx;
+  return total;
+}
+
+// <= ARTP_FEW_EDGES edges in ONE launch (kernels.h check_motions_few_kernel).  s1 / s2: host pointers (host_io: staged
+// through the mapped block, results read back from it) or device pointers (results to the caller's device arrays);
+// either way the verdict's status bytes come back through mapped memory and the call returns when they are there.
+static int run_edges_few(artp_ctx* c, int mode, bool host_io, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                         uint32_t* aux_out, double* last_t, double* last_state, double max_tasks_per_edge) {
+  char* hb = c->pin_edges;
+  char* db = c->pin_edges_dev;
+  volatile uint8_t* status = reinterpret_cast<volatile uint8_t*>(hb + FEW_EDGE_STATUS);
+  if (host_io) {
+    std::memcpy(c->pin_edges_in + FEW_EDGE_S1, s1, n * 7 * sizeof(double));
+    std::memcpy(c->pin_edges_in + FEW_EDGE_S2, s2, n * 7 * sizeof(double));
+  }
+  for (size_t i = 0; i < n; ++i) status[i] = 0;
+  // workgroups per edge: one per task of the longest edge (estimated; <= ~100 for edges shorter than the map), ~2048
+  // workgroups per launch at most
+  unsigned chunks = (unsigned)(2048 / n), want = (unsigned)(max_tasks_per_edge < 128.0 ? max_tasks_per_edge : 128.0) + 1u;
+  chunks = chunks > 128 ? 128 : (chunks < 16 ? 16 : chunks);
+  chunks = chunks > want ? want : chunks;
+  const unsigned tag = 0x80u;
+  const bool want_last = mode == 0 && last_t;
+  hipLaunchKernelGGL(check_motions_few_kernel, dim3(chunks, (unsigned)n), dim3(320), lds_few(c), c->stream, c->field[0],
+                     c->field[1], c->geom, c->robot, c->z_high - c->z_low, c->r3_extent_override, mode,
+                     host_io ? reinterpret_cast<const double*>(c->pin_edges_in_dev + FEW_EDGE_S1) : s1,
+                     host_io ? reinterpret_cast<const double*>(c->pin_edges_in_dev + FEW_EDGE_S2) : s2, (uint32_t)n, c->d_few_sync,
+                     reinterpret_cast<volatile uint8_t*>(db + FEW_EDGE_STATUS), host_io ? (uint8_t*)nullptr : valid,
+                     !aux_out ? (uint32_t*)nullptr : host_io ? reinterpret_cast<uint32_t*>(db + FEW_EDGE_AUX) : aux_out,
+                     !want_last ? (double*)nullptr : host_io ? reinterpret_cast<double*>(db + FEW_EDGE_LAST_T) : last_t,
+                     !(want_last && last_state) ? (double*)nullptr
+                         : host_io ? reinterpret_cast<double*>(db + FEW_EDGE_LAST_STATE) : last_state,
+                     c->caps_full, c->caps_foot_full, tag);
+  HIP_TRY(c, hipGetLastError());
+  bool done = false;
+  if (c->poll_labels) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0; !done; ++spin) {
+      done = true;
+      for (size_t i = 0; i < n; ++i) done = done && (status[i] & 0x80u);
+      if (!done && (spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+        break;
+    }
+  }
+  if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::atomic_thread_fence(std::memory_order_acquire);
+  unsigned flags = 0;
+  for (size_t i = 0; i < n; ++i) flags |= status[i];
+  if (flags & 4u) {
+    c->last_error = "an edge has non-finite states or needs more than 2^22 interpolation states";
+    return ARTP_ERR_INVALID_ARG;
+  }
+  if (flags & 2u) {
+    c->last_error = "a box window exceeded the LDS tile capacity";
+    return ARTP_ERR_CAPACITY;
+  }
+  if (host_io) {
+    for (size_t i = 0; i < n; ++i) valid[i] = status[i] & 1u;
+    if (aux_out) std::memcpy(aux_out, hb + FEW_EDGE_AUX, n * sizeof(uint32_t));
+    if (want_last) std::memcpy(last_t, hb + FEW_EDGE_LAST_T, n * sizeof(double));
+    if (want_last && last_state) std::memcpy(last_state, hb + FEW_EDGE_LAST_STATE, n * 7 * sizeof(double));
+  }
+  return ARTP_OK;
+}
+
 static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
                           uint8_t* valid, uint32_t* aux_out, double* last_t = nullptr, double* last_state = nullptr) {
   if (!c || (n && (!s1 || !s2 || !valid))) return ARTP_ERR_INVALID_ARG;
@@ -1782,6 +1923,10 @@ static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double*
   // one lock for the whole call: the staging buffers c->tmp[0..1] are shared by every host entry point
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
+  double few_max = 0.0;
+  if (n <= ARTP_FEW_EDGES && c->few_edges && c->have_field[0] && c->have_field[1] && (mode != 0 || c->have_z) &&
+      few_edges_task_estimate(c, mode, s1, s2, n, &few_max) <= 65536.0)
+    return run_edges_few(c, mode, true, s1, s2, n, valid, aux_out, last_t, last_state, few_max);
   int rc = ensure_tmp(c, 0, 2 * n * 7 * sizeof(double));
   if (rc) return rc;
   // tmp[1]: last_t (n doubles) | last_state (7n doubles) | aux (n u32) | valid (n)
@@ -1806,6 +1951,12 @@ static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double*
   return check_error_flag(c);
 }
 
+int artp_set_few_edges(artp_ctx* c, int enabled) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->few_edges = enabled != 0;
+  return ARTP_OK;
+}
 int artp_check_motions_dev(artp_ctx* c, const double* s1, const double* s2, size_t n, uint8_t* valid) {
   return run_edges_dev(c, 0, s1, s2, n, valid, nullptr);
 }
@@ -2776,6 +2927,9 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 #include "group.h"
 
 #ifdef ARTP_STAGE_TIMING
+extern "C" int artp_debug_few_trace(unsigned long long* out40) {
+  return hipMemcpyFromSymbol(out40, HIP_SYMBOL(artp::g_few_trace), 40 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_stage_cycles), 20 * sizeof(unsigned long long)) != hipSuccess)
     return -1;

@@ -339,26 +339,11 @@ validate_states_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb,
 // feet against the masked layer), each with its own LDS scratch, so the call costs the slowest box instead of
 // their sum.  The label is the AND over the boxes (the reference's short-circuit only skips work).  States and
 // labels may live in mapped host memory: one launch, no copies.
-__global__ void __launch_bounds__(320)
-validate_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const double* __restrict__ se3, size_t n,
-                    volatile uint8_t* valid, ScratchCaps caps_torso, ScratchCaps caps_foot,
-                    int* __restrict__ error_flag, unsigned done_tag) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int box_ok[5];
-  const int lane = threadIdx.x & 63;
-  const int k = threadIdx.x >> 6;  // box index, wave-uniform
-  const size_t i = blockIdx.x;
-  if (i >= n) return;
+// One box (k = 0 torso, 1..4 feet in the reference order) of one state on one wavefront, with the wavefront's own LDS
+// scratch: 1 / 0 = this box passes / fails the state, -1 = the window exceeded the scratch.
+__device__ __forceinline__ int few_box_ok(const FieldDev& fb, const FieldDev& ff, const MapGeom& g, const RobotDev& rb,
+                                          const double* st, int k, const WaveScratch& s, int lane) {
   const bool body = (k == 0);
-  WaveScratch s;
-  if (body) {
-    s = carve_scratch(smem, 0, caps_torso);
-  } else {
-    s = carve_scratch(smem + scratch_bytes_per_wave(caps_torso), k - 1, caps_foot);
-  }
-  double st[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
   float t[3], R[9];
   pose3_from_se3(st, t, R);
   const float ox = body ? rb.torso_off[0] : ((k <= 2) ? rb.feet_off_x : -rb.feet_off_x);
@@ -376,22 +361,41 @@ validate_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const doub
     pose[4 + 4 * r + 2] = R[3 * r + 2];
     pose[4 + 4 * r + 3] = 0.0f;
   }
-  int ok;
-  if (!map_is_inside(g, (double)pose[0], (double)pose[1])) {
-    ok = body ? 1 : !rb.unknown_space_untraversable;  // validity_checker_body.cpp:29-32, _feet.cpp:34-37
+  if (!map_is_inside(g, (double)pose[0], (double)pose[1]))
+    return body ? 1 : !rb.unknown_space_untraversable;  // validity_checker_body.cpp:29-32, _feet.cpp:34-37
+  BoxHF b;
+  int ec, r;
+  if (body) {
+    setup_box(fb, pose, rb.torso[0], rb.torso[1], rb.torso[2], b);
+    r = wave_check_box(fb, b, s, lane, &ec);
   } else {
-    BoxHF b;
-    int ec, r;
-    if (body) {
-      setup_box(fb, pose, rb.torso[0], rb.torso[1], rb.torso[2], b);
-      r = wave_check_box(fb, b, s, lane, &ec);
-    } else {
-      setup_box(ff, pose, rb.foot[0], rb.foot[1], rb.foot[2], b);
-      r = wave_check_box(ff, b, s, lane, &ec);
-    }
-    ok = (r < 0) ? -1 : (body ? !r : r);
-    if (r < 0 && lane == 0 && !done_tag) atomicExch(error_flag, 1);
+    setup_box(ff, pose, rb.foot[0], rb.foot[1], rb.foot[2], b);
+    r = wave_check_box(ff, b, s, lane, &ec);
   }
+  return (r < 0) ? -1 : (body ? !r : r);
+}
+
+__global__ void __launch_bounds__(320)
+validate_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const double* __restrict__ se3, size_t n,
+                    volatile uint8_t* valid, ScratchCaps caps_torso, ScratchCaps caps_foot,
+                    int* __restrict__ error_flag, unsigned done_tag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int box_ok[5];
+  const int lane = threadIdx.x & 63;
+  const int k = threadIdx.x >> 6;  // box index, wave-uniform
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  WaveScratch s;
+  if (k == 0) {
+    s = carve_scratch(smem, 0, caps_torso);
+  } else {
+    s = carve_scratch(smem + scratch_bytes_per_wave(caps_torso), k - 1, caps_foot);
+  }
+  double st[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) st[j] = se3[7 * i + j];
+  const int ok = few_box_ok(fb, ff, g, rb, st, k, s, lane);
+  if (ok < 0 && lane == 0 && !done_tag) atomicExch(error_flag, 1);
   if (lane == 0) box_ok[k] = ok;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -876,6 +880,44 @@ __device__ __forceinline__ unsigned clamp_task_count(double x, int* overflow) {
   return (unsigned)x;
 }
 
+// tasks of one edge: mode 0 -> *aux = nd = CompoundStateSpace::validSegmentCount, tasks = 1 (s2) + max(nd - 1, 0);
+// mode 1 -> *aux = tasks = n_interp = floor(lateral distance / 0.5).  ONE definition for the batch planner
+// (motion_plan_kernel) and the latency kernel (check_motions_few_kernel): the same operations, the same bits.
+__device__ __forceinline__ uint32_t edge_task_count(const MapGeom& g, double z_extent, double r3_extent_override, int mode,
+                                                    const double* a, const double* b, uint32_t* aux, int* overflow) {
+  if (mode == 0) {
+    // CompoundStateSpace::validSegmentCount: max over R^3 and SO3 of ceil(dist / (0.01*maxExtent));
+    // R^3 bounds = map centre -/+ FULL length (art_planner/src/planner.cpp:146-156).
+    const double ex = (g.pos_x + g.len_x) - (g.pos_x - g.len_x);
+    const double ey = (g.pos_y + g.len_y) - (g.pos_y - g.len_y);
+    double ext = 0.0;
+    ext += ex * ex;
+    ext += ey * ey;
+    ext += z_extent * z_extent;
+    // artp_set_r3_extent: the R^3 maxExtent frozen at an earlier map's bounds (OMPL keeps longestValidSegment_ from
+    // the first StateSpace::setup(), planner.cpp:146-163 never re-runs it)
+    const double seg_r3 = (r3_extent_override > 0.0 ? r3_extent_override : sqrt(ext)) * 0.01;
+    double d2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double diff = a[i] - b[i];
+      d2 += diff * diff;
+    }
+    const unsigned n_r3 = clamp_task_count(ceil(sqrt(d2) / seg_r3), overflow);
+    const double seg_so3 = (0.5 * 3.14159265358979323846) * 0.01;
+    const unsigned n_so3 = clamp_task_count(ceil(so3_arc_length(a + 3, b + 3) / seg_so3), overflow);
+    const unsigned nd = n_r3 > n_so3 ? n_r3 : n_so3;
+    *aux = nd;
+    return 1u + (nd >= 2 ? nd - 1 : 0u);
+  }
+  const double dx = b[0] - a[0];
+  const double dy = b[1] - a[1];
+  const double dist = sqrt(dx * dx + dy * dy);
+  const unsigned n_interp = clamp_task_count(floor(dist / 0.5), overflow);
+  *aux = n_interp;
+  return n_interp;
+}
+
 __global__ void __launch_bounds__(256)
 motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restrict__ s1,
                    const double* __restrict__ s2, size_t n, uint32_t* __restrict__ counts,
@@ -889,39 +931,8 @@ motion_plan_kernel(MapGeom g, double z_extent, int mode, const double* __restric
        e += (size_t)gridDim.x * blockDim.x) {
     const double* a = s1 + 7 * e;
     const double* b = s2 + 7 * e;
-    uint32_t cnt, ax;
-    if (mode == 0) {
-      // CompoundStateSpace::validSegmentCount: max over R^3 and SO3 of ceil(dist / (0.01*maxExtent));
-      // R^3 bounds = map centre -/+ FULL length (art_planner/src/planner.cpp:146-156).
-      const double ex = (g.pos_x + g.len_x) - (g.pos_x - g.len_x);
-      const double ey = (g.pos_y + g.len_y) - (g.pos_y - g.len_y);
-      double ext = 0.0;
-      ext += ex * ex;
-      ext += ey * ey;
-      ext += z_extent * z_extent;
-      // artp_set_r3_extent: the R^3 maxExtent frozen at an earlier map's bounds (OMPL keeps longestValidSegment_ from
-      // the first StateSpace::setup(), planner.cpp:146-163 never re-runs it)
-      const double seg_r3 = (r3_extent_override > 0.0 ? r3_extent_override : sqrt(ext)) * 0.01;
-      double d2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double diff = a[i] - b[i];
-        d2 += diff * diff;
-      }
-      const unsigned n_r3 = clamp_task_count(ceil(sqrt(d2) / seg_r3), &my_overflow);
-      const double seg_so3 = (0.5 * 3.14159265358979323846) * 0.01;
-      const unsigned n_so3 = clamp_task_count(ceil(so3_arc_length(a + 3, b + 3) / seg_so3), &my_overflow);
-      const unsigned nd = n_r3 > n_so3 ? n_r3 : n_so3;
-      ax = nd;
-      cnt = 1u + (nd >= 2 ? nd - 1 : 0u);
-    } else {
-      const double dx = b[0] - a[0];
-      const double dy = b[1] - a[1];
-      const double dist = sqrt(dx * dx + dy * dy);
-      const unsigned n_interp = clamp_task_count(floor(dist / 0.5), &my_overflow);
-      ax = n_interp;
-      cnt = n_interp;
-    }
+    uint32_t ax;
+    const uint32_t cnt = edge_task_count(g, z_extent, r3_extent_override, mode, a, b, &ax, &my_overflow);
     counts[e] = cnt;
     aux[e] = ax;
     valid[e] = 1;
@@ -1112,6 +1123,147 @@ last_valid_kernel(const double* __restrict__ s1, const double* __restrict__ s2, 
       for (int i = 0; i < 7; ++i) state_out[7 * e + i] = st[i];
     }
   }
+}
+
+// ---- latency form of checkMotion / the 0.5 m rule: a handful of edges per call ------------------------------------
+// The reference calls ob::MotionValidator::checkMotion one edge at a time on the solution path
+// (prm_motion_cost.cpp:652, lazy_prm_star_min_update.cpp:725, OMPL's PathSimplifier via planner.cpp:272).  <= 64 edges in
+// ONE launch: grid (chunks, n_edges), one workgroup per (edge, chunk), five wavefronts = the five boxes of a state side by
+// side (validate_few_kernel's layout).  The workgroup forms its edge's segment count and slerp constants itself, then
+// takes the tasks k = chunk, chunk + chunks, ... (mode 0: task 0 = s2, task k = interior state k; mode 1: task k =
+// interior state k + 1 of n_interp).  The first failing state in OMPL's order is an atomicMin over the failing tasks
+// ("order" as in reduce_edges_first_bad_kernel); workgroups stop as soon as the verdict (first overload) or a smaller
+// first failure (second overload) is known.  The LAST workgroup of an edge to arrive writes the verdict -- and the
+// lastValid pair -- and re-arms the edge's three words for the next call, so the call is one launch with no memset.
+// `status` may be mapped host memory (the host polls for done_tag like validate_few_kernel's caller).
+#define ARTP_FEW_EDGES 64
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_few_trace[5][8];  // [box wavefront][phase] wall_clock64 of workgroup (edge 0, chunk 1)
+#define ARTP_FEW_MARK(p) do { if (trace_me && lane == 0) g_few_trace[kbox][p] = wall_clock64(); } while (0)
+#else
+#define ARTP_FEW_MARK(p) do { } while (0)
+#endif
+struct FewEdgeSync { uint32_t first_bad, arrived, err, pad[61]; };  // device memory, one 256-byte line per edge; armed = {~0, 0, 0}
+// two workgroups per CU (LDS: ~63 KB each for the YAML robot): 10 wavefronts = 3 on one SIMD -> at most 168 VGPRs
+__global__ void __launch_bounds__(320, 3)  // HIP: second number = wavefronts per SIMD
+check_motions_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, double z_extent, double r3_extent_override,
+                         int mode, const double* __restrict__ s1, const double* __restrict__ s2, uint32_t n,
+                         FewEdgeSync* __restrict__ sync, volatile uint8_t* status, uint8_t* __restrict__ valid_dev,
+                         uint32_t* __restrict__ aux_out, double* __restrict__ last_t, double* __restrict__ last_state,
+                         ScratchCaps caps_torso, ScratchCaps caps_foot, unsigned done_tag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double ab[14];
+  __shared__ int box_ok[5];
+  __shared__ uint32_t known_s;
+  const int lane = threadIdx.x & 63;
+  const int kbox = threadIdx.x >> 6;  // box index, wave-uniform
+  const uint32_t e = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+  if (e >= n) return;
+#ifdef ARTP_STAGE_TIMING
+  const bool trace_me = e == 0 && chunk == 1;
+#endif
+  ARTP_FEW_MARK(0);
+  if (threadIdx.x < 14) ab[threadIdx.x] = threadIdx.x < 7 ? s1[7 * (size_t)e + threadIdx.x] : s2[7 * (size_t)e + threadIdx.x - 7];
+  __syncthreads();
+  double a[7], b[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    a[i] = ab[i];
+    b[i] = ab[7 + i];
+  }
+  ARTP_FEW_MARK(1);   // the edge is here (mapped host memory)
+  uint32_t aux;
+  int overflow = 0;
+  uint32_t tasks = edge_task_count(g, z_extent, r3_extent_override, mode, a, b, &aux, &overflow);
+  if (overflow) tasks = 0;
+  const uint32_t team = tasks < chunks ? (tasks ? tasks : 1u) : chunks;  // workgroups of this edge that take part
+  if (chunk >= team) return;
+  WaveScratch s;
+  if (kbox == 0) {
+    s = carve_scratch(smem, 0, caps_torso);
+  } else {
+    s = carve_scratch(smem + scratch_bytes_per_wave(caps_torso), kbox - 1, caps_foot);
+  }
+  const SlerpEdge se = slerp_edge(a + 3, b + 3);
+  const bool want_last = last_t != nullptr;
+  FewEdgeSync* sy = sync + e;
+  ARTP_FEW_MARK(2);
+  for (uint32_t k = chunk; k < tasks; k += chunks) {
+    const uint32_t order = mode == 0 ? (k == 0 ? (aux >= 1 ? aux - 1 : 0u) : k - 1) : k;
+    // what the edge's other workgroups have found so far, read ONCE per workgroup (the barriers below need a uniform
+    // decision): it only ever skips work
+    if (threadIdx.x == 0) known_s = __atomic_load_n(&sy->first_bad, __ATOMIC_RELAXED);
+    __syncthreads();
+    const uint32_t known = known_s;
+    if (want_last ? order >= known : known != 0xffffffffu) {
+      if (!want_last) break;
+      __syncthreads();   // everybody has read known_s before thread 0 refreshes it
+      continue;
+    }
+    double st[7];
+    if (mode == 0) {
+      if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st[i] = b[i];
+      } else {
+        se3_interpolate_pre(a, b, (double)k / (double)aux, se, st);
+      }
+    } else {
+      const double n_interp_div = 1.0 / (aux + 1);
+      se3_interpolate_pre(a, b, (k + 1) * n_interp_div, se, st);
+    }
+    ARTP_FEW_MARK(3);   // [2 -> 3]: segment count, slerp constants, the barrier of known_s, the interpolated state
+    const int ok = few_box_ok(fb, ff, g, rb, st, kbox, s, lane);
+    ARTP_FEW_MARK(4);   // this wavefront's box
+    if (lane == 0) box_ok[kbox] = ok;   // thread 0 read the previous task's values before the barrier above
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bool err = false, v = true;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        err = err || box_ok[q] < 0;
+        v = v && box_ok[q] > 0;
+      }
+      if (err) atomicOr(&sy->err, 2u);
+      if (!v || err) atomicMin(&sy->first_bad, order);
+    }
+  }
+  ARTP_FEW_MARK(5);     // all boxes met, verdict atomics issued (wavefront 0)
+  if (threadIdx.x != 0) return;
+  __threadfence();
+  const bool last_wg = atomicAdd(&sy->arrived, 1u) + 1u == team;
+  ARTP_FEW_MARK(6);
+  if (!last_wg) return;
+  // last workgroup of the edge: every other one's atomics are visible
+  __threadfence();
+  const uint32_t fbad = __atomic_load_n(&sy->first_bad, __ATOMIC_RELAXED);
+  const uint32_t er = __atomic_load_n(&sy->err, __ATOMIC_RELAXED) | (overflow ? 4u : 0u);
+  sy->first_bad = 0xffffffffu;
+  sy->arrived = 0u;
+  sy->err = 0u;
+  const bool v = fbad == 0xffffffffu && !er;
+  if (aux_out) aux_out[e] = aux;
+  if (want_last) {   // last_valid_kernel's rule
+    double st[7];
+    double t = 1.0;
+    if (fbad == 0xffffffffu) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) st[i] = b[i];
+    } else {
+      const int nd = (int)aux;
+      t = nd > 0 ? (double)fbad / (double)nd : (double)(nd - 1) / (double)nd;
+      se3_interpolate(a, b, t, st);
+    }
+    last_t[e] = t;
+    if (last_state) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) last_state[7 * (size_t)e + i] = st[i];
+    }
+  }
+  if (valid_dev) valid_dev[e] = (uint8_t)v;
+  __threadfence_system();   // the lastValid pair lands before the status byte the host polls for
+  status[e] = (uint8_t)((v ? 1u : 0u) | (er & 6u) | done_tag);
+  __threadfence_system();
 }
 
 // Labels != 0 of a batch.  Sixteen labels per load, one atomic per WORKGROUP of a grid of a few workgroups per CU: with

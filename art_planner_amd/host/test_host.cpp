@@ -156,6 +156,54 @@ int main(int argc, char** argv) {
   }
   bad += bad_last;
   bad += (mv.getCheckedMotionCount() != 2u * m_single) ? 1 : 0;
+  // ---- per-call latency of the MotionValidator seam (prm_motion_cost.cpp:652, lazy_prm_star_min_update.cpp:725 and
+  // OMPL's PathSimplifier call checkMotion one edge at a time): n = 1 through both overloads, a 32-edge solution path
+  // in one artp_check_motions call, and the same two with the latency kernel switched off (the batch pipeline)
+  double us_cm1 = 0, us_cm1_last = 0, us_cm32 = 0, us_cm1_batch = 0, us_cm32_batch = 0;
+  {
+    const int reps = 400;
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0 warms up
+      double t1 = now_us();
+      for (int i = 0; i < reps; ++i) {
+        toState(&s1[7 * (i % m_single)], &a);
+        toState(&s2[7 * (i % m_single)], &b);
+        bad += mv.checkMotion(&a, &b) != (motion_ok[i % m_single] != 0);
+      }
+      us_cm1 = (now_us() - t1) / reps;
+      t1 = now_us();
+      for (int i = 0; i < reps; ++i) {
+        toState(&s1[7 * (i % m_single)], &a);
+        toState(&s2[7 * (i % m_single)], &b);
+        std::pair<ob::State*, double> last(&lv, -7.0);
+        bad += mv.checkMotion(&a, &b, last) != (motion_ok[i % m_single] != 0);
+      }
+      us_cm1_last = (now_us() - t1) / reps;
+    }
+    const int np = m < 32 ? m : 32;
+    std::vector<uint8_t> okp(np);
+    auto time_path = [&](int calls) {
+      double t1 = now_us();
+      for (int i = 0; i < calls; ++i) {
+        const int at = (i * np) % (m - np + 1);
+        if (artp_check_motions(gpu->get(), &s1[7 * at], &s2[7 * at], np, okp.data()) != ARTP_OK) ++bad;
+        for (int k = 0; k < np; ++k) bad += okp[k] != motion_ok[at + k];
+      }
+      return (now_us() - t1) / calls;
+    };
+    time_path(20);
+    us_cm32 = time_path(200);
+    artp_set_few_edges(gpu->get(), 0);
+    time_path(5);
+    us_cm32_batch = time_path(50);
+    double t1 = now_us();
+    for (int i = 0; i < 100; ++i) {
+      toState(&s1[7 * (i % m_single)], &a);
+      toState(&s2[7 * (i % m_single)], &b);
+      bad += mv.checkMotion(&a, &b) != (motion_ok[i % m_single] != 0);
+    }
+    us_cm1_batch = (now_us() - t1) / 100;
+    artp_set_few_edges(gpu->get(), 1);
+  }
 
   // ---- StateSampler: the planners' rejection loop; sampler-issued states are pre-validated ----
   ob::SE3StateSpace space;
@@ -286,13 +334,19 @@ int main(int argc, char** argv) {
     }
     bad += (threw || prm.numVertices() != 302) ? 1 : 0;
   }
+  std::printf("checkMotion per call: 1 edge %.1f us (lastValid overload %.1f us), 32-edge path %.1f us; through the batch "
+              "pipeline: %.1f us / %.1f us\n", us_cm1, us_cm1_last, us_cm32, us_cm1_batch, us_cm32_batch);
   std::printf("host mirror: %d states batch + %d single (%.1f us per isValid on arbitrary states), %d motions (%d lastValid "
               "mismatches), rejection loop %d attempts / %d accepted at %.3f us per sampleUniform+isValid, %d labels flipped by a "
               "direct artp_update_layer_rect and served fresh, %d mismatches\n",
               n, n_single, us_single, m, bad_last, attempts, accepted, us_loop, stale_flips, bad);
   if (argc > 2) {
     std::ofstream o(argv[2]);
-    o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"sampler_loop_us_per_state\": " << us_loop
+    o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"check_motion_1_edge_us\": " << us_cm1
+      << ", \"check_motion_last_valid_1_edge_us\": " << us_cm1_last << ", \"check_motions_32_edge_path_us\": " << us_cm32
+      << ", \"check_motion_1_edge_us_batch_pipeline\": " << us_cm1_batch
+      << ", \"check_motions_32_edge_path_us_batch_pipeline\": " << us_cm32_batch
+      << ", \"sampler_loop_us_per_state\": " << us_loop
       << ", \"loop_attempts\": " << attempts << ", \"loop_accepted\": " << accepted << "}\n";
   }
   return bad == 0 ? 0 : 1;

@@ -175,6 +175,13 @@ int artp_set_z_bounds(artp_ctx* ctx, double z_low, double z_high);
  * StateSpace::setup(), so longestValidSegment_ stays at the FIRST planned map's extents. */
 int artp_set_r3_extent(artp_ctx* ctx, double max_extent);
 int artp_check_motions(artp_ctx* ctx, const double* s1, const double* s2, size_t n, uint8_t* valid);
+/* Latency form.  The reference calls checkMotion ONE edge at a time on the solution path (prm_motion_cost.cpp:652,
+ * lazy_prm_star_min_update.cpp:725, OMPL's PathSimplifier via planner.cpp:272): the HOST-buffer entry points
+ * (artp_check_motions, artp_check_motions_last_valid, artp_check_edges_interp) take n <= 64 edges in ONE kernel launch
+ * -- edges and verdicts through mapped host memory, no copies, no host round trip for the segment counts.  Same
+ * verdicts, lastValid pairs and error codes as the batch pipeline (tests/test_gpu_parity.py).  enabled = 0 sends small
+ * calls through the batch pipeline like large ones (default 1). */
+int artp_set_few_edges(artp_ctx* ctx, int enabled);
 int artp_check_motions_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
                            uint8_t* valid);
 /* ob::MotionValidator::checkMotion(s1, s2, std::pair<State*, double>& lastValid) (pure virtual in OMPL 1.4.2;

@@ -637,6 +637,86 @@ def test_check_motion_last_valid_golden(name):
         ctx.close()
 
 
+@pytest.mark.parametrize("name", golden_io.MAPS)
+def test_latency_path_few_edges_golden(name):
+    """<= 64 edges per HOST call take check_motions_few_kernel (one launch, edges and verdicts through mapped host
+    memory): the golden edges in chunks of 1..64 through all three entry points -- checkMotion's verdicts (real-ODE
+    bits), the lastValid pair (exact t, the batch pipeline's states bit for bit) and the 0.5 m rule with its counts."""
+    gm, _ = golden_io.load_boxes(name)
+    om = O.OracleMap(gm)
+    for rname, e in golden_io.load_edges(name).items():
+        ctx = _ctx(rname)
+        ctx.upload_map(gm, sampler=False)
+        rob = O.robot(rname)
+        m = min(len(e["s1"]), 1500)
+        s1, s2 = e["s1"][:m], e["s2"][:m]
+        ctx.set_few_edges(False)
+        b_ok, b_t, b_st = ctx.check_motions_last_valid(s1, s2)      # the batch pipeline on the same edges
+        ctx.set_few_edges(True)
+        cm, lv_ok, lv_t = np.empty(m, np.uint8), np.empty(m, np.uint8), np.empty(m)
+        lv_st, ei, nint = np.empty((m, 7)), np.empty(m, np.uint8), np.empty(m, np.uint32)
+        i, k = 0, 1
+        while i < m:
+            j = min(i + k, m)
+            cm[i:j] = ctx.check_motions(s1[i:j], s2[i:j])
+            lv_ok[i:j], lv_t[i:j], lv_st[i:j] = ctx.check_motions_last_valid(s1[i:j], s2[i:j])
+            ei[i:j], nint[i:j] = ctx.check_edges_interp(s1[i:j], s2[i:j])
+            i, k = j, k % 64 + 1
+        assert np.array_equal(cm, e["check_motion"][:m]), f"{name}/{rname}: {int((cm != e['check_motion'][:m]).sum())} verdicts"
+        assert np.array_equal(lv_ok, e["check_motion"][:m]) and np.array_equal(lv_ok, b_ok)
+        rok, rt, rst = om.check_motions_last_valid(rob, s1, s2)
+        assert np.array_equal(lv_t, rt) and np.array_equal(lv_t, b_t), f"lastValid.second differs on {int((lv_t != rt).sum())} edges"
+        assert np.array_equal(lv_st, b_st) and np.abs(lv_st - rst).max() <= 1e-12
+        assert np.array_equal(nint, e["n_interp"][:m]) and np.array_equal(ei, e["interp_valid"][:m])
+        # degenerate edges: s1 == s2 on an invalid and on a valid state (nd = 0: only s2 is tested; t = -inf when it fails)
+        inv = e["s2"][np.flatnonzero(e["check_motion"] == 0)]
+        inv = inv[om.states_valid(rob, inv) == 0][:3]
+        val = e["s2"][np.flatnonzero(e["check_motion"] != 0)][:3]
+        for pts in (inv, val):
+            if len(pts):
+                ok0, t0, _ = ctx.check_motions_last_valid(pts, pts)
+                rok0, rt0, _ = om.check_motions_last_valid(rob, pts, pts)
+                assert np.array_equal(ok0, rok0) and np.array_equal(t0, rt0)
+                assert np.array_equal(ctx.check_edges_interp(pts, pts)[0], np.ones(len(pts), np.uint8))   # n_interp = 0
+        ctx.close()
+
+
+def test_latency_path_few_edges_repeats_long_edges_and_no_polling(big_map, monkeypatch):
+    """The kernel re-arms its own per-edge words: 300 back-to-back calls of mixed size give the oracle's verdicts every
+    time; edges across the whole map (more tasks than workgroups of an edge: the strided loop); the same through
+    hipStreamSynchronize (ARTP_NO_POLL=1)."""
+    rob = O.robot("yaml")
+    om = O.OracleMap(big_map)
+    for no_poll in ("0", "1"):
+        monkeypatch.setenv("ARTP_NO_POLL", no_poll)
+        ctx = _ctx("yaml")
+        ctx.upload_map(big_map)
+        se3 = ctx.sample_states(11, 0, 6000)
+        acc = se3[ctx.validate_states(se3) != 0]
+        rng = np.random.default_rng(5)
+        ia = rng.integers(0, len(acc), 640)
+        a = acc[ia]
+        d = np.hypot(a[:, None, 0] - acc[None, :, 0], a[:, None, 1] - acc[None, :, 1])
+        d[np.arange(640), ia] = np.inf
+        near = acc[np.argsort(d, axis=1)[np.arange(640), rng.integers(0, 6, 640)]]   # one of the 6 nearest accepted states
+        far = acc[rng.integers(0, len(acc), 640)]
+        b = np.where((np.arange(640) % 4 == 0)[:, None], far, near)                  # every 4th edge spans the map
+        ref, _ = om.check_motions(rob, a, b)
+        rok, rt, _ = om.check_motions_last_valid(rob, a, b)
+        got = np.empty(640, np.uint8)
+        sizes = [1, 2, 3, 5, 8, 13, 21, 34, 55, 64]
+        i = c = 0
+        while i < 640:
+            j = min(640, i + sizes[c % len(sizes)])
+            got[i:j] = ctx.check_motions(a[i:j], b[i:j])
+            ok2, t2, _ = ctx.check_motions_last_valid(a[i:j], b[i:j])
+            assert np.array_equal(ok2, rok[i:j]) and np.array_equal(t2, rt[i:j])
+            i, c = j, c + 1
+        assert np.array_equal(got, ref), f"{int((got != ref).sum())} verdict mismatches (ARTP_NO_POLL={no_poll})"
+        assert 0 < int(ref.sum()) < 640
+        ctx.close()
+
+
 def test_sample_and_validate_host_form(big_map, ctx_yaml):
     """artp_sample_and_validate (host buffers): the states of artp_sample_states and the labels of
     artp_validate_states for the same (seed, index) range."""

@@ -192,6 +192,15 @@ def test_host_mirror_matches_oracle_through_the_ompl_shaped_interfaces(tmp_path)
     # state costs less than 25 us (one launch through mapped host memory)
     assert t["sampler_loop_us_per_state"] < 1.0, t
     assert t["isvalid_arbitrary_state_us"] < 25.0, t
+    # one checkMotion call = one launch (check_motions_few_kernel), not the batch pipeline; the CPU
+    # oracle's per-edge time on the same edges goes into the record next to it
+    import time
+    t0 = time.perf_counter()
+    om.check_motions(rob, s1, s2)
+    t["cpu_oracle_check_motion_us_per_edge"] = (time.perf_counter() - t0) / m * 1e6
+    json.dump(t, open(lat, "w"))
+    assert t["check_motion_1_edge_us"] < 40.0, t
+    assert t["check_motion_1_edge_us"] < t["check_motion_1_edge_us_batch_pipeline"], t
 
 
 @pytest.mark.gpu
