@@ -536,16 +536,26 @@ int artp_group_synchronize(artp_group* g, int timeout_ms) {
   };
   const auto t0 = std::chrono::steady_clock::now();
   for (const Wait& w : waits) {
-    if (hipSetDevice(w.device) != hipSuccess) return ARTP_ERR_HIP;
+    if (hipSetDevice(w.device) != hipSuccess)
+      return fail(ARTP_ERR_HIP, "member " + std::to_string(w.member) + ": hipSetDevice(" + std::to_string(w.device) + ") failed");
     for (;;) {
       if (g->aborted.load(std::memory_order_acquire)) return fail(ARTP_ERR_COMM, "group was aborted");
       const hipError_t q = hipStreamQuery(w.stream);
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady)
         return fail(ARTP_ERR_HIP, "member " + std::to_string(w.member) + " " + w.what + ": " + hipGetErrorString(q));
-      if (w.comm && g->rccl && !g->aborted.load(std::memory_order_acquire)) {
+      if (w.comm && g->rccl) {
+        // the communicator is looked at under the group's lock, re-read from the member: artp_group_abort destroys it
+        // (CommAbort) and clears the member's handle under the same lock, so a handle copied at entry is never used
+        // after the abort (check-then-use on a destroyed communicator)
         ncclResult_t ar = ncclSuccess;
-        if (g->rccl->CommGetAsyncError(w.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+        bool have = false;
+        {
+          std::lock_guard<std::mutex> lock(g->mu);
+          ncclComm_t live = g->aborted.load(std::memory_order_acquire) ? nullptr : g->m[w.member].comm;
+          if (live) have = g->rccl->CommGetAsyncError(live, &ar) == ncclSuccess;
+        }
+        if (have && ar != ncclSuccess && ar != ncclInProgress)
           return fail(ARTP_ERR_COMM, "member " + std::to_string(w.member) + ": RCCL async error: " + g->rccl->GetErrorString(ar));
       }
       if (timeout_ms >= 0) {
@@ -634,8 +644,13 @@ int artp_group_configure(artp_group* g, uint64_t seed, size_t batch, size_t mate
   {
     // the previous configuration's work must have drained before its buffers go; bounded: a peer that never arrived must
     // not hang a re-configuration for ever ($ARTP_GROUP_CONFIGURE_TIMEOUT_MS, default one minute)
+    // (-1 = wait for ever; anything that does not parse as an integer >= -1 keeps the default)
     int wait_ms = 60000;
-    if (const char* ev = std::getenv("ARTP_GROUP_CONFIGURE_TIMEOUT_MS")) wait_ms = std::atoi(ev);
+    if (const char* ev = std::getenv("ARTP_GROUP_CONFIGURE_TIMEOUT_MS")) {
+      char* end = nullptr;
+      const long v = std::strtol(ev, &end, 10);
+      if (end != ev && *end == '\0' && v >= -1 && v <= 86400000L) wait_ms = (int)v;
+    }
     const int rc = artp_group_synchronize(g, wait_ms);
     if (rc != ARTP_OK) return rc;
   }

@@ -980,7 +980,9 @@ static int inpaint_dev(artp_ctx* c, const float* d_in, int rows, int cols, int m
     if (hipMemcpy(d_out, tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(ARTP_ERR_HIP);
     return fail(ARTP_OK);
   }
-  const bool telea = (mode & ARTP_INPAINT_TELEA) != 0;
+  // Telea's march reads a 3 x 3 neighbourhood around every band pixel with cv::inpaint's border index rule: it needs at
+  // least two rows and two columns.  A one-row / one-column layer takes the device fill instead.
+  const bool telea = (mode & ARTP_INPAINT_TELEA) != 0 && rows >= 2 && cols >= 2;
   mode &= 1;
   hipLaunchKernelGGL(artp::inpaint_quantise_kernel, grid, blk, 0, st, d_in, (int)n, mode, lo, hi, q, known, d_holes);
   unsigned long long h = 0;
@@ -1050,7 +1052,7 @@ int artp_inpaint_layer(artp_ctx* c, const float* layer, int rows, int cols, int 
 }
 
 int artp_telea_inpaint_u8(const uint8_t* img, const uint8_t* mask, int h, int w, int range, uint8_t* out) {
-  if (!img || !mask || !out || h < 1 || w < 1 || range < 1 || range > 16) return ARTP_ERR_INVALID_ARG;
+  if (!img || !mask || !out || h < 2 || w < 2 || range < 1 || range > 16) return ARTP_ERR_INVALID_ARG;
   if (out != img) std::memcpy(out, img, (size_t)h * w);
   artp_telea::inpaint_u8(h, w, out, mask, range);
   return ARTP_OK;

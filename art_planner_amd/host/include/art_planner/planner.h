@@ -90,14 +90,18 @@ class Planner {
     ss_ = std::make_shared<og::SimpleSetup>(space_);
     const ob::SpaceInformationPtr si = ss_->getSpaceInformation();
     // planner.cpp:90-117: the planner by name, set as ss_'s planner, its maintainer.  The PRM planners are the shells over
-    // the batched roadmap (planners/*.h); the other names of the reference (rrt_star, inf_rrt_star, rrt_sharp,
-    // lazy_prm_star: OMPL's own planners, one isValid per state) have no batched counterpart and are refused like an
-    // unknown name.
+    // the batched roadmap (planners/*.h).  "lazy_prm_star" (the reference: OMPL's own og::LazyPRMstar, no maintainer,
+    // :98-99) is SUBSTITUTED by the LazyPRMStarMinUpdate shell without a maintainer -- the same LazyPRM* graph and lazy
+    // edge checks, no min-update upkeep.  The tree planners of the reference (rrt_star, inf_rrt_star, rrt_sharp: OMPL's own,
+    // one isValid per state) have no batched counterpart and THROW here like an unknown name.
     ob::PlannerPtr planner;
     if (params_->planner.name == "lazy_prm_star_min_update" || params_->planner.name == "lazy_prm_star") {
       auto p = std::make_shared<LazyPRMStarMinUpdate>(si);
       p->bindRoadmap(rb_);
-      p->setMaintainer(std::unique_ptr<LazyPRMStarMinUpdateMaintainer>(new LazyPRMStarMinUpdateMaintainer(map_, params_)));
+      // :110-115: the maintainer belongs to lazy_prm_star_min_update only.  It is handed the map pointer of this moment
+      // (null until the first setMap, as in the reference) and only carries the parameters of the upkeep Planner::setMap runs.
+      if (params_->planner.name == "lazy_prm_star_min_update")
+        p->setMaintainer(std::unique_ptr<LazyPRMStarMinUpdateMaintainer>(new LazyPRMStarMinUpdateMaintainer(map_, params_)));
       planner = p;
     } else if (params_->planner.name == "prm_motion_cost") {
       auto p = std::make_shared<PRMMotionCost>(si);
@@ -232,14 +236,11 @@ class Planner {
       // si_->setup() once it ran, so in the reference longestValidSegment_ -- and every checkMotion's segment count --
       // stays at the FIRST planned map's extents.  Default here: the resolution follows every map (what the bounds say);
       // setFreezeMotionResolution(true) reproduces the reference's behaviour.
-      if (!freeze_motion_resolution_ || !motion_resolution_set_) {
-        motion_validator_->setZBounds(low_[2], high_[2]);
-        if (freeze_motion_resolution_) {
-          const double ex = high_[0] - low_[0], ey = high_[1] - low_[1], ez = high_[2] - low_[2];
-          throwOnError(gpu_->get(), artp_set_r3_extent(gpu_->get(), std::sqrt(ex * ex + ey * ey + ez * ez)), "artp_set_r3_extent");
-        }
-        motion_resolution_set_ = true;
-      }
+      // The z bounds always follow the map (with a frozen extent they no longer enter the segment length); the frozen extent
+      // is captured ONCE: here when no map had been installed at the time of setFreezeMotionResolution(true), or right
+      // there when one had (a freeze after the first setMap used to freeze nothing).
+      motion_validator_->setZBounds(low_[2], high_[2]);
+      if (freeze_motion_resolution_ && !motion_resolution_set_) captureMotionResolution();
       sampler_allocator_.setMap(map_);
     }
 #endif
@@ -280,13 +281,28 @@ class Planner {
   }
 
 #ifdef ARTP_PLANNER_REFERENCE_SURFACE
-  // true: checkMotion keeps the segment length of the FIRST map planned on (the reference's behaviour, see setMap);
-  // false (default): it follows the bounds of every map.  Takes effect at the next setMap.
+  // true: checkMotion keeps the segment length of the FIRST map planned on (the reference's behaviour, see setMap) -- the map
+  // installed at the time of the call, else the next one; false (default): it follows the bounds of every map.
   void setFreezeMotionResolution(bool freeze) {
     std::lock_guard<std::mutex> lock(map_mutex_);
     freeze_motion_resolution_ = freeze;
-    if (!freeze) artp_set_r3_extent(gpu_->get(), 0.0);
+    motion_resolution_set_ = false;
+    if (!freeze) {
+      throwOnError(gpu_->get(), artp_set_r3_extent(gpu_->get(), 0.0), "artp_set_r3_extent");
+    } else if (map_) {
+      captureMotionResolution();   // the map planned on now is "the first map": later setMap calls keep its segment length
+    }
   }
+
+ private:
+  // fix checkMotion's R^3 maxExtent at the current bounds (caller holds map_mutex_)
+  void captureMotionResolution() {
+    const double ex = high_[0] - low_[0], ey = high_[1] - low_[1], ez = high_[2] - low_[2];
+    throwOnError(gpu_->get(), artp_set_r3_extent(gpu_->get(), std::sqrt(ex * ex + ey * ey + ez * ez)), "artp_set_r3_extent");
+    motion_resolution_set_ = true;
+  }
+
+ public:
 #endif
 
   void setSeed(uint64_t seed) {

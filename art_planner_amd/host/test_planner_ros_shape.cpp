@@ -81,6 +81,15 @@ class PlannerRosShape : protected Planner {
     unflattenSE3(b7, b.get());
     return ss_->getSpaceInformation()->getMotionValidator()->checkMotion(a.get(), b.get());
   }
+  // lastValid.second of checkMotion's second overload: (j - 1) / nd exposes the segment count nd
+  double lastValidFraction(const double* a7, const double* b7) {
+    ob::ScopedState<> a(space_), b(space_), lv(space_);
+    unflattenSE3(a7, a.get());
+    unflattenSE3(b7, b.get());
+    std::pair<ob::State*, double> last(lv.get(), -7.0);
+    const bool ok = ss_->getSpaceInformation()->getMotionValidator()->checkMotion(a.get(), b.get(), last);
+    return ok ? 1.0 : last.second;
+  }
   void clearPlanner() {  // planner_ros.cpp:359,373-374
     ss_->clear();
     ss_->setup();
@@ -267,7 +276,44 @@ int main(int argc, char** argv) {
     // `as<PRMMotionCost>()` on the LazyPRM* planner would be the reference's own bug; the LazyPRM* class has its override
     size_t n_ss = 0;
     CHECK(node->solveThroughSimpleSetup(sg, sg + 7, &n_ss) && n_ss >= 2);
-    node->freezeResolution(true);
+    // setFreezeMotionResolution(true) AFTER a map was installed must freeze at that map's extents.  Map B = map A
+    // with a 60 m spike in one corner cell (the z bounds, and with them the R^3 maxExtent, grow); the edge start -> 3 m above
+    // the goal fails at its end state, so lastValid.second = (nd - 1) / nd shows the segment count.
+    double up[7];
+    std::copy(sg + 7, sg + 14, up);
+    up[2] += 3.0;
+    auto map_b = [&]() {
+      auto g = std::make_unique<grid_map::GridMap>();
+      g->setGeometry(grid_map::Length(geo[0], geo[1]), geo[0] / rows, grid_map::Position(geo[2], geo[3]));
+      std::copy(elev.begin(), elev.end(), m.data());
+      m(0, 0) += 60.0f;
+      g->add(params->planner.elevation_layer, m);
+      std::copy(trav.begin(), trav.end(), m.data());
+      g->add(params->planner.traversability_layer, m);
+      return g;
+    };
+    const double t_a = node->lastValidFraction(sg, up);
+    CHECK(t_a > 0.0 && t_a < 1.0);
+    node->freezeResolution(true);            // map A is installed: its extents are the frozen ones
+    node->mapCallback(map_b());
+    const double t_b_frozen = node->lastValidFraction(sg, up);
+    CHECK(t_b_frozen == t_a);
+    node->freezeResolution(false);           // follows the installed map again, from this call on
+    const double t_b = node->lastValidFraction(sg, up);
+    CHECK(t_b != t_a && t_b > 0.0 && t_b < 1.0);
+    node->freezeResolution(true);            // ... and frozen at map B's
+    std::copy(elev.begin(), elev.end(), m.data());
+    {
+      auto g = std::make_unique<grid_map::GridMap>();
+      g->setGeometry(grid_map::Length(geo[0], geo[1]), geo[0] / rows, grid_map::Position(geo[2], geo[3]));
+      g->add(params->planner.elevation_layer, m);
+      std::copy(trav.begin(), trav.end(), m.data());
+      g->add(params->planner.traversability_layer, m);
+      node->mapCallback(std::move(g));       // map A again
+    }
+    CHECK(node->lastValidFraction(sg, up) == t_b);
+    std::printf("frozen motion resolution: lastValid.second %.6f on map A, %.6f on map B frozen at A, %.6f following B\n", t_a,
+                t_b_frozen, t_b);
   }
   std::printf("PlannerRos-shaped subclass: status %d, %zu path states, %d failed checks\n", static_cast<int>(status),
               path.size(), fails);

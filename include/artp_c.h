@@ -272,7 +272,9 @@ artp_ctx* artp_group_ctx(artp_group* g, int local);            /* owned by the g
 int artp_group_ranks_seen(artp_group* g, int* ranks_seen);
 /* Sizes of the state exchange: batch = S candidates per rank and step; every rank's first
  * min(accepted, materialise_cap) accepted states among its first prefix candidates (0 = all S) are re-materialised
- * on every member after the all-gather (0 = bitmaps only).  (Re)allocates the buffers; drains the group first. */
+ * on every member after the all-gather (0 = bitmaps only).  (Re)allocates the buffers; drains the group first -- for at
+ * most $ARTP_GROUP_CONFIGURE_TIMEOUT_MS milliseconds (default 60000; -1 = wait for ever; a value that is not an integer
+ * >= -1 keeps the default), after which the call returns ARTP_ERR_TIMEOUT with nothing reallocated. */
 int artp_group_configure(artp_group* g, uint64_t seed, size_t batch, size_t materialise_cap, size_t prefix);
 /* One step of the sharded rejection-sampling loop (prm_motion_cost.cpp:174-186 / lazy_prm_star_min_update.cpp:552-554
  * across the node), ASYNCHRONOUS: for every local member -- artp_sample_and_validate_dev on its shard
@@ -493,7 +495,8 @@ enum { ARTP_INPAINT_PLANNER = 0, ARTP_INPAINT_COST_NODE = 1,
        ARTP_INPAINT_TELEA = 2 };
 int artp_inpaint_layer(artp_ctx* ctx, const float* layer, int rows, int cols, int mode, float* out, uint64_t* n_holes);
 /* The fill alone (no context, no GPU): h x w row-major 8-bit image, mask != 0 = pixels to fill, radius `range`
- * (cv::inpaint(img, mask, out, range, cv::INPAINT_TELEA)); out may alias img. */
+ * (cv::inpaint(img, mask, out, range, cv::INPAINT_TELEA)); out may alias img.  h, w >= 2 (the march reads a 3 x 3
+ * neighbourhood; a one-row / one-column layer in artp_inpaint_layer takes the rim-inwards fill instead). */
 int artp_telea_inpaint_u8(const uint8_t* img, const uint8_t* mask, int h, int w, int range, uint8_t* out);
 /* name: elevation, traversability, normal_x/_y/_z, plane_fit_std_dev, traversability_thresholded_no_safety,
  * traversability_thresholded, elevation_masked, sample_probability, cum_prob, observed, n_samples (the blurred

@@ -74,3 +74,20 @@ def test_telea_fill_analytic_cases():
     img[7, 9] = 200
     ol = _telea(img, lone)
     assert ol[7, 9] == 200 and np.abs(ol.astype(int) - 200).max() <= 10
+
+
+def test_telea_refuses_degenerate_images():
+    """ADVICE r5: cv::inpaint's border index rule reads row / column 1 of the image, so a one-row or one-column image
+    would be read out of bounds: INVALID_ARG (status 1), nothing written."""
+    from art_planner_amd import _capi
+    L = _capi.load()
+    for h, w in ((1, 8), (8, 1), (1, 1)):
+        img = np.full((h, w), 9, np.uint8)
+        mask = np.zeros((h, w), np.uint8)
+        mask.flat[0] = 1
+        out = np.full((h, w), 123, np.uint8)
+        rc = L.artp_telea_inpaint_u8(img.ctypes.data, mask.ctypes.data, h, w, 3, out.ctypes.data)
+        assert rc != 0 and (out == 123).all()
+    two = np.array([[10, 10], [10, 10]], np.uint8)
+    m2 = np.array([[0, 1], [0, 0]], np.uint8)
+    assert abs(int(_telea(two, m2)[0, 1]) - 10) <= 1     # the smallest image the march accepts
