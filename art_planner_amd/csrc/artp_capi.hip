@@ -65,6 +65,8 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
+  artp_cost_query_fn ext_cost_fn = nullptr;   // artp_cost_set_external_query: the roadmap's learned-cost batches go here
+  void* ext_cost_user = nullptr;
   bool few_edges = true;      // <= ARTP_FEW_EDGES edges per HOST call: the one-launch latency kernel (artp_set_few_edges)
   bool edge_two_pass = true;  // artp_check_motions: coarse pass first ($ARTP_EDGE_TWO_PASS=0: one pass over all states)
   int edge_coarse_stride = ARTP_COARSE_STRIDE;  // $ARTP_COARSE_STRIDE (tuning)
@@ -703,6 +705,7 @@ const char* artp_status_string(int s) {
     case ARTP_ERR_NO_WEIGHTS: return "motion-cost weights not loaded";
     case ARTP_ERR_TIMEOUT: return "timed out waiting for a device group";
     case ARTP_ERR_COMM: return "RCCL unavailable or a communicator call failed";
+    case ARTP_ERR_COST_FUNC: return "Motion cost call failed";
     default: return "unknown status";
   }
 }
@@ -2838,8 +2841,14 @@ int artp_cost_update_map_layer(artp_ctx* c, const float* layer, int rows, int co
 int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) {
   if (!c || (b && (!edges || !cost))) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  if (!c->have_weights) return ARTP_ERR_NO_WEIGHTS;
-  if (!c->have_features) return ARTP_ERR_NO_MAP;
+  if (!c->have_weights) {
+    c->last_error = "artp_cost_load_weights has not been called";
+    return ARTP_ERR_NO_WEIGHTS;
+  }
+  if (!c->have_features) {
+    c->last_error = "artp_cost_update_map has not been called";
+    return ARTP_ERR_NO_MAP;
+  }
   if (b == 0) return ARTP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   // up to 2^16 edges (a roadmap update's query): four lanes per edge; above that a lane per edge fills the GPU.  Both
@@ -2857,6 +2866,32 @@ int artp_cost_query_dev(artp_ctx* c, const float* edges, size_t b, float* cost) 
     hipLaunchKernelGGL(fc_cost_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, c->stream, edges, b,
                        (const half_t*)c->d_feat, c->cost_geom, (const float*)c->d_fc, cost);
   HIP_TRY(c, hipGetLastError());
+  return ARTP_OK;
+}
+
+int artp_cost_set_external_query(artp_ctx* c, artp_cost_query_fn fn, void* user) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->ext_cost_fn = fn;
+  c->ext_cost_user = fn ? user : nullptr;
+  return ARTP_OK;
+}
+
+// The roadmap's learned-cost batch (device edge matrix in, device costs out, on the context's stream): the caller's
+// MotionCostFunc when one is installed -- the edge matrix goes to the host, through the function and back, exactly the
+// [B x 6] -> [B x 3] call of PRMMotionCostMaintainer::updateEdges (prm_motion_cost.cpp:27-73) -- else the device network.
+int roadmap_cost_query_dev(artp_ctx* c, const float* d_edges, size_t b, float* d_cost) {
+  if (!c->ext_cost_fn) return artp_cost_query_dev(c, d_edges, b, d_cost);
+  if (b == 0) return ARTP_OK;
+  std::vector<float> em(b * 6), c3(b * 3, 0.0f);
+  HIP_TRY(c, hipMemcpyAsync(em.data(), d_edges, b * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->ext_cost_fn(c->ext_cost_user, em.data(), b, c3.data()) != 0) {
+    c->last_error = "Motion cost call failed";   // motion_cost_objective.cpp:81
+    return ARTP_ERR_COST_FUNC;
+  }
+  HIP_TRY(c, hipMemcpyAsync(d_cost, c3.data(), b * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // c3 leaves scope
   return ARTP_OK;
 }
 

@@ -739,7 +739,7 @@ int roadmap_eval_edges_dev(artp_ctx* c, const artp_roadmap_params* prm, const do
     RM_HIP(hipMalloc(reinterpret_cast<void**>(&d_c3), (size_t)total * 3 * 4));
     hipLaunchKernelGGL(artp::chain_edge_matrix_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, d_s1, d_s2,
                        d_chain, (const uint32_t*)d_off, ne, d_em);
-    RM_TRY(artp_cost_query_dev(c, d_em, total, d_c3));
+    RM_TRY(roadmap_cost_query_dev(c, d_em, total, d_c3));   // the caller's MotionCostFunc when one is installed
     hipLaunchKernelGGL(artp::chain_motion_cost_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
                        (const float*)d_c3, (const uint32_t*)d_off, d_chain, ne, prm->w_energy,
                        prm->w_time, prm->w_risk, prm->risk_threshold, d_cost);

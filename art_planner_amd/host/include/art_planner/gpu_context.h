@@ -158,7 +158,15 @@ class GpuContext {
 
 using GpuContextPtr = std::shared_ptr<GpuContext>;
 
+// The caller's MotionCostFunc reported failure: the reference's own exception and text (motion_cost_objective.cpp:78-83).
+// Its own type so that the "rebuild / NOT_SOLVED" catch blocks of the mirror let it through, as the reference's
+// `catch (ompl::Exception&)` (planner.cpp:247) does.
+struct MotionCostCallFailed : std::runtime_error {
+  MotionCostCallFailed() : std::runtime_error("Motion cost call failed") {}
+};
+
 inline void throwOnError(artp_ctx* ctx, int rc, const char* what) {
+  if (rc == ARTP_ERR_COST_FUNC) throw MotionCostCallFailed();
   if (rc != ARTP_OK)
     throw std::runtime_error(std::string(what) + ": " + artp_status_string(rc) + " " + artp_last_error(ctx));
 }

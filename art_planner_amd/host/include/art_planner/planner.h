@@ -216,7 +216,8 @@ class Planner {
       try {
         const size_t dropped = prm_->grow(0);
         if (dropped) prm_->grow(dropped);
-      } catch (const std::exception&) {  // the old start / goal are gone with the map: rebuild at the next plan
+      } catch (const std::exception&) {  // the old start / goal are gone with the map (or the cost functor failed: the
+        //                                    reference's setMap never prices anything): rebuild -- and report -- at the next plan
         prm_->clear();
         rb_->built = false;
       }
@@ -305,6 +306,20 @@ class Planner {
  public:
 #endif
 
+#ifdef ARTP_PLANNER_REFERENCE_SURFACE
+  // "prm_motion_cost" only.  Default (false): the roadmap's edges are priced through the MotionCostFunc of the
+  // PRMMotionCostMaintainer the caller installed (prm_motion_cost.cpp:27-73) -- PlannerRos' service client stays the cost
+  // source.  true = explicit opt-in to the learned-cost network on the device (artp_cost_load_weights +
+  // artp_cost_update_map; no host round trip per batch); the functor is then out of the planning loop.
+  void setDevicePricing(bool on) {
+    std::lock_guard<std::mutex> lock(map_mutex_);
+    if (params_->planner.name != "prm_motion_cost") return;
+    ss_->getPlanner()->as<PRMMotionCost>()->setDevicePricing(on);
+    prm_->clear();          // edges priced by the other source are not comparable: the next plan() builds anew
+    rb_->built = false;
+  }
+#endif
+
   void setSeed(uint64_t seed) {
     seed_ = seed;
     prm_->setSeed(seed);
@@ -358,6 +373,8 @@ class Planner {
         solved_ = prm_->solveUntil(params_->planner.plan_time, 1000, &path_, &cost_);
       else
         solved_ = prm_->solve(&path_, &cost_);
+    } catch (const MotionCostCallFailed&) {
+      throw;   // not ours to absorb (planner.cpp:247 catches ompl::Exception only)
     } catch (const std::exception& e) {  // "All graph edges to goal where actually invalid" (:248-253)
       std::cout << e.what() << std::endl;
       solved_ = false;
@@ -377,6 +394,8 @@ class Planner {
     double cost_simple = cost_;
     try {
       prm_->simplify(&simple, &cost_simple);
+    } catch (const MotionCostCallFailed&) {
+      throw;   // not ours to absorb (planner.cpp:247 catches ompl::Exception only)
     } catch (const std::exception&) {
       std::cout << "Simplified path is invalid. Returning original." << std::endl;
       return path_;

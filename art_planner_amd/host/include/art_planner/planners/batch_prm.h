@@ -24,6 +24,7 @@ class BatchPRM {
   using StateArray = std::array<double, 7>;  // x y z qx qy qz qw (OMPL SE3 state, flattened)
 
   BatchPRM(const ParamsConstPtr& params, const GpuContextPtr& gpu) : params_(params), gpu_(gpu) {}
+  const GpuContextPtr& gpu() const { return gpu_; }
   ~BatchPRM() { clear(); }
   BatchPRM(const BatchPRM&) = delete;
   BatchPRM& operator=(const BatchPRM&) = delete;

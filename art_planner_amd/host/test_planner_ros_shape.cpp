@@ -131,6 +131,26 @@ class PlannerRosShape : protected Planner {
     CHECK(ss_->getPlanner()->as<PRMMotionCost>()->hasMaintainer());
   }
 
+  void installFailingMotionCost() {   // the service client whose call fails (planner_ros.cpp:296-300: `return false`)
+    auto fail = [](const MotionCostObjective::EdgeMatrix&, MotionCostObjective::EdgeMatrix*) -> bool { return false; };
+    ss_->getPlanner()->as<PRMMotionCost>()->setMaintainer(std::unique_ptr<PRMMotionCostMaintainer>(
+        new PRMMotionCostMaintainer(map_, params_, std::make_unique<MotionCostObjective::MotionCostFunc>(fail))));
+  }
+  void maintainerCounters(size_t* calls, size_t* edges) {
+    const PRMMotionCostMaintainer* m = ss_->getPlanner()->as<PRMMotionCost>()->maintainer();
+    *calls = m ? m->functorCalls() : 0;
+    *edges = m ? m->functorEdges() : 0;
+  }
+  void devicePricing(bool on) { setDevicePricing(on); }
+  // the solution path priced by the objective PlannerRos installed (the functor again, motion_cost_objective.cpp:36-95)
+  double lastCost() {
+    og::PathGeometric path = getSolutionPath(false);
+    double c = 0.0;
+    const std::vector<ob::State*>& st = path.getStates();
+    for (size_t i = 0; i + 1 < st.size(); ++i) c += ss_->getOptimizationObjective()->motionCost(st[i], st[i + 1]).value();
+    return c;
+  }
+
   // planner_ros.cpp:355-364 (updateMapAndPlan) and :369-378 (updateMapAndPlanFromCurrentRobotPose) without the map queue
   PlannerStatus clearAndPlan(const double* s7, const double* g7, bool from_robot_pose) {
     ss_->clear();
@@ -258,11 +278,42 @@ int main(int argc, char** argv) {
     unsigned nv = 0, ne = 0, ns = 0, ng = 0;
     mc->visualizePlannerGraph(false, &nv, &ne, &ns, &ng);
     CHECK(nv == 0 && ne == 0);   // nothing sampled yet
-    // without learned-cost weights on the device the roadmap's objective 2 has nothing to price with: the planner shell
-    // reports it through the status, it does not crash the node
+    // the roadmap is priced THROUGH the functor the node handed to the maintainer (prm_motion_cost.cpp:27-73):
+    // no weights are loaded on the device, the plan succeeds on the functor's costs alone, and the functor saw every edge
+    const int calls_before = calls;
     const PlannerStatus st_mc = mc->clearAndPlan(sg, sg + 7, true);
-    CHECK(st_mc == PlannerStatus::SOLVED || st_mc == PlannerStatus::NOT_SOLVED);
-    std::printf("prm_motion_cost node: objective cost %.3f over %d functor calls, plan status %d\n", c01, calls, static_cast<int>(st_mc));
+    CHECK(st_mc == PlannerStatus::SOLVED);
+    CHECK(calls > calls_before);
+    size_t f_calls = 0, f_edges = 0;
+    mc->maintainerCounters(&f_calls, &f_edges);
+    mc->visualizePlannerGraph(false, &nv, &ne, &ns, &ng);
+    CHECK(f_calls >= 1 && f_edges >= ne / 2 && ne > 0);   // at least one sub-edge query per undirected graph edge
+    // the path's cost is the functor's: w_e * 1 + w_t * length per query, no risk -- positive, finite, and at least
+    // w_t * (straight-line distance)
+    const double path_cost = mc->lastCost();
+    const double straight = std::hypot(sg[0] - sg[7], sg[1] - sg[8]);
+    CHECK(std::isfinite(path_cost) && path_cost >= p2->planner.prm_motion_cost.cost_weights.time * straight - 1e-6);
+    std::printf("prm_motion_cost node: objective cost %.3f; plan priced through the functor: status %d, %zu functor calls, %zu "
+                "edge rows, path cost %.3f\n", c01, static_cast<int>(st_mc), f_calls, f_edges, path_cost);
+    // a functor that reports failure (the service call failed): std::runtime_error("Motion cost call failed"),
+    // motion_cost_objective.cpp:78-83 -- through plan(), like the reference (planner.cpp:247 catches ompl::Exception only)
+    mc->installFailingMotionCost();
+    bool threw = false;
+    try {
+      (void)mc->clearAndPlan(sg, sg + 7, true);
+    } catch (const std::runtime_error& e) {
+      threw = std::string(e.what()) == "Motion cost call failed";
+    }
+    CHECK(threw);
+    // explicit opt-in to device pricing WITHOUT weights on the device: nothing to price with -- the planner shell reports
+    // it through the status, it does not crash the node and it does not fall back to the functor
+    mc->installMotionCost(&calls);
+    mc->devicePricing(true);
+    const int calls_dev = calls;
+    const PlannerStatus st_dev = mc->clearAndPlan(sg, sg + 7, true);
+    CHECK(st_dev == PlannerStatus::NOT_SOLVED && calls == calls_dev);
+    mc->devicePricing(false);
+    CHECK(mc->clearAndPlan(sg, sg + 7, true) == PlannerStatus::SOLVED && calls > calls_dev);
   }
 
   // ---- lazy_prm_star_min_update: planner data, OMPL's own entry, the frozen motion resolution ----
@@ -277,11 +328,12 @@ int main(int argc, char** argv) {
     size_t n_ss = 0;
     CHECK(node->solveThroughSimpleSetup(sg, sg + 7, &n_ss) && n_ss >= 2);
     // setFreezeMotionResolution(true) AFTER a map was installed must freeze at that map's extents.  Map B = map A
-    // with a 60 m spike in one corner cell (the z bounds, and with them the R^3 maxExtent, grow); the edge start -> 3 m above
-    // the goal fails at its end state, so lastValid.second = (nd - 1) / nd shows the segment count.
+    // with a 60 m spike in one corner cell (the z bounds, and with them the R^3 maxExtent, grow); the straight edge start -> 1 m
+    // above the goal fails part of the way along, so lastValid.second = (j - 1) / nd shows the segment count.
     double up[7];
     std::copy(sg + 7, sg + 14, up);
-    up[2] += 3.0;
+    std::copy(sg + 3, sg + 7, up + 3);   // the start's attitude: the R^3 distance alone sets the segment count
+    up[2] += 1.0;   // the feet leave the ground a fraction of the way along: the first failing j grows with nd
     auto map_b = [&]() {
       auto g = std::make_unique<grid_map::GridMap>();
       g->setGeometry(grid_map::Length(geo[0], geo[1]), geo[0] / rows, grid_map::Position(geo[2], geo[3]));
@@ -300,7 +352,7 @@ int main(int argc, char** argv) {
     CHECK(t_b_frozen == t_a);
     node->freezeResolution(false);           // follows the installed map again, from this call on
     const double t_b = node->lastValidFraction(sg, up);
-    CHECK(t_b != t_a && t_b > 0.0 && t_b < 1.0);
+    CHECK(t_b != t_a && t_b >= 0.0 && t_b < 1.0);
     node->freezeResolution(true);            // ... and frozen at map B's
     std::copy(elev.begin(), elev.end(), m.data());
     {

@@ -40,7 +40,8 @@ typedef enum {
   ARTP_ERR_CAPACITY = -5,    /* box too large for the LDS window tile of this context */
   ARTP_ERR_NO_WEIGHTS = -6,
   ARTP_ERR_TIMEOUT = -7,     /* artp_group_synchronize: a member's stream did not finish in time */
-  ARTP_ERR_COMM = -8         /* RCCL missing, or a communicator call failed (artp_group_last_error) */
+  ARTP_ERR_COMM = -8,        /* RCCL missing, or a communicator call failed (artp_group_last_error) */
+  ARTP_ERR_COST_FUNC = -9    /* the caller's motion-cost function (artp_cost_set_external_query) reported failure */
 } artp_status;
 
 /* Numeric fields of art_planner::Params the hot path reads
@@ -552,6 +553,15 @@ int artp_cost_set_hole_filling(artp_ctx* ctx, int enabled);
  * cost [B][3] = energy, time, risk (= 1 - prob; cost_query.py:65-69). */
 int artp_cost_query(artp_ctx* ctx, const float* edges, size_t b, float* cost);
 int artp_cost_query_dev(artp_ctx* ctx, const float* edges, size_t b, float* cost);
+/* The MotionCostFunc seam of PRMMotionCostMaintainer (prm_motion_cost.cpp:27-73: `func(edge_matrix, &edge_cost)` -- in
+ * PlannerRos a ROS service client, planner_ros.cpp:283-318).  With fn != NULL every batch the ROADMAP prices with the
+ * learned objective (artp_roadmap_params::objective == 2: build, grow, revalidate, set_query, simplify_path) goes
+ * through the caller's function instead of the device network: edges / cost are HOST buffers in artp_cost_query's
+ * layout, return 0 on success; any other value fails the roadmap call with ARTP_ERR_COST_FUNC (the reference throws
+ * std::runtime_error("Motion cost call failed"), motion_cost_objective.cpp:78-83).  No weights need to be loaded then.
+ * fn == NULL (default): device pricing (artp_cost_query_dev).  artp_cost_query itself is never redirected. */
+typedef int (*artp_cost_query_fn)(void* user, const float* edges, size_t b, float* cost);
+int artp_cost_set_external_query(artp_ctx* ctx, artp_cost_query_fn fn, void* user);
 /* diagnostics: the feature-map cell (row, col) CostQuery.__call__ gathers for each edge's start position
  * (cost_query.py:54-55: float64 arithmetic, clamp to [1, shape - 2], .long()) -- computed by the device function the
  * cost kernels use; the tests compare it with the reference's own CostQuery.  Host buffers. */
