@@ -36,14 +36,18 @@ SYMBOLS = [
     "artp_preprocess_params_defaults", "artp_preprocess_params_yaml", "artp_preprocess_map",
     "artp_preprocess_map_ex", "artp_preprocessed_change",
     "artp_preprocessed_get_layer", "artp_preprocessed_install", "artp_preprocessed_destroy",
-    "artp_inpaint_layer", "artp_cost_set_hole_filling",
+    "artp_inpaint_layer", "artp_cost_set_hole_filling", "artp_cost_set_external_query",
     "artp_cost_blob_bytes", "artp_cost_load_weights", "artp_cost_update_map_layer",
     "artp_cost_update_map", "artp_cost_query", "artp_cost_query_dev", "artp_cost_get_features", "artp_cost_debug_query_cells", "artp_cost_fc_path", "artp_set_r3_extent", "artp_telea_inpaint_u8",
 ]
 
 
+# artp_cost_query_fn: int (*)(void* user, const float* edges, size_t b, float* cost)
+COST_QUERY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float))
+
+
 class ArtpError(RuntimeError):
-    pass
+    status = None   # the artp_status code (include/artp_c.h) when the error came out of check()
 
 
 class Params(C.Structure):
@@ -203,6 +207,7 @@ def load():
     L.artp_preprocessed_destroy.restype = None
     L.artp_inpaint_layer.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(u64)]
     L.artp_cost_set_hole_filling.argtypes = [vp, i32]
+    L.artp_cost_set_external_query.argtypes = [vp, COST_QUERY_FN, vp]
     L.artp_cost_blob_bytes.argtypes = []
     L.artp_cost_blob_bytes.restype = sz
     L.artp_cost_load_weights.argtypes = [vp, vp, sz]
@@ -232,4 +237,6 @@ def check(ctx, rc: int, what: str) -> None:
         L = load()
         msg = L.artp_status_string(rc).decode()
         detail = L.artp_last_error(ctx).decode() if ctx else ""
-        raise ArtpError(f"{what} failed: {msg} ({rc}) {detail}")
+        err = ArtpError(f"{what} failed: {msg} ({rc}) {detail}")
+        err.status = rc
+        raise err

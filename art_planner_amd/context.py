@@ -308,6 +308,27 @@ class Context:
                                             C.byref(n)), "artp_inpaint_layer")
         return out, n.value
 
+    def cost_set_external_query(self, fn=None):
+        """The MotionCostFunc seam (prm_motion_cost.cpp:27-73): fn(edges [B, 6] float32) -> costs [B, 3] (or None = the
+        call failed) prices every learned-cost batch of this context's roadmaps; fn=None: device pricing."""
+        if fn is None:
+            self._ext_cost = None
+            self._chk(self.L.artp_cost_set_external_query(self.h, _capi.COST_QUERY_FN(0), None), "artp_cost_set_external_query")
+            return
+
+        def thunk(_user, edges, b, cost):
+            try:
+                out = fn(np.ctypeslib.as_array(edges, shape=(b, 6)).copy())
+                if out is None:
+                    return 1
+                np.ctypeslib.as_array(cost, shape=(b, 3))[:] = np.asarray(out, np.float32).reshape(b, 3)
+                return 0
+            except Exception:  # noqa: BLE001 -- an exception must not cross the C boundary
+                return 1
+
+        self._ext_cost = _capi.COST_QUERY_FN(thunk)   # kept alive as long as it is installed
+        self._chk(self.L.artp_cost_set_external_query(self.h, self._ext_cost, None), "artp_cost_set_external_query")
+
     def cost_set_hole_filling(self, enabled=True):
         self._chk(self.L.artp_cost_set_hole_filling(self.h, 1 if enabled else 0), "artp_cost_set_hole_filling")
 

@@ -183,6 +183,72 @@ def test_flat_map_path_is_near_the_straight_line():
     ctx.close()
 
 
+def test_roadmap_priced_through_an_external_cost_function(planning_setup):
+    """artp_cost_set_external_query = the MotionCostFunc seam of PRMMotionCostMaintainer (prm_motion_cost.cpp:27-73): the
+    roadmap's learned-cost batches go [B x 6] -> the caller's function -> [B x 3].  (a) a function that forwards to
+    artp_cost_query reproduces device pricing bit for bit; (b) an analytic function prices the graph by its own numbers,
+    without any weights in play; (c) a failing function fails the build with ARTP_ERR_COST_FUNC = "Motion cost call
+    failed" (motion_cost_objective.cpp:78-83) and the context stays usable."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import motion_cost_oracle as mo
+    import convert_weights
+    from art_planner_amd._capi import ArtpError
+    from art_planner_amd.roadmap import Roadmap
+    gm, ctx, start, goal = planning_setup
+    ctx.cost_load_weights(convert_weights.to_blob(mo.random_params(0)))
+    elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float32)
+    ctx.cost_update_map(elv, gm.res, gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+    kw = dict(n_milestones=1200, seed=5, k_neighbors=40, objective=2, cost_weights=(0.25, 1.0, 5.0), risk_threshold=0.55)
+    rm = Roadmap(ctx, start, goal, **kw)
+    dev = rm.export()
+    rm.close()
+    seen = []
+
+    def forward(edges):
+        seen.append(len(edges))
+        return ctx.cost_query(edges)
+
+    try:
+        ctx.cost_set_external_query(forward)
+        rm = Roadmap(ctx, start, goal, **kw)
+        ext = rm.export()
+        rm.close()
+        assert seen and sum(seen) >= len(dev["edge_cost"])
+        assert np.array_equal(ext["edges"], dev["edges"]) and np.array_equal(ext["edge_cost"], dev["edge_cost"])
+
+        # (b) energy 1 per query, time = lateral length, no risk: an edge of n_interp interior states costs
+        # 0.25 (n_interp + 1) + its sub-edges' lengths
+        def analytic(edges):
+            out = np.zeros((len(edges), 3), np.float32)
+            out[:, 0] = 1.0
+            out[:, 1] = np.hypot(edges[:, 0] - edges[:, 3], edges[:, 1] - edges[:, 4])
+            return out
+
+        ctx.cost_set_external_query(analytic)
+        rm = Roadmap(ctx, start, goal, **kw)
+        d = rm.export()
+        V, E = d["verts"], d["edges"].astype(np.int64)
+        length = np.hypot(V[E[:, 0], 0] - V[E[:, 1], 0], V[E[:, 0], 1] - V[E[:, 1], 1])
+        want = 0.25 * (d["edge_interp"] + 1.0) + length
+        assert np.isfinite(d["edge_cost"]).all() and np.abs(d["edge_cost"] - want).max() < 1e-4
+        path, cost, _ = rm.solve()
+        assert path is not None and cost >= np.hypot(*(start[:2] - goal[:2])) - 1e-6
+        rm.close()
+        # (c)
+        ctx.cost_set_external_query(lambda edges: None)
+        with pytest.raises(ArtpError) as ei:
+            Roadmap(ctx, start, goal, **kw)
+        assert ei.value.status == -9 and "Motion cost call failed" in str(ei.value)
+    finally:
+        ctx.cost_set_external_query(None)
+    rm = Roadmap(ctx, start, goal, **kw)
+    assert np.array_equal(rm.export()["edge_cost"], dev["edge_cost"])   # device pricing again
+    rm.close()
+
+
 def test_learned_cost_objective_matches_per_subedge_queries(planning_setup):
     """objective 2 = PRMMotionCostMaintainer::updateEdges: every sub-edge of a chain is one EdgeMatrix row
     (target x y yaw, start x y yaw); chain cost = sum of getCost over its rows, infinite as soon as one
