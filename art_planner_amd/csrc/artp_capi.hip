@@ -65,6 +65,7 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
+  int conv15_pair32 = 1;      // the 15 x 15 layer of launches with more tiles than CUs: conv15_pair32_kernel (0: conv_ksplit_kernel)
   artp_cost_query_fn ext_cost_fn = nullptr;   // artp_cost_set_external_query: the roadmap's learned-cost batches go here
   void* ext_cost_user = nullptr;
   bool few_edges = true;      // <= ARTP_FEW_EDGES edges per HOST call: the one-launch latency kernel (artp_set_few_edges)
@@ -133,6 +134,7 @@ struct artp_ctx {
   unsigned char* d_c12m = nullptr;     // the same as MFMA fragments, hi / lo half floats + bias[32] (conv12_mfma_kernel)
   int conv12_mfma = 1;                 // $ARTP_CONV12_MFMA=0: the VALU form (rounds 3-4)
   half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
+  half8* d_convw_p32 = nullptr;   // the 15 x 15 layer's weights stacked for row pairs (conv15_pair32_kernel)
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
   int feet_dense = 0;                  // $ARTP_FEET_DENSE=1: feet_stream2_kernel (corner arithmetic on dense lanes; measured: no faster)
@@ -838,6 +840,7 @@ void artp_destroy(artp_ctx* c) {
   if (c->d_c12m) (void)hipFree(c->d_c12m);
   for (int l = 0; l < 3; ++l)
     if (c->d_convw_chunk[l]) (void)hipFree(c->d_convw_chunk[l]);
+  if (c->d_convw_p32) (void)hipFree(c->d_convw_p32);
   for (int l = 0; l < 2; ++l)
     if (c->d_act[l]) (void)hipFree(c->d_act[l]);
   if (c->d_feat) (void)hipFree(c->d_feat);
@@ -2460,6 +2463,29 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
               }
               packed[((((size_t)kh * ksteps + ks) * s.nt + nt) * 64 + l) * 8 + j] = f32_to_f16_bits(v);
             }
+    if (l == 4) {
+      // the same layer for conv15_pair32_kernel: [kernel row -1 .. 15][k-step][k-half][channel][k-quad][8], kernel rows
+      // -1 and 15 all zero (Conv15P32Cfg); element j of (channel co, quad kq) = W[co][k = 32 ks + 16 sh + 8 kq + j]
+      using P32 = Conv15P32Cfg<6>;
+      std::vector<uint16_t> p32(P32::W_FRAGS * 8, 0);
+      for (int kh = 0; kh < s.kh; ++kh)
+        for (int ks = 0; ks < ksteps; ++ks)
+          for (int sh = 0; sh < 2; ++sh)
+            for (int co = 0; co < s.cout; ++co)
+              for (int kq = 0; kq < 2; ++kq)
+                for (int j = 0; j < 8; ++j) {
+                  const int kidx = ks * 32 + sh * 16 + kq * 8 + j;
+                  if (kidx >= krow) continue;
+                  const int kw = kidx / s.cin, ci = kidx % s.cin;
+                  const float v = w[(((size_t)co * s.cin + ci) * s.kh + kh) * s.kw + kw];
+                  p32[((size_t)(kh + 1) * P32::KH_FR + (size_t)ks * P32::KS_FR + sh * P32::SH_FR + co * 2 + kq) * 8 + j] =
+                      f32_to_f16_bits(v);
+                }
+      if (c->d_convw_p32) HIP_TRY(c, hipFree(c->d_convw_p32));
+      c->d_convw_p32 = nullptr;
+      HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convw_p32), p32.size() * 2));
+      HIP_TRY(c, hipMemcpy(c->d_convw_p32, p32.data(), p32.size() * 2, hipMemcpyHostToDevice));
+    }
     w += (size_t)s.cout * s.cin * s.kh * s.kw;
     if (c->d_convw[l]) HIP_TRY(c, hipFree(c->d_convw[l]));
     c->d_convw[l] = nullptr;
@@ -2746,7 +2772,25 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     // (launch 111.6 us against 108-111: the main loop runs at 17 cycles per MFMA either way, at ~1.65 GHz), so not the default.
     const char* evm = std::getenv("ARTP_KSPLIT_MS");
     const bool ms2 = !wide && xcd2 && evm && std::atoi(evm) == 2;
-    if (wide && !xcd2)
+    // round 6: more tiles than CUs -> the row-pair form on v_mfma_f32_32x32x16_f16, one 4-wavefront workgroup per CU; tile
+    // height 6 or 8 by rounds x height (800^2: 63 x 12 = 756 tiles of 6 rows = 2.95 rounds of 256)
+    const char* ev32 = std::getenv("ARTP_CONV15_PAIR32");   // A/B against conv_ksplit_kernel (tuning)
+    const bool pair32 = !wide && xcd2 && (ev32 ? std::atoi(ev32) != 0 : c->conv15_pair32 != 0);
+    if (pair32) {
+      auto cost32 = [&](int tr) {
+        const long tiles = (long)((wf + 31) / 32) * ((hf + tr - 1) / tr);
+        return ((tiles + c->n_cus - 1) / c->n_cus) * (long)tr;
+      };
+      auto launch32 = [&](auto kfn, int lds, int tr) -> int {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const unsigned blocks = (unsigned)(((wf + 31) / 32) * ((hf + tr - 1) / tr));
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw_p32,
+                           (const float*)c->d_convb[4], c->d_feat);
+        return ARTP_OK;
+      };
+      rcl = cost32(6) <= cost32(8) ? launch32(conv15_pair32_kernel<6>, Conv15P32Cfg<6>::LDS_BYTES, 6)
+                                   : launch32(conv15_pair32_kernel<8>, Conv15P32Cfg<8>::LDS_BYTES, 8);
+    } else if (wide && !xcd2)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8, false>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
     else if (wide)
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);

@@ -302,6 +302,222 @@ conv_ksplit_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8*
 #endif
 }
 
+// ---- round 6: the 15 x 15 layer on v_mfma_f32_32x32x16_f16, two output rows per accumulator set ---------------------
+// What the matrix cores sustain (tests/cpp/mfma_clock_probe.hip, profiles/r06_mfma_clock_probe.txt): 32x32x16 issues back
+// to back at 32.0 cycles from ONE wavefront per SIMD (0.84 of the nominal 2.5 PFLOP/s, 0.89 with two) where 16x16x32 needs
+// two wavefronts per SIMD for 17 cycles per 16 (0.74-0.78) and a lone wavefront gets 26 -- and it reads half the operand
+// registers per FLOP.  48 output channels are not a multiple of 32, so the M dimension is the channels of TWO output rows:
+// for the output row pair (2j, 2j + 1) and the patch row rho = 2j + t, kernel row t feeds row 2j and kernel row t - 1 feeds
+// row 2j + 1 FROM THE SAME ACTIVATIONS.  Stacked, that is a 96-row weight matrix per step t = 0 .. 15
+//     rows  0 .. 47 = W[kh = t][channel 0 .. 47]      (-> output row 2j)
+//     rows 48 .. 95 = W[kh = t - 1][channel 0 .. 47]  (-> output row 2j + 1)
+// = three 32-row blocks that share one activation fragment (32 pixels x 16 k).  W[-1] = W[15] = 0: step 0 skips block 2,
+// step 15 block 0, and half of block 1 is zero there -- 46 MFMAs per pair and k-half where 45 are needed.
+// Otherwise the K-split kernel above: the four wavefronts split the k-steps, the weight fragments go global -> registers
+// (ring, PD steps ahead), the activation rows come from the LDS patch through a register ring (ONE new row per step), the
+// partial tiles meet in LDS a row pair at a time.  One 4-wavefront workgroup per CU (a wavefront per SIMD, ~300 registers).
+template <int TR>
+struct Conv15P32Cfg {
+  static constexpr int KH = 15, KW = 15, CIN = 48, COUT = 48;
+  static constexpr int KROW = KW * CIN;                    // 720 halfs per kernel row
+  static constexpr int KSTEPS = (KROW + 31) / 32;          // 23 k-steps of 32 (two MFMA k-halves each)
+  static constexpr int TP = 32, NP = TR / 2, NSTEP = KH + 1;
+  static constexpr int PR = TR + KH - 1;
+  static constexpr int XPAD = (KSTEPS * 32 - KROW + CIN - 1) / CIN;
+  static constexpr int PPX = TP + KW - 1 + XPAD;
+  static constexpr int PIX_B = CIN * 2;
+  static constexpr int ROW_B = PPX * PIX_B;
+  static constexpr int A_BYTES = PR * ROW_B;
+  static constexpr int RED_BYTES = 4 * 12 * 64 * 16;       // one row pair: 4 wavefronts x (3 blocks x 4 quads) x 64 lanes x float4
+  static constexpr int STAGE_BYTES = TR * TP * COUT * 2;
+  static constexpr int LDS_BYTES = A_BYTES > RED_BYTES + STAGE_BYTES ? A_BYTES : RED_BYTES + STAGE_BYTES;
+  // packed weights: [kernel row -1 .. 15 (both ends zero)][k-step][k-half][channel 0 .. 47][k-quad 0 .. 1] half8
+  static constexpr int SH_FR = COUT * 2, KS_FR = 2 * SH_FR, KH_FR = KSTEPS * KS_FR;
+  static constexpr size_t W_FRAGS = (size_t)(KH + 2) * KH_FR;
+  static_assert(TR % 2 == 0 && TR >= 4, "row pairs");
+  static_assert(ROW_B % 16 == 0 && LDS_BYTES <= 160 * 1024, "16-byte chunks; one workgroup per CU");
+};
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// wp: Conv15P32Cfg's packed weights.  The three 32-row blocks of a step are not stored: a lane picks its stacked row's
+// (kernel row, channel) itself -- block 0: (t, m); block 1: (t, 32 + m) for m < 16, (t - 1, m - 16) above; block 2:
+// (t - 1, 16 + m) -- so the weights keep their size (1.2 MB in the L2s, not 2.3) and the kernel row a step read as "t" is
+// the one the next step reads as "t - 1", one step later in the same wavefront: an L1 hit.
+template <int TR, bool XCD = true, int RD = 4, int PD = 3>
+__global__ void __launch_bounds__(256, 1)
+conv15_pair32_kernel(const half_t* __restrict__ in, int Hin, int Win, const half8* __restrict__ wp,
+                     const float* __restrict__ bias, half_t* __restrict__ out) {
+  using Cfg = Conv15P32Cfg<TR>;
+  constexpr int KSTEPS = Cfg::KSTEPS, NP = Cfg::NP, NSTEP = Cfg::NSTEP, NTH = 256, NK = 4;
+  static_assert(NSTEP % RD == 0 && PD < RD, "the weight ring runs on across k-steps: slot = step % RD");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Hout = Hin - Cfg::KH + 1, Wout = Win - Cfg::KW + 1;
+  const int tiles_x = (Wout + Cfg::TP - 1) / Cfg::TP;
+  const int tile = XCD ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bx = tile % tiles_x, by = tile / tiles_x;
+  const int oy0 = by * TR, ox0 = bx * Cfg::TP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 31, kq = lane >> 5;
+  const char* a_lane = smem + px * Cfg::PIX_B + kq * 16;
+  // which k-steps a wavefront takes, and in which order, rotates with the workgroup index (conv_ksplit_kernel)
+  const int ks_first = (wave + (int)(blockIdx.x & 3u)) & 3;
+  const int nj = (KSTEPS - ks_first + NK - 1) / NK;
+  const int j0 = (int)((blockIdx.x >> 2) % (unsigned)nj);
+  auto ks_of = [&](int jj) {
+    const int j = jj + j0 < nj ? jj + j0 : jj + j0 - nj;
+    return ks_first + NK * j;
+  };
+  constexpr int SH_FR = Cfg::SH_FR, KS_FR = Cfg::KS_FR, KH_FR = Cfg::KH_FR;
+  // this lane's row in the three blocks, as an offset (in half8 units) from the (kernel row t, k-step, k-half 0) slab
+  const int off_b0 = px * 2 + kq;
+  const int off_b1 = px < 16 ? (32 + px) * 2 + kq : (px - 16) * 2 + kq - KH_FR;
+  const int off_b2 = (16 + px) * 2 + kq - KH_FR;
+  half8 w[RD][6];   // [slot][block * 2 + k-half]
+  // input patch -> LDS (conv_ksplit_kernel's copy: all loads of a thread in flight before its first LDS store)
+  {
+    constexpr int CPR = Cfg::ROW_B / 16;
+    constexpr int NIT = (Cfg::PR * CPR + NTH - 1) / NTH;
+    const long row_bytes = (long)Win * Cfg::PIX_B;
+    half8 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * NTH;
+      const int r = c / CPR, cc = c - r * CPR;
+      const long off = (long)ox0 * Cfg::PIX_B + (long)cc * 16;
+      const bool ok = c < Cfg::PR * CPR && oy0 + r < Hin && off + 16 <= row_bytes;
+      // unconditional load from a clamped address + select (hipcc serialises conditional loads: a trip to memory each)
+      const half8 ld = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(in) + (ok ? (long)(oy0 + r) * row_bytes + off : 0));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = ok ? ld[j] : (half_t)0;
+    }
+    {  // the ring's first PD steps, requested behind the patch
+      const half8* w0 = wp + (size_t)ks_of(0) * KS_FR + KH_FR;   // kernel row 0 = slab 1
+#pragma unroll
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          w[d][0 + sh] = w0[(size_t)d * KH_FR + sh * SH_FR + off_b0];
+          w[d][2 + sh] = w0[(size_t)d * KH_FR + sh * SH_FR + off_b1];
+          if (d > 0) w[d][4 + sh] = w0[(size_t)d * KH_FR + sh * SH_FR + off_b2];   // step 0 has no block 2
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * NTH;
+      const int r = c / CPR, cc = c - r * CPR;
+      if (c < Cfg::PR * CPR) *reinterpret_cast<half8*>(smem + r * Cfg::ROW_B + cc * 16) = v[it];
+    }
+  }
+  __syncthreads();
+
+  floatx16 acc[NP][3];
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][b][q] = 0.f;
+
+  for (int jj = 0; jj < nj; ++jj) {
+    const int ks = ks_of(jj);
+    const char* a_ks = a_lane + ks * 64;   // + row * ROW_B + k-half * 32
+    const half8* w_ks = wp + (size_t)ks * KS_FR + KH_FR;
+    const half8* w_nx = wp + (size_t)ks_of(jj + 1 < nj ? jj + 1 : jj) * KS_FR + KH_FR;  // the next k-step's (or a harmless re-read)
+    half8 a[TR][2];   // ring: slot rho % TR holds patch row rho (its two k-halves); row rho is used at steps t = rho - 2j
+#pragma unroll
+    for (int r = 0; r < TR - 1; ++r)
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) a[r][sh] = *reinterpret_cast<const half8*>(a_ks + r * Cfg::ROW_B + sh * 32);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {
+      // the row step t + 1 needs new (rho = t + TR - 1; its slot's last occupant, row t - 1, was last used at step t - 1)
+      if (t + TR - 1 < Cfg::PR) {
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+          a[(t + TR - 1) % TR][sh] = *reinterpret_cast<const half8*>(a_ks + (t + TR - 1) * Cfg::ROW_B + sh * 32);
+      }
+      {  // weights of step t + PD
+        const int tn = t + PD;
+#ifdef ARTP_P32_SAMEW   // bound experiment (wrong sums): every step reads the same 6 KB -- no weight stream from L2
+        const half8* src = wp + KH_FR + (size_t)(tn & 1) * KH_FR;
+#else
+        const half8* src = tn < NSTEP ? w_ks + (size_t)tn * KH_FR : w_nx + (size_t)(tn - NSTEP) * KH_FR;
+#endif
+        const int tt = tn < NSTEP ? tn : tn - NSTEP;
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          if (tt < NSTEP - 1) w[(t + PD) % RD][0 + sh] = src[sh * SH_FR + off_b0];
+          w[(t + PD) % RD][2 + sh] = src[sh * SH_FR + off_b1];
+          if (tt > 0) w[(t + PD) % RD][4 + sh] = src[sh * SH_FR + off_b2];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          const half8 x = a[(2 * j + t) % TR][sh];
+          if (t < NSTEP - 1) acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t % RD][0 + sh], x, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t % RD][2 + sh], x, acc[j][1], 0, 0, 0);
+          if (t > 0) acc[j][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t % RD][4 + sh], x, acc[j][2], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // The product is TRANSPOSED (weights = first operand): column (lane & 31) = pixel, register v of a block = stacked row
+  // 8 (v / 4) + 4 (lane >> 5) + v % 4 -- four consecutive channels of one output row per register quad.  The four partial
+  // tiles meet in LDS one row pair at a time (the patch is dead); wavefront w finishes the (block, quad) items w, w + 4, w + 8.
+  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+  floatx4* red = reinterpret_cast<floatx4*>(smem);
+  char* stage = smem + Cfg::RED_BYTES;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        red[((wave * 3 + b) * 4 + q) * 64 + lane] = floatx4{acc[j][b][4 * q], acc[j][b][4 * q + 1], acc[j][b][4 * q + 2], acc[j][b][4 * q + 3]};
+    __syncthreads();
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+      const int item = wave + 4 * i3, b = item >> 2, q = item & 3;
+      floatx4 v = red[((0 * 3 + b) * 4 + q) * 64 + lane];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const floatx4 pv = red[((ww * 3 + b) * 4 + q) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += pv[r];
+      }
+      const int R = 32 * b + 8 * q + 4 * kq;          // stacked row of v[0]
+      const int orow = 2 * j + (R >= 48 ? 1 : 0), ch = R >= 48 ? R - 48 : R;
+      const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + ch);
+      half4_t y4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = v[r] + bv[r];
+        y = fmaxf(y, 0.3f * y);
+        y4[r] = (half_t)y;
+      }
+      *reinterpret_cast<half4_t*>(stage + ((orow * Cfg::TP + px) * Cfg::COUT + ch) * 2) = y4;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = Cfg::TP * Cfg::COUT * 2 / 16;  // 16-byte chunks per tile row
+    for (int c = tid; c < TR * CPR; c += NTH) {
+      const int m = c / CPR, cc = c - m * CPR;
+      const int opx = (cc * 16) / (Cfg::COUT * 2);
+      if (oy0 + m < Hout && ox0 + opx < Wout)
+        *reinterpret_cast<half8*>(reinterpret_cast<char*>(out) + ((size_t)(oy0 + m) * Wout + ox0) * Cfg::COUT * 2 + cc * 16) =
+            *reinterpret_cast<const half8*>(stage + m * CPR * 16 + cc * 16);
+    }
+  }
+}
+
 // ---- round 5: the 15 x 15 layer as a PERSISTENT kernel that walks down 16-pixel column strips -------------------------
 // One workgroup per CU for the whole launch; it owns a run of vertically adjacent TR-row x 16-pixel tiles.
 //  * The patch rows live in an LDS RING of PR + TR rows: the tile below needs only TR new rows (24-27 KB instead of the
