@@ -19,7 +19,7 @@ SYMBOLS = [
     "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_sample_and_validate", "artp_check_motions_last_valid", "artp_check_motions_last_valid_dev",
-    "artp_set_z_bounds", "artp_set_few_edges", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
+    "artp_set_z_bounds", "artp_set_few_edges", "artp_set_edge_passes", "artp_cost_set_fc_path", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
     "artp_check_edges_interp_dev", "artp_compact_valid_dev", "artp_compact_valid_indices_dev", "artp_sample_states_at_dev",
     "artp_pack_edge_results_dev", "artp_cost_update_map_dev", "artp_pack_valid_bits_dev", "artp_indices_from_bits_dev",
     "artp_materialise_from_bits_dev",
@@ -92,12 +92,27 @@ class RoadmapParams(C.Structure):  # artp_roadmap_params (include/artp_c.h)
                 ("construction", C.c_int32), ("max_query_edge_length", C.c_double)]
 
 
-def load():
-    """Load libartp.so; raise ArtpError if it was not built (run `python -c 'import __graft_entry__ as
-    g; g.build()'` or `make -C art_planner_amd/csrc`)."""
+VARIANTS_LIB_PATH = os.path.join(_HERE, "csrc", "libartp_variants.so")   # make -C art_planner_amd/csrc variants
+_libs = {}
+
+
+def load(path=None):
+    """Load libartp.so (or another build of it: `path`, e.g. VARIANTS_LIB_PATH -- the forms that were measured and did not
+    become the default, for the tests that pin their parity); raise ArtpError if it was not built (run `python -c 'import
+    __graft_entry__ as g; g.build()'` or `make -C art_planner_amd/csrc`).  A context belongs to the library that made it."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
+    if path is not None and os.path.abspath(path) != LIB_PATH:
+        path = os.path.abspath(path)
+        if path not in _libs:
+            _libs[path] = _load_path(path)
+        return _libs[path]
+    _lib = _load_path(LIB_PATH)
+    return _lib
+
+
+def _load_path(LIB_PATH):
     if not os.path.exists(LIB_PATH):
         raise ArtpError(f"{LIB_PATH} is missing: build the HIP extension first "
                         "(make -C art_planner_amd/csrc). There is no CPU fallback.")
@@ -141,6 +156,8 @@ def load():
     L.artp_map_version.restype = C.c_uint64
     L.artp_set_z_bounds.argtypes = [vp, dbl, dbl]
     L.artp_set_few_edges.argtypes = [vp, i32]
+    L.artp_set_edge_passes.argtypes = [vp, i32, i32]
+    L.artp_cost_set_fc_path.argtypes = [vp, i32]
     for name in ("artp_check_motions_last_valid", "artp_check_motions_last_valid_dev"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, vp, vp, vp]
     for name in ("artp_check_motions", "artp_check_motions_dev"):
@@ -228,13 +245,12 @@ def load():
                                                   "artp_preprocess_params_yaml", "artp_preprocessed_destroy",
                                                   "artp_group_destroy"):
             fn.restype = C.c_int
-    _lib = L
     return L
 
 
-def check(ctx, rc: int, what: str) -> None:
+def check(ctx, rc: int, what: str, L=None) -> None:
     if rc != 0:
-        L = load()
+        L = L or load()
         msg = L.artp_status_string(rc).decode()
         detail = L.artp_last_error(ctx).decode() if ctx else ""
         err = ArtpError(f"{what} failed: {msg} ({rc}) {detail}")

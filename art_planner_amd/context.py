@@ -27,12 +27,13 @@ class Context:
     """Mirrors what art_planner::Planner owns for the hot path: the validity checker's two height
     fields, the sampler's layers and the state-space bounds (art_planner/src/planner.cpp:75-163)."""
 
-    def __init__(self, device: int = 0, params="yaml"):
-        self.L = _capi.load()
+    def __init__(self, device: int = 0, params="yaml", lib=None):
+        """lib: path of another build of the library (e.g. _capi.VARIANTS_LIB_PATH); default libartp.so."""
+        self.L = _capi.load(lib)
         self.params = params if isinstance(params, _capi.Params) else make_params(params)
         h = C.c_void_p()
         rc = self.L.artp_create(device, C.byref(self.params), C.byref(h))
-        _capi.check(None, rc, "artp_create")
+        _capi.check(None, rc, "artp_create", self.L)
         self.h = h
         self.device = device
 
@@ -64,7 +65,7 @@ class Context:
         return self.L.artp_device_arch(self.h).decode()
 
     def _chk(self, rc, what):
-        _capi.check(self.h, rc, what)
+        _capi.check(self.h, rc, what, self.L)
 
     # ---- map ---------------------------------------------------------------------------------
     def upload_layer(self, slot, layer, len_x, len_y, pos_x=0.0, pos_y=0.0):
@@ -134,6 +135,9 @@ class Context:
     def set_few_edges(self, enabled=True):
         """<= 64 edges per host call: the one-launch latency kernel (default) or the batch pipeline (enabled=False)."""
         self._chk(self.L.artp_set_few_edges(self.h, 1 if enabled else 0), "artp_set_few_edges")
+
+    def set_edge_passes(self, two_pass=True, coarse_stride=0):
+        self._chk(self.L.artp_set_edge_passes(self.h, 1 if two_pass else 0, coarse_stride), "artp_set_edge_passes")
 
     def check_motions(self, s1, s2):
         s1 = np.ascontiguousarray(s1, np.float64).reshape(-1, 7)
@@ -328,6 +332,9 @@ class Context:
 
         self._ext_cost = _capi.COST_QUERY_FN(thunk)   # kept alive as long as it is installed
         self._chk(self.L.artp_cost_set_external_query(self.h, self._ext_cost, None), "artp_cost_set_external_query")
+
+    def cost_set_fc_path(self, mfma=True):
+        self._chk(self.L.artp_cost_set_fc_path(self.h, 1 if mfma else 0), "artp_cost_set_fc_path")
 
     def cost_set_hole_filling(self, enabled=True):
         self._chk(self.L.artp_cost_set_hole_filling(self.h, 1 if enabled else 0), "artp_cost_set_hole_filling")

@@ -65,11 +65,11 @@ struct artp_ctx {
   bool have_sampler = false;
   double z_low = 0.0, z_high = 0.0;
   bool have_z = false;
-  int conv15_pair32 = 1;      // the 15 x 15 layer of launches with more tiles than CUs: conv15_pair32_kernel (0: conv_ksplit_kernel)
+  int fc_mfma_wanted = 1;     // artp_cost_set_fc_path: 1 = FCpart on the matrix cores (self-checked at load), 0 = the fp32 VALU kernels
   artp_cost_query_fn ext_cost_fn = nullptr;   // artp_cost_set_external_query: the roadmap's learned-cost batches go here
   void* ext_cost_user = nullptr;
   bool few_edges = true;      // <= ARTP_FEW_EDGES edges per HOST call: the one-launch latency kernel (artp_set_few_edges)
-  bool edge_two_pass = true;  // artp_check_motions: coarse pass first ($ARTP_EDGE_TWO_PASS=0: one pass over all states)
+  bool edge_two_pass = true;  // artp_check_motions: coarse pass first (artp_set_edge_passes)
   int edge_coarse_stride = ARTP_COARSE_STRIDE;  // $ARTP_COARSE_STRIDE (tuning)
   // map tables (pipeline.h): per layer 6 levels of {max, min} + 6 levels of non-finite / NaN flag bytes, the
   // partner table and the raw cross products it is built from
@@ -134,12 +134,12 @@ struct artp_ctx {
   unsigned char* d_c12m = nullptr;     // the same as MFMA fragments, hi / lo half floats + bias[32] (conv12_mfma_kernel)
   int conv12_mfma = 1;                 // $ARTP_CONV12_MFMA=0: the VALU form (rounds 3-4)
   half8* d_convw_chunk[3] = {nullptr, nullptr, nullptr};  // conv3..5 B fragments in chunk order (conv345_kernel)
-  half8* d_convw_p32 = nullptr;   // the 15 x 15 layer's weights stacked for row pairs (conv15_pair32_kernel)
+  half8* d_convw_p32 = nullptr;   // variants build: the 15 x 15 layer's weights for conv15_pair32_kernel
   float* d_fc = nullptr;               // FcWeights::TOTAL floats
   char* d_fc_mfma = nullptr;           // FcMfma::TOTAL bytes: the same MLP in MFMA fragment order (fc_mfma_pack)
   int feet_dense = 0;                  // $ARTP_FEET_DENSE=1: feet_stream2_kernel (corner arithmetic on dense lanes; measured: no faster)
   double r3_extent_override = 0.0;     // artp_set_r3_extent: > 0 = checkMotion's R^3 maxExtent, whatever the installed map's bounds
-  int fc_mfma = 1;                     // $ARTP_FC_MFMA=0: the fp32 VALU kernels (tuning / comparison)
+  int fc_mfma = 1;                     // the kernel artp_cost_query uses now (artp_cost_fc_path)
   int fc_selfcheck = -1;               // artp_cost_load_weights' probe batch: 1 = the MFMA kernel agreed with the fp32 one,
                                        // 0 = it did not (fc_mfma forced to 0), -1 = not run
   float fc_selfcheck_err = 0.f;        // largest |MFMA - fp32| of the probe batch
@@ -626,10 +626,12 @@ int launch_validate_pipeline(artp_ctx* c, const double* se3, size_t n, uint8_t* 
                      dim3(ARTP_CLASSIFY_THREADS), 0, c->stream,
                      c->field[0], c->field[1], c->tables[0], c->tables[1], c->geom, c->robot, (const PoseRec*)recs, n,
                      valid, q);
-  if (c->feet_dense)   // round 5 experiment: the corner stage's plane / contact arithmetic on dense lanes (pipeline.h feet_stream2_kernel)
+#ifdef ARTP_VARIANTS
+  if (c->feet_dense)   // round 5 experiment: the corner stage's plane / contact arithmetic on dense lanes (pipeline_variants.h)
     hipLaunchKernelGGL(feet_stream2_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, ARTP_FEET_WAVES_PER_SIMD)), dim3(64 * ARTP_STREAM_WAVES), 0,
                        c->stream, c->field[1], c->robot, q, valid);
   else
+#endif
     hipLaunchKernelGGL(feet_stream_kernel<ARTP_STREAM_WAVES>, dim3(grid_sub(c, ARTP_FEET_WAVES_PER_SIMD)), dim3(64 * ARTP_STREAM_WAVES), 0,
                        c->stream, c->field[1], c->robot, q, valid);
   hipLaunchKernelGGL(feet_lane_kernel, dim3((unsigned)c->n_cus * 8), dim3(ARTP_LANE_THREADS), 0, c->stream,
@@ -786,11 +788,11 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
     c->pin_labels = static_cast<volatile uint8_t*>(pl);
     c->pin_states_dev = static_cast<double*>(psd);
     c->pin_labels_dev = static_cast<uint8_t*>(pld);
-    const char* e = std::getenv("ARTP_NO_POLL");
+    const char* e = std::getenv("ARTP_NO_POLL");   // one of the library's three environment variables (include/artp_c.h)
     c->poll_labels = !(e && e[0] == '1');
-    if (const char* tp = std::getenv("ARTP_EDGE_TWO_PASS")) c->edge_two_pass = tp[0] != '0';
+#ifdef ARTP_VARIANTS
     if (const char* fd = std::getenv("ARTP_FEET_DENSE")) c->feet_dense = fd[0] != '0';
-    if (const char* cs = std::getenv("ARTP_COARSE_STRIDE")) c->edge_coarse_stride = std::atoi(cs) >= 2 ? std::atoi(cs) : ARTP_COARSE_STRIDE;
+#endif
   }
   fill_robot(c);
   *out = c;
@@ -1957,6 +1959,13 @@ static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double*
   return check_error_flag(c);
 }
 
+int artp_set_edge_passes(artp_ctx* c, int two_pass, int coarse_stride) {
+  if (!c || (coarse_stride != 0 && coarse_stride < 2)) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->edge_two_pass = two_pass != 0;
+  c->edge_coarse_stride = coarse_stride ? coarse_stride : ARTP_COARSE_STRIDE;
+  return ARTP_OK;
+}
 int artp_set_few_edges(artp_ctx* c, int enabled) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -2463,6 +2472,7 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
               }
               packed[((((size_t)kh * ksteps + ks) * s.nt + nt) * 64 + l) * 8 + j] = f32_to_f16_bits(v);
             }
+#ifdef ARTP_VARIANTS
     if (l == 4) {
       // the same layer for conv15_pair32_kernel: [kernel row -1 .. 15][k-step][k-half][channel][k-quad][8], kernel rows
       // -1 and 15 all zero (Conv15P32Cfg); element j of (channel co, quad kq) = W[co][k = 32 ks + 16 sh + 8 kq + j]
@@ -2486,6 +2496,7 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
       HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_convw_p32), p32.size() * 2));
       HIP_TRY(c, hipMemcpy(c->d_convw_p32, p32.data(), p32.size() * 2, hipMemcpyHostToDevice));
     }
+#endif
     w += (size_t)s.cout * s.cin * s.kh * s.kw;
     if (c->d_convw[l]) HIP_TRY(c, hipFree(c->d_convw[l]));
     c->d_convw[l] = nullptr;
@@ -2584,8 +2595,7 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
     fc_mfma_pack(w, &blob);
     if (!c->d_fc_mfma) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_fc_mfma), blob.size()));
     HIP_TRY(c, hipMemcpy(c->d_fc_mfma, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    c->fc_mfma = 1;
-    if (const char* e = std::getenv("ARTP_FC_MFMA")) c->fc_mfma = std::atoi(e) != 0;
+    c->fc_mfma = c->fc_mfma_wanted;   // artp_cost_set_fc_path
   }
   c->have_weights = true;
   // The MFMA form of the MLP depends on a software-managed hazard of the matrix pipe (cost_kernels.h FCM_SHAPE_CHANGE) that
@@ -2598,6 +2608,19 @@ int artp_cost_load_weights(artp_ctx* c, const void* blob, size_t bytes) {
   return ARTP_OK;
 }
 
+int artp_cost_set_fc_path(artp_ctx* c, int mfma) {
+  if (!c) return ARTP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->fc_mfma_wanted = mfma != 0;
+  if (!c->have_weights) return ARTP_OK;       // takes effect at artp_cost_load_weights
+  if (!mfma) {
+    c->fc_mfma = 0;
+    return ARTP_OK;
+  }
+  if (c->fc_mfma) return ARTP_OK;
+  c->fc_mfma = 1;
+  return cost_fc_selfcheck(c);                // back to the matrix cores only through the probe batch
+}
 int artp_cost_fc_path(artp_ctx* c, int* mfma, int* selfcheck, float* max_abs_diff) {
   if (!c) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -2642,11 +2665,17 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     // (B) conv3 -> conv4 -> pool3 -> conv5 with LDS-resident halo tiles -> Bf [h5][w5][48]; (C) the 15 x 15 layer.
     // round 5: (A) on the matrix cores -- inside (B)'s patch phase (conv345_kernel<T, true, true>: no launch, no 24-channel
     // image), or as a launch of its own ($ARTP_CONV12_FUSED=0: conv12_mfma_kernel); the VALU form stays behind $ARTP_CONV12_MFMA=0
-    const char* ecm = std::getenv("ARTP_CONV12_MFMA");   // tuning / tests, read at every update like the switches below
+    fuse12 = true;   // the product: conv1 o conv2 inside conv345's patch phase, XCD-aware tile numbering
+#ifdef ARTP_VARIANTS
+    bool c12m = true, xcd = true;
+    // tuning / tests, read at every update: conv1 o conv2 as a launch of its own ($ARTP_CONV12_FUSED=0: conv12_mfma_kernel),
+    // its VALU form ($ARTP_CONV12_MFMA=0: conv12_pool_kernel), launch-order tile numbering ($ARTP_CNN_XCD=0)
+    const char* ecm = std::getenv("ARTP_CONV12_MFMA");
     const char* ecf = std::getenv("ARTP_CONV12_FUSED");
     const char* ecx = std::getenv("ARTP_CNN_XCD");
-    const bool c12m = ecm ? ecm[0] != '0' : c->conv12_mfma != 0;
-    fuse12 = c12m && (ecf ? ecf[0] != '0' : true) && (ecx ? ecx[0] != '0' : true);
+    if (ecx) xcd = ecx[0] != '0';
+    c12m = ecm ? ecm[0] != '0' : c->conv12_mfma != 0;
+    fuse12 = c12m && (ecf ? ecf[0] != '0' : true) && xcd;
     if (fuse12) {
     } else if (c12m) {
       const unsigned blocks_m = (unsigned)(((wpp + C12M_PX - 1) / C12M_PX) * ((hp + C12M_PY - 1) / C12M_PY));
@@ -2657,6 +2686,7 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
       hipLaunchKernelGGL(conv12_pool_kernel, dim3(blocks_a), dim3(256), 0, st, d_map, H, W,
                          (const float*)c->d_c12, (const float*)(c->d_c12 + 600), A);
     }
+#endif
     // tile edge of (B): one workgroup per CU, and a partly filled last round costs a full round -- rounds x patch
     // area decides (400 x 400: 144 tiles of 16 = one round; 800 x 800: 484 tiles of 18 = two rounds against three of 16)
     auto rounds_cost = [&](int t) {
@@ -2677,18 +2707,26 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     int t_best = 16;
     for (int t : {12, 18})
       if (rounds_cost(t) < rounds_cost(t_best)) t_best = t;
+#ifdef ARTP_VARIANTS
     if (const char* ev = std::getenv("ARTP_C345_T")) t_best = std::atoi(ev);  // tuning
-    const char* evx = std::getenv("ARTP_CNN_XCD");   // tuning: 0 = tiles in launch order (rounds 3-4)
-    const bool xcd = evx ? std::atoi(evx) != 0 : true;
-    const int rcb = fuse12 ? (t_best == 18   ? launch_b(conv345_kernel<18, true, true>, C345Cfg<18>::LDS_BYTES, 18)
-                              : t_best == 12 ? launch_b(conv345_kernel<12, true, true>, C345Cfg<12>::LDS_BYTES, 12)
-                                             : launch_b(conv345_kernel<16, true, true>, C345Cfg<16>::LDS_BYTES, 16))
-                    : xcd ? (t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
-                           : t_best == 12 ? launch_b(conv345_kernel<12>, C345Cfg<12>::LDS_BYTES, 12)
-                                          : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16))
-                        : (t_best == 18   ? launch_b(conv345_kernel<18, false>, C345Cfg<18>::LDS_BYTES, 18)
-                           : t_best == 12 ? launch_b(conv345_kernel<12, false>, C345Cfg<12>::LDS_BYTES, 12)
-                                          : launch_b(conv345_kernel<16, false>, C345Cfg<16>::LDS_BYTES, 16));
+#endif
+    int rcb;
+    if (fuse12)
+      rcb = t_best == 18   ? launch_b(conv345_kernel<18, true, true>, C345Cfg<18>::LDS_BYTES, 18)
+            : t_best == 12 ? launch_b(conv345_kernel<12, true, true>, C345Cfg<12>::LDS_BYTES, 12)
+                           : launch_b(conv345_kernel<16, true, true>, C345Cfg<16>::LDS_BYTES, 16);
+#ifdef ARTP_VARIANTS
+    else
+      rcb = xcd ? (t_best == 18   ? launch_b(conv345_kernel<18>, C345Cfg<18>::LDS_BYTES, 18)
+                   : t_best == 12 ? launch_b(conv345_kernel<12>, C345Cfg<12>::LDS_BYTES, 12)
+                                  : launch_b(conv345_kernel<16>, C345Cfg<16>::LDS_BYTES, 16))
+                : (t_best == 18   ? launch_b(conv345_kernel<18, false>, C345Cfg<18>::LDS_BYTES, 18)
+                   : t_best == 12 ? launch_b(conv345_kernel<12, false>, C345Cfg<12>::LDS_BYTES, 12)
+                                  : launch_b(conv345_kernel<16, false>, C345Cfg<16>::LDS_BYTES, 16));
+#else
+    else
+      return ARTP_ERR_INVALID_ARG;   // not reachable: the product always fuses
+#endif
     if (rcb != ARTP_OK) return rcb;
     HIP_TRY(c, hipGetLastError());
     A = Bf;  // the 15 x 15 layer below reads conv5's output
@@ -2709,6 +2747,28 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
         best = tr;
       }
     }
+#ifndef ARTP_VARIANTS
+    // the product: conv_ksplit_kernel, XCD-aware tile order.  No more 8-row tiles than CUs (C3: 242): one 8-wavefront
+    // workgroup per CU, two wavefronts per SIMD; else 4-wavefront workgroups, two per CU, of the tile height chosen above
+    auto launch = [&](auto kfn, int lds, int tr, int threads = 256) -> int {
+      HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      const unsigned blocks = (unsigned)(((wf + 15) / 16) * ((hf + tr - 1) / tr));
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(threads), lds, st, (const half_t*)A, h5, w5, (const half8*)c->d_convw[4],
+                         (const float*)c->d_convb[4], c->d_feat);
+      return ARTP_OK;
+    };
+    int rcl;
+    const long tiles8 = (long)((wf + 15) / 16) * ((hf + 7) / 8);
+    if (tiles8 <= c->n_cus)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8, 8>::LDS_BYTES, 8, 512);
+    else if (best == 9)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 9>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 9>::LDS_BYTES, 9);
+    else if (best == 10)
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 10>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 10>::LDS_BYTES, 10);
+    else
+      rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8>::LDS_BYTES, 8);
+#else
+    // the variants build: every form that was built and measured, behind its environment switch (read at every update)
     auto launch = [&](auto kfn, int lds, int tr, int threads = 256) -> int {
       if (const char* evp = std::getenv("ARTP_KSPLIT_ONE_PER_CU")) {   // experiment: a workgroup on its own (LDS padded past half a CU's)
         if (evp[0] != '0' && lds < 96 * 1024) lds = 96 * 1024;
@@ -2775,7 +2835,7 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
     // round 6: more tiles than CUs -> the row-pair form on v_mfma_f32_32x32x16_f16, one 4-wavefront workgroup per CU; tile
     // height 6 or 8 by rounds x height (800^2: 63 x 12 = 756 tiles of 6 rows = 2.95 rounds of 256)
     const char* ev32 = std::getenv("ARTP_CONV15_PAIR32");   // A/B against conv_ksplit_kernel (tuning)
-    const bool pair32 = !wide && xcd2 && (ev32 ? std::atoi(ev32) != 0 : c->conv15_pair32 != 0);
+    const bool pair32 = !wide && xcd2 && (ev32 && std::atoi(ev32) != 0);
     if (pair32) {
       auto cost32 = [&](int tr) {
         const long tiles = (long)((wf + 31) / 32) * ((hf + tr - 1) / tr);
@@ -2804,6 +2864,7 @@ static int cost_run_cnn(artp_ctx* c, const float* d_map, int H, int W) {
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 10>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 10>::LDS_BYTES, 10);
     else
       rcl = launch(conv_ksplit_kernel<15, 15, 48, 48, 3, true, 8>, ConvKsplitCfg<15, 15, 48, 48, 3, true, 8>::LDS_BYTES, 8);
+#endif
     if (rcl != ARTP_OK) return rcl;
   }
   HIP_TRY(c, hipGetLastError());

@@ -31,6 +31,17 @@
 #include <tuple>
 #include <vector>
 
+// Tuning / comparison switches of the solve loop ($ARTP_SOLVE_TIMING, $ARTP_LAZY_INFORMED, $ARTP_SOLVE_SEQUENCE, $ARTP_LAZY_ROOT,
+// $ARTP_SOLVE_ASTAR): read in the variants build only (make variants, -DARTP_VARIANTS); the product has no such switches.
+static inline const char* variant_env(const char* name) {
+#ifdef ARTP_VARIANTS
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 namespace artp {
 
 // OMPL CompoundStateSpace::distance for SE3: RealVectorStateSpace L2 + SO3StateSpace::distance (arc length)
@@ -2273,7 +2284,7 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
                        int* n_replans) {
   artp_ctx* c = rm->ctx;
   const size_t ne = rm->eu.size();
-  const bool timing = std::getenv("ARTP_SOLVE_TIMING") != nullptr;
+  const bool timing = variant_env("ARTP_SOLVE_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_csr = now(), t_full = 0, t_check = 0, t_repair = 0, t_pre = 0;
   size_t n_check_calls = 0, n_checked = 0, sub_total = 0, n_pre = 0;
@@ -2291,7 +2302,7 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
   // never pays for the whole tree; the tree is built when the first edge has to go
   bool have_tree = false;
   int replans = 0;
-  const char* env_inf = std::getenv("ARTP_LAZY_INFORMED");
+  const char* env_inf = variant_env("ARTP_LAZY_INFORMED");
   bool informed = env_inf ? std::atoi(env_inf) != 0 : true;
   const double informed_beta[5] = {1.06, 1.25, 1.6, 2.5, INFINITY};
   int informed_round = 0, wrong_side = 0, since_switch = 0, n_switch = 0, pinned_root = -1;
@@ -2308,7 +2319,7 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
       std::fprintf(stderr, "[solve] largest repairs (vertices @ position/path states, ms):");
       for (size_t i = 0; i < ss.size() && i < 12; ++i) std::fprintf(stderr, " %u@%u/%u %.3f", ss[i].n, ss[i].bad, ss[i].np, ss[i].ms);
       std::fprintf(stderr, "; median %u\n", ss[ss.size() / 2].n);
-      if (std::getenv("ARTP_SOLVE_SEQUENCE")) {
+      if (variant_env("ARTP_SOLVE_SEQUENCE")) {
         std::fprintf(stderr, "[solve] sequence (position/states:vertices):");
         for (const SubStat& q : sub_sizes) std::fprintf(stderr, " %u/%u:%u", q.bad, q.np, q.n);
         std::fprintf(stderr, "\n");
@@ -2480,7 +2491,7 @@ int roadmap_solve_tree(artp_roadmap* rm, double* path_se3, size_t cap_states, si
       // the order among equal-cost paths is that of a search from the START (LazyTree::before): with the directional
       // objective, where equal sums are real, the tree stays there
       if (rm->params.objective == 1) pinned_root = 0;
-      const char* env_root = std::getenv("ARTP_LAZY_ROOT");  // tuning aid: 0 / 1 pins the root
+      const char* env_root = variant_env("ARTP_LAZY_ROOT");  // tuning aid (variants build): 0 / 1 pins the root
       if (env_root) pinned_root = std::atoi(env_root) != 0 ? 1 : 0;
       const uint32_t new_root = pinned_root >= 0 ? (uint32_t)pinned_root : (where < 0.5 ? 1u : 0u);  // the far end
       // the distances to the OTHER end (what the informed set of the precheck is made of) on a second host thread while
@@ -2535,7 +2546,7 @@ int artp_roadmap_solve(artp_roadmap* rm, double* path_se3, size_t cap_states, si
   *n_path = 0;
   *cost = INFINITY;
   // roadmaps the host searches: the shortest-path tree with deletion repair and cached motion verdicts
-  if (rm->nv() < ARTP_SSSP_MIN_VERTICES && !std::getenv("ARTP_SOLVE_ASTAR"))
+  if (rm->nv() < ARTP_SSSP_MIN_VERTICES && !variant_env("ARTP_SOLVE_ASTAR"))
     return roadmap_solve_tree(rm, path_se3, cap_states, n_path, cost, n_replans);
   int replans = 0;
   std::vector<uint32_t> path;

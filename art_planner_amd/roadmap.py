@@ -21,7 +21,7 @@ class Roadmap:
         density_map: the PreprocessedMap of the installed map (Context.preprocess_map) -- needed for the in-build
         re-weighting of the sampling distribution (recompute_density_after_n_samples > 0)."""
         self.ctx = ctx
-        self.L = _capi.load()
+        self.L = ctx.L   # the library that made the context
         p = _capi.RoadmapParams()
         self.L.artp_roadmap_params_defaults(C.byref(p))
         p.seed, p.first_index, p.n_milestones, p.k_neighbors = seed, first_index, n_milestones, k_neighbors

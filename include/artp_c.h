@@ -183,6 +183,10 @@ int artp_check_motions(artp_ctx* ctx, const double* s1, const double* s2, size_t
  * verdicts, lastValid pairs and error codes as the batch pipeline (tests/test_gpu_parity.py).  enabled = 0 sends small
  * calls through the batch pipeline like large ones (default 1). */
 int artp_set_few_edges(artp_ctx* ctx, int enabled);
+/* How large batches of artp_check_motions run (first overload): two_pass != 0 (default) = s2 and every coarse_stride-th
+ * interior state of every edge first, the rest only for the edges still alive (an edge is valid iff all its states are, so
+ * the verdicts do not depend on it); two_pass == 0 = one pass over all states.  coarse_stride >= 2, 0 = the default (8). */
+int artp_set_edge_passes(artp_ctx* ctx, int two_pass, int coarse_stride);
 int artp_check_motions_dev(artp_ctx* ctx, const double* s1, const double* s2, size_t n,
                            uint8_t* valid);
 /* ob::MotionValidator::checkMotion(s1, s2, std::pair<State*, double>& lastValid) (pure virtual in OMPL 1.4.2;
@@ -532,6 +536,9 @@ int artp_cost_load_weights(artp_ctx* ctx, const void* blob, size_t bytes);
  * artp_cost_load_weights runs a probe batch through both and falls back to fp32 if they disagree (*selfcheck: 1 agreed,
  * 0 disagreed, -1 not run; *max_abs_diff = the probe's largest difference).  Any pointer may be NULL. */
 int artp_cost_fc_path(artp_ctx* ctx, int* mfma, int* selfcheck, float* max_abs_diff);
+/* mfma == 0: artp_cost_query on the fp32 VALU kernels (comparison / a toolchain whose self-check fails); != 0 (default): the
+ * MFMA form, entered only through the self-check.  Before artp_cost_load_weights it sets what the load will choose. */
+int artp_cost_set_fc_path(artp_ctx* ctx, int mfma);
 /* CostPredictor.updateFeatures (predictor.py:28-36) + CostQuery.setMapParams (cost_query.py:26-35):
  * elev_xy is the server's map array [rows][cols] row-major with index a growing along world x and b
  * along world y (cost_query_server.py:66-74), holes already inpainted; (cx, cy) = map centre. */

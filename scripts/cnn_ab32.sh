@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of the 15 x 15 layer: conv15_pair32_kernel (default above 256 tiles) against conv_ksplit_kernel, + per-kernel trace
+# the switches below are read by the VARIANTS build only (make -C art_planner_amd/csrc variants)
+export ARTP_LIB=${ARTP_LIB:-$GRAFT_REPO_ROOT/art_planner_amd/csrc/libartp_variants.so}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 timeout 600 python -m pytest tests/test_motion_cost.py -m gpu -q -x -p no:cacheprovider -k "c3_c4 or anchor or reference" 2>&1 | tail -5

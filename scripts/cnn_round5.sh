@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-5 GPU visit for the feature extractor: MFMA hazard probe, parity tests, timing of the variants, phase cycles,
 # kernel trace.    gpurun --timeout 900 -- 'bash scripts/cnn_round5.sh <tag>'
+# the switches below are read by the VARIANTS build only (make -C art_planner_amd/csrc variants)
+export ARTP_LIB=${ARTP_LIB:-$GRAFT_REPO_ROOT/art_planner_amd/csrc/libartp_variants.so}
 TAG=${1:-r05a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT

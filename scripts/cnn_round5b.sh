@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-5 evidence for the feature extractor's final form: conv1 o conv2 A/B (fused / own launch / VALU), phase cycles, the 15 x 15
 # launch as a Gantt chart, what the matrix cores sustain, kernel trace, MFMA PMC.   gpurun --timeout 900 -- 'bash scripts/cnn_round5b.sh'
+# the switches below are read by the VARIANTS build only (make -C art_planner_amd/csrc variants)
+export ARTP_LIB=${ARTP_LIB:-$GRAFT_REPO_ROOT/art_planner_amd/csrc/libartp_variants.so}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT

@@ -1,6 +1,8 @@
 #!/bin/bash
 # conv1 o conv2 on the matrix cores vs the VALU form: parity tests, A/B timing, kernel trace.
 #   gpurun --timeout 900 -- 'bash scripts/conv12_ab.sh <tag>'
+# the switches below are read by the VARIANTS build only (make -C art_planner_amd/csrc variants)
+export ARTP_LIB=${ARTP_LIB:-$GRAFT_REPO_ROOT/art_planner_amd/csrc/libartp_variants.so}
 TAG=${1:-r05k}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT

@@ -1,4 +1,4 @@
-"""Tuning aid: the cost query (R9) with the MFMA MLP and with the fp32 VALU kernels ($ARTP_FC_MFMA=0, own process):
+"""Tuning aid: the cost query (R9) with the MFMA MLP and with the fp32 VALU kernels (artp_cost_set_fc_path(ctx, 0) -- $ARTP_FC_MFMA=0 is this script's own switch for it, own process):
 time per batch (HIP events) at 50 000 and 2^20 edges, and the costs themselves for a comparison."""
 import os, sys, subprocess
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from synthetic import raw_map
     dev = torch.device("cuda", 0)
     ctx = Context(0, "yaml"); ctx.use_torch_stream()
+    ctx.cost_set_fc_path(os.environ.get("ARTP_FC_MFMA", "1") != "0")   # the script's own switch -> the setter
     ctx.cost_load_weights(convert_weights.to_blob(convert_weights.random_params(0)))
     g = raw_map(400, 0.04, seed=1234)
     elv = np.ascontiguousarray(g["elevation"][::-1, ::-1]).astype(np.float32)

@@ -39,6 +39,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             o += nn * 48 + nn
         b[-4 * TOTAL:] = w.tobytes()
         ctx = Context(0, "yaml"); ctx.use_torch_stream()
+        ctx.cost_set_fc_path(os.environ.get("ARTP_FC_MFMA", "1") != "0")   # the script's own switch -> the setter
         ctx.cost_load_weights(bytes(b))
         ctx.cost_update_map(elv, g.res, g.len_x, g.len_y)
         res.append(ctx.cost_query(e))

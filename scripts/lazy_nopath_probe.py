@@ -1,6 +1,8 @@
 """Tuning aid: one no-path case of scripts/roadmap_campaign.py (perlin200/77, directional objective, construction 2)
 under the solver's environment switches: which of them changes the number of lazy removals."""
-import os, sys, subprocess
+import os
+# the $ARTP_LAZY_* / $ARTP_SOLVE_ASTAR switches are read by the variants build only: run with
+#   ARTP_LIB=art_planner_amd/csrc/libartp_variants.so python scripts/lazy_nopath_probe.py, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")): sys.path.insert(0, p)

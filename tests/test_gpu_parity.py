@@ -83,31 +83,6 @@ def test_frozen_motion_resolution_keeps_the_first_maps_segment_length(big_map):
 
 
 @pytest.mark.parametrize("name", golden_io.MAPS)
-def test_dense_feet_stream_variant_gives_the_same_labels(name, big_map, monkeypatch):
-    """$ARTP_FEET_DENSE=1 selects feet_stream2_kernel (the corner stage's plane / contact arithmetic on dense lanes: round 5's
-    lane-utilisation experiment, kept although it is no faster): same labels as the real ODE's on the bulk states and as
-    the default kernel's on 2^19 sampler states of the C2 map."""
-    from art_planner_amd.context import Context
-    gm, _, states, _ = golden_io.load_bulk(name)
-    monkeypatch.setenv("ARTP_FEET_DENSE", "1")
-    dense = {r: Context(0, r) for r in ("yaml", "defaults")}
-    monkeypatch.delenv("ARTP_FEET_DENSE")
-    for rname, ctx in dense.items():
-        ctx.upload_map(gm, sampler=False)
-        assert np.array_equal(ctx.validate_states(states[rname]["se3"]), states[rname]["valid"]), f"{name}/{rname}"
-    if name == golden_io.MAPS[0]:
-        ref = _ctx("yaml")
-        ref.upload_map(big_map)
-        se3 = ref.sample_states(42, 0, 1 << 19)
-        want = ref.validate_states(se3)
-        dense["yaml"].upload_map(big_map)
-        assert np.array_equal(dense["yaml"].validate_states(se3), want)
-        ref.close()
-    for ctx in dense.values():
-        ctx.close()
-
-
-@pytest.mark.parametrize("name", golden_io.MAPS)
 def test_bulk_reference_golden(name):
     """SURVEY.md 8c volumes on the GPU box: 20 000 dPoses per (map, box), 20 000 states and 2 000 edges per (map,
     robot) against the real patched ODE's labels (tests/golden/bulk_*.npz; ~320 k box poses, 120 k states, 12 k edges
@@ -937,7 +912,7 @@ def test_map_writes_are_ordered_against_the_other_lanes(big_map):
 def test_check_motion_two_pass_equals_one_pass_and_the_oracle(big_map, monkeypatch):
     """artp_check_motions on batches of >= 4096 edges runs in two passes (s2 + every 8th interior state of every edge, then
     the rest of the edges still alive: kernels.h ARTP_COARSE_STRIDE).  An edge is valid iff all its states are, so the
-    verdicts must equal the single pass's ($ARTP_EDGE_TWO_PASS=0) for every stride -- and the oracle's on a sample --
+    verdicts must equal the single pass's (artp_set_edge_passes(ctx, 0, 0)) for every stride -- and the oracle's on a sample --
     incl. edges of zero length, rotation-only edges and edges ending on invalid states."""
     rob = O.robot("yaml")
     om = O.OracleMap(big_map)
@@ -958,16 +933,15 @@ def test_check_motion_two_pass_equals_one_pass_and_the_oracle(big_map, monkeypat
     b[2::19] = se3[lab == 0][:len(b[2::19])]         # invalid end state
     base.close()
     got = {}
-    for name, env in (("one", {"ARTP_EDGE_TWO_PASS": "0"}), ("two", {}), ("two_s3", {"ARTP_COARSE_STRIDE": "3"}),
-                      ("two_s16", {"ARTP_COARSE_STRIDE": "16"})):
-        for k in ("ARTP_EDGE_TWO_PASS", "ARTP_COARSE_STRIDE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = _ctx("yaml")
-        ctx.upload_map(big_map)
+    ctx = _ctx("yaml")
+    ctx.upload_map(big_map)
+    for name, passes in (("one", (False, 0)), ("two", (True, 0)), ("two_s3", (True, 3)), ("two_s16", (True, 16))):
+        ctx.set_edge_passes(*passes)          # artp_set_edge_passes
         got[name] = ctx.check_motions(a, b)
-        ctx.close()
+    from art_planner_amd._capi import ArtpError
+    with pytest.raises(ArtpError):
+        ctx.set_edge_passes(True, 1)          # a stride of 1 is not a subsample
+    ctx.close()
     assert 0.05 < got["one"].mean() < 0.95
     for name in ("two", "two_s3", "two_s16"):
         assert np.array_equal(got[name], got["one"]), name

@@ -247,51 +247,6 @@ def test_gpu_gather_and_costs_equal_the_reference_cost_query(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [400, 800, 141])
-def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypatch):
-    """Round 5 kept these behind environment switches: conv1 o conv2 as its own launch or fused (ARTP_CONV12_FUSED=0 / 1), its
-    VALU form (ARTP_CONV12_MFMA=0), the 15 x 15 layer as K slice x row half on 18-row tiles (ARTP_KSPLIT_MS=2, 800^2 only), and two things (read at every feature-map update): the persistent strip-walking
-    form of the 15 x 15 layer (conv_kwalk_kernel, ARTP_KWALK=1, three variants and two tile heights: built, measured slower) and
-    the launch-order tile numbering (ARTP_CNN_XCD=0).  Every one of them must produce the default's features: the same
-    products in fp32 accumulators, only the summation order of the K slices differs (one fp16 ulp of the stored feature), and equal
-    the numpy oracle like the default does."""
-    from art_planner_amd.context import Context
-    from synthetic import make_map
-    gm = make_map(n, 0.04, seed=1234 if n == 400 else 77)
-    elv = np.ascontiguousarray(gm["elevation"][::-1, ::-1]).astype(np.float16).astype(np.float32)
-    p = mo.random_params(0)
-    ctx = Context(0, "yaml")
-    ctx.cost_load_weights(convert_weights.to_blob(p))
-    base = _gpu_features(ctx, elv, gm.res)
-    _assert_features_close(base, mo.cnn_features(p, elv), f"default {n}")
-    settings = [{"ARTP_CONV12_FUSED": "0"}, {"ARTP_CONV12_FUSED": "1"}, {"ARTP_CONV12_MFMA": "0"}, {"ARTP_CNN_XCD": "0"}, {"ARTP_KSPLIT_MS": "2"}, {"ARTP_KWALK": "1"}, {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "1"},
-                {"ARTP_KWALK": "1", "ARTP_KWALK_VARIANT": "2"}, {"ARTP_KWALK": "1", "ARTP_KWALK_TR": "8"},
-                {"ARTP_KWALK": "1", "ARTP_KWALK_TR": "10", "ARTP_CNN_XCD": "0"}]
-    for env in settings:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        f = _gpu_features(ctx, elv, gm.res)
-        for k in env:
-            monkeypatch.delenv(k)
-        d = np.abs(f - base)
-        if "ARTP_CONV12_FUSED" in env:
-            # conv1 o conv2 as a launch of its own or inside conv345's patch phase: the same MFMA tiles, the same bits
-            assert np.array_equal(f, base), (env, float(d.max()))
-            continue
-        if "ARTP_CONV12_MFMA" in env:
-            # the VALU form of conv1 o conv2 adds its 25 products in another order: single half-float ulps of the FIRST
-            # activation, carried through four more layers -- held to the oracle like the default, and close to it
-            _assert_features_close(f, mo.cnn_features(p, elv), f"{env} {n}")
-            assert d.max() < 2e-2 and d.mean() < 2e-4, (env, float(d.max()), float(d.mean()))
-            continue
-        # one fp16 unit in the last place of the stored feature at most (another order of the same fp32 partial sums)
-        assert (d <= 1.0e-3 + np.abs(base) * 2.0 ** -9).all() and d.mean() < 1e-4, (env, float(d.max()), float(d.mean()))
-        # (not bit-equal even for the tile order alone: conv_ksplit_kernel rotates the order of its K slices with the
-        # workgroup index, so another workgroup sums a tile's partial products in another order)
-    ctx.close()
-
-
-@pytest.mark.gpu
 def test_gpu_cost_full_map_properties(big_map):
     """C3 size (400x400): feature map 176x176; queries are deterministic, depend only on the start cell
     and the delta pose, and clamp at the feature-map border like the reference."""
@@ -316,14 +271,10 @@ def test_gpu_cost_full_map_properties(big_map):
     co = mo.fc_costs(p, np.transpose(f, (2, 0, 1)), e[:4096], big_map.res, big_map.len_x, big_map.len_y)
     # the MLP runs as MFMA tiles with half-float hi / lo operand pairs (cost_kernels.h fc_cost_mfma_kernel): fp32 accuracy
     assert np.abs(c1[:4096] - co).max() < 5e-5
-    # ... and equals the fp32 VALU kernels (a lane per edge / four lanes per edge; $ARTP_FC_MFMA=0 at weight load)
-    import os
-    os.environ["ARTP_FC_MFMA"] = "0"
-    try:
-        ctx_v = Context(0, "yaml")
-        ctx_v.cost_load_weights(convert_weights.to_blob(p))
-    finally:
-        os.environ.pop("ARTP_FC_MFMA", None)
+    # ... and equals the fp32 VALU kernels (a lane per edge / four lanes per edge; artp_cost_set_fc_path(ctx, 0) before the load)
+    ctx_v = Context(0, "yaml")
+    ctx_v.cost_set_fc_path(False)
+    ctx_v.cost_load_weights(convert_weights.to_blob(p))
     ctx_v.cost_update_map(elv, big_map.res, big_map.len_x, big_map.len_y)
     assert ctx_v.cost_fc_path() == {"mfma": 0, "selfcheck": -1, "max_abs_diff": 0.0}
     c_v = ctx_v.cost_query(e)                               # 50 000 edges <= 2^16: fc_cost_split_kernel, four lanes per edge

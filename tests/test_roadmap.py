@@ -1161,54 +1161,3 @@ def test_path_segments_are_priced_with_max_query_edge_length(planning_setup):
         rm.close()
     # the graph (and the plan found on it) is priced per sub-edge of the 0.5 m chain whatever max_query_edge_length is
     assert costs[0.5][0] == costs[0.25][0] and np.array_equal(costs[0.5][1], costs[0.25][1])
-
-
-@pytest.mark.gpu
-def test_lazy_path_check_breaks_cost_ties_like_the_search_from_scratch():
-    """With the directional objective equal path costs are REAL: a chain of edges priced by their yaw differences costs
-    exactly |yaw_end - yaw_start| / max_ang_vel whichever way it goes, so the lazy path check's removal sequence depends on
-    which of several equally cheap paths the search returns.  The shortest-path tree that replaces the per-round search
-    (DESIGN 4.5) must return the one a search from scratch returns (roadmap.h LazyTree::before): same removed SET and
-    same number of removals as the round-per-search loop (ARTP_SOLVE_ASTAR) and as the oracle's restatement of the
-    reference loop -- on a query WITHOUT a valid path, where the loop runs until start and goal fall apart (hundreds of
-    rounds; the first build of the tree got 273 removals here, the reference order has 275)."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
-    import oracle_py as O
-    import prm_incremental as PI
-    from art_planner_amd.context import Context
-    from art_planner_amd.roadmap import Roadmap
-    from synthetic import make_map
-    gm = make_map(200, 0.04, seed=77)
-    ctx = Context(0, "yaml")
-    ctx.upload_map(gm)
-    se3 = ctx.sample_states(42, 0, 1 << 15)
-    acc = se3[ctx.validate_states(se3) != 0]
-    near = lambda xy: acc[np.argmin(np.hypot(acc[:, 0] - xy[0], acc[:, 1] - xy[1]))]
-    q = 0.3 * gm.len_x
-    s, g = near((gm.pos_x - q, gm.pos_y - q)), near((gm.pos_x + q, gm.pos_y + q))
-    n_ms = min(1200, len(acc))
-    got = {}
-    for tag, env in (("tree", None), ("search per round", "1")):
-        if env is None:
-            os.environ.pop("ARTP_SOLVE_ASTAR", None)
-        else:
-            os.environ["ARTP_SOLVE_ASTAR"] = env
-        try:
-            rm = Roadmap(ctx, s, g, n_milestones=n_ms, seed=42, construction=2, objective=1, max_replans=100000)
-            p, c, removed = rm.solve()
-            ex = rm.export()
-            got[tag] = (p is None, removed, np.asarray(ex["edge_removed"], np.uint8).copy(), ex["edges"].copy())
-            rm.close()
-        finally:
-            os.environ.pop("ARTP_SOLVE_ASTAR", None)
-    assert got["tree"][0] and got["search per round"][0], "this query has no valid path on this map"
-    assert got["tree"][1] == got["search per round"][1] and got["tree"][1] > 100
-    assert np.array_equal(got["tree"][2], got["search per round"][2])
-    om, rob = O.OracleMap(gm), O.robot("yaml")
-    ref = PI.lazy_prm_star_min_update(om, rob, acc, s, g, n_ms, cost_fn=_directional_cost, max_replans=100000)
-    assert ref["path"] is None and ref["lazy_removals"] == got["tree"][1]
-    left = {(int(u), int(v)) for (u, v), r in zip(got["tree"][3], got["tree"][2]) if not r}
-    assert left == set(ref["graph"].edges.keys())
-    ctx.close()
