@@ -64,8 +64,8 @@ struct RcclApi {
   std::string error;
 };
 
-// One binding per process.  Candidates: $ARTP_RCCL_LIB, a copy the process already holds (torch ships its own
-// librccl.so), then the ROCm installation's.
+// One binding per process.  Candidates: $ARTP_RCCL_LIB (if set it is THE choice: a failure to load it is an error), a copy
+// the process already holds (torch ships its own librccl.so), then the ROCm installation's.
 inline RcclApi& rccl_storage() {
   static RcclApi api;
   return api;
@@ -75,11 +75,19 @@ inline RcclApi* rccl_api() {
   static std::once_flag once;
   std::call_once(once, [&api] {
     std::vector<std::string> names;
-    if (const char* e = std::getenv("ARTP_RCCL_LIB")) names.push_back(e);
     void* h = nullptr;
+    static const char kEnv[] = "ARTP_RCCL_LIB";   // (one copy of the name in the binary: the message is built from it)
+    if (const char* e = std::getenv(kEnv)) {   // an explicit choice goes first, also in front of a loaded copy
+      h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+      if (!h) {
+        const char* de = dlerror();
+        api.error = std::string(e) + " (named by the environment variable " + kEnv + "): " + (de ? de : "dlopen failed");
+        return;
+      }
+    }
     for (const char* n : {"librccl.so", "librccl.so.1"}) {
-      h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
       if (h) break;
+      h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     }
     for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) names.push_back(n);
     for (size_t k = 0; !h && k < names.size(); ++k) h = dlopen(names[k].c_str(), RTLD_NOW | RTLD_LOCAL);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -144,6 +145,9 @@ int check_step(artp_group* g, artp_ctx* ref, const std::vector<int>& devices, ui
   return 0;
 }
 
+int exercise_group(artp_group* g, const char* name, const std::vector<int>& devices, const MapData& map, artp_ctx* ref,
+                   std::string* json);
+
 int run_group(const char* name, const std::vector<int>& devices, int transport, const MapData& map, artp_ctx* ref,
               const artp_params& params, std::string* json) {
   artp_group* g = nullptr;
@@ -151,13 +155,21 @@ int run_group(const char* name, const std::vector<int>& devices, int transport, 
   CHECK(rc == 0, "%s: artp_group_create -> %s", name, artp_status_string(rc));
   const int W = artp_group_world_size(g);
   CHECK(W == (int)devices.size() && artp_group_local_count(g) == W, "%s: sizes", name);
-  for (int l = 0; l < W; ++l) {
-    CHECK(artp_group_rank(g, l) == l, "rank numbering");
+  for (int l = 0; l < W; ++l) CHECK(artp_group_rank(g, l) == l, "rank numbering");
+  return exercise_group(g, name, devices, map, ref, json);
+}
+
+// everything a group is asked to do, on a group however it was made: `devices` = the devices of its LOCAL members (all W of
+// a single-process group; one of a one-process-per-GPU rank).  Every process checks ALL W ranks' blocks on its members.
+int exercise_group(artp_group* g, const char* name, const std::vector<int>& devices, const MapData& map, artp_ctx* ref,
+                   std::string* json) {
+  const int W = artp_group_world_size(g), NL = artp_group_local_count(g);
+  CHECK(NL == (int)devices.size(), "%s: local members", name);
+  for (int l = 0; l < NL; ++l)
     CHECK(upload_map(artp_group_ctx(g, l), map) == 0, "%s: map upload on member %d: %s", name, l,
           artp_last_error(artp_group_ctx(g, l)));
-  }
   int seen = 0;
-  rc = artp_group_ranks_seen(g, &seen);
+  int rc = artp_group_ranks_seen(g, &seen);
   CHECK(rc == 0 && seen == W, "%s: ranks seen %d of %d (%s)", name, seen, W, artp_group_last_error(g));
 
   const uint64_t seed = 20260927;
@@ -188,10 +200,13 @@ int run_group(const char* name, const std::vector<int>& devices, int transport, 
 
   // (4) the edge exchange: rank r owns n_r edges, every third (+r) valid
   const size_t ecap = 1500;
-  std::vector<artp_group_edges> per(W);
+  std::vector<artp_group_edges> per(NL);
   std::vector<std::vector<uint32_t>> expect(W);
   std::vector<void*> to_free;
-  for (int l = 0; l < W; ++l) {
+  for (int l = 0; l < W; ++l) {   // l = RANK: every process knows what every rank sends
+    int local = -1;
+    for (int q = 0; q < NL; ++q)
+      if (artp_group_rank(g, q) == l) local = q;
     const size_t n = 1000 + 100 * (size_t)l;
     std::vector<uint8_t> v(n);
     std::vector<uint32_t> ei(n), ej(n);
@@ -211,7 +226,8 @@ int run_group(const char* name, const std::vector<int>& devices, int transport, 
         }
       }
     }
-    (void)hipSetDevice(devices[l]);
+    if (local < 0) continue;   // another process's rank
+    (void)hipSetDevice(devices[local]);
     void *dv, *di, *dj, *dc;
     CHECK(hipMalloc(&dv, n) == hipSuccess && hipMalloc(&di, 4 * n) == hipSuccess && hipMalloc(&dj, 4 * n) == hipSuccess &&
               hipMalloc(&dc, 12 * n) == hipSuccess,
@@ -220,7 +236,7 @@ int run_group(const char* name, const std::vector<int>& devices, int transport, 
     (void)hipMemcpy(di, ei.data(), 4 * n, hipMemcpyHostToDevice);
     (void)hipMemcpy(dj, ej.data(), 4 * n, hipMemcpyHostToDevice);
     (void)hipMemcpy(dc, cost.data(), 12 * n, hipMemcpyHostToDevice);
-    per[l] = {static_cast<uint8_t*>(dv), static_cast<uint32_t*>(di), static_cast<uint32_t*>(dj), static_cast<float*>(dc), n};
+    per[local] = {static_cast<uint8_t*>(dv), static_cast<uint32_t*>(di), static_cast<uint32_t*>(dj), static_cast<float*>(dc), n};
     for (void* p : {dv, di, dj, dc}) to_free.push_back(p);
   }
   for (int round = 0; round < 2; ++round) {  // twice: the second exchange waits for the first on the device
@@ -228,7 +244,7 @@ int run_group(const char* name, const std::vector<int>& devices, int transport, 
     CHECK(rc == 0, "%s: exchange_edges: %s", name, artp_group_last_error(g));
   }
   CHECK(artp_group_synchronize(g, 60000) == 0, "synchronize");
-  for (int l = 0; l < W; ++l) {
+  for (int l = 0; l < NL; ++l) {
     const uint32_t* rec = nullptr;
     const uint64_t* cnt = nullptr;
     CHECK(artp_group_edge_buffers(g, l, &rec, &cnt) == 0, "edge_buffers");
@@ -329,6 +345,46 @@ int main(int argc, char** argv) {
   if (!read_map(argv[1], &map)) return 2;
   artp_params params;
   artp_params_yaml(&params);
+  // One process per rank (torchrun / mpirun style), all on device 0:  test_group <fixture> --rank R W <id-file>
+  // Rank 0 makes the id (artp_group_unique_id) and leaves it in <id-file>; the others wait for the file -- the launcher's
+  // hand-off of the 128 bytes.  With the real RCCL this needs W GPUs; tests/test_host_mirror.py runs it on ONE GPU with
+  // $ARTP_RCCL_LIB = tests/cpp/loopback_rccl.cpp (a test double behind the same ncclAllGather / ncclAllReduce call sites).
+  if (argc >= 6 && std::string(argv[2]) == "--rank") {
+    const int rank = std::atoi(argv[3]), world = std::atoi(argv[4]);
+    const std::string id_file = argv[5];
+    uint8_t id[ARTP_GROUP_ID_BYTES];
+    if (rank == 0) {
+      if (artp_group_unique_id(id) != 0) { std::printf("FAIL: artp_group_unique_id\n"); return 1; }
+      std::ofstream o(id_file + ".tmp", std::ios::binary);
+      o.write(reinterpret_cast<const char*>(id), sizeof(id));
+      o.close();
+      std::rename((id_file + ".tmp").c_str(), id_file.c_str());
+    } else {
+      bool got = false;
+      for (int tries = 0; tries < 3000 && !got; ++tries) {
+        std::ifstream in(id_file, std::ios::binary);
+        got = in && in.read(reinterpret_cast<char*>(id), sizeof(id));
+        if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+      }
+      if (!got) { std::printf("FAIL: rank %d never saw the id file\n", rank); return 1; }
+    }
+    artp_ctx* ref_r = nullptr;
+    if (artp_create(0, &params, &ref_r) != 0 || upload_map(ref_r, map) != 0) return 1;
+    artp_group* g = nullptr;
+    const int rc = artp_group_create_rank(0, rank, world, id, &params, &g);
+    if (rc != 0) { std::printf("FAIL: artp_group_create_rank(rank %d of %d) -> %s\n", rank, world, artp_status_string(rc)); return 1; }
+    if (artp_group_world_size(g) != world || artp_group_local_count(g) != 1 || artp_group_rank(g, 0) != rank) return 1;
+    std::string json_r;
+    const std::string nm = "rank_" + std::to_string(rank) + "_of_" + std::to_string(world) + "_processes_on_device_0";
+    if (exercise_group(g, nm.c_str(), std::vector<int>{0}, map, ref_r, &json_r)) return 1;
+    artp_destroy(ref_r);
+    if (argc > 6) {
+      std::ofstream o(argv[6]);
+      o << json_r << "\n";
+    }
+    std::printf("test_group rank %d of %d ok\n", rank, world);
+    return 0;
+  }
   if (artp_shard_first_index(3, 2, 8, 1000) != (3ull * 8 + 2) * 1000) return 1;
 
   artp_ctx* ref = nullptr;

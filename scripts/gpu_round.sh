@@ -33,6 +33,12 @@ except Exception as e:
     print("bench parse failed", e)
     print(open("$OUT/bench_$TAG.err").read()[-2000:])
 PY
+# the multi-GPU code path with ONE rank (torch.distributed / RCCL world size 1: communicator, bitmap all-gather, re-materialisation and
+# the edge exchange are real, the scaling is not): its contract line goes to profiles/ next to the default run's
+cd $GRAFT_REPO_ROOT
+timeout 600 python bench.py --gpus 1 --force-dist --skip-extras --no-pmc --no-cpu-baseline > $OUT/bench_force_dist_$TAG.json 2> $OUT/bench_force_dist_$TAG.err
+echo "bench --force-dist rc $?"
+tail -1 $OUT/bench_force_dist_$TAG.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('force-dist value', d['value'], 'ms/step', d['ms_per_step'], 'distributed', json.dumps(d.get('distributed'))[:600], 'gather_error', d.get('gather_error'))" || tail -5 $OUT/bench_force_dist_$TAG.err
 mkdir -p $OUT/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
 # --lanes 1: one batch at a time on one stream, the configuration of roofline.kernel_ms (rocprofv3 serialises the

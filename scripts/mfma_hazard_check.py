@@ -17,7 +17,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_KERNELS = ["fc_cost_mfma_kernel", "conv12_mfma_kernel", "conv345_kernel", "conv_ksplit_kernel", "conv_kwalk_kernel"]
+DEFAULT_KERNELS = ["fc_cost_mfma_kernel", "conv345_kernel", "conv_ksplit_kernel"]              # libartp.so
+VARIANT_KERNELS = ["conv12_mfma_kernel", "conv_kwalk_kernel", "conv15_pair32_kernel"]             # + with -DARTP_VARIANTS
 MIN_MIX, MIN_RD, MIN_WR = 5, 7, 4
 WINDOW = 24  # wait states looked at behind an MFMA
 

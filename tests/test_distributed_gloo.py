@@ -158,3 +158,70 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     k = int(ref_ij[7, 1])
     st = smp.sample(rob, 42, k, 1)[0][0]
     assert O.OracleMap(gm).states_valid(rob, st[None])[0] == 1     # an endpoint id is a valid state of the stream
+
+
+def _synthetic_worker(rank, port, world, out_dir):
+    """Capacity agreement, rank offsets and edge-record packing for any world size, on synthetic labels (rank r accepts
+    every (r + 2)-th candidate; its edges connect consecutive accepted candidates, ids above 2^31 included)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    batch = 4096
+    pos = np.arange(rank, batch, rank + 2)                   # accepted in-batch indices of this rank
+    cap = agree_capacity(len(pos), batch, dev, slack=1.0)
+    caps = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(caps, torch.tensor([cap], dtype=torch.int64))
+    assert len({int(c.item()) for c in caps}) == 1            # the SAME capacity on every rank ...
+    assert cap == min(batch, max(len(np.arange(r, batch, r + 2)) for r in range(world)) + 1024)   # ... = the largest count + slack
+    gi = ValidIndexGatherer(world, cap, dev)
+    ge = EdgeResultGatherer(world, cap, dev)
+    gb = ValidBitmapGatherer(world, batch, dev)
+    for step in (0, 5):
+        idx = torch.zeros(cap, dtype=torch.int32)
+        idx[:len(pos)] = torch.from_numpy(pos.astype(np.int32))
+        gi.gather(idx, torch.tensor([len(pos)], dtype=torch.int64))
+        g, ok = gi.global_indices(step, batch)
+        want = np.concatenate([np.arange(r, batch, r + 2) + shard_first_index(step, r, world, batch) for r in range(world)])
+        assert ok and np.array_equal(g.numpy(), want)
+        valid = np.zeros(batch, np.uint8)
+        valid[pos] = 1
+        gb.gather(torch.from_numpy(np.packbits(valid, bitorder="little").view(np.int64).copy()))
+        assert torch.equal(gb.global_indices(step), g)
+        # 20-byte records {u32 i, u32 j, f32 cost[3]} in int32 storage
+        n_e = len(pos) - 1
+        rec = np.zeros((cap, 5), np.int32)
+        rec[:n_e, 0] = pos[:-1].astype(np.uint32).view(np.int32)
+        rec[:n_e, 1] = (pos[1:].astype(np.uint32) | (np.uint32(0x80000000) if rank % 2 else np.uint32(0))).view(np.int32)
+        rec[:n_e, 2:] = (np.arange(3 * n_e, dtype=np.float32).reshape(n_e, 3) + 1000.0 * rank).view(np.int32)
+        ge.gather(torch.from_numpy(rec), torch.tensor([n_e], dtype=torch.int64))
+        ij, cost, ok3 = ge.global_records(step, batch)
+        assert ok3
+        at = 0
+        for r in range(world):
+            p_r = np.arange(r, batch, r + 2)
+            base = shard_first_index(step, r, world, batch)
+            hi = 0x80000000 if r % 2 else 0
+            assert np.array_equal(ij[at:at + len(p_r) - 1, 0].numpy(), p_r[:-1] + base)
+            assert np.array_equal(ij[at:at + len(p_r) - 1, 1].numpy(), (p_r[1:] | hi) + base)      # unsigned 32-bit ids survive
+            assert np.array_equal(cost[at:at + len(p_r) - 1].numpy(),
+                                  np.arange(3 * (len(p_r) - 1), dtype=np.float32).reshape(-1, 3) + 1000.0 * r)
+            at += len(p_r) - 1
+        assert at == len(ij)
+    # a block that does not fit is reported, not truncated silently
+    small = ValidIndexGatherer(world, 8, dev)
+    small.gather(torch.zeros(8, dtype=torch.int32), torch.tensor([9 if rank == world - 1 else 3], dtype=torch.int64))
+    assert small.global_indices(0, batch)[1] is False
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_capacity_agreement_rank_offsets_and_edge_records_for_any_world_size(tmp_path, world):
+    """the exchange's host logic at W = 2, 4, 8 (gloo, CPU): one agreed block capacity, every rank's block
+    at its rank offset with the shard's first index added, unsigned 32-bit ids and bit-cast float costs through the 20-byte
+    records, overflow reported."""
+    mp.spawn(_synthetic_worker, args=(_free_port(), world, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))

@@ -80,6 +80,66 @@ def test_device_group_through_the_c_abi(tmp_path):
     assert "art_planner::DeviceGroup (class): ok" in r.stdout   # the same through host/include/art_planner/device_group.h
 
 
+def _build_loopback_rccl(out_dir):
+    """tests/cpp/loopback_rccl.cpp -> libloopback_rccl.so (g++; a TEST DOUBLE for librccl.so, see its header)."""
+    so = os.path.join(str(out_dir), "libloopback_rccl.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", so,
+                           os.path.join(common.ROOT, "tests", "cpp", "loopback_rccl.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
+    return so
+
+
+def test_loopback_rccl_double_builds_and_exports_what_group_h_binds(tmp_path):
+    import ctypes as C
+    so = _build_loopback_rccl(tmp_path)
+    L = C.CDLL(so)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclCommAbort", "ncclCommGetAsyncError",
+                 "ncclAllGather", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert hasattr(L, name), name     # csrc/group.h ARTP_RCCL_SYM: a missing one disables the binding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_group_one_process_per_rank_on_one_gpu(tmp_path, world):
+    """artp_group_create_rank with W > 1 -- W PROCESSES, the id made by rank 0 and handed to the others
+    through a file, each rank's own communicator, the all-gathers of the bitmap / edge blocks at the rank offsets, steps in
+    flight on the double buffers -- on ONE GPU.  The real RCCL refuses two ranks on a device ("Duplicate GPU detected",
+    scripts/rccl_same_gpu_probe.py), so $ARTP_RCCL_LIB points libartp.so at tests/cpp/loopback_rccl.cpp, a test double
+    behind the same ncclAllGather / ncclAllReduce call sites (staging buffers shared by hipIpcMemHandle).  Every process
+    compares ALL W ranks' blocks with what a plain context computes for those shards (test_group.cpp exercise_group).
+    What this does NOT execute: ncclCommInitRank of the real library across devices."""
+    _build()
+    so = _build_loopback_rccl(tmp_path)
+    import oracle_py as O
+    from synthetic import make_map
+    gm = make_map(160, 0.04, seed=7)
+    rob = O.robot("yaml")
+    fin = gm["elevation"][np.isfinite(gm["elevation"])]
+    zb = (float(fin.min()) - rob.reach_z / 2, float(fin.max()) + rob.reach_z / 2)
+    path = tmp_path / "map.bin"
+    with open(path, "wb") as f:
+        _write_map_part(f, gm, zb)
+    env = dict(os.environ, ARTP_RCCL_LIB=so, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    id_file = str(tmp_path / f"id_{world}.bin")
+    procs = [subprocess.Popen([BIN_GROUP, str(path), "--rank", str(r), str(world), id_file, str(tmp_path / f"rank{r}.json")],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        print(o)
+        assert p.returncode == 0 and f"test_group rank {r} of {world} ok" in o, o
+    out_dir = os.path.join(common.ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"group_ranks_{world}.json"), "w") as f:
+        f.write("[" + ", ".join(open(tmp_path / f"rank{r}.json").read().strip() for r in range(world)) + "]\n")
+
+
 def test_real_library_branches_compile():
     """The preprocessor branches INTEGRATION.md tells a maintainer to build -- ARTP_HAVE_OMPL (`#include
     <ompl/base/...>`) and ARTP_HAVE_EIGEN (`EdgeMatrix` = the Eigen row-major matrix) -- through a compiler:

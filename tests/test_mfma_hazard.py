@@ -74,9 +74,10 @@ def test_mfma_kernels_keep_the_measured_distances(tmp_path):
     asm = H.compile_asm(str(tmp_path / "artp.s"))
     res = H.check_file(asm, H.DEFAULT_KERNELS)
     names = " ".join(n for n, _, _ in res)
-    for k in ("fc_cost_mfma_kernel", "conv345_kernel", "conv_ksplit_kernel", "conv_kwalk_kernel"):
+    for k in H.DEFAULT_KERNELS:
         assert k in names, f"{k} not found in the assembly"
-    assert sum(r["mfma"] for _, r, _ in res) > 3000
+    assert not any(k in open(asm).read() for k in H.VARIANT_KERNELS)   # the lost forms are not in the product
+    assert sum(r["mfma"] for _, r, _ in res) > 2000
     bad = [(n, v) for n, _, viol in res for v in viol]
     assert not bad, bad
     # the cost-query MLP is the one kernel that mixes shapes: it must show the guarded distance
@@ -84,6 +85,21 @@ def test_mfma_kernels_keep_the_measured_distances(tmp_path):
     assert fc and all(r["shapes"] == {"16x16x16", "16x16x32"} and r["mix"] is not None and r["mix"] >= H.MIN_MIX for r in fc)
     # the convolutions use one shape only
     assert all(r["shapes"] == {"16x16x32"} and r["mix"] is None for n, r, _ in res if "conv" in n)
+
+
+@needs_hipcc
+def test_variant_mfma_kernels_keep_the_measured_distances(tmp_path):
+    """The same for the variants build (-DARTP_VARIANTS: conv1 o conv2 as its own launch, the persistent 15 x 15 kernel, the
+    15 x 15 layer on v_mfma_f32_32x32x16_f16): one shape per kernel, no violation."""
+    asm = H.compile_asm(str(tmp_path / "artp_variants.s"), defs=("-DARTP_VARIANTS",))
+    res = H.check_file(asm, H.VARIANT_KERNELS)
+    names = " ".join(n for n, _, _ in res)
+    for k in H.VARIANT_KERNELS:
+        assert k in names, f"{k} not found in the assembly"
+    bad = [(n, v) for n, _, viol in res for v in viol]
+    assert not bad, bad
+    for n, r, _ in res:
+        assert r["mix"] is None and r["shapes"] == ({"32x32x16"} if "conv15_pair32" in n else {"16x16x32"}), (n, r["shapes"])
 
 
 @pytest.mark.gpu
