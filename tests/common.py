@@ -117,3 +117,31 @@ def slab_slit_map(n=120, res=0.05) -> GridMap:
     gm.add("elevation_masked", hm)
     gm.add("elevation_nan", hn)
     return gm
+
+
+def oracle_states_valid_threaded(gm, rob, se3, n_threads=None):
+    """The CPU oracle's labels of a LARGE state list: one private checker per thread (the C calls release the GIL), static
+    partition -- the full 2^20-state batches of the GPU suite take a second or two on the GPU box's host cores instead of
+    20 s on one (the driver's suite checks every label of its full-size batches, not a sample)."""
+    import threading
+    import oracle_py as O
+    se3 = np.ascontiguousarray(se3, np.float64).reshape(-1, 7)
+    if n_threads is None:
+        try:
+            n_threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            n_threads = 4
+    out = np.empty(len(se3), np.uint8)
+    chunks = np.array_split(np.arange(len(se3)), n_threads)
+    maps = [O.OracleMap(gm) for _ in range(n_threads)]
+
+    def work(k):
+        if len(chunks[k]):
+            out[chunks[k]] = maps[k].states_valid(rob, se3[chunks[k]])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out
