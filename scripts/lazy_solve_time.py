@@ -37,7 +37,9 @@ if __name__ == "__main__":
         print("RESULT " + json.dumps(run()))
         sys.exit(0)
     new = run()
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ARTP_SOLVE_ASTAR="1", ARTP_LIB=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "art_planner_amd", "csrc", "libartp_variants.so"))  # read by the variants build only,
+    # $ARTP_SOLVE_ASTAR is read by the variants build only
+    vlib = os.path.join(ROOT, "art_planner_amd", "csrc", "libartp_variants.so")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ARTP_SOLVE_ASTAR="1", ARTP_LIB=vlib),
                        capture_output=True, text=True)
     old = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     for k in new:

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-6 evidence that is not part of gpu_round.sh: the latency form of checkMotion (per-call times, kernel durations, the
+# phase timestamps of one workgroup), the feature extractor's per-kernel trace, the LazyPRM* solve breakdown.
+#   gpurun --timeout 1200 -- 'bash scripts/r06_extras.sh'
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r06_extras
+mkdir -p $OUT
+{
+  echo "== per-call latency of the host-buffer edge API (scripts/edge_latency.py: C2 map, YAML robot, edges between accepted states < 2 m apart)"
+  python scripts/edge_latency.py 2>/dev/null
+  echo
+  echo "== kernel durations of check_motions_few_kernel by call size (rocprofv3 --kernel-trace, scripts/prof_few.sh)"
+  bash scripts/prof_few.sh 2>/dev/null | grep "n= "
+  echo
+  echo "== phase timestamps of ONE workgroup (edge 0, chunk 1), timing build (scripts/few_trace.py; us)"
+  make -s -C art_planner_amd/csrc timing > /dev/null 2>&1
+  ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/few_trace.py 2>/dev/null | grep -A1 "^edge [0-5] " | grep -v "^--"
+} > $OUT/few_edges.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/cnn/trace -o trace -- python $GRAFT_REPO_ROOT/scripts/cnn_bench.py 50 > $OUT/cnn_bench.log 2>&1
+{
+  echo "== feature extractor, kernels only (scripts/cnn_bench.py 50, HIP events)"; grep "^map" $OUT/cnn_bench.log
+  echo "== per kernel (rocprofv3 --kernel-trace --stats of the same command)"
+  python $GRAFT_REPO_ROOT/scripts/prof_summary.py $OUT/cnn 2>&1 | grep -E "^==|^kernel|conv"
+} > $OUT/cnn_kernel_trace.txt 2>&1
+rm -rf $OUT/cnn
+cd $GRAFT_REPO_ROOT
+ARTP_SOLVE_TIMING=1 ARTP_LIB=art_planner_amd/csrc/libartp_variants.so python scripts/lazy_timing.py > $OUT/lazy_solve_breakdown.txt 2>&1
+tail -4 $OUT/few_edges.txt; cat $OUT/cnn_kernel_trace.txt | head -12; tail -3 $OUT/lazy_solve_breakdown.txt | cut -c1-300
