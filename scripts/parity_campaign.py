@@ -61,7 +61,20 @@ def edge_campaign(ctx, gm, rob, se3, labels):
     ok, t, st, ok0, oki, ni = (np.concatenate([p_[k] for p_ in parts]) for k in range(6))
     bad = int((g_ok != ok0).sum()) + int((g_ok2 != ok).sum()) + int((g_t != t).sum()) + int((g_oki != oki).sum()) + \
         int((g_ni != ni).sum()) + int((np.abs(g_st - st).max(axis=1) > 1e-12).sum())
-    return bad, float(ok0.mean()), float(oki.mean())
+    # the latency form (<= 64 edges per host call: check_motions_few_kernel) on a slice of the same edges, chunks of 1 .. 64:
+    # the same verdicts, lastValid pairs (states bit-equal to the batch pipeline's) and interpolation counts
+    mf = min(m, 2048)
+    i, k, bad_few = 0, 1, 0
+    while i < mf:
+        j = min(i + k, mf)
+        f_ok = ctx.check_motions(a[i:j], b[i:j])
+        f_ok2, f_t, f_st = ctx.check_motions_last_valid(a[i:j], b[i:j])
+        f_oki, f_ni = ctx.check_edges_interp(a[i:j], b[i:j])
+        bad_few += int((f_ok != ok0[i:j]).sum()) + int((f_ok2 != ok[i:j]).sum()) + int((f_t != t[i:j]).sum()) + \
+            int((f_oki != oki[i:j]).sum()) + int((f_ni != ni[i:j]).sum()) + int((f_st != g_st[i:j]).any(axis=1).sum())
+        i, k = j, k % 64 + 1
+    _EDGE_JOB["bad_few"] = (bad_few, mf)
+    return bad + bad_few, float(ok0.mean()), float(oki.mean())
 
 base = make_map(240, 0.04, seed=31)
 
@@ -128,14 +141,16 @@ for mapname, robot in cases:
     if n_edges:
         bad_e, vf, vi = edge_campaign(ctx, gm, rob, se3, vo)
         bad_total += bad_e
+        bf, mf = _EDGE_JOB.get("bad_few", (0, 0))
         edge_txt = (f" | {n_edges} edges x (checkMotion, lastValid pair, 0.5 m rule + n_interp): mismatches={bad_e} "
-                    f"(valid {vf:.3f} / {vi:.3f})")
+                    f"(valid {vf:.3f} / {vi:.3f}); of which the latency form on {mf} of them in calls of 1..64 edges: {bf}")
     lines.append(f"{mapname:9s} {robot:8s} states={n} valid={vg.mean():.3f} mismatches={bad} latency-path mismatches={bad_few}/4096 "
                  f"counters={ctx.pipeline_counters()}{edge_txt} ({time.time() - t0:.1f}s)")
     print(lines[-1], flush=True)
     ctx.close()
 lines.append(f"TOTAL MISMATCHES {bad_total} over {n * len(cases)} states (batch pipeline) + {4096 * len(cases)} (latency path)" +
-             (f" + {n_edges * len(cases)} edges through each of the three edge entry points" if n_edges else ""))
+             (f" + {n_edges * len(cases)} edges through each of the three edge entry points (+ {min(n_edges, 2048) * len(cases)} "
+              "of them again through the one-launch latency form)" if n_edges else ""))
 print(lines[-1])
 out = os.path.join(ROOT, "gpurun_out", "parity_campaign.txt")
 os.makedirs(os.path.dirname(out), exist_ok=True)
