@@ -16,7 +16,7 @@ SYMBOLS = [
     "artp_device_arch", "artp_create", "artp_destroy", "artp_set_stream", "artp_use_own_stream",
     "artp_synchronize", "artp_set_lane", "artp_get_lane", "artp_map_version",
     "artp_upload_layer", "artp_update_layer_rect", "artp_update_layer_rects", "artp_check_boxes", "artp_check_boxes_dev",
-    "artp_validate_states", "artp_validate_states_dev", "artp_upload_sampler_layers",
+    "artp_validate_states", "artp_validate_states_dev", "artp_set_persistent_latency", "artp_persistent_latency_stats", "artp_upload_sampler_layers",
     "artp_sample_states", "artp_sample_states_dev", "artp_sample_and_validate_dev",
     "artp_sample_and_validate", "artp_check_motions_last_valid", "artp_check_motions_last_valid_dev",
     "artp_set_z_bounds", "artp_set_few_edges", "artp_set_edge_passes", "artp_cost_set_fc_path", "artp_check_motions", "artp_check_motions_dev", "artp_check_edges_interp",
@@ -156,6 +156,8 @@ def _load_path(LIB_PATH):
     L.artp_map_version.restype = C.c_uint64
     L.artp_set_z_bounds.argtypes = [vp, dbl, dbl]
     L.artp_set_few_edges.argtypes = [vp, i32]
+    L.artp_set_persistent_latency.argtypes = [vp, i32]
+    L.artp_persistent_latency_stats.argtypes = [vp, C.POINTER(u64 * 2)]
     L.artp_set_edge_passes.argtypes = [vp, i32, i32]
     L.artp_cost_set_fc_path.argtypes = [vp, i32]
     for name in ("artp_check_motions_last_valid", "artp_check_motions_last_valid_dev"):

@@ -132,6 +132,15 @@ class Context:
                   "artp_sample_states")
         return out
 
+    def set_persistent_latency(self, enabled=True):
+        """<= 16 states per host call through ONE resident workgroup polling a mailbox (no launch per call); off by default."""
+        self._chk(self.L.artp_set_persistent_latency(self.h, 1 if enabled else 0), "artp_set_persistent_latency")
+
+    def persistent_latency_stats(self):
+        out = (C.c_uint64 * 2)()
+        self._chk(self.L.artp_persistent_latency_stats(self.h, C.byref(out)), "artp_persistent_latency_stats")
+        return {"launches": int(out[0]), "requests": int(out[1])}
+
     def set_few_edges(self, enabled=True):
         """<= 64 edges per host call: the one-launch latency kernel (default) or the batch pipeline (enabled=False)."""
         self._chk(self.L.artp_set_few_edges(self.h, 1 if enabled else 0), "artp_set_few_edges")

@@ -412,6 +412,125 @@ validate_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const doub
   }
 }
 
+// ---- persistent latency service for isValid (round 6; opt-in: artp_set_persistent_latency) -------------------------------
+// validate_few_kernel costs ~8 us of kernel and ~8 us of launch + completion per call.  The service removes the launch: ONE
+// resident workgroup (five wavefronts = the five boxes of a state) polls a mailbox in mapped host memory; the host writes the
+// states and bumps req_seq, the workgroup validates them (few_box_ok: the very function of the launch-per-call path) and
+// answers with the labels and resp_seq.  It never outlives its usefulness: it leaves when told to (quit), after
+// ARTP_SVC_IDLE_TICKS (200 us) without a request, or after ARTP_SVC_LIFE_TICKS (2 s) whatever happens (s_memrealtime ticks of 10 ns) --
+// a host that died or a protocol bug costs a bounded wait, never a hung GPU.  The host restarts it on demand and ALWAYS
+// after a map write (the field arguments are captured at launch; artp_map_version).
+struct SvcMailbox {   // mapped (coherent) host memory
+  // request: ONE 64-byte line the workgroup polls with one 16-lane load -- the host writes the state first and the sequence
+  // number last (x86 stores become visible in order), the device reads the line again once it has seen the new number
+  volatile uint32_t req_seq;
+  volatile uint32_t n_quit;        // bits 0-7 number of states (1 or 2), bit 8 = leave
+  double state0[7];
+  double state1[7];                // second state of a two-state call: read AFTER the new sequence number was seen
+  uint32_t pad0[34];               // the response starts on its own 128-byte line (offset 256)
+  // response: ONE 32-bit word {sequence number's low 24 bits << 8 | labels} (label of state i in bits 2i (valid) and 2i + 1
+  // (LDS scratch overflow)): a single dword store certainly arrives in one piece, number and labels together
+  volatile uint32_t resp;
+  uint32_t pad_resp;
+  volatile uint32_t running;       // 1 while the kernel is resident
+  volatile uint32_t served;        // requests answered by this incarnation
+  uint32_t pad1[28];
+};
+static_assert(sizeof(SvcMailbox) == 384, "request line, second state, response line");
+// 200 us without a request: a burst of isValid() calls from a host loop arrives every 10-20 us; once it ends the workgroup
+// is gone before anything else can trip over it (hipFree / hipDeviceSynchronize wait for EVERY stream of the device: a
+// resident kernel would stall them for as long as it stays)
+#define ARTP_SVC_IDLE_TICKS 20000ull
+#define ARTP_SVC_LIFE_TICKS 200000000ull   // 2 s in all
+__global__ void __launch_bounds__(320)
+validate_service_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, SvcMailbox* mb, uint32_t last_seq,
+                        ScratchCaps caps_torso, ScratchCaps caps_foot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int box_ok[5];
+  __shared__ uint32_t s_line[16 + 14];   // the request line, then the second state
+  __shared__ uint32_t s_exit;
+  const int lane = threadIdx.x & 63;
+  const int k = threadIdx.x >> 6;
+  WaveScratch s;
+  if (k == 0) {
+    s = carve_scratch(smem, 0, caps_torso);
+  } else {
+    s = carve_scratch(smem + scratch_bytes_per_wave(caps_torso), k - 1, caps_foot);
+  }
+  const unsigned long long t_start = wall_clock64();
+  unsigned long long t_idle = t_start;
+  uint32_t served = 0;
+  const volatile uint32_t* line = reinterpret_cast<const volatile uint32_t*>(mb);
+  for (;;) {
+    if (k == 0) {   // wavefront 0 polls: lanes 0..15 fetch the request line, one PCIe read per poll
+      uint32_t leave = 0, w = 0, seq;
+      for (;;) {
+        if (lane < 16) w = line[lane];
+        seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (seq != last_seq) break;
+        const uint32_t nq = (uint32_t)__builtin_amdgcn_readlane((int)w, 1);
+        const unsigned long long now = wall_clock64();   // s_memrealtime: a scalar, the same for every lane
+        if ((nq & 0x100u) || now - t_idle > ARTP_SVC_IDLE_TICKS || now - t_start > ARTP_SVC_LIFE_TICKS) {
+          leave = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      // The poll's 64 bytes may reach the host as more than one read (32-byte sectors), so the sector with the sequence number
+      // could be newer than the one with the state's tail: fetch the line ONCE MORE now that the number is known to be there
+      // (the host wrote the state before it).  A precaution worth one PCIe round trip, not a measured failure.
+      if (!leave && lane < 16) w = line[lane];
+      if (lane < 16) s_line[lane] = w;
+      if (!leave && ((uint32_t)__builtin_amdgcn_readlane((int)w, 1) & 0xffu) > 1u && lane < 14)
+        s_line[16 + lane] = reinterpret_cast<const volatile uint32_t*>(mb->state1)[lane];   // after the sequence number
+      if (lane == 0) s_exit = leave;
+    }
+    __syncthreads();
+    if (s_exit) {
+      if (threadIdx.x == 0) {
+        mb->running = 0u;
+        __threadfence_system();
+      }
+      return;
+    }
+    const uint32_t seq = s_line[0];
+    uint32_t n = s_line[1] & 0xffu;
+    n = n < 1u ? 1u : (n > 2u ? 2u : n);
+    uint32_t bits = 0;   // (meaningful in thread 0)
+    for (uint32_t i = 0; i < n; ++i) {
+      double st[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const uint32_t lo = s_line[(i ? 16 : 2) + 2 * j], hi = s_line[(i ? 16 : 2) + 2 * j + 1];
+        st[j] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      }
+      const int ok = few_box_ok(fb, ff, g, rb, st, k, s, lane);
+      wave_lds_sync();
+      if (lane == 0) box_ok[k] = ok;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        bool err = false, v = true;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          err = err || box_ok[q] < 0;
+          v = v && box_ok[q] > 0;
+        }
+        bits |= ((v && !err ? 1u : 0u) | (err ? 2u : 0u)) << (2 * i);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      mb->resp = (seq << 8) | bits;   // ONE dword: number and labels arrive together
+      __threadfence_system();
+      ++served;
+      mb->served = served;
+    }
+    last_seq = seq;               // every thread: the pollers are ALL lanes of wavefront 0, and the loop's exit conditions must be
+    t_idle = wall_clock64();      // wave-uniform (a lane with a stale idle clock left the poll loop alone, with the PREVIOUS request's words)
+    __syncthreads();
+  }
+}
+
 // ---- R6 ------------------------------------------------------------------------------------------
 // Counter-based uniform01 (replaces ompl::RNG::uniform01): splitmix64 finaliser over
 // (seed, index, k) -- integer-exact, identical on host and device.

@@ -118,6 +118,26 @@ int main(int argc, char** argv) {
     bad += checker.isValid(&st) != (expected[i] != 0);
   }
   const double us_single = (now_us() - t0) / n_single;
+  // the same through the persistent latency service (artp_set_persistent_latency: one resident workgroup polling a mailbox
+  // in mapped host memory, no launch per call) -- same labels
+  double us_single_svc = 0;
+  {
+    bad += artp_set_persistent_latency(gpu->get(), 1) != ARTP_OK;
+    for (int i = 0; i < 50; ++i) {   // starts the service
+      toState(&se3[7 * i], &st);
+      bad += checker.isValid(&st) != (expected[i] != 0);
+    }
+    t0 = now_us();
+    for (int i = 0; i < n_single; ++i) {
+      toState(&se3[7 * i], &st);
+      bad += checker.isValid(&st) != (expected[i] != 0);
+    }
+    us_single_svc = (now_us() - t0) / n_single;
+    uint64_t svc_stats[2] = {0, 0};
+    bad += artp_persistent_latency_stats(gpu->get(), svc_stats) != ARTP_OK;
+    bad += (svc_stats[1] < (uint64_t)n_single || svc_stats[0] < 1) ? 1 : 0;
+    bad += artp_set_persistent_latency(gpu->get(), 0) != ARTP_OK;
+  }
   // a checker without a map must answer false, not throw (ob::StateValidityChecker::isValid never throws)
   {
     auto gpu2 = std::make_shared<GpuContext>(params, 0);
@@ -334,6 +354,8 @@ int main(int argc, char** argv) {
     }
     bad += (threw || prm.numVertices() != 302) ? 1 : 0;
   }
+  std::printf("isValid on an arbitrary state: %.1f us per call (one launch), %.1f us through the persistent service\n", us_single,
+              us_single_svc);
   std::printf("checkMotion per call: 1 edge %.1f us (lastValid overload %.1f us), 32-edge path %.1f us; through the batch "
               "pipeline: %.1f us / %.1f us\n", us_cm1, us_cm1_last, us_cm32, us_cm1_batch, us_cm32_batch);
   std::printf("host mirror: %d states batch + %d single (%.1f us per isValid on arbitrary states), %d motions (%d lastValid "
@@ -342,7 +364,8 @@ int main(int argc, char** argv) {
               n, n_single, us_single, m, bad_last, attempts, accepted, us_loop, stale_flips, bad);
   if (argc > 2) {
     std::ofstream o(argv[2]);
-    o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"check_motion_1_edge_us\": " << us_cm1
+    o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"isvalid_arbitrary_state_us_persistent_service\": " << us_single_svc
+      << ", \"check_motion_1_edge_us\": " << us_cm1
       << ", \"check_motion_last_valid_1_edge_us\": " << us_cm1_last << ", \"check_motions_32_edge_path_us\": " << us_cm32
       << ", \"check_motion_1_edge_us_batch_pipeline\": " << us_cm1_batch
       << ", \"check_motions_32_edge_path_us_batch_pipeline\": " << us_cm32_batch

@@ -135,6 +135,16 @@ int artp_check_boxes_dev(artp_ctx* ctx, int slot, const float box_lengths[3], co
 /* Up to 16 states without `detail` take the latency path: one launch, one workgroup per state with the five
  * boxes side by side, states / labels through mapped pinned host memory (no copies). */
 int artp_validate_states(artp_ctx* ctx, const double* se3, size_t n, uint8_t* valid, int8_t* detail);
+/* Persistent latency service for the per-state isValid() of the host mirror (validity_checker.cpp:39-45: one OMPL call =
+ * one state).  enabled != 0: artp_validate_states calls with one or two states and no `detail` are answered by ONE RESIDENT
+ * workgroup that polls a mailbox in mapped host memory -- no kernel launch per call.  The workgroup is started on demand on a
+ * stream of its own, restarted after every map write (artp_map_version) and leaves by itself after 200 us without a
+ * request (2 s at most in all): it cannot outlive a host that stopped calling, and a burst's end frees the device before
+ * a hipFree / hipDeviceSynchronize (which wait for every stream) can trip over it.  Same labels as the launch-per-call path
+ * (the same device function).  Off by default: it holds five wavefronts and ~63 KB of LDS of one CU while resident.
+ * artp_persistent_latency_stats: out[0] = launches of the service so far, out[1] = requests it answered. */
+int artp_set_persistent_latency(artp_ctx* ctx, int enabled);
+int artp_persistent_latency_stats(artp_ctx* ctx, uint64_t out[2]);
 int artp_validate_states_dev(artp_ctx* ctx, const double* se3, size_t n, uint8_t* valid,
                              int8_t* detail);
 

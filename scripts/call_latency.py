@@ -11,3 +11,10 @@ for n in (1, 64, 128, 129, 1024):
     t0 = time.perf_counter()
     for _ in range(200): ctx.validate_states(se3[:n])
     print(n, "states:", (time.perf_counter() - t0) / 200 * 1e6, "us per call")
+ctx.set_persistent_latency(True)
+for n in (1, 4, 16):
+    ctx.validate_states(se3[:n])
+    t0 = time.perf_counter()
+    for r in range(2000): ctx.validate_states(se3[r:r + n])
+    print(n, "states through the persistent service:", (time.perf_counter() - t0) / 2000 * 1e6, "us per call", ctx.persistent_latency_stats())
+ctx.set_persistent_latency(False)

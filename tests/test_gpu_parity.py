@@ -568,6 +568,57 @@ def test_latency_path_few_states_golden(name, rname):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", golden_io.MAPS)
+def test_persistent_latency_service_golden(name):
+    """artp_set_persistent_latency: one or two states per host call answered by ONE RESIDENT workgroup polling a mailbox in mapped
+    host memory (validate_service_kernel) -- the golden states' real-ODE labels in chunks of 1..16; the service is restarted
+    by a map write (and the labels follow the NEW map), leaves by itself when the calls stop, and is started again on demand."""
+    import time
+    gm, _ = golden_io.load_boxes(name)
+    for rname in ("yaml", "defaults"):
+        s = golden_io.load_states(name)[rname]
+        se3, ref = s["se3"][:1000], s["valid"][:1000]
+        ctx = _ctx(rname)
+        ctx.upload_map(gm, sampler=False)
+        ctx.set_persistent_latency(True)
+        got = np.empty(len(se3), np.uint8)
+        i, k = 0, 1
+        while i < len(se3):
+            got[i:i + k] = ctx.validate_states(se3[i:i + k])   # calls of 1 and 2 states: the service; 3..16: one launch
+            i += k
+            k = k % 16 + 1
+        assert np.array_equal(got, ref), f"{name}/{rname}: {int((got != ref).sum())} label mismatches through the service"
+        st = ctx.persistent_latency_stats()
+        assert st["requests"] >= 2 * (1000 // 136) and 1 <= st["launches"] <= st["requests"]
+        # a map write in between: the service restarts and answers for the NEW map (the body layer raised by 0.25 m: the
+        # oracle on that map says which of the formerly valid states still are)
+        import copy
+        acc = se3[ref != 0][:16]
+        if len(acc):
+            gm_new = copy.copy(gm)
+            gm_new.layers = dict(gm.layers)
+            gm_new.layers["elevation"] = np.asfortranarray(gm["elevation"] + np.float32(0.25))
+            want = O.OracleMap(gm_new).states_valid(O.robot(rname), acc)
+            ctx.upload_layer(0, gm_new["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+            before = ctx.persistent_latency_stats()["launches"]
+            got_new = np.concatenate([ctx.validate_states(acc[i:i + 1]) for i in range(len(acc))])
+            assert np.array_equal(got_new, want)
+            assert ctx.persistent_latency_stats()["launches"] == before + 1
+            ctx.upload_layer(0, gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+            assert np.concatenate([ctx.validate_states(acc[i:i + 1]) for i in range(len(acc))]).all()
+        # idle: the workgroup leaves by itself (200 us), the next call starts it again
+        time.sleep(0.05)
+        before = ctx.persistent_latency_stats()["launches"]
+        assert np.array_equal(ctx.validate_states(se3[:2]), ref[:2])
+        assert ctx.persistent_latency_stats()["launches"] == before + 1
+        # larger batches and the detail form are not the service's: unchanged paths, same labels
+        assert np.array_equal(ctx.validate_states(se3[:300]), ref[:300])
+        ctx.set_persistent_latency(False)
+        n_req = ctx.persistent_latency_stats()["requests"]
+        assert np.array_equal(ctx.validate_states(se3[:1]), ref[:1]) and ctx.persistent_latency_stats()["requests"] == n_req
+        ctx.close()
+
+
 def test_latency_path_without_polling(big_map, monkeypatch):
     """ARTP_NO_POLL=1: the same labels through hipStreamSynchronize instead of the mapped-memory poll."""
     monkeypatch.setenv("ARTP_NO_POLL", "1")

@@ -259,6 +259,7 @@ def test_host_mirror_matches_oracle_through_the_ompl_shaped_interfaces(tmp_path)
     om.check_motions(rob, s1, s2)
     t["cpu_oracle_check_motion_us_per_edge"] = (time.perf_counter() - t0) / m * 1e6
     json.dump(t, open(lat, "w"))
+    assert t["isvalid_arbitrary_state_us_persistent_service"] < t["isvalid_arbitrary_state_us"], t   # no launch per call
     assert t["check_motion_1_edge_us"] < 40.0, t
     assert t["check_motion_1_edge_us"] < t["check_motion_1_edge_us_batch_pipeline"], t
 
