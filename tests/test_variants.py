@@ -23,9 +23,8 @@ from test_roadmap import _directional_cost  # noqa: E402
 
 def _vctx(kind):
     from art_planner_amd.context import Context
-    if not os.path.exists(_capi.VARIANTS_LIB_PATH):
-        import subprocess
-        subprocess.check_call(["make", "-s", "-C", os.path.dirname(_capi.VARIANTS_LIB_PATH), "variants"])
+    import subprocess   # always through make: a no-op when libartp_variants.so is current, a rebuild when a source changed
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(_capi.VARIANTS_LIB_PATH), "variants"])
     return Context(0, kind, lib=_capi.VARIANTS_LIB_PATH)
 
 
