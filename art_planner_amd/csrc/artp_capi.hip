@@ -108,7 +108,7 @@ struct artp_ctx {
   uint64_t svc_launches = 0, svc_requests = 0;
   // latency path of the edge checks (<= ARTP_FEW_EDGES edges per call): one mapped block
   //   s1 | s2 (64 x 7 f64 each) | last_t (64 f64) | last_state (64 x 7 f64) | aux (64 u32) | status (64 u8)
-  char* pin_edges_in = nullptr;           // s1 | s2 of a call, host view (non-coherent mapping)
+  char* pin_edges_in = nullptr;           // s1 | s2 of a call, host view
   char* pin_edges_in_dev = nullptr;
   char* pin_edges = nullptr;              // host view
   char* pin_edges_dev = nullptr;          // device view
@@ -891,10 +891,10 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
       void *pe = nullptr, *ped = nullptr;
       std::vector<FewEdgeSync> armed(ARTP_FEW_EDGES, FewEdgeSync{0xffffffffu, 0u, 0u, {0u}});
       void *pi = nullptr, *pid = nullptr;
-      // the edges (host -> device): NON-coherent mapped memory, i.e. cacheable in the device's L2 for the length of a
-      // kernel -- every workgroup of a call reads its edge, and only the first read of a line crosses PCIe.  The
-      // results (device -> host, polled) stay in coherent memory.
-      if (hipHostMalloc(&pi, 2 * ARTP_FEW_EDGES * 7 * sizeof(double), hipHostMallocMapped | hipHostMallocNonCoherent) == hipSuccess &&
+      // the edges (host -> device) in a block of their own, apart from the polled results.  Plain coherent mapped memory:
+      // a non-coherent mapping (L2-cacheable for the length of a kernel, so that only the first workgroup's read of an
+      // edge crosses PCIe) was measured -- no difference at any call size -- and is not worth a second coherence rule.
+      if (hipHostMalloc(&pi, 2 * ARTP_FEW_EDGES * 7 * sizeof(double), hipHostMallocMapped) == hipSuccess &&
           hipHostGetDevicePointer(&pid, pi, 0) == hipSuccess) {
         c->pin_edges_in = static_cast<char*>(pi);
         c->pin_edges_in_dev = static_cast<char*>(pid);

@@ -132,13 +132,14 @@ def contract_line(full):
     raise RuntimeError(f"bench contract line is {len(line)} bytes")
 
 
-def emit(full, stream=None):
-    """BENCH_DETAIL line (everything) first, then the contract line LAST."""
+def emit(full, stream=None, partial=False):
+    """BENCH_DETAIL line (everything) first, then the contract line LAST.  partial: a run with parts switched off (--no-pmc,
+    --skip-extras, --no-cpu-baseline: the profiler's and the scripts' runs) keeps its record apart from the default run's."""
     stream = stream or sys.stdout
     detail_path = None
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        detail_path = os.path.join("gpurun_out", "bench_detail.json")
+        detail_path = os.path.join("gpurun_out", "bench_detail_partial.json" if partial else "bench_detail.json")
         with open(os.path.join(ROOT, detail_path), "w") as f:
             json.dump(_clean(full, 100000), f, indent=1)
     except Exception:
@@ -1836,7 +1837,7 @@ def main():
         time.sleep(5)
         return
     wd.done()
-    emit(out)
+    emit(out, partial=bool(args.no_pmc or args.skip_extras or args.no_cpu_baseline or N > 1))
     if dist is not None:
         wd.line_printed = True
         wd.stage("final barrier", args.watchdog)

@@ -71,7 +71,9 @@ def edge_campaign(ctx, gm, rob, se3, labels):
         f_ok2, f_t, f_st = ctx.check_motions_last_valid(a[i:j], b[i:j])
         f_oki, f_ni = ctx.check_edges_interp(a[i:j], b[i:j])
         bad_few += int((f_ok != ok0[i:j]).sum()) + int((f_ok2 != ok[i:j]).sum()) + int((f_t != t[i:j]).sum()) + \
-            int((f_oki != oki[i:j]).sum()) + int((f_ni != ni[i:j]).sum()) + int((f_st != g_st[i:j]).any(axis=1).sum())
+            int((f_oki != oki[i:j]).sum()) + int((f_ni != ni[i:j]).sum()) + \
+            int((~((f_st == g_st[i:j]) | (np.isnan(f_st) & np.isnan(g_st[i:j])))).any(axis=1).sum())   # (nd = 0 on an invalid
+        #                                                                    state: t = -inf, the interpolated state is NaN in both)
         i, k = j, k % 64 + 1
     _EDGE_JOB["bad_few"] = (bad_few, mf)
     return bad + bad_few, float(ok0.mean()), float(oki.mean())
