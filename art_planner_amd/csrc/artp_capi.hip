@@ -933,6 +933,7 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
 void artp_destroy(artp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  svc_stop(c);   // the resident latency workgroup (if any) leaves before anything it reads is freed
   park_lane(c);
   for (auto& l : c->lanes)
     if (l.init && l.stream) (void)hipStreamSynchronize(l.stream);
@@ -979,7 +980,6 @@ void artp_destroy(artp_ctx* c) {
   if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->d_map_f32) (void)hipFree(c->d_map_f32);
   if (c->d_diff) (void)hipFree(c->d_diff);
-  svc_stop(c);
   if (c->svc) (void)hipHostFree(c->svc);
   if (c->svc_stream) (void)hipStreamDestroy(c->svc_stream);
   if (c->svc_after_map) (void)hipEventDestroy(c->svc_after_map);
