@@ -106,6 +106,21 @@ struct artp_ctx {
   uint32_t svc_seq = 0;
   uint64_t svc_map_version = 0;
   uint64_t svc_launches = 0, svc_requests = 0;
+  // the same switch keeps a POOL of workgroups resident for edge calls of one or two edges (check_motions_pool_kernel)
+  bool pool_launched = false;
+  hipStream_t pool_stream = nullptr;
+  hipEvent_t pool_after_map = nullptr;
+  EdgeMailbox* pool_mb = nullptr;         // host view (request): DEVICE memory written through the PCIe BAR when the device
+  EdgeMailbox* pool_mb_dev = nullptr;     //   exposes all of it (pool_mb_in_device), mapped host memory otherwise
+  bool pool_mb_in_device = false;
+  PoolResponse* pool_resp = nullptr;      // host view (per-workgroup slots)
+  PoolResponse* pool_resp_dev = nullptr;
+  PoolCtl* pool_ctl = nullptr;            // device memory
+  unsigned pool_wgs = ARTP_POOL_WGS;
+  bool pool_allow_bar = true;             // (variants build: ARTP_POOL_BAR=0 keeps the request block in mapped host memory)
+  uint32_t pool_seq = 0;
+  uint64_t pool_map_version = 0;
+  uint64_t pool_launches = 0, pool_requests = 0;
   // latency path of the edge checks (<= ARTP_FEW_EDGES edges per call): one mapped block
   //   s1 | s2 (64 x 7 f64 each) | last_t (64 f64) | last_state (64 x 7 f64) | aux (64 u32) | status (64 u8)
   char* pin_edges_in = nullptr;           // s1 | s2 of a call, host view
@@ -730,6 +745,7 @@ const char* artp_device_arch(const artp_ctx* ctx) { return ctx ? ctx->arch.c_str
 // ---- persistent latency service (kernels.h validate_service_kernel) ------------------------------------------------
 // Tell the resident workgroup to leave and wait until it has (it polls `quit` every few microseconds; bounded by its own
 // idle / lifetime limits whatever happens).
+static void pool_stop(artp_ctx* c);
 static void svc_stop(artp_ctx* c) {
   if (!c->svc || !c->svc_launched) return;
   c->svc->n_quit = 0x100u;
@@ -836,15 +852,18 @@ int artp_set_persistent_latency(artp_ctx* c, int enabled) {
   std::lock_guard<std::recursive_mutex> lock(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   c->svc_enabled = enabled != 0;
-  if (!c->svc_enabled) svc_stop(c);
+  if (!c->svc_enabled) {
+    svc_stop(c);
+    pool_stop(c);
+  }
   return ARTP_OK;
 }
 
 int artp_persistent_latency_stats(artp_ctx* c, uint64_t out[2]) {
   if (!c || !out) return ARTP_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  out[0] = c->svc_launches;
-  out[1] = c->svc_requests;
+  out[0] = c->svc_launches + c->pool_launches;
+  out[1] = c->svc_requests + c->pool_requests;
   return ARTP_OK;
 }
 
@@ -923,6 +942,11 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
     c->poll_labels = !(e && e[0] == '1');
 #ifdef ARTP_VARIANTS
     if (const char* fd = std::getenv("ARTP_FEET_DENSE")) c->feet_dense = fd[0] != '0';
+    if (const char* pw = std::getenv("ARTP_POOL_WGS")) {
+      const long v = std::strtol(pw, nullptr, 10);
+      if (v >= 1 && v <= ARTP_POOL_MAX_WGS) c->pool_wgs = (unsigned)v;
+    }
+    if (const char* pb = std::getenv("ARTP_POOL_BAR")) c->pool_allow_bar = pb[0] != '0';
 #endif
   }
   fill_robot(c);
@@ -933,7 +957,8 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
 void artp_destroy(artp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  svc_stop(c);   // the resident latency workgroup (if any) leaves before anything it reads is freed
+  svc_stop(c);   // the resident latency workgroups (if any) leave before anything they read is freed
+  pool_stop(c);
   park_lane(c);
   for (auto& l : c->lanes)
     if (l.init && l.stream) (void)hipStreamSynchronize(l.stream);
@@ -983,6 +1008,11 @@ void artp_destroy(artp_ctx* c) {
   if (c->svc) (void)hipHostFree(c->svc);
   if (c->svc_stream) (void)hipStreamDestroy(c->svc_stream);
   if (c->svc_after_map) (void)hipEventDestroy(c->svc_after_map);
+  if (c->pool_stream) (void)hipStreamDestroy(c->pool_stream);
+  if (c->pool_after_map) (void)hipEventDestroy(c->pool_after_map);
+  if (c->pool_mb) (void)(c->pool_mb_in_device ? hipFree(c->pool_mb) : hipHostFree(c->pool_mb));
+  if (c->pool_resp) (void)hipHostFree(c->pool_resp);
+  if (c->pool_ctl) (void)hipFree(c->pool_ctl);
   if (c->pin_edges) (void)hipHostFree(c->pin_edges);
   if (c->pin_edges_in) (void)hipHostFree(c->pin_edges_in);
   if (c->d_few_sync) (void)hipFree(c->d_few_sync);
@@ -2062,6 +2092,202 @@ static int run_edges_few(artp_ctx* c, int mode, bool host_io, const double* s1, 
   return ARTP_OK;
 }
 
+// ---- resident pool for calls of one or two edges (kernels.h check_motions_pool_kernel) --------------------------------
+static bool pool_any_exited(const artp_ctx* c) {
+  for (unsigned w = 0; w < c->pool_wgs; ++w)
+    if (c->pool_resp->exited[w]) return true;
+  return false;
+}
+
+// Host stores into the request block have left the core's write-combining buffers (the block may be device memory behind
+// the PCIe BAR) and are ordered against the stores that follow.
+static inline void pool_store_fence() {
+#if defined(__x86_64__)
+  __builtin_ia32_sfence();
+#endif
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+static void pool_stop(artp_ctx* c) {
+  if (!c->pool_mb || !c->pool_launched) return;
+  // (line 0 is never READ by the host -- a read across the BAR is a microsecond: the request number is c->pool_seq)
+  reinterpret_cast<volatile uint64_t*>(&c->pool_mb->line[0])[0] = ((uint64_t)0x100u << 32) | c->pool_seq;
+  pool_store_fence();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    bool all = true;
+    for (unsigned w = 0; w < c->pool_wgs; ++w) all = all && c->pool_resp->exited[w];
+    if (all || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+  }
+  (void)hipStreamSynchronize(c->pool_stream);   // every workgroup has returned (at the latest after the lifetime limit)
+  c->pool_launched = false;
+}
+
+static int pool_start(artp_ctx* c) {
+  if (!c->pool_mb) {
+    void *p = nullptr, *pd = nullptr, *r = nullptr, *rd = nullptr;
+    // The request block.  Polled by EVERY workgroup: in mapped host memory each poll is a PCIe read and the reads of P
+    // workgroups queue up (round trip of a request number, tests/cpp/bar_pingpong_probe.hip, profiles/r06_edge_pool.txt:
+    // 2.0 us with one polling workgroup, 5.8 us with 32, 11.4 us with 64); in DEVICE memory that the host writes through the
+    // BAR the poll never leaves the device (2.4 us whatever the number of workgroups).
+    int large_bar = 0;
+    (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device);
+    if (large_bar && c->pool_allow_bar && hipExtMallocWithFlags(&p, sizeof(EdgeMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+      HIP_TRY(c, hipMemset(p, 0, sizeof(EdgeMailbox)));
+      c->pool_mb = c->pool_mb_dev = static_cast<EdgeMailbox*>(p);
+      c->pool_mb_in_device = true;
+    } else {
+      (void)hipGetLastError();
+      HIP_TRY(c, hipHostMalloc(&p, sizeof(EdgeMailbox), hipHostMallocMapped));
+      c->pool_mb = static_cast<EdgeMailbox*>(p);
+      HIP_TRY(c, hipHostGetDevicePointer(&pd, p, 0));
+      c->pool_mb_dev = static_cast<EdgeMailbox*>(pd);
+      std::memset(p, 0, sizeof(EdgeMailbox));
+    }
+    HIP_TRY(c, hipHostMalloc(&r, sizeof(PoolResponse), hipHostMallocMapped));
+    c->pool_resp = static_cast<PoolResponse*>(r);
+    HIP_TRY(c, hipHostGetDevicePointer(&rd, r, 0));
+    c->pool_resp_dev = static_cast<PoolResponse*>(rd);
+    std::memset(r, 0, sizeof(PoolResponse));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->pool_ctl), sizeof(PoolCtl)));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->pool_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->pool_after_map, hipEventDisableTiming));
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(check_motions_pool_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few(c)));
+  }
+  if (c->pool_seq >= 0xfffffff0u) {   // the request numbers wrap: every tag back to "never"
+    for (int l = 0; l < 5; ++l) reinterpret_cast<volatile uint64_t*>(&c->pool_mb->line[l])[0] = 0;
+    std::memset(c->pool_resp, 0, sizeof(PoolResponse));
+    c->pool_seq = 0;
+  }
+  HIP_TRY(c, hipEventRecord(c->pool_after_map, c->stream));          // behind the map writes already enqueued
+  HIP_TRY(c, hipStreamWaitEvent(c->pool_stream, c->pool_after_map, 0));
+  HIP_TRY(c, hipMemsetAsync(c->pool_ctl, 0, sizeof(PoolCtl), c->pool_stream));
+  reinterpret_cast<volatile uint64_t*>(&c->pool_mb->line[0])[0] = c->pool_seq;   // word 0: nothing to do, do not leave
+  for (unsigned w = 0; w < ARTP_POOL_MAX_WGS; ++w) c->pool_resp->exited[w] = 0;
+  pool_store_fence();
+  hipLaunchKernelGGL(check_motions_pool_kernel, dim3(c->pool_wgs), dim3(320), lds_few(c), c->pool_stream, c->field[0],
+                     c->field[1], c->geom, c->robot, c->pool_mb_dev, c->pool_resp_dev, c->pool_ctl, c->pool_seq,
+                     c->pool_mb_in_device ? 0 : 1, c->caps_full, c->caps_foot_full);
+  HIP_TRY(c, hipGetLastError());
+  c->pool_launched = true;
+  c->pool_map_version = c->map_version.load(std::memory_order_acquire);
+  ++c->pool_launches;
+  return ARTP_OK;
+}
+
+// One or two edges (host pointers) through the resident pool; results as run_edges_few's.  The z bounds and the R3 extent
+// override travel with every request (setters change them without a map write).  The host reduces the workgroups' slots:
+// smallest failing order over the pool = DiscreteMotionValidator's first invalid state.
+static int run_edges_pool(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n, uint8_t* valid,
+                          uint32_t* aux_out, double* last_t, double* last_state) {
+  const bool want_last = mode == 0 && last_t;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool stale = c->pool_launched && c->pool_map_version != c->map_version.load(std::memory_order_acquire);
+    if (stale || (c->pool_launched && (c->pool_seq >= 0xfffffff0u || pool_any_exited(c)))) pool_stop(c);
+    if (!c->pool_launched) {
+      const int rc = pool_start(c);
+      if (rc) return rc;
+    }
+    EdgeMailbox* mb = c->pool_mb;
+    const unsigned P = c->pool_wgs;
+    for (size_t i = 0; i < n; ++i) {
+      std::memcpy(mb->line[i ? 3 : 0].v, s1 + 7 * i, 7 * sizeof(double));
+      std::memcpy(mb->line[i ? 4 : 1].v, s2 + 7 * i, 7 * sizeof(double));
+    }
+    mb->line[2].v[0] = c->z_high - c->z_low;
+    mb->line[2].v[1] = c->r3_extent_override;
+    // every line's payload is globally visible before its tag; line 0's tag and word go out as one 8-byte store, last
+    pool_store_fence();
+    const uint32_t seq = ++c->pool_seq;
+    const uint32_t word = (uint32_t)n | (mode ? 0x200u : 0u) | (want_last ? 0x400u : 0u);
+    if (n > 1) {
+      mb->line[4].tag = seq;
+      mb->line[3].tag = seq;
+    }
+    mb->line[2].tag = seq;
+    mb->line[1].tag = seq;
+    reinterpret_cast<volatile uint64_t*>(&mb->line[0])[0] = ((uint64_t)word << 32) | seq;
+    pool_store_fence();
+    const auto t0 = std::chrono::steady_clock::now();
+    // per edge: the slot of the workgroup task 0 fell to (it carries the edge's task count), then the slots of the
+    // min(tasks, P) workgroups that had a task; the next edge's tasks continue the numbering
+    bool gone = false, done = false;
+    size_t e = 0;
+    unsigned lead = 0, idx = 0, cnt = 1, flags = 0;
+    uint64_t base = 0;
+    uint32_t fbad = 0xffffffffu, who = 0, aux = 0;
+    for (unsigned spin = 0; !done; ++spin) {
+      for (;;) {
+        const unsigned w = (lead + idx) % P;
+        const volatile PoolSlot& sl = c->pool_resp->slot[e][w];
+        if (sl.tag != seq) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (idx == 0) {
+          const uint32_t tasks = sl.flags >> 3;
+          cnt = tasks < P ? (tasks ? tasks : 1u) : P;
+          base += tasks;
+          aux = sl.aux;
+        }
+        flags |= sl.flags & 7u;
+        if (sl.first_bad < fbad) {
+          fbad = sl.first_bad;
+          who = w;
+        }
+        if (++idx < cnt) continue;
+        // the edge is complete
+        valid[e] = fbad == 0xffffffffu && !(flags & 6u);
+        if (aux_out) aux_out[e] = aux;
+        if (want_last) {   // check_motions_few_kernel's finalization rule
+          if (fbad == 0xffffffffu) {
+            last_t[e] = 1.0;
+            if (last_state) std::memcpy(last_state + 7 * e, s2 + 7 * e, 7 * sizeof(double));
+          } else {
+            const int nd = (int)aux;
+            last_t[e] = nd > 0 ? (double)fbad / (double)nd : (double)(nd - 1) / (double)nd;
+            if (last_state)
+              std::memcpy(last_state + 7 * e, const_cast<const double*>(c->pool_resp->last_state[e][who]), 7 * sizeof(double));
+          }
+        }
+        if (++e == n) {
+          done = true;
+          break;
+        }
+        lead = (unsigned)(base % P);
+        idx = 0;
+        cnt = 1;
+        fbad = 0xffffffffu;
+      }
+      if (!done && (spin & 255u) == 255u) {
+        if (pool_any_exited(c)) { gone = true; break; }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+      }
+    }
+    if (done) {
+      ++c->pool_requests;
+      if (flags & 4u) {
+        c->last_error = "an edge has non-finite states or needs more than 2^22 interpolation states";
+        return ARTP_ERR_INVALID_ARG;
+      }
+      if (flags & 2u) {
+        c->last_error = "a box window exceeded the LDS tile capacity";
+        return ARTP_ERR_CAPACITY;
+      }
+      return ARTP_OK;
+    }
+    if (gone) {
+      pool_stop(c);
+      --c->pool_seq;   // post it again under the same number (slots already answered for it hold the same answers)
+      continue;
+    }
+    c->last_error = "the resident edge pool did not answer within 50 ms";
+    pool_stop(c);
+    return ARTP_ERR_TIMEOUT;
+  }
+  c->last_error = "the resident edge pool could not be (re)started";
+  return ARTP_ERR_TIMEOUT;
+}
+
 static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double* s2, size_t n,
                           uint8_t* valid, uint32_t* aux_out, double* last_t = nullptr, double* last_state = nullptr) {
   if (!c || (n && (!s1 || !s2 || !valid))) return ARTP_ERR_INVALID_ARG;
@@ -2071,8 +2297,12 @@ static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double*
   HIP_TRY(c, hipSetDevice(c->device));
   double few_max = 0.0;
   if (n <= ARTP_FEW_EDGES && c->few_edges && c->have_field[0] && c->have_field[1] && (mode != 0 || c->have_z) &&
-      few_edges_task_estimate(c, mode, s1, s2, n, &few_max) <= 65536.0)
+      few_edges_task_estimate(c, mode, s1, s2, n, &few_max) <= 65536.0) {
+    // (at most eight rounds per workgroup: one that has run out of tasks must not reach its idle limit while others work)
+    if (c->svc_enabled && n <= ARTP_POOL_MAX_EDGES && few_max * n <= 8.0 * c->pool_wgs)
+      return run_edges_pool(c, mode, s1, s2, n, valid, aux_out, last_t, last_state);
     return run_edges_few(c, mode, true, s1, s2, n, valid, aux_out, last_t, last_state, few_max);
+  }
   int rc = ensure_tmp(c, 0, 2 * n * 7 * sizeof(double));
   if (rc) return rc;
   // tmp[1]: last_t (n doubles) | last_state (7n doubles) | aux (n u32) | valid (n)
@@ -3207,6 +3437,9 @@ int artp_cost_get_features(artp_ctx* c, float* out, int* fh, int* fw) {
 #ifdef ARTP_STAGE_TIMING
 extern "C" int artp_debug_few_trace(unsigned long long* out40) {
   return hipMemcpyFromSymbol(out40, HIP_SYMBOL(artp::g_few_trace), 40 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int artp_debug_pool_trace(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(artp::g_pool_trace), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 extern "C" int artp_debug_stage_cycles(unsigned long long* out20, int reset) {
   if (out20 && hipMemcpyFromSymbol(out20, HIP_SYMBOL(artp::g_stage_cycles), 20 * sizeof(unsigned long long)) != hipSuccess)

@@ -1385,6 +1385,220 @@ check_motions_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, doubl
   __threadfence_system();
 }
 
+// ---- the same without a launch: a resident POOL of workgroups (round 6; artp_set_persistent_latency) -----------------------
+// One or two edges per host call.  EVERY workgroup polls the request block itself, takes the tasks wg, wg + P, ... of the
+// call's edges and writes what IT found -- the smallest failing order, flags, the lastValid state of that order -- to its own
+// slot in mapped host memory; the host waits for the slots of the workgroups that had a task and reduces them (min / or).
+// No device-side arrival counter, no finalizing workgroup, no hop through a dispatcher: the first form of this kernel had all
+// three (one workgroup polling the host, the others spinning on a device word; last arriver writes the verdict) and spent
+// 2.4 us in the dispatcher's second PCIe round trip and fence, 1.8 us until a worker held the request, 0.6 + 1.6 us in arrival
+// and finalization -- 12.4 us of device time per request against 6.2 us now (profiles/r06_edge_pool.txt).
+// The request block is five 64-byte lines, each {tag, word, 7 doubles}.  It lives in DEVICE memory that the host writes through
+// the PCIe BAR (payloads, store fence, tags): polling never leaves the device, so its cost does not depend on P.  (In mapped
+// host memory -- the fallback without a large BAR, `reread` = 1 -- every poll is a PCIe read and the reads of P workgroups
+// queue up: 5.8 us per round trip with 32 pollers, 11.4 us with 64, against 2.4 us through the BAR; there the lines are
+// fetched once more after the tags match, since nothing orders the sectors of one read.)
+// Each workgroup leaves by itself: `leave` bit, 200 us without a request, ARTP_SVC_LIFE_TICKS at the latest.
+#define ARTP_POOL_WGS 128
+#define ARTP_POOL_MAX_WGS 128
+#define ARTP_POOL_MAX_EDGES 2
+struct PoolLine { volatile uint32_t tag, word; double v[7]; };   // word of line 0: bits 0-7 edges, bit 8 leave, bit 9 mode, bit 10 lastValid wanted
+struct EdgeMailbox {   // mapped (coherent) host memory, host -> device
+  PoolLine line[5];    // 0: s1 of edge 0 | 1: s2 of edge 0 | 2: z_extent, r3_extent_override | 3, 4: edge 1
+};
+static_assert(sizeof(PoolLine) == 64 && sizeof(EdgeMailbox) == 320, "one PCIe read per line");
+struct PoolSlot { uint32_t tag, first_bad, flags, aux; };   // flags: 2 = tile capacity, 4 = segment-count overflow; bits 3..: the edge's task count
+struct PoolResponse {   // mapped host memory, device -> host
+  PoolSlot slot[ARTP_POOL_MAX_EDGES][ARTP_POOL_MAX_WGS];
+  double last_state[ARTP_POOL_MAX_EDGES][ARTP_POOL_MAX_WGS][7];   // written in front of the slot when first_bad != ~0 and wanted
+  volatile uint8_t exited[ARTP_POOL_MAX_WGS];
+};
+struct PoolCtl { unsigned long long known[ARTP_POOL_MAX_EDGES]; };   // device: (request number << 32) | ~(smallest failing order so far)
+#ifdef ARTP_STAGE_TIMING
+__device__ unsigned long long g_pool_trace[16];   // wall_clock64 of the phases of one request (scripts/pool_trace.py)
+#define ARTP_POOL_MARK(p, cond) do { if ((cond) && lane == 0 && kbox == 0) g_pool_trace[p] = wall_clock64(); } while (0)
+#else
+#define ARTP_POOL_MARK(p, cond) do { } while (0)
+#endif
+__global__ void __launch_bounds__(320, 2)   // one workgroup per CU: 256 VGPRs
+check_motions_pool_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const EdgeMailbox* mb, PoolResponse* resp, PoolCtl* ctl,
+                          uint32_t last_seq, int reread, ScratchCaps caps_torso, ScratchCaps caps_foot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double s_edges[2][14], s_zr[2];
+  __shared__ int box_ok[5];
+  __shared__ uint32_t known_s, s_hdr, s_seq, s_exit;
+  const int lane = threadIdx.x & 63;
+  const int kbox = threadIdx.x >> 6;
+  const uint32_t wg = blockIdx.x, P = gridDim.x;
+  WaveScratch s;
+  if (kbox == 0) {
+    s = carve_scratch(smem, 0, caps_torso);
+  } else {
+    s = carve_scratch(smem + scratch_bytes_per_wave(caps_torso), kbox - 1, caps_foot);
+  }
+  const unsigned long long t_start = wall_clock64();
+  unsigned long long t_idle = t_start;
+  const volatile unsigned long long* words = reinterpret_cast<const volatile unsigned long long*>(mb);
+  for (;;) {
+    if (kbox == 0) {   // wavefront 0 polls: lanes 0..23 = lines 0..2 (8 x 8 bytes each)
+      uint32_t leave = 0, seq = last_seq, hdr = 0;
+      for (;;) {
+        unsigned long long q = 0;
+        if (lane < 24) q = words[lane];
+        const unsigned long long h = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        seq = (uint32_t)h;
+        hdr = (uint32_t)(h >> 32);
+        // the three lines carry the same NEW number: their payloads are this request's
+        const bool tag_lane = lane < 24 && (lane & 7) == 0;
+        const bool stale_line = tag_lane && (uint32_t)q != seq;
+        if (seq != last_seq && __ballot(stale_line) == 0ull) {
+          if (reread && lane < 24) q = words[lane];   // (mapped host memory: see above)
+          if (lane < 24 && (lane & 7)) {
+            const int line = lane >> 3, i = (lane & 7) - 1;
+            if (line < 2) {
+              reinterpret_cast<unsigned long long*>(s_edges[0])[7 * line + i] = q;
+            } else if (i < 2) {
+              reinterpret_cast<unsigned long long*>(s_zr)[i] = q;
+            }
+          }
+          if ((hdr & 0xffu) > 1u) {   // the second edge: lines 3 and 4, until they carry the number too
+            for (;;) {
+              unsigned long long q2 = 0;
+              if (lane < 16) q2 = words[24 + lane];
+              const bool stale2 = lane < 16 && (lane & 7) == 0 && (uint32_t)q2 != seq;
+              if (__ballot(stale2) == 0ull) {
+                if (reread && lane < 16) q2 = words[24 + lane];
+                if (lane < 16 && (lane & 7)) reinterpret_cast<unsigned long long*>(s_edges[1])[7 * (lane >> 3) + (lane & 7) - 1] = q2;
+                break;
+              }
+              if (wall_clock64() - t_start > ARTP_SVC_LIFE_TICKS) { leave = 1; break; }
+            }
+          }
+          break;
+        }
+        const unsigned long long now = wall_clock64();
+        if ((seq == last_seq && (hdr & 0x100u)) || now - t_idle > ARTP_SVC_IDLE_TICKS || now - t_start > ARTP_SVC_LIFE_TICKS) {
+          leave = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (lane == 0) {
+        s_exit = leave;
+        s_hdr = hdr;
+        s_seq = seq;
+      }
+    }
+    __syncthreads();
+    if (s_exit) {
+      if (threadIdx.x == 0) {
+        resp->exited[wg] = 1;
+        __threadfence_system();
+      }
+      return;
+    }
+    ARTP_POOL_MARK(0, wg == 1);   // workgroup 1 holds the request
+    const uint32_t hdr = s_hdr, seq = s_seq, n = (hdr & 0xffu) > 1u ? 2u : 1u;
+    const int mode = (hdr >> 9) & 1u;
+    const bool want_last = mode == 0 && ((hdr >> 10) & 1u);
+    const double z_extent = s_zr[0], r3_extent_override = s_zr[1];
+    uint32_t base = 0;   // tasks of the edges in front of the current one: the call's tasks are numbered through its edges
+    for (uint32_t e = 0; e < n; ++e) {
+      double a[7], b[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        a[i] = s_edges[e][i];
+        b[i] = s_edges[e][7 + i];
+      }
+      uint32_t aux;
+      int overflow = 0;
+      uint32_t tasks = edge_task_count(g, z_extent, r3_extent_override, mode, a, b, &aux, &overflow);
+      if (overflow) tasks = 0;
+      const SlerpEdge se = slerp_edge(a + 3, b + 3);
+      const uint32_t first = (wg + P - base % P) % P;
+      base += tasks;
+      uint32_t my_bad = 0xffffffffu, my_err = overflow ? 4u : 0u;   // thread 0's
+      ARTP_POOL_MARK(1, wg == 1 && e == 0);   // segment count, slerp constants
+      for (uint32_t k = first; k < tasks; k += P) {
+        const uint32_t order = mode == 0 ? (k == 0 ? (aux >= 1 ? aux - 1 : 0u) : k - 1) : k;
+        if (k != first) {
+          // a later round of a long edge: what the other workgroups have found so far, read once per workgroup (it only ever
+          // skips work; the verdict is the host's minimum over every workgroup's own finding)
+          if (threadIdx.x == 0) {
+            const unsigned long long w = __hip_atomic_load(&ctl->known[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            known_s = (uint32_t)(w >> 32) == seq ? ~(uint32_t)w : 0xffffffffu;
+          }
+          __syncthreads();
+          const uint32_t known = known_s;
+          __syncthreads();   // (read by everybody before thread 0 writes it again)
+          if (want_last ? order >= known : known != 0xffffffffu) {
+            if (!want_last) break;
+            continue;
+          }
+        }
+        double st[7];
+        if (mode == 0) {
+          if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) st[i] = b[i];
+          } else {
+            se3_interpolate_pre(a, b, (double)k / (double)aux, se, st);
+          }
+        } else {
+          const double n_interp_div = 1.0 / (aux + 1);
+          se3_interpolate_pre(a, b, (k + 1) * n_interp_div, se, st);
+        }
+        ARTP_POOL_MARK(2, wg == 1 && e == 0);   // the interpolated state
+        const int ok = few_box_ok(fb, ff, g, rb, st, kbox, s, lane);
+        ARTP_POOL_MARK(3, wg == 1 && e == 0);   // its box
+        if (lane == 0) box_ok[kbox] = ok;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          bool err = false, v = true;
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            err = err || box_ok[q] < 0;
+            v = v && box_ok[q] > 0;
+          }
+          if (err) my_err |= 2u;
+          if ((!v || err) && order < my_bad) {
+            my_bad = order;
+            if (tasks > P) atomicMax(&ctl->known[e], ((unsigned long long)seq << 32) | (uint32_t)~order);
+          }
+        }
+        __syncthreads();   // box_ok is the next task's again
+      }
+      // workgroups without a task of this edge stay silent, except the one task 0 falls to (it reports the task count, from
+      // which the host knows whose slots to wait for, and a segment-count overflow)
+      if (threadIdx.x == 0 && (first < tasks || first == 0)) {
+        if (want_last && my_bad != 0xffffffffu) {   // the lastValid state of THIS workgroup's finding (last_valid_kernel's rule)
+          const int nd = (int)aux;
+          const double t = nd > 0 ? (double)my_bad / (double)nd : (double)(nd - 1) / (double)nd;
+          double st[7];
+          se3_interpolate(a, b, t, st);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) resp->last_state[e][wg][i] = st[i];
+          __threadfence_system();   // ... lands before the slot that announces it
+        }
+        // one 16-byte store with system scope (volatile: sc0 sc1, written through -- a plain store may stay in the L2 until a
+        // fence or the end of the kernel): one PCIe write, no fence on the way
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 rec;
+        rec.x = seq;
+        rec.y = my_bad;
+        rec.z = my_err | (tasks << 3);
+        rec.w = aux;
+        *reinterpret_cast<volatile u32x4*>(&resp->slot[e][wg]) = rec;
+        ARTP_POOL_MARK(4, wg == 1 && e == 0);
+      }
+    }
+    last_seq = s_seq;
+    t_idle = wall_clock64();
+    __syncthreads();
+  }
+}
+
 // Labels != 0 of a batch.  Sixteen labels per load, one atomic per WORKGROUP of a grid of a few workgroups per CU: with
 // an atomic per wavefront of a wavefront-per-256-labels grid (32 768 atomics on one word for 2^22 labels) the counter's
 // L2 atomic unit was the whole 0.4 ms of the kernel.

@@ -179,7 +179,7 @@ int main(int argc, char** argv) {
   // ---- per-call latency of the MotionValidator seam (prm_motion_cost.cpp:652, lazy_prm_star_min_update.cpp:725 and
   // OMPL's PathSimplifier call checkMotion one edge at a time): n = 1 through both overloads, a 32-edge solution path
   // in one artp_check_motions call, and the same two with the latency kernel switched off (the batch pipeline)
-  double us_cm1 = 0, us_cm1_last = 0, us_cm32 = 0, us_cm1_batch = 0, us_cm32_batch = 0;
+  double us_cm1 = 0, us_cm1_last = 0, us_cm32 = 0, us_cm1_batch = 0, us_cm32_batch = 0, us_cm1_pool = 0, us_cm1_last_pool = 0;
   {
     const int reps = 400;
     for (int pass = 0; pass < 2; ++pass) {   // pass 0 warms up
@@ -199,6 +199,28 @@ int main(int argc, char** argv) {
       }
       us_cm1_last = (now_us() - t1) / reps;
     }
+    // the same two through the resident edge pool (artp_set_persistent_latency: no launch per call)
+    bad += artp_set_persistent_latency(gpu->get(), 1) != ARTP_OK;
+    for (int pass = 0; pass < 2; ++pass) {
+      double t1 = now_us();
+      for (int i = 0; i < reps; ++i) {
+        toState(&s1[7 * (i % m_single)], &a);
+        toState(&s2[7 * (i % m_single)], &b);
+        bad += mv.checkMotion(&a, &b) != (motion_ok[i % m_single] != 0);
+      }
+      us_cm1_pool = (now_us() - t1) / reps;
+      t1 = now_us();
+      for (int i = 0; i < reps; ++i) {
+        toState(&s1[7 * (i % m_single)], &a);
+        toState(&s2[7 * (i % m_single)], &b);
+        std::pair<ob::State*, double> last(&lv, -7.0);
+        const bool ok = mv.checkMotion(&a, &b, last);
+        bad += ok != (motion_ok[i % m_single] != 0);
+        if (!ok) bad += last.second != last_t[i % m_single];   // (untouched on success, like OMPL)
+      }
+      us_cm1_last_pool = (now_us() - t1) / reps;
+    }
+    bad += artp_set_persistent_latency(gpu->get(), 0) != ARTP_OK;
     const int np = m < 32 ? m : 32;
     std::vector<uint8_t> okp(np);
     auto time_path = [&](int calls) {
@@ -357,7 +379,8 @@ int main(int argc, char** argv) {
   std::printf("isValid on an arbitrary state: %.1f us per call (one launch), %.1f us through the persistent service\n", us_single,
               us_single_svc);
   std::printf("checkMotion per call: 1 edge %.1f us (lastValid overload %.1f us), 32-edge path %.1f us; through the batch "
-              "pipeline: %.1f us / %.1f us\n", us_cm1, us_cm1_last, us_cm32, us_cm1_batch, us_cm32_batch);
+              "pipeline: %.1f us / %.1f us; 1 edge through the resident pool: %.1f us (lastValid overload %.1f us)\n", us_cm1,
+              us_cm1_last, us_cm32, us_cm1_batch, us_cm32_batch, us_cm1_pool, us_cm1_last_pool);
   std::printf("host mirror: %d states batch + %d single (%.1f us per isValid on arbitrary states), %d motions (%d lastValid "
               "mismatches), rejection loop %d attempts / %d accepted at %.3f us per sampleUniform+isValid, %d labels flipped by a "
               "direct artp_update_layer_rect and served fresh, %d mismatches\n",
@@ -367,6 +390,8 @@ int main(int argc, char** argv) {
     o << "{\"isvalid_arbitrary_state_us\": " << us_single << ", \"isvalid_arbitrary_state_us_persistent_service\": " << us_single_svc
       << ", \"check_motion_1_edge_us\": " << us_cm1
       << ", \"check_motion_last_valid_1_edge_us\": " << us_cm1_last << ", \"check_motions_32_edge_path_us\": " << us_cm32
+      << ", \"check_motion_1_edge_us_resident_pool\": " << us_cm1_pool
+      << ", \"check_motion_last_valid_1_edge_us_resident_pool\": " << us_cm1_last_pool
       << ", \"check_motion_1_edge_us_batch_pipeline\": " << us_cm1_batch
       << ", \"check_motions_32_edge_path_us_batch_pipeline\": " << us_cm32_batch
       << ", \"sampler_loop_us_per_state\": " << us_loop

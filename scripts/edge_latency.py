@@ -39,4 +39,25 @@ for name, few in modes:
             ctx.check_motions_last_valid(a[i:i + n], b[i:i + n])
         t2 = time.perf_counter()
         print(f"{name:5s} n={n:3d}: checkMotion {(t1 - t0) / reps * 1e6:8.1f} us/call, lastValid overload {(t2 - t1) / reps * 1e6:8.1f} us/call")
+# the resident pool (artp_set_persistent_latency): calls of one and two edges without a launch
+ctx.set_few_edges(True)
+ctx.set_persistent_latency(True)
+for n in (1, 2):
+    reps = 2000
+    for _ in range(20):
+        ctx.check_motions(a[:n], b[:n])
+    s0 = ctx.persistent_latency_stats()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        i = (r * n) % (len(a) - n)
+        ctx.check_motions(a[i:i + n], b[i:i + n])
+    t1 = time.perf_counter()
+    for r in range(reps):
+        i = (r * n) % (len(a) - n)
+        ctx.check_motions_last_valid(a[i:i + n], b[i:i + n])
+    t2 = time.perf_counter()
+    s1 = ctx.persistent_latency_stats()
+    print(f"pool  n={n:3d}: checkMotion {(t1 - t0) / reps * 1e6:8.1f} us/call, lastValid overload {(t2 - t1) / reps * 1e6:8.1f} us/call "
+          f"({s1['requests'] - s0['requests']} requests, {s1['launches'] - s0['launches']} launches)")
+ctx.set_persistent_latency(False)
 ctx.close()

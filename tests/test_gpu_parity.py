@@ -704,6 +704,145 @@ def test_latency_path_few_edges_golden(name):
         ctx.close()
 
 
+@pytest.mark.parametrize("name", golden_io.MAPS)
+def test_resident_edge_pool_golden(name):
+    """artp_set_persistent_latency also keeps a POOL of workgroups resident for edge calls of one or two edges
+    (check_motions_pool_kernel): the golden edges one and two at a time through all three entry points -- real-ODE verdicts,
+    the lastValid pair (exact t, the batch pipeline's states bit for bit), the 0.5 m rule and its counts; degenerate edges;
+    z bounds changed between calls (they travel with the request); a map write restarts the pool (verdicts of the NEW map);
+    it leaves by itself when the calls stop and comes back on demand; an edge across the whole map."""
+    import copy
+    import time
+    gm, _ = golden_io.load_boxes(name)
+    om = O.OracleMap(gm)
+    for rname, e in golden_io.load_edges(name).items():
+        ctx = _ctx(rname)
+        ctx.upload_map(gm, sampler=False)
+        rob = O.robot(rname)
+        m = min(len(e["s1"]), 900)
+        s1, s2 = e["s1"][:m], e["s2"][:m]
+        b_ok, b_t, b_st = ctx.check_motions_last_valid(s1, s2)      # the batch pipeline on the same edges
+        ctx.set_persistent_latency(True)
+        cm, lv_ok, lv_t = np.empty(m, np.uint8), np.empty(m, np.uint8), np.empty(m)
+        lv_st, ei, nint = np.empty((m, 7)), np.empty(m, np.uint8), np.empty(m, np.uint32)
+        i, k = 0, 1
+        while i < m:
+            j = min(i + k, m)
+            cm[i:j] = ctx.check_motions(s1[i:j], s2[i:j])
+            lv_ok[i:j], lv_t[i:j], lv_st[i:j] = ctx.check_motions_last_valid(s1[i:j], s2[i:j])
+            ei[i:j], nint[i:j] = ctx.check_edges_interp(s1[i:j], s2[i:j])
+            i, k = j, k % 2 + 1
+        st = ctx.persistent_latency_stats()
+        assert st["requests"] >= 3 * (m // 2) and 1 <= st["launches"] < st["requests"]
+        assert np.array_equal(cm, e["check_motion"][:m]), f"{name}/{rname}: {int((cm != e['check_motion'][:m]).sum())} verdicts"
+        assert np.array_equal(lv_ok, e["check_motion"][:m]) and np.array_equal(lv_ok, b_ok)
+        rok, rt, rst = om.check_motions_last_valid(rob, s1, s2)
+        assert np.array_equal(lv_t, rt) and np.array_equal(lv_t, b_t), f"lastValid.second differs on {int((lv_t != rt).sum())} edges"
+        assert np.array_equal(lv_st, b_st) and np.abs(lv_st - rst).max() <= 1e-12
+        assert np.array_equal(nint, e["n_interp"][:m]) and np.array_equal(ei, e["interp_valid"][:m])
+        inv = e["s2"][np.flatnonzero(e["check_motion"] == 0)]
+        inv = inv[om.states_valid(rob, inv) == 0][:2]
+        val = e["s2"][np.flatnonzero(e["check_motion"] != 0)][:2]
+        for pts in (inv, val):
+            if len(pts):
+                ok0, t0, _ = ctx.check_motions_last_valid(pts, pts)
+                rok0, rt0, _ = om.check_motions_last_valid(rob, pts, pts)
+                assert np.array_equal(ok0, rok0) and np.array_equal(t0, rt0)
+                assert np.array_equal(ctx.check_edges_interp(pts, pts)[0], np.ones(len(pts), np.uint8))
+        # other z bounds (a coarser checkMotion resolution): no restart, the counts of the batch path with the same bounds
+        zl, zh = ctx.z_bounds
+        ctx.set_z_bounds(zl - 30.0, zh + 30.0)
+        before = ctx.persistent_latency_stats()["launches"]
+        got = np.concatenate([ctx.check_motions_last_valid(s1[q:q + 1], s2[q:q + 1])[1] for q in range(40)])
+        assert ctx.persistent_latency_stats()["launches"] <= before + 1   # (+1 only if it had gone idle meanwhile)
+        ctx.set_persistent_latency(False)
+        want = ctx.check_motions_last_valid(s1[:40], s2[:40])[1]
+        ctx.set_persistent_latency(True)
+        assert np.array_equal(got, want)
+        ctx.set_z_bounds(zl, zh)
+        # a map write: restart, verdicts of the new map (body layer raised by 0.25 m)
+        gm_new = copy.copy(gm)
+        gm_new.layers = dict(gm.layers)
+        gm_new.layers["elevation"] = np.asfortranarray(gm["elevation"] + np.float32(0.25))
+        want, _ = O.OracleMap(gm_new).check_motions(rob, s1[:24], s2[:24])
+        ctx.check_motions(s1[:1], s2[:1])
+        before = ctx.persistent_latency_stats()["launches"]
+        ctx.upload_layer(0, gm_new["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+        got = np.concatenate([ctx.check_motions(s1[q:q + 2], s2[q:q + 2]) for q in range(0, 24, 2)])
+        assert np.array_equal(got, want)
+        assert ctx.persistent_latency_stats()["launches"] == before + 1
+        ctx.upload_layer(0, gm["elevation"], gm.len_x, gm.len_y, gm.pos_x, gm.pos_y)
+        # idle exit and restart on demand
+        assert np.array_equal(ctx.check_motions(s1[:2], s2[:2]), e["check_motion"][:2])
+        time.sleep(0.05)
+        before = ctx.persistent_latency_stats()["launches"]
+        assert np.array_equal(ctx.check_motions(s1[:2], s2[:2]), e["check_motion"][:2])
+        assert ctx.persistent_latency_stats()["launches"] == before + 1
+        # an edge across the map (more tasks than workgroups: the strided loop) and larger calls (not the pool's)
+        far1, far2 = s1[:1], s1[m // 2:m // 2 + 1]
+        assert np.array_equal(ctx.check_motions_last_valid(far1, far2)[1], om.check_motions_last_valid(rob, far1, far2)[1])
+        assert np.array_equal(ctx.check_motions(s1[:50], s2[:50]), e["check_motion"][:50])
+        ctx.set_persistent_latency(False)
+        n_req = ctx.persistent_latency_stats()["requests"]
+        assert np.array_equal(ctx.check_motions(s1[:1], s2[:1]), e["check_motion"][:1])
+        assert ctx.persistent_latency_stats()["requests"] == n_req
+        ctx.close()
+
+
+def test_resident_edge_pool_restart_races(big_map):
+    """The pool's workgroups leave on their own after 200 us without a request.  Calls spaced AROUND that limit (a request that
+    goes out while some workgroups have left and others have not), back-to-back calls, calls of both sizes and overloads,
+    interleaved with the resident isValid service and with batch launches on the context's stream: 6000 calls, every verdict
+    and lastValid pair equal to the batch pipeline's for the same edge."""
+    import time
+    ctx = _ctx("yaml")
+    ctx.upload_map(big_map)
+    se3 = ctx.sample_states(21, 0, 6000)
+    lab = ctx.validate_states(se3)
+    acc = se3[lab != 0]
+    rng = np.random.default_rng(8)
+    m = 1500
+    ia = rng.integers(0, len(acc), m)
+    a = acc[ia]
+    d = np.hypot(a[:, None, 0] - acc[None, :, 0], a[:, None, 1] - acc[None, :, 1])
+    d[np.arange(m), ia] = np.inf
+    b = acc[np.argsort(d, axis=1)[np.arange(m), rng.integers(0, 8, m)]]
+    b[::9] = acc[rng.integers(0, len(acc), len(b[::9]))]            # every 9th edge spans the map
+    ok, t, st = ctx.check_motions_last_valid(a, b)
+    oki, ni = ctx.check_edges_interp(a, b)
+    assert 0 < int(ok.sum()) < m
+    ctx.set_persistent_latency(True)
+    gaps = [0.0, 0.0, 0.0, 150e-6, 190e-6, 200e-6, 210e-6, 230e-6, 300e-6, 1e-3]
+    bad = 0
+    for r in range(6000):
+        i = int(rng.integers(0, m - 1))
+        k = 1 + (r & 1)
+        which = r % 3
+        if which == 0:
+            bad += int((ctx.check_motions(a[i:i + k], b[i:i + k]) != ok[i:i + k]).sum())
+        elif which == 1:
+            o2, t2, s2 = ctx.check_motions_last_valid(a[i:i + k], b[i:i + k])
+            bad += int((o2 != ok[i:i + k]).sum()) + int((t2 != t[i:i + k]).sum())
+            bad += int((~((s2 == st[i:i + k]) | (np.isnan(s2) & np.isnan(st[i:i + k])))).any(axis=1).sum())
+        else:
+            o3, n3 = ctx.check_edges_interp(a[i:i + k], b[i:i + k])
+            bad += int((o3 != oki[i:i + k]).sum()) + int((n3 != ni[i:i + k]).sum())
+        if r % 7 == 0:
+            bad += int((ctx.validate_states(se3[i:i + 1]) != lab[i:i + 1]).sum())      # the resident isValid workgroup
+        if r % 97 == 0:
+            bad += int((ctx.validate_states(se3[:2000]) != lab[:2000]).sum())           # a batch launch next to the pool
+        g = gaps[int(rng.integers(0, len(gaps)))]
+        if g:
+            t_end = time.perf_counter() + g
+            while time.perf_counter() < t_end:
+                pass
+    st_ = ctx.persistent_latency_stats()
+    assert bad == 0, f"{bad} mismatches through the resident pool"
+    assert st_["launches"] >= 20 and st_["requests"] >= 6000      # it did leave and come back many times
+    ctx.set_persistent_latency(False)
+    ctx.close()
+
+
 def test_latency_path_few_edges_repeats_long_edges_and_no_polling(big_map, monkeypatch):
     """The kernel re-arms its own per-edge words: 300 back-to-back calls of mixed size give the oracle's verdicts every
     time; edges across the whole map (more tasks than workgroups of an edge: the strided loop); the same through

@@ -70,6 +70,40 @@ def test_dense_feet_stream_variant_gives_the_same_labels(name, big_map, monkeypa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"ARTP_POOL_BAR": "0", "ARTP_POOL_WGS": "16"}, {"ARTP_POOL_WGS": "5"}, {"ARTP_POOL_WGS": "64"}])
+def test_resident_edge_pool_fallback_request_block_and_other_pool_sizes(env, monkeypatch):
+    """The resident edge pool's request block in MAPPED HOST memory ($ARTP_POOL_BAR=0: what a device without a large BAR gets;
+    every workgroup's poll is then a PCIe read, and the lines are fetched a second time after the tags match) and pools of
+    other sizes ($ARTP_POOL_WGS: 5 workgroups = many rounds per edge and the cross-workgroup early exit; 64): the golden
+    edges' verdicts, lastValid pairs and interpolation counts, one and two edges per call."""
+    name = golden_io.MAPS[0]
+    gm, _ = golden_io.load_boxes(name)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for rname, e in golden_io.load_edges(name).items():
+        ctx = _vctx(rname)
+        ctx.upload_map(gm, sampler=False)
+        m = min(len(e["s1"]), 400)
+        s1, s2 = e["s1"][:m], e["s2"][:m]
+        b_ok, b_t, b_st = ctx.check_motions_last_valid(s1, s2)
+        ctx.set_persistent_latency(True)
+        i, k, bad = 0, 1, 0
+        while i < m:
+            j = min(i + k, m)
+            bad += int((ctx.check_motions(s1[i:j], s2[i:j]) != e["check_motion"][i:j]).sum())
+            ok, t, st = ctx.check_motions_last_valid(s1[i:j], s2[i:j])
+            bad += int((ok != b_ok[i:j]).sum()) + int((t != b_t[i:j]).sum())
+            bad += int((~((st == b_st[i:j]) | (np.isnan(st) & np.isnan(b_st[i:j])))).any(axis=1).sum())
+            oki, ni = ctx.check_edges_interp(s1[i:j], s2[i:j])
+            bad += int((oki != e["interp_valid"][i:j]).sum()) + int((ni != e["n_interp"][i:j]).sum())
+            i, k = j, k % 2 + 1
+        assert bad == 0, f"{rname} {env}: {bad} mismatches"
+        assert ctx.persistent_latency_stats()["requests"] > 0
+        ctx.set_persistent_latency(False)
+        ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [400, 800, 141])
 def test_kernel_variants_of_the_15x15_layer_and_the_tile_order_agree(n, monkeypatch):
     """Kept behind environment switches of the VARIANTS build (cost_kernels_variants.h; profiles/r05_cnn_variants.txt, r06_cnn_variants.txt): conv1 o conv2 as its own launch or fused (ARTP_CONV12_FUSED=0 / 1), its
