@@ -109,6 +109,14 @@ class GpuContext {
   GpuContext& operator=(const GpuContext&) = delete;
   artp_ctx* get() const { return ctx_; }
 
+  // isValid() on an arbitrary state and checkMotion() on one edge WITHOUT a kernel launch per call: resident workgroups poll
+  // for requests (artp_set_persistent_latency).  Off by default: while they are resident (until 200 us after the last
+  // call) hipDeviceSynchronize / hipFree of the process wait for them, and up to half the CUs are theirs.
+  void setPersistentLatency(bool on) {
+    const int rc = artp_set_persistent_latency(ctx_, on ? 1 : 0);
+    if (rc != ARTP_OK) throw std::runtime_error(std::string("artp_set_persistent_latency: ") + artp_last_error(ctx_));
+  }
+
   // ---- validated-state blocks (see ValidatedStateBlock) ----
   // The epoch of a block is the map version INSIDE the artp_ctx (artp_map_version): every upload, rectangle update,
   // install or sampler re-weighting bumps it, whoever issued it.  mapChanged() only drops the dead blocks early.

@@ -142,6 +142,7 @@ class PlannerRosShape : protected Planner {
     *edges = m ? m->functorEdges() : 0;
   }
   void devicePricing(bool on) { setDevicePricing(on); }
+  void persistentLatency(bool on) { setPersistentLatency(on); }
   // the solution path priced by the objective PlannerRos installed (the functor again, motion_cost_objective.cpp:36-95)
   double lastCost() {
     og::PathGeometric path = getSolutionPath(false);
@@ -253,6 +254,16 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 2; ++k) CHECK(std::fabs(path.front()[k] - sg[k]) < 0.31 && std::fabs(path.back()[k] - sg[7 + k]) < 0.31);
     for (size_t i = 0; i < path.size(); ++i) CHECK(node->stateValid(path[i].data()));
     for (size_t i = 0; i + 1 < path.size(); ++i) CHECK(node->motionValid(path[i].data(), path[i + 1].data()));
+    // the same per-call seams answered by the resident workgroups (Planner::setPersistentLatency): same answers;
+    // planning with it switched on still solves
+    node->persistentLatency(true);
+    for (size_t i = 0; i < path.size(); ++i) CHECK(node->stateValid(path[i].data()));
+    for (size_t i = 0; i + 1 < path.size(); ++i) CHECK(node->motionValid(path[i].data(), path[i + 1].data()));
+    std::vector<std::vector<double>> path2;
+    CHECK(node->planFromTo(sg, sg + 7, &path2) == PlannerStatus::SOLVED);
+    for (size_t i = 0; i + 1 < path2.size(); ++i) CHECK(node->motionValid(path2[i].data(), path2[i + 1].data()));
+    node->persistentLatency(false);
+    for (size_t i = 0; i + 1 < path2.size(); ++i) CHECK(node->motionValid(path2[i].data(), path2[i + 1].data()));
   }
   node->clearPlanner();
 

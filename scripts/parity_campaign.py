@@ -76,7 +76,21 @@ def edge_campaign(ctx, gm, rob, se3, labels):
         #                                                                    state: t = -inf, the interpolated state is NaN in both)
         i, k = j, k % 64 + 1
     _EDGE_JOB["bad_few"] = (bad_few, mf)
-    return bad + bad_few, float(ok0.mean()), float(oki.mean())
+    # ... and through the resident pool (artp_set_persistent_latency: calls of one and two edges, no launch)
+    ctx.set_persistent_latency(True)
+    i, k, bad_pool = 0, 1, 0
+    while i < mf:
+        j = min(i + k, mf)
+        f_ok = ctx.check_motions(a[i:j], b[i:j])
+        f_ok2, f_t, f_st = ctx.check_motions_last_valid(a[i:j], b[i:j])
+        f_oki, f_ni = ctx.check_edges_interp(a[i:j], b[i:j])
+        bad_pool += int((f_ok != ok0[i:j]).sum()) + int((f_ok2 != ok[i:j]).sum()) + int((f_t != t[i:j]).sum()) + \
+            int((f_oki != oki[i:j]).sum()) + int((f_ni != ni[i:j]).sum()) + \
+            int((~((f_st == g_st[i:j]) | (np.isnan(f_st) & np.isnan(g_st[i:j])))).any(axis=1).sum())
+        i, k = j, k % 2 + 1
+    ctx.set_persistent_latency(False)
+    _EDGE_JOB["bad_pool"] = (bad_pool, mf)
+    return bad + bad_few + bad_pool, float(ok0.mean()), float(oki.mean())
 
 base = make_map(240, 0.04, seed=31)
 
@@ -144,15 +158,17 @@ for mapname, robot in cases:
         bad_e, vf, vi = edge_campaign(ctx, gm, rob, se3, vo)
         bad_total += bad_e
         bf, mf = _EDGE_JOB.get("bad_few", (0, 0))
+        bp, mp_ = _EDGE_JOB.get("bad_pool", (0, 0))
         edge_txt = (f" | {n_edges} edges x (checkMotion, lastValid pair, 0.5 m rule + n_interp): mismatches={bad_e} "
-                    f"(valid {vf:.3f} / {vi:.3f}); of which the latency form on {mf} of them in calls of 1..64 edges: {bf}")
+                    f"(valid {vf:.3f} / {vi:.3f}); of which the latency form on {mf} of them in calls of 1..64 edges: {bf}, "
+                    f"the resident pool on {mp_} of them in calls of 1..2 edges: {bp}")
     lines.append(f"{mapname:9s} {robot:8s} states={n} valid={vg.mean():.3f} mismatches={bad} latency-path mismatches={bad_few}/4096 "
                  f"counters={ctx.pipeline_counters()}{edge_txt} ({time.time() - t0:.1f}s)")
     print(lines[-1], flush=True)
     ctx.close()
 lines.append(f"TOTAL MISMATCHES {bad_total} over {n * len(cases)} states (batch pipeline) + {4096 * len(cases)} (latency path)" +
              (f" + {n_edges * len(cases)} edges through each of the three edge entry points (+ {min(n_edges, 2048) * len(cases)} "
-              "of them again through the one-launch latency form)" if n_edges else ""))
+              "of them again through the one-launch latency form and through the resident pool)" if n_edges else ""))
 print(lines[-1])
 out = os.path.join(ROOT, "gpurun_out", "parity_campaign.txt")
 os.makedirs(os.path.dirname(out), exist_ok=True)

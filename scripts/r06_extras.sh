@@ -16,6 +16,20 @@ mkdir -p $OUT
   make -s -C art_planner_amd/csrc timing > /dev/null 2>&1
   ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/few_trace.py 2>/dev/null | grep -A1 "^edge [0-5] " | grep -v "^--"
 } > $OUT/few_edges.txt 2>&1
+{
+  echo "== round trip of a request number: host -> polling workgroups -> host (tests/cpp/bar_pingpong_probe.hip)"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w -o /tmp/bar_pingpong_probe tests/cpp/bar_pingpong_probe.hip 2>/dev/null && timeout 120 /tmp/bar_pingpong_probe 2>/dev/null
+  echo
+  echo "== checkMotion per call by edge length and verdict: one launch per call vs the resident pool (scripts/pool_slope.py)"
+  python scripts/pool_slope.py 2>/dev/null
+  echo
+  echo "== the resident pool: phases of workgroup 1 for one request, timing build (scripts/pool_trace.py; us)"
+  ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/pool_trace.py 2>/dev/null | grep "^edge"
+  echo
+  echo "== pool size and request block placement, variants build (scripts/edge_latency.py --few-only)"
+  for w in 32 64 128; do echo "ARTP_POOL_WGS=$w"; ARTP_LIB=art_planner_amd/csrc/libartp_variants.so ARTP_POOL_WGS=$w python scripts/edge_latency.py --few-only 2>/dev/null | grep "^pool"; done
+  echo "ARTP_POOL_BAR=0 (request block in mapped host memory), 128 workgroups"; ARTP_LIB=art_planner_amd/csrc/libartp_variants.so ARTP_POOL_BAR=0 python scripts/edge_latency.py --few-only 2>/dev/null | grep "^pool"
+} > $OUT/edge_pool.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/cnn/trace -o trace -- python $GRAFT_REPO_ROOT/scripts/cnn_bench.py 50 > $OUT/cnn_bench.log 2>&1
 {
@@ -26,4 +40,4 @@ rocprofv3 --kernel-trace --stats -d $OUT/cnn/trace -o trace -- python $GRAFT_REP
 rm -rf $OUT/cnn
 cd $GRAFT_REPO_ROOT
 ARTP_SOLVE_TIMING=1 ARTP_LIB=art_planner_amd/csrc/libartp_variants.so python scripts/lazy_timing.py > $OUT/lazy_solve_breakdown.txt 2>&1
-tail -4 $OUT/few_edges.txt; cat $OUT/cnn_kernel_trace.txt | head -12; tail -3 $OUT/lazy_solve_breakdown.txt | cut -c1-300
+tail -4 $OUT/few_edges.txt; tail -12 $OUT/edge_pool.txt; cat $OUT/cnn_kernel_trace.txt | head -12; tail -3 $OUT/lazy_solve_breakdown.txt | cut -c1-300
