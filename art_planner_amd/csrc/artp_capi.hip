@@ -110,14 +110,12 @@ struct artp_ctx {
   bool pool_launched = false;
   hipStream_t pool_stream = nullptr;
   hipEvent_t pool_after_map = nullptr;
-  EdgeMailbox* pool_mb = nullptr;         // host view (request): DEVICE memory written through the PCIe BAR when the device
-  EdgeMailbox* pool_mb_dev = nullptr;     //   exposes all of it (pool_mb_in_device), mapped host memory otherwise
-  bool pool_mb_in_device = false;
+  EdgeMailbox* pool_mb = nullptr;         // the request block: DEVICE memory that the host writes through the PCIe BAR
+  int pool_bar = -1;                      // does the device expose its memory to the host (large BAR)?  -1 = not asked yet
   PoolResponse* pool_resp = nullptr;      // host view (per-workgroup slots)
   PoolResponse* pool_resp_dev = nullptr;
   PoolCtl* pool_ctl = nullptr;            // device memory
   unsigned pool_wgs = ARTP_POOL_WGS;
-  bool pool_allow_bar = true;             // (variants build: ARTP_POOL_BAR=0 keeps the request block in mapped host memory)
   uint32_t pool_seq = 0;
   uint64_t pool_map_version = 0;
   uint64_t pool_launches = 0, pool_requests = 0;
@@ -946,7 +944,6 @@ int artp_create(int device, const artp_params* params, artp_ctx** out) {
       const long v = std::strtol(pw, nullptr, 10);
       if (v >= 1 && v <= ARTP_POOL_MAX_WGS) c->pool_wgs = (unsigned)v;
     }
-    if (const char* pb = std::getenv("ARTP_POOL_BAR")) c->pool_allow_bar = pb[0] != '0';
 #endif
   }
   fill_robot(c);
@@ -1010,7 +1007,7 @@ void artp_destroy(artp_ctx* c) {
   if (c->svc_after_map) (void)hipEventDestroy(c->svc_after_map);
   if (c->pool_stream) (void)hipStreamDestroy(c->pool_stream);
   if (c->pool_after_map) (void)hipEventDestroy(c->pool_after_map);
-  if (c->pool_mb) (void)(c->pool_mb_in_device ? hipFree(c->pool_mb) : hipHostFree(c->pool_mb));
+  if (c->pool_mb) (void)hipFree(c->pool_mb);
   if (c->pool_resp) (void)hipHostFree(c->pool_resp);
   if (c->pool_ctl) (void)hipFree(c->pool_ctl);
   if (c->pin_edges) (void)hipHostFree(c->pin_edges);
@@ -2108,6 +2105,25 @@ static inline void pool_store_fence() {
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
 
+// The pool needs a device whose memory the host can write (large BAR); otherwise edge calls keep their launch per call.
+static bool pool_available(artp_ctx* c) {
+  if (c->pool_bar < 0) {
+    int large_bar = 0;
+    void* p = nullptr;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar &&
+        hipExtMallocWithFlags(&p, sizeof(EdgeMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+      // the request block: DEVICE memory the host writes through the PCIe BAR (kernels.h), cleared the same way
+      c->pool_mb = static_cast<EdgeMailbox*>(p);
+      for (size_t i = 0; i < sizeof(EdgeMailbox) / 8; ++i) reinterpret_cast<volatile uint64_t*>(p)[i] = 0;
+      c->pool_bar = 1;
+    } else {
+      (void)hipGetLastError();
+      c->pool_bar = 0;
+    }
+  }
+  return c->pool_bar == 1;
+}
+
 static void pool_stop(artp_ctx* c) {
   if (!c->pool_mb || !c->pool_launched) return;
   // (line 0 is never READ by the host -- a read across the BAR is a microsecond: the request number is c->pool_seq)
@@ -2124,26 +2140,8 @@ static void pool_stop(artp_ctx* c) {
 }
 
 static int pool_start(artp_ctx* c) {
-  if (!c->pool_mb) {
-    void *p = nullptr, *pd = nullptr, *r = nullptr, *rd = nullptr;
-    // The request block.  Polled by EVERY workgroup: in mapped host memory each poll is a PCIe read and the reads of P
-    // workgroups queue up (round trip of a request number, tests/cpp/bar_pingpong_probe.hip, profiles/r06_edge_pool.txt:
-    // 2.0 us with one polling workgroup, 5.8 us with 32, 11.4 us with 64); in DEVICE memory that the host writes through the
-    // BAR the poll never leaves the device (2.4 us whatever the number of workgroups).
-    int large_bar = 0;
-    (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device);
-    if (large_bar && c->pool_allow_bar && hipExtMallocWithFlags(&p, sizeof(EdgeMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
-      HIP_TRY(c, hipMemset(p, 0, sizeof(EdgeMailbox)));
-      c->pool_mb = c->pool_mb_dev = static_cast<EdgeMailbox*>(p);
-      c->pool_mb_in_device = true;
-    } else {
-      (void)hipGetLastError();
-      HIP_TRY(c, hipHostMalloc(&p, sizeof(EdgeMailbox), hipHostMallocMapped));
-      c->pool_mb = static_cast<EdgeMailbox*>(p);
-      HIP_TRY(c, hipHostGetDevicePointer(&pd, p, 0));
-      c->pool_mb_dev = static_cast<EdgeMailbox*>(pd);
-      std::memset(p, 0, sizeof(EdgeMailbox));
-    }
+  if (!c->pool_resp) {
+    void *r = nullptr, *rd = nullptr;
     HIP_TRY(c, hipHostMalloc(&r, sizeof(PoolResponse), hipHostMallocMapped));
     c->pool_resp = static_cast<PoolResponse*>(r);
     HIP_TRY(c, hipHostGetDevicePointer(&rd, r, 0));
@@ -2167,8 +2165,8 @@ static int pool_start(artp_ctx* c) {
   for (unsigned w = 0; w < ARTP_POOL_MAX_WGS; ++w) c->pool_resp->exited[w] = 0;
   pool_store_fence();
   hipLaunchKernelGGL(check_motions_pool_kernel, dim3(c->pool_wgs), dim3(320), lds_few(c), c->pool_stream, c->field[0],
-                     c->field[1], c->geom, c->robot, c->pool_mb_dev, c->pool_resp_dev, c->pool_ctl, c->pool_seq,
-                     c->pool_mb_in_device ? 0 : 1, c->caps_full, c->caps_foot_full);
+                     c->field[1], c->geom, c->robot, c->pool_mb, c->pool_resp_dev, c->pool_ctl, c->pool_seq, c->caps_full,
+                     c->caps_foot_full);
   HIP_TRY(c, hipGetLastError());
   c->pool_launched = true;
   c->pool_map_version = c->map_version.load(std::memory_order_acquire);
@@ -2299,7 +2297,7 @@ static int run_edges_host(artp_ctx* c, int mode, const double* s1, const double*
   if (n <= ARTP_FEW_EDGES && c->few_edges && c->have_field[0] && c->have_field[1] && (mode != 0 || c->have_z) &&
       few_edges_task_estimate(c, mode, s1, s2, n, &few_max) <= 65536.0) {
     // (at most eight rounds per workgroup: one that has run out of tasks must not reach its idle limit while others work)
-    if (c->svc_enabled && n <= ARTP_POOL_MAX_EDGES && few_max * n <= 8.0 * c->pool_wgs)
+    if (c->svc_enabled && n <= ARTP_POOL_MAX_EDGES && few_max * n <= 8.0 * c->pool_wgs && pool_available(c))
       return run_edges_pool(c, mode, s1, s2, n, valid, aux_out, last_t, last_state);
     return run_edges_few(c, mode, true, s1, s2, n, valid, aux_out, last_t, last_state, few_max);
   }

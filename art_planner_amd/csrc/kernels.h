@@ -1395,9 +1395,9 @@ check_motions_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, doubl
 // and finalization -- 12.4 us of device time per request against 6.2 us now (profiles/r06_edge_pool.txt).
 // The request block is five 64-byte lines, each {tag, word, 7 doubles}.  It lives in DEVICE memory that the host writes through
 // the PCIe BAR (payloads, store fence, tags): polling never leaves the device, so its cost does not depend on P.  (In mapped
-// host memory -- the fallback without a large BAR, `reread` = 1 -- every poll is a PCIe read and the reads of P workgroups
-// queue up: 5.8 us per round trip with 32 pollers, 11.4 us with 64, against 2.4 us through the BAR; there the lines are
-// fetched once more after the tags match, since nothing orders the sectors of one read.)
+// host memory every poll is a PCIe read and the reads of P workgroups queue up: 3.2 - 5.8 us per round trip of a request
+// number with 32 pollers, 6 - 11 us with 64, against 2.3 us through the BAR; a pool of 32 polling the host answered in 31 us,
+// slower than one launch per call -- so without a large BAR there is no pool and the calls take check_motions_few_kernel.)
 // Each workgroup leaves by itself: `leave` bit, 200 us without a request, ARTP_SVC_LIFE_TICKS at the latest.
 #define ARTP_POOL_WGS 128
 #define ARTP_POOL_MAX_WGS 128
@@ -1422,7 +1422,7 @@ __device__ unsigned long long g_pool_trace[16];   // wall_clock64 of the phases 
 #endif
 __global__ void __launch_bounds__(320, 2)   // one workgroup per CU: 256 VGPRs
 check_motions_pool_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, const EdgeMailbox* mb, PoolResponse* resp, PoolCtl* ctl,
-                          uint32_t last_seq, int reread, ScratchCaps caps_torso, ScratchCaps caps_foot) {
+                          uint32_t last_seq, ScratchCaps caps_torso, ScratchCaps caps_foot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double s_edges[2][14], s_zr[2];
   __shared__ int box_ok[5];
@@ -1453,7 +1453,6 @@ check_motions_pool_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, cons
         const bool tag_lane = lane < 24 && (lane & 7) == 0;
         const bool stale_line = tag_lane && (uint32_t)q != seq;
         if (seq != last_seq && __ballot(stale_line) == 0ull) {
-          if (reread && lane < 24) q = words[lane];   // (mapped host memory: see above)
           if (lane < 24 && (lane & 7)) {
             const int line = lane >> 3, i = (lane & 7) - 1;
             if (line < 2) {
@@ -1468,7 +1467,6 @@ check_motions_pool_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, cons
               if (lane < 16) q2 = words[24 + lane];
               const bool stale2 = lane < 16 && (lane & 7) == 0 && (uint32_t)q2 != seq;
               if (__ballot(stale2) == 0ull) {
-                if (reread && lane < 16) q2 = words[24 + lane];
                 if (lane < 16 && (lane & 7)) reinterpret_cast<unsigned long long*>(s_edges[1])[7 * (lane >> 3) + (lane & 7) - 1] = q2;
                 break;
               }

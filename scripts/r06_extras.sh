@@ -26,9 +26,8 @@ mkdir -p $OUT
   echo "== the resident pool: phases of workgroup 1 for one request, timing build (scripts/pool_trace.py; us)"
   ARTP_LIB=art_planner_amd/csrc/libartp_timing.so python scripts/pool_trace.py 2>/dev/null | grep "^edge"
   echo
-  echo "== pool size and request block placement, variants build (scripts/edge_latency.py --few-only)"
+  echo "== pool size, variants build (scripts/edge_latency.py --few-only)"
   for w in 32 64 128; do echo "ARTP_POOL_WGS=$w"; ARTP_LIB=art_planner_amd/csrc/libartp_variants.so ARTP_POOL_WGS=$w python scripts/edge_latency.py --few-only 2>/dev/null | grep "^pool"; done
-  echo "ARTP_POOL_BAR=0 (request block in mapped host memory), 128 workgroups"; ARTP_LIB=art_planner_amd/csrc/libartp_variants.so ARTP_POOL_BAR=0 python scripts/edge_latency.py --few-only 2>/dev/null | grep "^pool"
 } > $OUT/edge_pool.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/cnn/trace -o trace -- python $GRAFT_REPO_ROOT/scripts/cnn_bench.py 50 > $OUT/cnn_bench.log 2>&1

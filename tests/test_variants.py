@@ -70,12 +70,11 @@ def test_dense_feet_stream_variant_gives_the_same_labels(name, big_map, monkeypa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"ARTP_POOL_BAR": "0", "ARTP_POOL_WGS": "16"}, {"ARTP_POOL_WGS": "5"}, {"ARTP_POOL_WGS": "64"}])
-def test_resident_edge_pool_fallback_request_block_and_other_pool_sizes(env, monkeypatch):
-    """The resident edge pool's request block in MAPPED HOST memory ($ARTP_POOL_BAR=0: what a device without a large BAR gets;
-    every workgroup's poll is then a PCIe read, and the lines are fetched a second time after the tags match) and pools of
-    other sizes ($ARTP_POOL_WGS: 5 workgroups = many rounds per edge and the cross-workgroup early exit; 64): the golden
-    edges' verdicts, lastValid pairs and interpolation counts, one and two edges per call."""
+@pytest.mark.parametrize("env", [{"ARTP_POOL_WGS": "5"}, {"ARTP_POOL_WGS": "64"}])
+def test_resident_edge_pool_of_other_sizes(env, monkeypatch):
+    """The resident edge pool with other numbers of workgroups ($ARTP_POOL_WGS, variants build: 5 = many rounds per edge and the
+    cross-workgroup early exit on every edge; 64): the golden edges' verdicts, lastValid pairs and interpolation counts, one
+    and two edges per call."""
     name = golden_io.MAPS[0]
     gm, _ = golden_io.load_boxes(name)
     for k, v in env.items():
