@@ -1399,8 +1399,8 @@ check_motions_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, doubl
 // number with 32 pollers, 6 - 11 us with 64, against 2.3 us through the BAR; a pool of 32 polling the host answered in 31 us,
 // slower than one launch per call -- so without a large BAR there is no pool and the calls take check_motions_few_kernel.)
 // Each workgroup leaves by itself: `leave` bit, 200 us without a request, ARTP_SVC_LIFE_TICKS at the latest.
-#define ARTP_POOL_WGS 128
-#define ARTP_POOL_MAX_WGS 128
+#define ARTP_POOL_WGS 256
+#define ARTP_POOL_MAX_WGS 256
 #define ARTP_POOL_MAX_EDGES 2
 struct PoolLine { volatile uint32_t tag, word; double v[7]; };   // word of line 0: bits 0-7 edges, bit 8 leave, bit 9 mode, bit 10 lastValid wanted
 struct EdgeMailbox {   // mapped (coherent) host memory, host -> device
