@@ -1673,6 +1673,52 @@ def main():
     except Exception as ex:  # pragma: no cover
         preprocess = {"error": repr(ex)}
 
+    # ---- per-call latency of the OMPL seams (one state / one edge per host call), driven from Python ------------
+    per_call = None
+    try:
+        if args.skip_extras or multi:
+            raise RuntimeError("skipped")
+        cl = Context(local_rank, "yaml")
+        cl.upload_map(gm)
+        st_l = cl.sample_states(seed, 0, 8192)
+        lab_l = cl.validate_states(st_l)
+        acc_l = st_l[lab_l != 0]
+        acc_l = acc_l[np.argsort(acc_l[:, 0])]
+        a_l, b_l = acc_l[:-1], acc_l[1:]
+        keep_l = np.hypot(a_l[:, 0] - b_l[:, 0], a_l[:, 1] - b_l[:, 1]) < 2.0
+        a_l, b_l = np.ascontiguousarray(a_l[keep_l][:256]), np.ascontiguousarray(b_l[keep_l][:256])
+        want_l = cl.check_motions(a_l, b_l)
+
+        def per_call_us(fn, reps):
+            for r in range(20):
+                fn(r)
+            t0 = time.perf_counter()
+            for r in range(reps):
+                fn(r)
+            return (time.perf_counter() - t0) / reps * 1e6
+
+        bad_l = [0]
+
+        def one_state(r):
+            i = r % 4096
+            bad_l[0] += int(cl.validate_states(st_l[i:i + 1])[0] != lab_l[i])
+
+        def one_edge(r):
+            i = r % len(a_l)
+            bad_l[0] += int(cl.check_motions(a_l[i:i + 1], b_l[i:i + 1])[0] != want_l[i])
+
+        per_call = {"how": "host-buffer C ABI through ctypes (≈3 us of Python per call included); edges between accepted states "
+                           "< 2 m apart; test_host.cpp measures the same seams from C++ (profiles/*_host_latency.json)",
+                    "is_valid_1_state_us": per_call_us(one_state, 1000), "check_motion_1_edge_us": per_call_us(one_edge, 1000)}
+        cl.set_persistent_latency(True)
+        per_call["is_valid_1_state_us_resident"] = per_call_us(one_state, 2000)
+        per_call["check_motion_1_edge_us_resident"] = per_call_us(one_edge, 2000)
+        cl.set_persistent_latency(False)
+        per_call["label_mismatches"] = bad_l[0]
+        cl.close()
+    except Exception as ex:  # pragma: no cover
+        per_call = {"error": repr(ex)}
+
     # ---- C4 extras: 800 x 800 @ 0.04 m map, Params-default robot ---------------------------------------------
     c4 = None
     try:
@@ -1825,7 +1871,7 @@ def main():
         "valid_fraction": valid_frac, "label_hash_batch0": label_hash,
         "sampler_ms_per_batch": sample_ms, "edges": edges, "pipeline_counts_batch0": pipeline_counts,
         "motion_cost_c3": motion_cost, "replan_cycle_c5": c5, "roadmap_n1": roadmap, "preprocess_n2": preprocess,
-        "c4_800_defaults": c4, "distributed": dist_extras,
+        "c4_800_defaults": c4, "per_call_latency": per_call, "distributed": dist_extras,
         "device": ctx.arch, "gather_error": gather_error,
     }
     try:  # RCCL prints a version banner through C stdio; push it out BEFORE the JSON so that the line is the last one
