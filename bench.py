@@ -117,7 +117,7 @@ def contract_line(full):
             out[k] = full.get(k)
     d = full.get("distributed")
     if d:
-        out["distributed"] = _pick(d, ("world_size", "rccl_ranks_seen", "exchange", "headline_includes_exchange",
+        out["distributed"] = _pick(d, ("world_size", "rccl_ranks_seen", "exchange", "headline_includes_exchange", "rehearsal",
                                        "no_exchange", "states_per_s_default", "states_per_s_materialise_all",
                                        "states_per_s_materialise_none", "edge_exchange_edges_per_s", "error"))
     for max_str in (200, 120, 80, 48):          # clip the prose harder until the line fits
@@ -763,7 +763,7 @@ def self_launch(n_gpus, argv):
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` does from outside).  Returns the exit code."""
     import socket
     found = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if found < n_gpus:
+    if found < n_gpus and "--rehearse-on-one-gpu" not in argv:
         raise SystemExit(f"bench.py --gpus {n_gpus}: needs {n_gpus} GPUs on this node, found {found}")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -785,6 +785,10 @@ def main():
     ap.add_argument("--edges", type=int, default=1 << 18)
     ap.add_argument("--map", type=int, default=400)
     ap.add_argument("--res", type=float, default=0.04)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path on a one-GPU box, not a measurement: every rank uses GPU 0, "
+                         "torch.distributed runs over gloo and the device group over the library $ARTP_RCCL_LIB names "
+                         "(tests/cpp/loopback_rccl.cpp: RCCL refuses two ranks on one GPU); the line says so in `rehearsal`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
@@ -820,8 +824,10 @@ def main():
         # no launcher: spawn the N ranks ourselves (rank 0 of the child job prints the JSON line on our stdout)
         raise SystemExit(self_launch(N, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse_on_one_gpu and not os.environ.get("ARTP_RCCL_LIB"):
+        raise SystemExit("--rehearse-on-one-gpu needs $ARTP_RCCL_LIB (the loopback test double): RCCL itself refuses two ranks on one GPU")
     if world != N:
         raise SystemExit(f"bench.py --gpus {N} was launched with WORLD_SIZE={world}: start it as `python bench.py --gpus {N}` "
                          f"(it spawns its own ranks) or under `python -m torch.distributed.run --nproc-per-node {N} "
@@ -837,7 +843,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from art_planner_amd.context import Context
     from art_planner_amd.distributed import DeviceGroup, shard_first_index
@@ -1163,6 +1172,8 @@ def main():
                        "exchange": ("artp_group_* of the C ABI (librccl bound by libartp.so; one call per step)"
                                     if use_grp is not None else "torch.distributed " + dist.get_backend()),
                        "headline_includes_exchange": bool(headline_gathers),
+                       "rehearsal": ("NOT a measurement: %d ranks share GPU 0, torch.distributed over gloo, the device group over "
+                                     "$ARTP_RCCL_LIB = %s" % (world, os.environ.get("ARTP_RCCL_LIB"))) if args.rehearse_on_one_gpu else None,
                        "materialise_default": args.materialise, "no_exchange": no_exchange,
                        "per_rank_ms_per_step": per_rank_ms,
                        "states_per_s_default": value if headline_gathers else N * S * k2 / timed_region(k2, "default")}

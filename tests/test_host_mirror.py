@@ -1,5 +1,6 @@
 """The C++ host mirror (art_planner_amd/host: reference class names/signatures over the C ABI)."""
 import os
+import sys
 import struct
 import subprocess
 
@@ -95,6 +96,41 @@ def test_loopback_rccl_double_builds_and_exports_what_group_h_binds(tmp_path):
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclCommAbort", "ncclCommGetAsyncError",
                  "ncclAllGather", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
         assert hasattr(L, name), name     # csrc/group.h ARTP_RCCL_SYM: a missing one disables the binding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_n_ranks_rehearsal_on_one_gpu(tmp_path, world):
+    """bench.py's N > 1 path end to end on a ONE-GPU box, launched the way the driver launches it (torch.distributed.run, one
+    process per rank): the RCCL id made by rank 0 and broadcast, artp_group_create_rank in every rank, the bitmap all-gather
+    and re-materialisation inside the timed steps, the barrier + max-over-ranks clock, ONE contract line from rank 0 with
+    world_size = rccl_ranks_seen = N.  --rehearse-on-one-gpu: every rank uses GPU 0, torch.distributed over gloo, the group
+    over the loopback test double (RCCL refuses two ranks on a GPU) -- a rehearsal of the code path, not a measurement, and
+    the line says so."""
+    import json
+    import socket
+    so = _build_loopback_rccl(tmp_path)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, ARTP_RCCL_LIB=so, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(common.ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
+           "--batch", str(1 << 20), "--rehearse-on-one-gpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=common.ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = r.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    assert len(line) <= 6144
+    assert d["n_gpus"] == world and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    dd = d["distributed"]
+    assert dd["world_size"] == world and dd["rccl_ranks_seen"] == world and dd["headline_includes_exchange"] is True
+    assert "artp_group" in dd["exchange"] and "NOT a measurement" in dd["rehearsal"]
+    assert d.get("gather_error") is None
+    out_dir = os.path.join(common.ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"bench_rehearsal_{world}_ranks_one_gpu.json"), "w") as f:
+        f.write(line + "\n")
 
 
 @pytest.mark.gpu
