@@ -144,8 +144,8 @@ int artp_validate_states(artp_ctx* ctx, const double* se3, size_t n, uint8_t* va
  * (the same device function).  Off by default: it holds five wavefronts and ~63 KB of LDS of one CU while resident.
  * The same switch covers ob::MotionValidator::checkMotion one edge at a time (prm_motion_cost.cpp:652,
  * lazy_prm_star_min_update.cpp:725, OMPL's PathSimplifier): artp_check_motions / artp_check_motions_last_valid /
- * artp_check_edges_interp calls with one or two edges (host pointers; at most 8 x 128 interpolation states) are answered by a
- * resident POOL of 128 workgroups with the same start / restart / idle rules.  Every workgroup polls a request block in
+ * artp_check_edges_interp calls with one or two edges (host pointers; at most 8 x 256 interpolation states) are answered by a
+ * resident POOL of 256 workgroups (one per CU) with the same start / restart / idle rules.  Every workgroup polls a request block in
  * device memory that the host writes through the PCIe BAR, runs its share of the edge's states and reports to a slot of its
  * own in mapped host memory; the host reduces the slots.  (A device that does not expose its memory to the host -- no large
  * BAR -- has no pool: these calls keep their one launch per call.)
