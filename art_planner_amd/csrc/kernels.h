@@ -1403,10 +1403,10 @@ check_motions_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, doubl
 #define ARTP_POOL_MAX_WGS 256
 #define ARTP_POOL_MAX_EDGES 2
 struct PoolLine { volatile uint32_t tag, word; double v[7]; };   // word of line 0: bits 0-7 edges, bit 8 leave, bit 9 mode, bit 10 lastValid wanted
-struct EdgeMailbox {   // mapped (coherent) host memory, host -> device
+struct EdgeMailbox {   // DEVICE memory (fine-grained), written by the host through the BAR
   PoolLine line[5];    // 0: s1 of edge 0 | 1: s2 of edge 0 | 2: z_extent, r3_extent_override | 3, 4: edge 1
 };
-static_assert(sizeof(PoolLine) == 64 && sizeof(EdgeMailbox) == 320, "one PCIe read per line");
+static_assert(sizeof(PoolLine) == 64 && sizeof(EdgeMailbox) == 320, "a tag per 64-byte line");
 struct PoolSlot { uint32_t tag, first_bad, flags, aux; };   // flags: 2 = tile capacity, 4 = segment-count overflow; bits 3..: the edge's task count
 struct PoolResponse {   // mapped host memory, device -> host
   PoolSlot slot[ARTP_POOL_MAX_EDGES][ARTP_POOL_MAX_WGS];
