@@ -115,6 +115,7 @@ struct artp_ctx {
   PoolResponse* pool_resp = nullptr;      // host view (per-workgroup slots)
   PoolResponse* pool_resp_dev = nullptr;
   PoolCtl* pool_ctl = nullptr;            // device memory
+  uint64_t pool_shadow[5][7] = {};        // the payload words of the request block as last written
   unsigned pool_wgs = ARTP_POOL_WGS;
   uint32_t pool_seq = 0;
   uint64_t pool_map_version = 0;
@@ -2154,7 +2155,7 @@ static int pool_start(artp_ctx* c) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few(c)));
   }
   if (c->pool_seq >= 0xfffffff0u) {   // the request numbers wrap: every tag back to "never"
-    for (int l = 0; l < 5; ++l) reinterpret_cast<volatile uint64_t*>(&c->pool_mb->line[l])[0] = 0;
+    reinterpret_cast<volatile uint64_t*>(&c->pool_mb->line[0])[0] = 0;
     std::memset(c->pool_resp, 0, sizeof(PoolResponse));
     c->pool_seq = 0;
   }
@@ -2189,23 +2190,27 @@ static int run_edges_pool(artp_ctx* c, int mode, const double* s1, const double*
     }
     EdgeMailbox* mb = c->pool_mb;
     const unsigned P = c->pool_wgs;
-    for (size_t i = 0; i < n; ++i) {
-      std::memcpy(mb->line[i ? 3 : 0].v, s1 + 7 * i, 7 * sizeof(double));
-      std::memcpy(mb->line[i ? 4 : 1].v, s2 + 7 * i, 7 * sizeof(double));
-    }
-    mb->line[2].v[0] = c->z_high - c->z_low;
-    mb->line[2].v[1] = c->r3_extent_override;
-    // every line's payload is globally visible before its tag; line 0's tag and word go out as one 8-byte store, last
-    pool_store_fence();
+    // the block as the device will see it (c->pool_shadow: the host never reads across the BAR): payloads, header word, checksum
     const uint32_t seq = ++c->pool_seq;
     const uint32_t word = (uint32_t)n | (mode ? 0x200u : 0u) | (want_last ? 0x400u : 0u);
-    if (n > 1) {
-      mb->line[4].tag = seq;
-      mb->line[3].tag = seq;
+    uint64_t (*sh)[7] = c->pool_shadow;
+    for (size_t i = 0; i < n; ++i) {
+      std::memcpy(sh[i ? 3 : 0], s1 + 7 * i, 7 * sizeof(double));
+      std::memcpy(sh[i ? 4 : 1], s2 + 7 * i, 7 * sizeof(double));
     }
-    mb->line[2].tag = seq;
-    mb->line[1].tag = seq;
-    reinterpret_cast<volatile uint64_t*>(&mb->line[0])[0] = ((uint64_t)word << 32) | seq;
+    const double zr[2] = {c->z_high - c->z_low, c->r3_extent_override};
+    std::memcpy(sh[2], zr, sizeof(zr));
+    sh[2][2] = ((uint64_t)seq << 32) | word;
+    uint64_t sum = pool_mix((uint64_t)seq, 64u);
+    for (unsigned l = 0; l < 5; ++l)
+      for (unsigned i = 0; i < 7; ++i)
+        if (8 * l + 1 + i != ARTP_POOL_SUM_LANE) sum ^= pool_mix(sh[l][i], 8 * l + 1 + i);
+    sh[2][6] = sum;
+    for (unsigned l = 0; l < (n > 1 ? 5u : 3u); ++l) std::memcpy(mb->line[l].v, sh[l], 7 * sizeof(uint64_t));
+    // the payload has left the write-combining buffers before the doorbell (line 0's number) is rung; what the device accepts
+    // is decided by the checksum, not by this order
+    pool_store_fence();
+    reinterpret_cast<volatile uint64_t*>(&mb->line[0])[0] = seq;
     pool_store_fence();
     const auto t0 = std::chrono::steady_clock::now();
     // per edge: the slot of the workgroup task 0 fell to (it carries the edge's task count), then the slots of the
@@ -2221,15 +2226,26 @@ static int run_edges_pool(artp_ctx* c, int mode, const double* s1, const double*
         const volatile PoolSlot& sl = c->pool_resp->slot[e][w];
         if (sl.tag != seq) break;
         std::atomic_thread_fence(std::memory_order_acquire);
+        // the slot as a whole: taken when its check word verifies (with the lastValid state it announces), else not there yet
+        const uint32_t s_bad = sl.first_bad, s_flags = sl.flags, s_aux = sl.aux, s_check = sl.check;
+        uint64_t state_xor = 0;
+        if (want_last && s_bad != 0xffffffffu)
+          for (int i = 0; i < 7; ++i) {
+            uint64_t u;
+            const double v = c->pool_resp->last_state[e][w][i];
+            std::memcpy(&u, &v, 8);
+            state_xor ^= u;
+          }
+        if (pool_slot_check(seq, s_bad, s_flags, s_aux, state_xor) != s_check) break;
         if (idx == 0) {
-          const uint32_t tasks = sl.flags >> 3;
+          const uint32_t tasks = s_flags >> 3;
           cnt = tasks < P ? (tasks ? tasks : 1u) : P;
           base += tasks;
-          aux = sl.aux;
+          aux = s_aux;
         }
-        flags |= sl.flags & 7u;
-        if (sl.first_bad < fbad) {
-          fbad = sl.first_bad;
+        flags |= s_flags & 7u;
+        if (s_bad < fbad) {
+          fbad = s_bad;
           who = w;
         }
         if (++idx < cnt) continue;
@@ -2273,9 +2289,8 @@ static int run_edges_pool(artp_ctx* c, int mode, const double* s1, const double*
       }
       return ARTP_OK;
     }
-    if (gone) {
+    if (gone) {   // post it again, under a NEW number, to a fresh pool: whatever the old one still wrote carries the old one
       pool_stop(c);
-      --c->pool_seq;   // post it again under the same number (slots already answered for it hold the same answers)
       continue;
     }
     c->last_error = "the resident edge pool did not answer within 50 ms";

@@ -1394,20 +1394,43 @@ check_motions_few_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, doubl
 // 2.4 us in the dispatcher's second PCIe round trip and fence, 1.8 us until a worker held the request, 0.6 + 1.6 us in arrival
 // and finalization -- 12.4 us of device time per request against 6.2 us now (profiles/r06_edge_pool.txt).
 // The request block is five 64-byte lines, each {tag, word, 7 doubles}.  It lives in DEVICE memory that the host writes through
-// the PCIe BAR (payloads, store fence, tags): polling never leaves the device, so its cost does not depend on P.  (In mapped
-// host memory every poll is a PCIe read and the reads of P workgroups queue up: 3.2 - 5.8 us per round trip of a request
-// number with 32 pollers, 6 - 11 us with 64, against 2.3 us through the BAR; a pool of 32 polling the host answered in 31 us,
-// slower than one launch per call -- so without a large BAR there is no pool and the calls take check_motions_few_kernel.)
+// the PCIe BAR: polling never leaves the device, so its cost does not depend on P.  (In mapped host memory every poll is a PCIe
+// read and the reads of P workgroups queue up: 3.2 - 5.8 us per round trip of a request number with 32 pollers, 6 - 11 us
+// with 64, against 2.3 us through the BAR; a pool of 32 polling the host answered in 31 us, slower than one launch per call
+// -- so without a large BAR there is no pool and the calls take check_motions_few_kernel.)
+// Protocol: the host writes the 35 payload words -- edges, bounds, a header word {request number, mode bits} and a CHECKSUM of
+// the other 34 and the number --, a store fence, then the number into line 0 (the doorbell).  A workgroup that sees a new
+// number takes the request only if the checksum of what it read verifies; each answer slot carries a check word over its
+// fields and the lastValid state it announces, and the host takes a slot only when that verifies.  Neither side depends on
+// how stores are combined, split or ordered on the way.  (The first form trusted per-line tags and 16-byte stores: a soak of
+// 1.5 million calls found one wrong answer, twice -- scripts/pool_soak.py, profiles/r06_edge_pool.txt.)
 // Each workgroup leaves by itself: `leave` bit, 200 us without a request, ARTP_SVC_LIFE_TICKS at the latest.
 #define ARTP_POOL_WGS 256
 #define ARTP_POOL_MAX_WGS 256
 #define ARTP_POOL_MAX_EDGES 2
-struct PoolLine { volatile uint32_t tag, word; double v[7]; };   // word of line 0: bits 0-7 edges, bit 8 leave, bit 9 mode, bit 10 lastValid wanted
+struct PoolLine { volatile uint32_t tag, word; double v[7]; };   // line 0: tag = the request number (the doorbell), word bit 8 = leave
 struct EdgeMailbox {   // DEVICE memory (fine-grained), written by the host through the BAR
-  PoolLine line[5];    // 0: s1 of edge 0 | 1: s2 of edge 0 | 2: z_extent, r3_extent_override | 3, 4: edge 1
+  PoolLine line[5];    // 0: s1 of edge 0 | 1: s2 of edge 0 | 2: z_extent, r3_extent_override, header word, .., checksum | 3, 4: edge 1
 };
+// as 8-byte words of the block: line 2's v[2] = header {request number << 32 | bits 0-7 edges, bit 9 mode, bit 10 lastValid
+// wanted}, line 2's v[6] = checksum of the other 34 payload words and the number
+#define ARTP_POOL_HDR_LANE 19
+#define ARTP_POOL_SUM_LANE 23
+__host__ __device__ inline unsigned long long pool_mix(unsigned long long x, unsigned pos) {
+  x ^= (unsigned long long)(pos + 1u) * 0x9E3779B97F4A7C15ull;
+  x *= 0xFF51AFD7ED558CCDull;
+  return x ^ (x >> 29);
+}
+__host__ __device__ inline uint32_t pool_slot_check(uint32_t tag, uint32_t first_bad, uint32_t flags, uint32_t aux, unsigned long long state_xor) {
+  const unsigned long long x = pool_mix(((unsigned long long)tag << 32) | first_bad, 1u) ^ pool_mix(((unsigned long long)flags << 32) | aux, 2u) ^
+                               pool_mix(state_xor, 3u);
+  return (uint32_t)(x ^ (x >> 32));
+}
 static_assert(sizeof(PoolLine) == 64 && sizeof(EdgeMailbox) == 320, "a tag per 64-byte line");
-struct PoolSlot { uint32_t tag, first_bad, flags, aux; };   // flags: 2 = tile capacity, 4 = segment-count overflow; bits 3..: the edge's task count
+// flags: 2 = tile capacity, 4 = segment-count overflow; bits 3..: the edge's task count.  check = pool_slot_check of the other
+// four words and of the xor of the 7 doubles of last_state (0 when none was written): the host takes a slot when its check
+// verifies, so it cannot act on a slot that reached it in pieces
+struct PoolSlot { uint32_t tag, first_bad, flags, aux, check, pad[3]; };
 struct PoolResponse {   // mapped host memory, device -> host
   PoolSlot slot[ARTP_POOL_MAX_EDGES][ARTP_POOL_MAX_WGS];
   double last_state[ARTP_POOL_MAX_EDGES][ARTP_POOL_MAX_WGS][7];   // written in front of the slot when first_bad != ~0 and wanted
@@ -1440,43 +1463,51 @@ check_motions_pool_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, cons
   unsigned long long t_idle = t_start;
   const volatile unsigned long long* words = reinterpret_cast<const volatile unsigned long long*>(mb);
   for (;;) {
-    if (kbox == 0) {   // wavefront 0 polls: lanes 0..23 = lines 0..2 (8 x 8 bytes each)
+    if (kbox == 0) {   // wavefront 0 polls: lanes 0..39 = the five lines (8 x 8 bytes each)
       uint32_t leave = 0, seq = last_seq, hdr = 0;
       for (;;) {
         unsigned long long q = 0;
-        if (lane < 24) q = words[lane];
+        if (lane < 40) q = words[lane];
         const unsigned long long h = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) |
                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
         seq = (uint32_t)h;
-        hdr = (uint32_t)(h >> 32);
-        // the three lines carry the same NEW number: their payloads are this request's
-        const bool tag_lane = lane < 24 && (lane & 7) == 0;
-        const bool stale_line = tag_lane && (uint32_t)q != seq;
-        if (seq != last_seq && __ballot(stale_line) == 0ull) {
-          if (lane < 24 && (lane & 7)) {
-            const int line = lane >> 3, i = (lane & 7) - 1;
-            if (line < 2) {
-              reinterpret_cast<unsigned long long*>(s_edges[0])[7 * line + i] = q;
-            } else if (i < 2) {
-              reinterpret_cast<unsigned long long*>(s_zr)[i] = q;
-            }
-          }
-          if ((hdr & 0xffu) > 1u) {   // the second edge: lines 3 and 4, until they carry the number too
-            for (;;) {
-              unsigned long long q2 = 0;
-              if (lane < 16) q2 = words[24 + lane];
-              const bool stale2 = lane < 16 && (lane & 7) == 0 && (uint32_t)q2 != seq;
-              if (__ballot(stale2) == 0ull) {
-                if (lane < 16 && (lane & 7)) reinterpret_cast<unsigned long long*>(s_edges[1])[7 * (lane >> 3) + (lane & 7) - 1] = q2;
-                break;
-              }
-              if (wall_clock64() - t_start > ARTP_SVC_LIFE_TICKS) { leave = 1; break; }
-            }
-          }
+        // `leave` comes FIRST, whatever the number next to it: the host stops the pool with a request pending when some
+        // workgroups have already left on their own (it posts that request again to a fresh pool)
+        if ((uint32_t)(h >> 32) & 0x100u) {
+          leave = 1;
           break;
         }
+        if (seq != last_seq) {
+          // A new number in line 0.  The request is what the CHECKSUM says it is: the host wrote the 35 payload words (the
+          // header word {request number, mode bits} and the checksum among them), a store fence, then this number; the
+          // checksum covers every payload word and the number, so a view of the block that mixes two requests -- a line
+          // fetched in two halves at different moments, write-combined stores leaving the host in another order than
+          // assumed, a number whose word arrives before its payload -- does not verify and is simply read again.
+          // (Tags per line and a second read were the first form: one wrong answer in 1.5 million soak calls.)
+          const bool payload = lane < 40 && (lane & 7) != 0 && lane != ARTP_POOL_SUM_LANE;
+          unsigned long long sum = payload ? pool_mix(q, (unsigned)lane) : 0ull;
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) sum ^= __shfl_xor(sum, off, 64);
+          sum ^= pool_mix((unsigned long long)seq, 64u);
+          const unsigned long long want = __shfl(q, ARTP_POOL_SUM_LANE, 64);
+          const unsigned long long hw = __shfl(q, ARTP_POOL_HDR_LANE, 64);
+          if (sum == want && (uint32_t)(hw >> 32) == seq) {
+            hdr = (uint32_t)hw;
+            if (lane < 40 && (lane & 7)) {
+              const int line = lane >> 3, i = (lane & 7) - 1;
+              if (line < 2) {
+                reinterpret_cast<unsigned long long*>(s_edges[0])[7 * line + i] = q;
+              } else if (line == 2) {
+                if (i < 2) reinterpret_cast<unsigned long long*>(s_zr)[i] = q;
+              } else {
+                reinterpret_cast<unsigned long long*>(s_edges[1])[7 * (line - 3) + i] = q;
+              }
+            }
+            break;
+          }
+        }
         const unsigned long long now = wall_clock64();
-        if ((seq == last_seq && (hdr & 0x100u)) || now - t_idle > ARTP_SVC_IDLE_TICKS || now - t_start > ARTP_SVC_LIFE_TICKS) {
+        if (now - t_idle > ARTP_SVC_IDLE_TICKS || now - t_start > ARTP_SVC_LIFE_TICKS) {
           leave = 1;
           break;
         }
@@ -1570,24 +1601,33 @@ check_motions_pool_kernel(FieldDev fb, FieldDev ff, MapGeom g, RobotDev rb, cons
       // workgroups without a task of this edge stay silent, except the one task 0 falls to (it reports the task count, from
       // which the host knows whose slots to wait for, and a segment-count overflow)
       if (threadIdx.x == 0 && (first < tasks || first == 0)) {
+        unsigned long long state_xor = 0ull;
         if (want_last && my_bad != 0xffffffffu) {   // the lastValid state of THIS workgroup's finding (last_valid_kernel's rule)
           const int nd = (int)aux;
           const double t = nd > 0 ? (double)my_bad / (double)nd : (double)(nd - 1) / (double)nd;
           double st[7];
           se3_interpolate(a, b, t, st);
 #pragma unroll
-          for (int i = 0; i < 7; ++i) resp->last_state[e][wg][i] = st[i];
+          for (int i = 0; i < 7; ++i) {
+            resp->last_state[e][wg][i] = st[i];
+            state_xor ^= (unsigned long long)__double_as_longlong(st[i]);
+          }
           __threadfence_system();   // ... lands before the slot that announces it
         }
-        // one 16-byte store with system scope (volatile: sc0 sc1, written through -- a plain store may stay in the L2 until a
-        // fence or the end of the kernel): one PCIe write, no fence on the way
+        // two 16-byte stores with system scope (volatile: sc0 sc1, written through -- a plain store may stay in the L2 until a
+        // fence or the end of the kernel), no fence on the way
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 rec;
+        const uint32_t fl = my_err | (tasks << 3);
+        u32x4 rec, rec2;
         rec.x = seq;
         rec.y = my_bad;
-        rec.z = my_err | (tasks << 3);
+        rec.z = fl;
         rec.w = aux;
-        *reinterpret_cast<volatile u32x4*>(&resp->slot[e][wg]) = rec;
+        rec2.x = pool_slot_check(seq, my_bad, fl, aux, state_xor);
+        rec2.y = rec2.z = rec2.w = 0u;
+        volatile u32x4* out = reinterpret_cast<volatile u32x4*>(&resp->slot[e][wg]);
+        out[0] = rec;
+        out[1] = rec2;
         ARTP_POOL_MARK(4, wg == 1 && e == 0);
       }
     }
