@@ -2273,7 +2273,15 @@ static int run_edges_pool(artp_ctx* c, int mode, const double* s1, const double*
         fbad = 0xffffffffu;
       }
       if (!done && (spin & 255u) == 255u) {
-        if (pool_any_exited(c)) { gone = true; break; }
+        // Has the workgroup whose slot is awaited left (idle limit reached as the request went out)?  Only then is the
+        // request posted again: workgroups WITHOUT a task of it may well leave while the others are still working on a slow
+        // one (a 200 us request on a map full of unknown cells), and those others still answer.  Its slot is written in
+        // front of its exit flag, so a flag without a verifying slot means it never saw the request.
+        const unsigned w = (lead + idx) % P;
+        if (c->pool_resp->exited[w]) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          if (c->pool_resp->slot[e][w].tag != seq) { gone = true; break; }
+        }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
       }
     }

@@ -843,6 +843,54 @@ def test_resident_edge_pool_restart_races(big_map):
     ctx.close()
 
 
+def test_resident_edge_pool_requests_longer_than_the_idle_limit():
+    """A request may take longer than the 200 us after which an idle workgroup leaves (a robot twice ANYmal's size on a map
+    riddled with unknown cells: windows the tables cannot answer are walked sample by sample): the workgroups WITHOUT a task
+    of it leave meanwhile, the ones with a task still answer, and the host must wait for those instead of posting the request
+    to a fresh pool again and again (which ended in ARTP_ERR_TIMEOUT after three attempts in the round-6 campaign).  Verdicts,
+    lastValid pairs and interpolation counts of 400 edges, one and two per call, against the batch pipeline."""
+    import copy
+    from art_planner_amd.context import Context, make_params
+    from synthetic import make_map
+    rng = np.random.default_rng(11)
+    gm = copy.deepcopy(make_map(240, 0.04, seed=31))
+    e_, m_ = gm["elevation"].copy(), gm["elevation_masked"].copy()
+    e_[rng.random(e_.shape) < 0.01] = np.nan
+    m_[rng.random(e_.shape) < 0.01] = np.nan
+    gm.layers["elevation"] = np.asfortranarray(e_)
+    gm.layers["elevation_masked"] = np.asfortranarray(m_)
+    prm = make_params("yaml")
+    prm.torso_length, prm.torso_width, prm.torso_height = 1.9, 1.0, 0.3
+    prm.feet_off_x, prm.feet_off_y, prm.feet_off_z = 0.7, 0.45, -0.6
+    prm.reach_x, prm.reach_y, prm.reach_z = 0.6, 0.35, 0.25
+    ctx = Context(0, prm)
+    ctx.upload_map(gm, sampler=False)
+    se3 = common.random_states(gm, 4000, rng, z_off=(0.0, 0.06), tilt=0.25, spread=0.53)
+    n_e = 400
+    a = se3[rng.integers(0, len(se3), n_e)].copy()
+    b = se3[rng.integers(0, len(se3), n_e)].copy()
+    d = rng.uniform(-1.4, 1.4, (n_e, 2))
+    b[:, 0], b[:, 1] = a[:, 0] + d[:, 0], a[:, 1] + d[:, 1]
+    b[:, 2] = a[:, 2] + rng.normal(0, 0.03, n_e)
+    ok, t, st = ctx.check_motions_last_valid(a, b)
+    oki, ni = ctx.check_edges_interp(a, b)
+    ctx.set_persistent_latency(True)
+    i, k, bad = 0, 1, 0
+    while i < n_e:
+        j = min(i + k, n_e)
+        bad += int((ctx.check_motions(a[i:j], b[i:j]) != ok[i:j]).sum())
+        o2, t2, s2 = ctx.check_motions_last_valid(a[i:j], b[i:j])
+        bad += int((o2 != ok[i:j]).sum()) + int((t2 != t[i:j]).sum())
+        bad += int((~((s2 == st[i:j]) | (np.isnan(s2) & np.isnan(st[i:j])))).any(axis=1).sum())
+        o3, n3 = ctx.check_edges_interp(a[i:j], b[i:j])
+        bad += int((o3 != oki[i:j]).sum()) + int((n3 != ni[i:j]).sum())
+        i, k = j, k % 2 + 1
+    assert bad == 0
+    assert ctx.persistent_latency_stats()["requests"] >= 3 * (n_e // 2)
+    ctx.set_persistent_latency(False)
+    ctx.close()
+
+
 def test_latency_path_few_edges_repeats_long_edges_and_no_polling(big_map, monkeypatch):
     """The kernel re-arms its own per-edge words: 300 back-to-back calls of mixed size give the oracle's verdicts every
     time; edges across the whole map (more tasks than workgroups of an edge: the strided loop); the same through
