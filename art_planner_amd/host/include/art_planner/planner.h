@@ -322,7 +322,7 @@ class Planner {
 
   // The per-call seams of OMPL (StateValidityChecker::isValid on arbitrary states, MotionValidator::checkMotion one edge at
   // a time: PathSimplifier, the lazy planners' path check) answered by resident workgroups instead of a launch per call
-  // (GpuContext::setPersistentLatency; 17 -> 12 us and 33 -> 24 us per call on an MI355X).
+  // (GpuContext::setPersistentLatency; 17 -> 12 us and 33 -> 25 us per call on an MI355X).
   void setPersistentLatency(bool on) { gpu_->setPersistentLatency(on); }
 
   void setSeed(uint64_t seed) {
