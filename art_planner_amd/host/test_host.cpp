@@ -180,6 +180,8 @@ int main(int argc, char** argv) {
   // OMPL's PathSimplifier call checkMotion one edge at a time): n = 1 through both overloads, a 32-edge solution path
   // in one artp_check_motions call, and the same two with the latency kernel switched off (the batch pipeline)
   double us_cm1 = 0, us_cm1_last = 0, us_cm32 = 0, us_cm1_batch = 0, us_cm32_batch = 0, us_cm1_pool = 0, us_cm1_last_pool = 0;
+  double us_cm1_short = 0, us_cm1_short_pool = 0;
+  int n_short = 0;
   {
     const int reps = 400;
     for (int pass = 0; pass < 2; ++pass) {   // pass 0 warms up
@@ -221,6 +223,32 @@ int main(int argc, char** argv) {
       us_cm1_last_pool = (now_us() - t1) / reps;
     }
     bad += artp_set_persistent_latency(gpu->get(), 0) != ARTP_OK;
+    // the PRM-sized motions of the fixture alone (end states less than 2 m apart: what the reference's planners connect),
+    // one launch per call and through the resident pool
+    {
+      std::vector<int> short_idx;
+      for (int i = 0; i < m_single; ++i)
+        if (std::hypot(s1[7 * i] - s2[7 * i], s1[7 * i + 1] - s2[7 * i + 1]) < 2.0) short_idx.push_back(i);
+      n_short = (int)short_idx.size();
+      if (n_short >= 20) {
+        for (int svc = 0; svc < 2; ++svc) {
+          bad += artp_set_persistent_latency(gpu->get(), svc) != ARTP_OK;
+          double t1 = 0;
+          for (int pass = 0; pass < 2; ++pass) {
+            t1 = now_us();
+            for (int i = 0; i < reps; ++i) {
+              const int j = short_idx[i % n_short];
+              toState(&s1[7 * j], &a);
+              toState(&s2[7 * j], &b);
+              bad += mv.checkMotion(&a, &b) != (motion_ok[j] != 0);
+            }
+            t1 = (now_us() - t1) / reps;
+          }
+          (svc ? us_cm1_short_pool : us_cm1_short) = t1;
+        }
+        bad += artp_set_persistent_latency(gpu->get(), 0) != ARTP_OK;
+      }
+    }
     const int np = m < 32 ? m : 32;
     std::vector<uint8_t> okp(np);
     auto time_path = [&](int calls) {
@@ -379,8 +407,9 @@ int main(int argc, char** argv) {
   std::printf("isValid on an arbitrary state: %.1f us per call (one launch), %.1f us through the persistent service\n", us_single,
               us_single_svc);
   std::printf("checkMotion per call: 1 edge %.1f us (lastValid overload %.1f us), 32-edge path %.1f us; through the batch "
-              "pipeline: %.1f us / %.1f us; 1 edge through the resident pool: %.1f us (lastValid overload %.1f us)\n", us_cm1,
-              us_cm1_last, us_cm32, us_cm1_batch, us_cm32_batch, us_cm1_pool, us_cm1_last_pool);
+              "pipeline: %.1f us / %.1f us; 1 edge through the resident pool: %.1f us (lastValid overload %.1f us); the %d motions "
+              "shorter than 2 m alone: %.1f us per call, %.1f us through the pool\n", us_cm1,
+              us_cm1_last, us_cm32, us_cm1_batch, us_cm32_batch, us_cm1_pool, us_cm1_last_pool, n_short, us_cm1_short, us_cm1_short_pool);
   std::printf("host mirror: %d states batch + %d single (%.1f us per isValid on arbitrary states), %d motions (%d lastValid "
               "mismatches), rejection loop %d attempts / %d accepted at %.3f us per sampleUniform+isValid, %d labels flipped by a "
               "direct artp_update_layer_rect and served fresh, %d mismatches\n",
@@ -392,6 +421,9 @@ int main(int argc, char** argv) {
       << ", \"check_motion_last_valid_1_edge_us\": " << us_cm1_last << ", \"check_motions_32_edge_path_us\": " << us_cm32
       << ", \"check_motion_1_edge_us_resident_pool\": " << us_cm1_pool
       << ", \"check_motion_last_valid_1_edge_us_resident_pool\": " << us_cm1_last_pool
+      << ", \"check_motion_1_edge_us_motions_under_2m\": " << us_cm1_short
+      << ", \"check_motion_1_edge_us_motions_under_2m_resident_pool\": " << us_cm1_short_pool
+      << ", \"motions_under_2m\": " << n_short
       << ", \"check_motion_1_edge_us_batch_pipeline\": " << us_cm1_batch
       << ", \"check_motions_32_edge_path_us_batch_pipeline\": " << us_cm32_batch
       << ", \"sampler_loop_us_per_state\": " << us_loop

@@ -244,6 +244,12 @@ def test_host_mirror_matches_oracle_through_the_ompl_shaped_interfaces(tmp_path)
     # motions: accepted state i -> accepted state i+1 (any length), plus some that end on an invalid state
     m = 300
     s1, s2 = acc[:m].copy(), acc[1:m + 1].copy()
+    # every other motion PRM-sized: to one of the three nearest accepted states (the reference connects milestones to their
+    # nearest neighbours; test_host.cpp times the motions shorter than 2 m apart from the map-spanning ones)
+    dd = np.hypot(s1[:, None, 0] - acc[None, :, 0], s1[:, None, 1] - acc[None, :, 1])
+    dd[np.arange(m), np.arange(m)] = np.inf
+    near = acc[np.argsort(dd, axis=1)[np.arange(m), np.random.default_rng(3).integers(0, 3, m)]]
+    s2[1::2] = near[1::2]
     s2[::9] = se3[expected == 0][:len(s2[::9])]
     ok, last_t, last_state = om.check_motions_last_valid(rob, s1, s2)
     ok0, _ = om.check_motions(rob, s1, s2)
